@@ -1,0 +1,107 @@
+"""ctypes binding of libhnswgpu.so (C ABI: include/hnswgpu.h).
+
+The library is built in-tree by ``build()`` (hipcc, gfx950 only).  There is NO CPU fallback: if
+the shared object is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+SO = os.path.join(PKG, "libhnswgpu.so")
+
+COSINE, L2, DOT = 0, 1, 2
+
+
+class HnswGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libhnswgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False, jobs=4):
+    """Compile every HIP source for gfx950 into hnsw-clj_amd/libhnswgpu.so (hipcc cross-compiles
+    without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(os.path.dirname(PKG), "include", "hnswgpu.h"))
+    stale = (not os.path.exists(SO)) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs)
+    if force or stale:
+        cmd = ["make", "-C", CSRC, "-j%d" % jobs] + (["-B"] if force else [])
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return SO
+
+
+_lib = None
+
+_SIGS = {
+    # name: (argtypes)
+    "hnswgpu_version": [],
+    "hnswgpu_device_count": ["p"],
+    "hnswgpu_create": ["p", "i64", "i32", "i32", "i32", "p"],
+    "hnswgpu_create_dev": ["p", "i64", "i32", "i64", "i32", "i32", "p", "p"],
+    "hnswgpu_destroy": ["p"],
+    "hnswgpu_info": ["p", "p", "p", "p", "p", "p"],
+    "hnswgpu_sync": ["p"],
+    "hnswgpu_pair_distance": ["i32", "p", "p", "i32", "i32", "p"],
+    "hnswgpu_batch_distances": ["p", "p", "p", "i32", "p"],
+    "hnswgpu_norms": ["p", "p"],
+    "hnswgpu_exact_knn": ["p", "p", "i32", "i32", "p", "p"],
+    "hnswgpu_exact_knn_dev": ["p", "p", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_set_graph": ["p", "p", "p", "i32", "p", "p", "i32", "i32", "i32"],
+    "hnswgpu_hnsw_build": ["p", "i32", "i32", "i64"],
+    "hnswgpu_graph_sizes": ["p", "p", "p", "p", "p", "p"],
+    "hnswgpu_get_graph": ["p", "p", "p", "p", "p"],
+    "hnswgpu_hnsw_search": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_hnsw_search_dev": ["p", "p", "i32", "i32", "i32", "p", "p", "p", "p"],
+    "hnswgpu_ivf_build": ["p", "i32", "i32", "i64"],
+    "hnswgpu_set_ivf": ["p", "p", "i32", "p", "p"],
+    "hnswgpu_get_ivf": ["p", "p", "p", "p"],
+    "hnswgpu_kmeans_assign": ["p", "p", "i32", "p", "p"],
+    "hnswgpu_kmeanspp": ["p", "i32", "i64", "p"],
+    "hnswgpu_ivf_search": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_ivf_search_dev": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_ivf_search_lists": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_merge_topk_dev": ["i32", "p", "p", "i32", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_set_profiling": ["p", "i32"],
+    "hnswgpu_get_profile": ["p", "i32", "p", "p", "i32"],
+}
+_T = {"p": C.c_void_p, "i32": C.c_int32, "i64": C.c_int64}
+
+EXPORTS = sorted(list(_SIGS) + ["hnswgpu_last_error"])
+
+
+def lib():
+    """Load libhnswgpu.so.  torch (when installed) is imported FIRST so that this library binds to
+    the same HIP runtime (libamdhip64.so.7) as torch in every process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise ImportError(
+            "%s is missing: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
+            "g.build()'`). There is no CPU fallback." % SO)
+    try:
+        import torch  # noqa: F401  (pins the HIP runtime; torch is plumbing, not the product)
+    except ImportError:
+        pass
+    L = C.CDLL(SO)
+    for name, args in _SIGS.items():
+        fn = getattr(L, name)
+        fn.restype = C.c_int
+        fn.argtypes = [_T[a] for a in args]
+    L.hnswgpu_last_error.restype = C.c_char_p
+    L.hnswgpu_last_error.argtypes = []
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise HnswGpuError(rc, lib().hnswgpu_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int32(0)
+    check(lib().hnswgpu_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,561 @@
+// engine.hip -- index lifetime, distance seams, exact kNN and the shared scan/merge launchers of
+// libhnswgpu.so (C ABI: include/hnswgpu.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "engine.hpp"
+
+namespace hg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int pick_nch(int64_t ld) {
+    int64_t nvec = ld / 4;
+    int need = static_cast<int>((nvec + kWave - 1) / kWave);
+    const int opts[] = {1, 2, 3, 4, 6, 8, 12};
+    for (int o : opts)
+        if (o >= need) return o;
+    return 0;
+}
+
+static int rb_of(int nch) { return nch <= 3 ? 8 : (nch <= 6 ? 4 : 2); }
+int scan_rows_per_iter(int nch) { return kNWave * rb_of(nch); }
+
+#define HG_DISPATCH(nch, l2, CALL)                                        \
+    do {                                                                  \
+        if (l2) {                                                         \
+            switch (nch) {                                                \
+                case 1: CALL(1, 8, true); break;                          \
+                case 2: CALL(2, 8, true); break;                          \
+                case 3: CALL(3, 8, true); break;                          \
+                case 4: CALL(4, 4, true); break;                          \
+                case 6: CALL(6, 4, true); break;                          \
+                case 8: CALL(8, 2, true); break;                          \
+                case 12: CALL(12, 2, true); break;                        \
+                default: set_error("unsupported row length"); return HNSWGPU_ELIMIT; \
+            }                                                             \
+        } else {                                                          \
+            switch (nch) {                                                \
+                case 1: CALL(1, 8, false); break;                         \
+                case 2: CALL(2, 8, false); break;                         \
+                case 3: CALL(3, 8, false); break;                         \
+                case 4: CALL(4, 4, false); break;                         \
+                case 6: CALL(6, 4, false); break;                         \
+                case 8: CALL(8, 2, false); break;                         \
+                case 12: CALL(12, 2, false); break;                       \
+                default: set_error("unsupported row length"); return HNSWGPU_ELIMIT; \
+            }                                                             \
+        }                                                                 \
+    } while (0)
+
+int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st) {
+    if (n <= 0) return 0;
+    unsigned grid = static_cast<unsigned>((n + kNWave - 1) / kNWave);
+#define CALL(N, R, L) hipLaunchKernelGGL((row_norms_kernel<N>), dim3(grid), dim3(kWG), 0, st, rows, ld, n, out)
+    HG_DISPATCH(nch, false, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_scan(int nch, const ScanArgs &a, hipStream_t st) {
+    int64_t blocks = static_cast<int64_t>(a.npairs) * a.nchunks;
+    if (blocks <= 0) return 0;
+    HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "scan grid too large (%lld blocks)", (long long)blocks);
+    size_t lds = a.mode == MODE_TOPK ? sizeof(uint64_t) * kNWave * a.k : 0;
+    HG_REQUIRE(lds <= 64 * 1024, HNSWGPU_ELIMIT, "k too large for the scan kernel (k=%d)", a.k);
+    bool l2 = a.metric == METRIC_L2;
+#define CALL(N, R, L) \
+    hipLaunchKernelGGL((scan_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a)
+    HG_DISPATCH(nch, l2, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(kWave) void merge_topk_kernel(MergeArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *list = reinterpret_cast<uint64_t *>(smem);
+    const int lane = threadIdx.x;
+    const int q = blockIdx.x;
+    const uint64_t *in = a.partial + static_cast<int64_t>(q) * a.keys_per_query;
+    int cnt = 0;
+    uint64_t thr = ~0ull;
+    for (int64_t base = 0; base < a.keys_per_query; base += kWave) {
+        int64_t i = base + lane;
+        uint64_t key = i < a.keys_per_query ? in[i] : ~0ull;
+        uint64_t mask = __ballot(key < thr);
+        while (mask) {
+            int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+            mask &= mask - 1;
+            uint64_t kb = __shfl(key, b, kWave);
+            if (kb < thr) {
+                wave_insert(list, cnt, a.k, kb, lane);
+                thr = cnt == a.k ? list[a.k - 1] : ~0ull;
+            }
+        }
+    }
+    for (int i = lane; i < a.k; i += kWave) {
+        bool ok = i < cnt;
+        uint64_t key = ok ? list[i] : ~0ull;
+        a.out_ord[static_cast<int64_t>(q) * a.k + i] = ok ? static_cast<uint32_t>(key) : 0xffffffffu;
+        a.out_dist[static_cast<int64_t>(q) * a.k + i] = ok ? key_dist(key) : __uint_as_float(0x7f800000u);
+    }
+}
+
+int launch_merge(const MergeArgs &a, hipStream_t st) {
+    if (a.nq <= 0) return 0;
+    size_t lds = sizeof(uint64_t) * a.k;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(a.nq), dim3(kWave), lds, st, a);
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gather(int nch, const GatherArgs &a, hipStream_t st) {
+    if (a.m <= 0) return 0;
+    bool l2 = a.metric == METRIC_L2;
+#define CALL(N, R, L)                                                                                      \
+    hipLaunchKernelGGL((gather_dist_kernel<N, R, L>), dim3((a.m + kNWave * R - 1) / (kNWave * R)), dim3(kWG), 0, \
+                       st, a)
+    HG_DISPATCH(nch, l2, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+void prof_begin(hnswgpu_index *idx, int slot, hipStream_t st, hipEvent_t *e0) {
+    *e0 = nullptr;
+    if (!idx->prof || slot < 0) return;
+    if (hipEventCreate(e0) != hipSuccess) {
+        *e0 = nullptr;
+        return;
+    }
+    (void)hipEventRecord(*e0, st);
+}
+void prof_end(hnswgpu_index *idx, int slot, hipStream_t st, hipEvent_t e0) {
+    if (!e0) return;
+    hipEvent_t e1;
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return;
+    }
+    (void)hipEventRecord(e1, st);
+    idx->prof_ev[slot].push_back({e0, e1});
+}
+
+int plan_chunks(int nch, int64_t max_rows, int64_t npairs, int32_t *chunk_rows) {
+    // enough workgroups to fill 256 CUs several times over, but no chunk below one loop trip of
+    // every wave; chunk_rows is a multiple of the rows one workgroup consumes per iteration
+    const int64_t per_iter = scan_rows_per_iter(nch);
+    if (max_rows < 1) max_rows = 1;
+    int64_t target_blocks = 8192;
+    int64_t want = (target_blocks + npairs - 1) / (npairs > 0 ? npairs : 1);
+    if (want < 1) want = 1;
+    int64_t max_chunks = (max_rows + per_iter - 1) / per_iter;
+    if (want > max_chunks) want = max_chunks;
+    int64_t cr = (max_rows + want - 1) / want;
+    cr = ((cr + per_iter - 1) / per_iter) * per_iter;
+    *chunk_rows = static_cast<int32_t>(cr);
+    return static_cast<int>((max_rows + cr - 1) / cr);
+}
+
+int scan_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_query, int64_t max_rows,
+              hipStream_t st, int prof_slot) {
+    a.mode = MODE_TOPK;
+    a.npairs = nq * pairs_per_query;
+    a.nchunks = plan_chunks(idx->nch, max_rows, a.npairs, &a.chunk_rows);
+    int64_t keys_per_query = static_cast<int64_t>(pairs_per_query) * a.nchunks * kNWave * a.k;
+    HG_TRY(idx->s_partial.ensure(sizeof(uint64_t) * keys_per_query * nq));
+    HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * a.k));
+    HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * a.k));
+    a.partial = idx->s_partial.as<uint64_t>();
+    hipEvent_t e0;
+    prof_begin(idx, prof_slot, st, &e0);
+    HG_TRY(launch_scan(idx->nch, a, st));
+    prof_end(idx, prof_slot, st, e0);
+    MergeArgs m;
+    m.partial = a.partial;
+    m.keys_per_query = keys_per_query;
+    m.nq = nq;
+    m.k = a.k;
+    m.out_ord = idx->s_ord.as<uint32_t>();
+    m.out_dist = idx->s_dist.as<float>();
+    HG_TRY(launch_merge(m, st));
+    return 0;
+}
+
+int upload_queries(hnswgpu_index *idx, const float *Q, int32_t nq, hipStream_t st) {
+    size_t bytes = sizeof(float) * static_cast<size_t>(nq) * idx->dim;
+    HG_TRY(idx->s_q.ensure(bytes));
+    HG_HIP(hipMemcpyAsync(idx->s_q.p, Q, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+__global__ void ord_to_ids_kernel(const uint32_t *ord, int64_t cnt, int32_t *ids) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < cnt) ids[i] = ord[i] == 0xffffffffu ? -1 : static_cast<int32_t>(ord[i]);
+}
+
+// [nshard][nq][k] (id, dist) -> [nq][k]; ties keep the lower shard (then the lower rank) first
+__global__ __launch_bounds__(kWave) void merge_shards_kernel(const int32_t *ids, const float *dist, int nshard,
+                                                             int nq, int k, int32_t *out_ids, float *out_dist) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *list = reinterpret_cast<uint64_t *>(smem);
+    const int lane = threadIdx.x, q = blockIdx.x;
+    int cnt = 0;
+    uint64_t thr = ~0ull;
+    const int tot = nshard * k;
+    for (int base = 0; base < tot; base += kWave) {
+        int i = base + lane;
+        uint64_t key = ~0ull;
+        if (i < tot) {
+            int s = i / k, r = i % k;
+            int64_t src = (static_cast<int64_t>(s) * nq + q) * k + r;
+            if (ids[src] >= 0) key = make_key(dist[src], static_cast<uint32_t>(i));
+        }
+        uint64_t mask = __ballot(key < thr);
+        while (mask) {
+            int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+            mask &= mask - 1;
+            uint64_t kb = __shfl(key, b, kWave);
+            if (kb < thr) {
+                wave_insert(list, cnt, k, kb, lane);
+                thr = cnt == k ? list[k - 1] : ~0ull;
+            }
+        }
+    }
+    for (int i = lane; i < k; i += kWave) {
+        bool ok = i < cnt;
+        int32_t id = -1;
+        float d = __uint_as_float(0x7f800000u);
+        if (ok) {
+            uint32_t o = static_cast<uint32_t>(list[i]);
+            int s = o / k, r = o % k;
+            int64_t src = (static_cast<int64_t>(s) * nq + q) * k + r;
+            id = ids[src];
+            d = dist[src];
+        }
+        out_ids[static_cast<int64_t>(q) * k + i] = id;
+        out_dist[static_cast<int64_t>(q) * k + i] = d;
+    }
+}
+
+}  // namespace hg
+
+using namespace hg;
+
+extern "C" {
+
+int hnswgpu_version(void) { return HNSWGPU_VERSION; }
+const char *hnswgpu_last_error(void) { return g_err; }
+
+int hnswgpu_device_count(int32_t *count) {
+    HG_REQUIRE(count, HNSWGPU_EINVAL, "count is null");
+    int c = 0;
+    HG_HIP(hipGetDeviceCount(&c));
+    *count = c;
+    return 0;
+}
+
+static int create_common(int64_t n, int32_t dim, int32_t metric, int32_t device, hnswgpu_index **out) {
+    HG_REQUIRE(out, HNSWGPU_EINVAL, "out is null");
+    HG_REQUIRE(n >= 0 && n < 2147483647LL, HNSWGPU_EINVAL, "n out of range (%lld)", (long long)n);
+    HG_REQUIRE(dim >= 1, HNSWGPU_EINVAL, "dim must be >= 1");
+    HG_REQUIRE(metric >= 0 && metric <= 2, HNSWGPU_EINVAL, "unknown metric %d", metric);
+    int64_t ld = (static_cast<int64_t>(dim) + 3) / 4 * 4;
+    int nch = pick_nch(ld);
+    HG_REQUIRE(nch > 0, HNSWGPU_ELIMIT, "dim %d > 3072 is not supported", dim);
+    HG_HIP(hipSetDevice(device));
+    hnswgpu_index *idx = new (std::nothrow) hnswgpu_index();
+    HG_REQUIRE(idx, HNSWGPU_ENOMEM, "host allocation failed");
+    idx->device = device;
+    idx->metric = metric;
+    idx->n = n;
+    idx->dim = dim;
+    idx->ld = ld;
+    idx->nch = nch;
+    *out = idx;
+    return 0;
+}
+
+static int finish_create(hnswgpu_index *idx, hipStream_t st) {
+    if (idx->n > 0) {
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norms), sizeof(float) * idx->n));
+        HG_TRY(launch_norms(idx->nch, idx->d_base, idx->ld, idx->n, idx->d_norms, st));
+    }
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int hnswgpu_create(const float *base, int64_t n, int32_t dim, int32_t metric, int32_t device,
+                   hnswgpu_index **out) {
+    HG_REQUIRE(out, HNSWGPU_EINVAL, "out is null");
+    *out = nullptr;
+    HG_REQUIRE(base || n == 0, HNSWGPU_EINVAL, "base is null");
+    hnswgpu_index *idx = nullptr;
+    HG_TRY(create_common(n, dim, metric, device, &idx));
+    int rc = [&]() -> int {
+        HG_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+        if (n > 0) {
+            HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_base), sizeof(float) * n * idx->ld));
+            if (idx->ld == dim) {
+                HG_HIP(hipMemcpyAsync(idx->d_base, base, sizeof(float) * n * dim, hipMemcpyHostToDevice, idx->stream));
+            } else {
+                HG_HIP(hipMemsetAsync(idx->d_base, 0, sizeof(float) * n * idx->ld, idx->stream));
+                HG_HIP(hipMemcpy2DAsync(idx->d_base, sizeof(float) * idx->ld, base, sizeof(float) * dim,
+                                        sizeof(float) * dim, n, hipMemcpyHostToDevice, idx->stream));
+            }
+        }
+        return finish_create(idx, idx->stream);
+    }();
+    if (rc != 0) {
+        hnswgpu_destroy(idx);
+        return rc;
+    }
+    *out = idx;
+    return 0;
+}
+
+int hnswgpu_create_dev(const float *d_base, int64_t n, int32_t dim, int64_t ld, int32_t metric, int32_t device,
+                       void *stream, hnswgpu_index **out) {
+    HG_REQUIRE(out, HNSWGPU_EINVAL, "out is null");
+    *out = nullptr;
+    HG_REQUIRE(d_base || n == 0, HNSWGPU_EINVAL, "d_base is null");
+    HG_REQUIRE(ld >= dim, HNSWGPU_EINVAL, "ld < dim");
+    hnswgpu_index *idx = nullptr;
+    HG_TRY(create_common(n, dim, metric, device, &idx));
+    int rc = [&]() -> int {
+        HG_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+        hipStream_t st = stream ? static_cast<hipStream_t>(stream) : idx->stream;
+        if (n > 0) {
+            HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_base), sizeof(float) * n * idx->ld));
+            if (idx->ld != dim) HG_HIP(hipMemsetAsync(idx->d_base, 0, sizeof(float) * n * idx->ld, st));
+            HG_HIP(hipMemcpy2DAsync(idx->d_base, sizeof(float) * idx->ld, d_base, sizeof(float) * ld,
+                                    sizeof(float) * dim, n, hipMemcpyDeviceToDevice, st));
+        }
+        return finish_create(idx, st);
+    }();
+    if (rc != 0) {
+        hnswgpu_destroy(idx);
+        return rc;
+    }
+    *out = idx;
+    return 0;
+}
+
+int hnswgpu_destroy(hnswgpu_index *idx) {
+    if (!idx) return 0;
+    (void)hipSetDevice(idx->device);
+    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,
+                    idx->d_cent,  idx->d_cnorms, idx->d_lrows,  idx->d_lnorms,  idx->d_listoff, idx->d_listids};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    DevBuf *bufs[] = {&idx->s_q,   &idx->s_partial, &idx->s_ord,   &idx->s_dist, &idx->s_pairs, &idx->s_ids,
+                      &idx->s_outd, &idx->s_probes,  &idx->s_stats, &idx->s_misc, &idx->s_misc2};
+    for (DevBuf *b : bufs) b->release();
+    for (int s = 0; s < PROF_N; s++)
+        for (auto &pr : idx->prof_ev[s]) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    delete idx;
+    return 0;
+}
+
+int hnswgpu_info(const hnswgpu_index *idx, int64_t *n, int32_t *dim, int32_t *metric, int32_t *has_graph,
+                 int32_t *nlist) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    if (n) *n = idx->n;
+    if (dim) *dim = idx->dim;
+    if (metric) *metric = idx->metric;
+    if (has_graph) *has_graph = idx->has_graph ? 1 : 0;
+    if (nlist) *nlist = idx->nlist;
+    return 0;
+}
+
+int hnswgpu_sync(hnswgpu_index *idx) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_HIP(hipSetDevice(idx->device));
+    HG_HIP(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+int hnswgpu_pair_distance(int32_t metric, const float *a, const float *b, int32_t dim, int32_t device, float *out) {
+    HG_REQUIRE(a && b && out, HNSWGPU_EINVAL, "null argument");
+    hnswgpu_index *idx = nullptr;
+    HG_TRY(hnswgpu_create(b, 1, dim, metric, device, &idx));
+    int rc = hnswgpu_batch_distances(idx, a, nullptr, 1, out);
+    hnswgpu_destroy(idx);
+    return rc;
+}
+
+int hnswgpu_batch_distances(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out) {
+    HG_REQUIRE(idx && q && (out || m == 0), HNSWGPU_EINVAL, "null argument");
+    HG_REQUIRE(m >= 0, HNSWGPU_EINVAL, "m < 0");
+    if (m == 0) return 0;
+    HG_REQUIRE(ids || m <= idx->n, HNSWGPU_EINVAL, "m > n with implicit ids");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(upload_queries(idx, q, 1, st));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * m));
+    GatherArgs g;
+    g.rows = idx->d_base;
+    g.row_norms = idx->d_norms;
+    g.ld = idx->ld;
+    g.n = idx->n;
+    g.q = idx->s_q.as<float>();
+    g.dim = idx->dim;
+    g.metric = idx->metric;
+    g.ids = nullptr;
+    if (ids) {
+        HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * m));
+        HG_HIP(hipMemcpyAsync(idx->s_ids.p, ids, sizeof(int32_t) * m, hipMemcpyHostToDevice, st));
+        g.ids = idx->s_ids.as<int32_t>();
+    }
+    g.m = m;
+    g.out = idx->s_outd.as<float>();
+    HG_TRY(launch_gather(idx->nch, g, st));
+    HG_HIP(hipMemcpyAsync(out, g.out, sizeof(float) * m, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int hnswgpu_norms(hnswgpu_index *idx, float *out_norms) {
+    HG_REQUIRE(idx && (out_norms || idx->n == 0), HNSWGPU_EINVAL, "null argument");
+    if (idx->n == 0) return 0;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    HG_HIP(hipMemcpyAsync(out_norms, idx->d_norms, sizeof(float) * idx->n, hipMemcpyDeviceToHost, idx->stream));
+    HG_HIP(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+static int exact_knn_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t *d_ids,
+                             float *d_dist, hipStream_t st) {
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = idx->d_base;
+    a.row_norms = idx->d_norms;
+    a.ld = idx->ld;
+    a.nrows_all = idx->n;
+    a.Q = d_Q;
+    a.qld = idx->dim;
+    a.q_norms = nullptr;
+    a.dim = idx->dim;
+    a.metric = idx->metric;
+    a.pairs = nullptr;
+    a.k = k;
+    HG_TRY(scan_topk(idx, a, nq, 1, idx->n, st, PROF_IVF_SCAN));
+    int64_t cnt = static_cast<int64_t>(nq) * k;
+    hipLaunchKernelGGL(ord_to_ids_kernel, dim3(static_cast<unsigned>((cnt + 255) / 256)), dim3(256), 0, st,
+                       idx->s_ord.as<uint32_t>(), cnt, d_ids);
+    HG_HIP(hipGetLastError());
+    HG_HIP(hipMemcpyAsync(d_dist, idx->s_dist.p, sizeof(float) * cnt, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+static int check_search_args(const hnswgpu_index *idx, const void *Q, int32_t nq, int32_t k, const void *ids,
+                             const void *dist) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(nq >= 0, HNSWGPU_EINVAL, "nq < 0");
+    HG_REQUIRE(k >= 1, HNSWGPU_EINVAL, "k must be >= 1");
+    HG_REQUIRE(k <= 1024, HNSWGPU_ELIMIT, "k > 1024 is not supported");
+    HG_REQUIRE(nq == 0 || (Q && ids && dist), HNSWGPU_EINVAL, "null argument");
+    return 0;
+}
+
+static void fill_empty(int32_t *ids, float *dist, int64_t cnt) {
+    for (int64_t i = 0; i < cnt; i++) {
+        ids[i] = -1;
+        dist[i] = __builtin_inff();
+    }
+}
+
+int hnswgpu_exact_knn_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t *d_out_ids,
+                          float *d_out_dist, void *stream) {
+    HG_TRY(check_search_args(idx, d_Q, nq, k, d_out_ids, d_out_dist));
+    if (nq == 0) return 0;
+    HG_REQUIRE(idx->n > 0, HNSWGPU_ESTATE, "empty index: use the host entry point");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : idx->stream;
+    return exact_knn_enqueue(idx, d_Q, nq, k, d_out_ids, d_out_dist, st);
+}
+
+int hnswgpu_exact_knn(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t *out_ids,
+                      float *out_dist) {
+    HG_TRY(check_search_args(idx, Q, nq, k, out_ids, out_dist));
+    if (nq == 0) return 0;
+    int64_t cnt = static_cast<int64_t>(nq) * k;
+    if (idx->n == 0) {
+        fill_empty(out_ids, out_dist, cnt);
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(upload_queries(idx, Q, nq, st));
+    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
+    HG_TRY(exact_knn_enqueue(idx, idx->s_q.as<float>(), nq, k, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(), st));
+    HG_HIP(hipMemcpyAsync(out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipMemcpyAsync(out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int hnswgpu_merge_topk_dev(int32_t device, const int32_t *d_ids, const float *d_dist, int32_t nshard, int32_t nq,
+                           int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream) {
+    HG_REQUIRE(nshard >= 1 && nq >= 0 && k >= 1, HNSWGPU_EINVAL, "bad sizes");
+    HG_REQUIRE(k <= 1024, HNSWGPU_ELIMIT, "k > 1024 is not supported");
+    if (nq == 0) return 0;
+    HG_REQUIRE(d_ids && d_dist && d_out_ids && d_out_dist, HNSWGPU_EINVAL, "null argument");
+    HG_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(merge_shards_kernel, dim3(nq), dim3(kWave), sizeof(uint64_t) * k,
+                       static_cast<hipStream_t>(stream), d_ids, d_dist, nshard, nq, k, d_out_ids, d_out_dist);
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->prof = on != 0;
+    return 0;
+}
+
+int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int64_t *launches, int32_t reset) {
+    HG_REQUIRE(idx && which >= 0 && which < PROF_N, HNSWGPU_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    for (auto &pr : idx->prof_ev[which]) {
+        HG_HIP(hipEventSynchronize(pr.second));
+        float ms = 0.0f;
+        HG_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        idx->prof_ms[which] += ms;
+        idx->prof_cnt[which] += 1;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    idx->prof_ev[which].clear();
+    if (total_ms) *total_ms = idx->prof_ms[which];
+    if (launches) *launches = idx->prof_cnt[which];
+    if (reset) {
+        idx->prof_ms[which] = 0;
+        idx->prof_cnt[which] = 0;
+    }
+    return 0;
+}
+
+}  // extern "C"

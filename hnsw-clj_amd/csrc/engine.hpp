@@ -1,0 +1,136 @@
+// engine.hpp -- host-side state of one index handle + helpers shared by the translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/hnswgpu.h"
+#include "kernels.hpp"
+
+namespace hg {
+
+void set_error(const char *fmt, ...);
+
+#define HG_HIP(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            hg::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return _e == hipErrorOutOfMemory ? HNSWGPU_ENOMEM : HNSWGPU_EHIP;                    \
+        }                                                                                        \
+    } while (0)
+
+#define HG_TRY(expr)             \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+#define HG_REQUIRE(cond, code, ...)  \
+    do {                             \
+        if (!(cond)) {               \
+            hg::set_error(__VA_ARGS__); \
+            return (code);           \
+        }                            \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) {
+            HG_HIP(hipFree(p));
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + bytes / 4 + 256;
+        HG_HIP(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const {
+        return static_cast<T *>(p);
+    }
+};
+
+enum { PROF_IVF_SCAN = 0, PROF_HNSW = 1, PROF_ASSIGN = 2, PROF_N = 3 };
+
+}  // namespace hg
+
+struct hnswgpu_index {
+    int device = 0;
+    int metric = 0;
+    int64_t n = 0;
+    int dim = 0;
+    int64_t ld = 0;  // row stride in floats (multiple of 4)
+    int nch = 0;     // 256-float chunks per row (template parameter NCH)
+    float *d_base = nullptr;
+    float *d_norms = nullptr;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+
+    // HNSW graph (device + host mirror for export)
+    bool has_graph = false;
+    int M = 0, M0 = 0, entry = -1, max_level = 0;
+    int64_t up_blocks = 0;
+    int32_t *d_levels = nullptr, *d_l0 = nullptr, *d_upadj = nullptr;
+    int64_t *d_upoff = nullptr;
+    std::vector<int32_t> h_levels, h_l0, h_upadj;
+    std::vector<int64_t> h_upoff;
+
+    // IVF-FLAT (device: centroids + rows re-ordered so every list is contiguous)
+    int nlist = 0;
+    int64_t max_list_len = 0;
+    float *d_cent = nullptr, *d_cnorms = nullptr, *d_lrows = nullptr, *d_lnorms = nullptr;
+    int64_t *d_listoff = nullptr;
+    int32_t *d_listids = nullptr;
+    std::vector<float> h_cent;
+    std::vector<int64_t> h_listoff;
+    std::vector<int32_t> h_listids;
+
+    // scratch (grown on demand, reused across calls; calls are serialised by `mu`)
+    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2;
+
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[hg::PROF_N];
+    double prof_ms[hg::PROF_N] = {0, 0, 0};
+    int64_t prof_cnt[hg::PROF_N] = {0, 0, 0};
+};
+
+namespace hg {
+
+int pick_nch(int64_t ld);  // 0 if unsupported
+
+// launch wrappers (engine.hip / hnsw.hip)
+int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);
+int launch_scan(int nch, const ScanArgs &a, hipStream_t st);
+int launch_merge(const MergeArgs &a, hipStream_t st);
+int launch_gather(int nch, const GatherArgs &a, hipStream_t st);
+int launch_hnsw(int nch, const HnswArgs &a, hipStream_t st);
+int scan_rows_per_iter(int nch);  // kNWave * RB
+
+// pick chunking for a scan: returns nchunks, sets chunk_rows
+int plan_chunks(int nch, int64_t max_rows, int64_t npairs, int32_t *chunk_rows);
+
+// scan + merge: per-query ascending top-k of (ord, dist) into s_ord / s_dist ([nq][k])
+int scan_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_query, int64_t max_rows,
+              hipStream_t st, int prof_slot);
+
+void prof_begin(hnswgpu_index *idx, int slot, hipStream_t st, hipEvent_t *e0);
+void prof_end(hnswgpu_index *idx, int slot, hipStream_t st, hipEvent_t e0);
+
+int upload_queries(hnswgpu_index *idx, const float *Q, int32_t nq, hipStream_t st);
+
+}  // namespace hg

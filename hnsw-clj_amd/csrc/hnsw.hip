@@ -1,0 +1,466 @@
+// hnsw.hip -- HNSW graph import/export, batched GPU search and batched GPU-assisted build.
+// Reference: src/hnsw/ultra_fast.clj (file:line cited per function).
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "engine.hpp"
+#include "javarandom.hpp"
+
+namespace hg {
+
+static size_t hnsw_lds_bytes(int cap, int nwords) {
+    return sizeof(uint2) * 2 * cap + sizeof(int32_t) * 3 * kMaxDeg + sizeof(int32_t) * 16 + sizeof(uint32_t) * nwords;
+}
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+int launch_hnsw(int nch, const HnswArgs &a, hipStream_t st) {
+    if (a.nq <= 0) return 0;
+    size_t lds = hnsw_lds_bytes(a.cap, a.nwords);
+    HG_REQUIRE(lds <= kMaxLds, HNSWGPU_ELIMIT,
+               "HNSW search state (%zu B: ef=%d, n=%lld) exceeds the 160 KiB LDS of a CU", lds, a.ef, (long long)a.n);
+    bool l2 = a.metric == METRIC_L2;
+#define CALL(N, R, L)                                                                                      \
+    do {                                                                                                   \
+        if (lds > 48 * 1024)                                                                               \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<N, R, L>),      \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+        hipLaunchKernelGGL((hnsw_search_kernel<N, R, L>), dim3(a.nq), dim3(kWG), lds, st, a);              \
+    } while (0)
+    switch (nch) {
+        case 1: if (l2) CALL(1, 8, true); else CALL(1, 8, false); break;
+        case 2: if (l2) CALL(2, 8, true); else CALL(2, 8, false); break;
+        case 3: if (l2) CALL(3, 8, true); else CALL(3, 8, false); break;
+        case 4: if (l2) CALL(4, 4, true); else CALL(4, 4, false); break;
+        case 6: if (l2) CALL(6, 4, true); else CALL(6, 4, false); break;
+        case 8: if (l2) CALL(8, 2, true); else CALL(8, 2, false); break;
+        case 12: if (l2) CALL(12, 2, true); else CALL(12, 2, false); break;
+        default: set_error("unsupported row length"); return HNSWGPU_ELIMIT;
+    }
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+static void free_graph(hnswgpu_index *idx) {
+    void *ptrs[] = {idx->d_levels, idx->d_l0, idx->d_upadj, idx->d_upoff};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    idx->d_levels = idx->d_l0 = idx->d_upadj = nullptr;
+    idx->d_upoff = nullptr;
+    idx->has_graph = false;
+}
+
+static int alloc_graph(hnswgpu_index *idx, int M, int M0, int64_t up_blocks) {
+    int64_t n = std::max<int64_t>(idx->n, 1);
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_levels), sizeof(int32_t) * n));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_l0), sizeof(int32_t) * n * M0));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_upoff), sizeof(int64_t) * (n + 1)));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_upadj), sizeof(int32_t) * std::max<int64_t>(up_blocks, 1) * M));
+    idx->M = M;
+    idx->M0 = M0;
+    idx->up_blocks = up_blocks;
+    return 0;
+}
+
+static void fill_args(const hnswgpu_index *idx, HnswArgs &a) {
+    memset(&a, 0, sizeof(a));
+    a.rows = idx->d_base;
+    a.row_norms = idx->d_norms;
+    a.ld = idx->ld;
+    a.n = idx->n;
+    a.dim = idx->dim;
+    a.metric = idx->metric;
+    a.l0_adj = idx->d_l0;
+    a.M0 = idx->M0;
+    a.up_off = idx->d_upoff;
+    a.up_adj = idx->d_upadj;
+    a.M = idx->M;
+    a.entry = idx->entry;
+    a.max_level = idx->max_level;
+    a.nwords = static_cast<int32_t>((idx->n + 31) / 32);
+}
+
+static int search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t ef,
+                          int32_t *d_ids, float *d_dist, int64_t *d_stats, hipStream_t st) {
+    HnswArgs a;
+    fill_args(idx, a);
+    a.Q = d_Q;
+    a.qld = idx->dim;
+    a.nq = nq;
+    a.ef = ef;
+    a.k = k;
+    a.cap = ef + kGhost;
+    a.out_ids = d_ids;
+    a.out_dist = d_dist;
+    a.stats = d_stats;
+    hipEvent_t e0;
+    prof_begin(idx, PROF_HNSW, st, &e0);
+    int rc = launch_hnsw(idx->nch, a, st);
+    prof_end(idx, PROF_HNSW, st, e0);
+    return rc;
+}
+
+struct HostGraph {
+    int64_t n;
+    int M, M0;
+    std::vector<int32_t> levels, l0, l0_cnt, up, up_cnt;
+    std::vector<float> l0_d, up_d;
+    std::vector<int64_t> up_off;
+    int entry = -1, top = -1;
+
+    int32_t *adj(int32_t node, int lc, float **d, int32_t **cnt, int *m) {
+        if (lc == 0) {
+            *d = &l0_d[static_cast<size_t>(node) * (M0 + 1)];
+            *cnt = &l0_cnt[node];
+            *m = M0;
+            return &l0[static_cast<size_t>(node) * (M0 + 1)];
+        }
+        int64_t blk = up_off[node] + (lc - 1);
+        *d = &up_d[static_cast<size_t>(blk) * (M + 1)];
+        *cnt = &up_cnt[blk];
+        *m = M;
+        return &up[static_cast<size_t>(blk) * (M + 1)];
+    }
+
+    // one direction of "Connect bidirectionally" (ultra_fast.clj:255-266) + prune-connections-ultra
+    // (:279-299): an over-full list keeps its m closest by (distance, insertion order).  Edge
+    // distances are stored with the edges, so pruning needs no distance evaluation.
+    void add_edge(int32_t from, int32_t to, int lc, float dist) {
+        float *d;
+        int32_t *cnt;
+        int m;
+        int32_t *a = adj(from, lc, &d, &cnt, &m);
+        for (int i = 0; i < *cnt; i++)
+            if (a[i] == to) return;
+        a[*cnt] = to;
+        d[*cnt] = dist;
+        (*cnt)++;
+        if (*cnt > m) {
+            int worst = 0;  // stable sort + take m == drop the last of the largest
+            for (int i = 1; i < *cnt; i++)
+                if (d[i] >= d[worst]) worst = i;
+            // keep the survivors in (distance, order) order like sort-by would
+            std::vector<std::pair<float, int>> o;
+            o.reserve(*cnt);
+            for (int i = 0; i < *cnt; i++)
+                if (i != worst) o.push_back({d[i], i});
+            std::stable_sort(o.begin(), o.end(),
+                             [](const std::pair<float, int> &x, const std::pair<float, int> &y) { return x.first < y.first; });
+            std::vector<int32_t> na(m);
+            std::vector<float> nd(m);
+            for (int i = 0; i < m; i++) {
+                na[i] = a[o[i].second];
+                nd[i] = d[o[i].second];
+            }
+            for (int i = 0; i < m; i++) {
+                a[i] = na[i];
+                d[i] = nd[i];
+            }
+            *cnt = m;
+        }
+    }
+};
+
+static int upload_graph(hnswgpu_index *idx, const HostGraph &g, hipStream_t st, std::vector<int32_t> &tmp0,
+                        std::vector<int32_t> &tmpu) {
+    const int64_t n = g.n;
+    tmp0.assign(static_cast<size_t>(n) * g.M0, -1);
+    for (int64_t i = 0; i < n; i++)
+        for (int j = 0; j < g.l0_cnt[i] && j < g.M0; j++) tmp0[i * g.M0 + j] = g.l0[i * (g.M0 + 1) + j];
+    const int64_t blocks = g.up_off[n];
+    tmpu.assign(static_cast<size_t>(std::max<int64_t>(blocks, 1)) * g.M, -1);
+    for (int64_t b = 0; b < blocks; b++)
+        for (int j = 0; j < g.up_cnt[b] && j < g.M; j++) tmpu[b * g.M + j] = g.up[b * (g.M + 1) + j];
+    HG_HIP(hipMemcpyAsync(idx->d_l0, tmp0.data(), sizeof(int32_t) * tmp0.size(), hipMemcpyHostToDevice, st));
+    HG_HIP(hipMemcpyAsync(idx->d_upadj, tmpu.data(), sizeof(int32_t) * tmpu.size(), hipMemcpyHostToDevice, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // namespace hg
+
+using namespace hg;
+
+extern "C" {
+
+int hnswgpu_set_graph(hnswgpu_index *idx, const int32_t *levels, const int32_t *l0_adj, int32_t M0,
+                      const int64_t *up_off, const int32_t *up_adj, int32_t M, int32_t entry, int32_t max_level) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    const int64_t n = idx->n;
+    HG_REQUIRE(n == 0 || (levels && l0_adj && up_off), HNSWGPU_EINVAL, "null argument");
+    HG_REQUIRE(M >= 1 && M0 >= 1 && M0 <= kMaxDeg && M <= kMaxDeg, HNSWGPU_ELIMIT, "need 1 <= M, M0 <= %d", kMaxDeg);
+    int64_t blocks = n > 0 ? up_off[n] : 0;
+    if (n > 0) {
+        HG_REQUIRE(entry >= 0 && entry < n, HNSWGPU_EINVAL, "entry out of range");
+        HG_REQUIRE(max_level >= 0 && levels[entry] >= max_level, HNSWGPU_EINVAL, "entry level < max_level");
+        HG_REQUIRE(up_off[0] == 0, HNSWGPU_EINVAL, "up_off[0] != 0");
+        for (int64_t i = 0; i < n; i++) {
+            HG_REQUIRE(levels[i] >= 0 && up_off[i + 1] - up_off[i] == levels[i], HNSWGPU_EINVAL,
+                       "up_off is not the prefix sum of levels at node %lld", (long long)i);
+            HG_REQUIRE(levels[i] <= max_level, HNSWGPU_EINVAL, "node %lld level > max_level", (long long)i);
+        }
+        HG_REQUIRE(blocks == 0 || up_adj, HNSWGPU_EINVAL, "up_adj is null");
+        // every edge must point at a node that exists on that layer: the kernel trusts this
+        for (int64_t i = 0; i < n * M0; i++)
+            HG_REQUIRE(l0_adj[i] >= -1 && l0_adj[i] < n, HNSWGPU_EINVAL, "l0_adj entry out of range");
+        for (int64_t i = 0; i < n; i++)
+            for (int lv = 1; lv <= levels[i]; lv++)
+                for (int j = 0; j < M; j++) {
+                    int32_t nb = up_adj[(up_off[i] + lv - 1) * M + j];
+                    HG_REQUIRE(nb >= -1 && nb < n, HNSWGPU_EINVAL, "up_adj entry out of range");
+                    HG_REQUIRE(nb < 0 || levels[nb] >= lv, HNSWGPU_EINVAL,
+                               "edge %lld->%d on layer %d: target has no such layer", (long long)i, nb, lv);
+                }
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    free_graph(idx);
+    HG_TRY(alloc_graph(idx, M, M0, blocks));
+    if (n > 0) {
+        HG_HIP(hipMemcpyAsync(idx->d_levels, levels, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(idx->d_l0, l0_adj, sizeof(int32_t) * n * M0, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(idx->d_upoff, up_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
+        if (blocks > 0)
+            HG_HIP(hipMemcpyAsync(idx->d_upadj, up_adj, sizeof(int32_t) * blocks * M, hipMemcpyHostToDevice, st));
+        HG_HIP(hipStreamSynchronize(st));
+        idx->h_levels.assign(levels, levels + n);
+        idx->h_l0.assign(l0_adj, l0_adj + n * M0);
+        idx->h_upoff.assign(up_off, up_off + n + 1);
+        idx->h_upadj.assign(up_adj, up_adj + blocks * M);
+    } else {
+        idx->h_levels.clear();
+        idx->h_l0.clear();
+        idx->h_upoff.assign(1, 0);
+        idx->h_upadj.clear();
+    }
+    idx->entry = n > 0 ? entry : -1;
+    idx->max_level = n > 0 ? max_level : 0;
+    idx->has_graph = true;
+    return 0;
+}
+
+int hnswgpu_graph_sizes(const hnswgpu_index *idx, int32_t *M, int32_t *M0, int64_t *up_blocks, int32_t *entry,
+                        int32_t *max_level) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(idx->has_graph, HNSWGPU_ESTATE, "index has no graph");
+    if (M) *M = idx->M;
+    if (M0) *M0 = idx->M0;
+    if (up_blocks) *up_blocks = idx->up_blocks;
+    if (entry) *entry = idx->entry;
+    if (max_level) *max_level = idx->max_level;
+    return 0;
+}
+
+int hnswgpu_get_graph(const hnswgpu_index *idx, int32_t *levels, int32_t *l0_adj, int64_t *up_off,
+                      int32_t *up_adj) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(idx->has_graph, HNSWGPU_ESTATE, "index has no graph");
+    if (levels && !idx->h_levels.empty()) memcpy(levels, idx->h_levels.data(), sizeof(int32_t) * idx->h_levels.size());
+    if (l0_adj && !idx->h_l0.empty()) memcpy(l0_adj, idx->h_l0.data(), sizeof(int32_t) * idx->h_l0.size());
+    if (up_off) memcpy(up_off, idx->h_upoff.data(), sizeof(int64_t) * idx->h_upoff.size());
+    if (up_adj && !idx->h_upadj.empty()) memcpy(up_adj, idx->h_upadj.data(), sizeof(int32_t) * idx->h_upadj.size());
+    return 0;
+}
+
+static int check_hnsw_args(const hnswgpu_index *idx, const void *Q, int32_t nq, int32_t k, int32_t *ef,
+                           const void *ids, const void *dist) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(nq >= 0 && k >= 1, HNSWGPU_EINVAL, "need nq >= 0 and k >= 1");
+    HG_REQUIRE(nq == 0 || (Q && ids && dist), HNSWGPU_EINVAL, "null argument");
+    HG_REQUIRE(idx->has_graph, HNSWGPU_ESTATE, "index has no graph (call hnswgpu_hnsw_build / hnswgpu_set_graph)");
+    if (*ef <= 0) *ef = k > 50 ? k : 50;  // ef = (max k 50), ultra_fast.clj:355
+    if (*ef < k) *ef = k;
+    HG_REQUIRE(*ef <= 4096, HNSWGPU_ELIMIT, "ef > 4096 is not supported");
+    return 0;
+}
+
+int hnswgpu_hnsw_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t ef,
+                            int32_t *d_out_ids, float *d_out_dist, int64_t *d_stats, void *stream) {
+    HG_TRY(check_hnsw_args(idx, d_Q, nq, k, &ef, d_out_ids, d_out_dist));
+    if (nq == 0) return 0;
+    HG_REQUIRE(idx->n > 0, HNSWGPU_ESTATE, "empty index: use the host entry point");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : idx->stream;
+    return search_enqueue(idx, d_Q, nq, k, ef, d_out_ids, d_out_dist, d_stats, st);
+}
+
+int hnswgpu_hnsw_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t ef, int32_t *out_ids,
+                        float *out_dist, int64_t *stats) {
+    HG_TRY(check_hnsw_args(idx, Q, nq, k, &ef, out_ids, out_dist));
+    if (nq == 0) return 0;
+    int64_t cnt = static_cast<int64_t>(nq) * k;
+    if (idx->n == 0) {  // (if (or (nil? entry-point) (zero? size)) [] ...), ultra_fast.clj:349-351
+        for (int64_t i = 0; i < cnt; i++) {
+            out_ids[i] = -1;
+            out_dist[i] = __builtin_inff();
+        }
+        if (stats) memset(stats, 0, sizeof(int64_t) * 2 * nq);
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(upload_queries(idx, Q, nq, st));
+    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
+    HG_TRY(idx->s_stats.ensure(sizeof(int64_t) * 2 * nq));
+    HG_TRY(search_enqueue(idx, idx->s_q.as<float>(), nq, k, ef, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(),
+                          idx->s_stats.as<int64_t>(), st));
+    HG_HIP(hipMemcpyAsync(out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipMemcpyAsync(out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
+    if (stats) HG_HIP(hipMemcpyAsync(stats, idx->s_stats.p, sizeof(int64_t) * 2 * nq, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// build-index / insert-batch (ultra_fast.clj:303-344) as batched insertion: every node of a batch
+// runs the reference's per-level search (search-layer-ultra with ef-construction at layer 0 and 1
+// above, :250-251) on the GPU against the graph as it stood when the batch started, then the
+// host links the batch in row order (:255-266) and prunes over-full lists (:279-299).
+// Level draw: floor(ml * -ln U), ml = 1/ln 2 (:133,:143-147), U from java.util.Random(seed).
+// Differences from the reference's sequential insert-single, stated in DESIGN.md: nodes of one
+// batch do not see each other (batches grow from 1 to at most 1/8 of the graph, capped); the walk
+// starts at the top layer with ef = 1 instead of at min(level, entry-level) (:247-248); each node
+// links to its m CLOSEST candidates (the reference's `(take m candidates)` takes PriorityQueue
+// array order, which is unspecified).
+int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, int64_t seed) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(M >= 1 && 2 * M <= kMaxDeg, HNSWGPU_ELIMIT, "need 1 <= M <= %d", kMaxDeg / 2);
+    HG_REQUIRE(ef_construction >= 1 && ef_construction <= 4096, HNSWGPU_ELIMIT, "need 1 <= ef_construction <= 4096");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    const int64_t n = idx->n;
+    const int M0 = 2 * M;
+    HostGraph g;
+    g.n = n;
+    g.M = M;
+    g.M0 = M0;
+    g.levels.resize(n);
+    g.up_off.assign(n + 1, 0);
+    {
+        JavaRandom rng(seed);
+        const double ml = 1.0 / log(2.0);
+        for (int64_t i = 0; i < n; i++) {
+            double u = rng.next_double();
+            int lv = u > 0.0 ? static_cast<int>(ml * (-log(u))) : 30;
+            g.levels[i] = std::min(lv, 30);
+            g.up_off[i + 1] = g.up_off[i] + g.levels[i];
+        }
+    }
+    const int64_t blocks = n > 0 ? g.up_off[n] : 0;
+    free_graph(idx);
+    HG_TRY(alloc_graph(idx, M, M0, blocks));
+    if (n == 0) {
+        idx->h_levels.clear();
+        idx->h_l0.clear();
+        idx->h_upoff.assign(1, 0);
+        idx->h_upadj.clear();
+        idx->entry = -1;
+        idx->max_level = 0;
+        idx->has_graph = true;
+        return 0;
+    }
+    g.l0.assign(static_cast<size_t>(n) * (M0 + 1), -1);
+    g.l0_d.assign(static_cast<size_t>(n) * (M0 + 1), 0.f);
+    g.l0_cnt.assign(n, 0);
+    g.up.assign(static_cast<size_t>(std::max<int64_t>(blocks, 1)) * (M + 1), -1);
+    g.up_d.assign(static_cast<size_t>(std::max<int64_t>(blocks, 1)) * (M + 1), 0.f);
+    g.up_cnt.assign(std::max<int64_t>(blocks, 1), 0);
+    int maxlv = 1;
+    for (int64_t i = 0; i < n; i++) maxlv = std::max(maxlv, g.levels[i]);
+    HG_HIP(hipMemcpyAsync(idx->d_levels, g.levels.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    HG_HIP(hipMemcpyAsync(idx->d_upoff, g.up_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
+
+    const int64_t maxB = 2048;
+    const int ef = ef_construction;
+    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * maxB * M0));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * maxB * M0));
+    HG_TRY(idx->s_misc.ensure(sizeof(int32_t) * maxB * (2 + maxlv)));   // q_rows, q_levels, up_out_ids
+    HG_TRY(idx->s_misc2.ensure(sizeof(float) * maxB * maxlv));           // up_out_dist
+    int32_t *d_qrows = idx->s_misc.as<int32_t>();
+    int32_t *d_qlev = d_qrows + maxB;
+    int32_t *d_upids = d_qlev + maxB;
+    std::vector<int32_t> h_ids(maxB * M0), h_up(maxB * maxlv), h_qrows(maxB), h_qlev(maxB), tmp0, tmpu;
+    std::vector<float> h_d(maxB * M0), h_upd(maxB * maxlv);
+
+    g.entry = 0;  // first element becomes the entry point (:229-231)
+    g.top = g.levels[0];
+    int64_t done = 1;
+    while (done < n) {
+        int64_t B = std::min<int64_t>({maxB, std::max<int64_t>(1, done / 8), n - done});
+        HG_TRY(upload_graph(idx, g, st, tmp0, tmpu));
+        for (int64_t b = 0; b < B; b++) {
+            h_qrows[b] = static_cast<int32_t>(done + b);
+            h_qlev[b] = g.levels[done + b];
+        }
+        HG_HIP(hipMemcpyAsync(d_qrows, h_qrows.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(d_qlev, h_qlev.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, st));
+        HnswArgs a;
+        fill_args(idx, a);
+        a.entry = g.entry;
+        a.max_level = g.top;
+        a.Q = idx->d_base;
+        a.qld = idx->ld;
+        a.q_rows = d_qrows;
+        a.q_levels = d_qlev;
+        a.nq = static_cast<int32_t>(B);
+        a.ef = ef;
+        a.k = M0;
+        a.cap = ef + kGhost;
+        a.out_ids = idx->s_ids.as<int32_t>();
+        a.out_dist = idx->s_outd.as<float>();
+        a.stats = nullptr;
+        a.up_out_ids = d_upids;
+        a.up_out_dist = idx->s_misc2.as<float>();
+        a.up_stride = maxlv;
+        HG_TRY(launch_hnsw(idx->nch, a, st));
+        HG_HIP(hipMemcpyAsync(h_ids.data(), a.out_ids, sizeof(int32_t) * B * M0, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipMemcpyAsync(h_d.data(), a.out_dist, sizeof(float) * B * M0, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipMemcpyAsync(h_up.data(), a.up_out_ids, sizeof(int32_t) * B * maxlv, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipMemcpyAsync(h_upd.data(), a.up_out_dist, sizeof(float) * B * maxlv, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipStreamSynchronize(st));
+        const int top_at_start = g.top;
+        for (int64_t b = 0; b < B; b++) {
+            const int32_t id = static_cast<int32_t>(done + b);
+            const int L = g.levels[id];
+            for (int lc = std::min(L, top_at_start); lc >= 1; lc--) {
+                int32_t nb = h_up[b * maxlv + (lc - 1)];
+                if (nb < 0 || nb == id) continue;
+                float d = h_upd[b * maxlv + (lc - 1)];
+                g.add_edge(id, nb, lc, d);
+                g.add_edge(nb, id, lc, d);
+            }
+            const int take = std::min(M0, ef);
+            for (int t = 0; t < take; t++) {
+                int32_t nb = h_ids[b * M0 + t];
+                if (nb < 0) break;
+                if (nb == id) continue;
+                g.add_edge(id, nb, 0, h_d[b * M0 + t]);
+                g.add_edge(nb, id, 0, h_d[b * M0 + t]);
+            }
+            if (L > g.top) {  // :271-273
+                g.entry = id;
+                g.top = L;
+            }
+        }
+        done += B;
+    }
+    HG_TRY(upload_graph(idx, g, st, tmp0, tmpu));
+    idx->h_levels = g.levels;
+    idx->h_upoff = g.up_off;
+    idx->h_l0.swap(tmp0);
+    tmpu.resize(static_cast<size_t>(blocks) * M);
+    idx->h_upadj.swap(tmpu);
+    idx->entry = g.entry;
+    idx->max_level = std::max(g.top, 0);
+    idx->has_graph = true;
+    return 0;
+}
+
+}  // extern "C"

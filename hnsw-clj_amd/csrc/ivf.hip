@@ -1,0 +1,460 @@
+// ivf.hip -- IVF-FLAT on the device: k-means++ / Lloyd build, list layout, batched nprobe search.
+// Reference: src/hnsw/ann/partition/ivf_flat.clj (file:line cited per function).
+#include <float.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "engine.hpp"
+#include "javarandom.hpp"
+
+namespace hg {
+
+// probes[q][p] = p-th nearest centroid; pairs[q*nprobe+p] = that list's row range + the offset of
+// its rows in the query's concatenated candidate stream (ties are broken in that order, which is
+// the order search-ivf-flat concatenates partitions in, ivf_flat.clj:281-294)
+__global__ void probe_pairs_kernel(const uint32_t *ord, int nq, int nprobe, const int64_t *listoff, Pair *pairs,
+                                   int32_t *probes) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    uint32_t base = 0;
+    for (int p = 0; p < nprobe; p++) {
+        uint32_t l = ord[static_cast<int64_t>(q) * nprobe + p];
+        Pair pr;
+        pr.q = q;
+        pr.ord_base = base;
+        if (l == 0xffffffffu) {
+            pr.row_begin = pr.row_end = 0;
+            if (probes) probes[static_cast<int64_t>(q) * nprobe + p] = -1;
+        } else {
+            pr.row_begin = listoff[l];
+            pr.row_end = listoff[l + 1];
+            if (probes) probes[static_cast<int64_t>(q) * nprobe + p] = static_cast<int32_t>(l);
+        }
+        base += static_cast<uint32_t>(pr.row_end - pr.row_begin);
+        pairs[static_cast<int64_t>(q) * nprobe + p] = pr;
+    }
+}
+
+__global__ void ivf_decode_kernel(const uint32_t *ord, int nq, int k, const Pair *pairs, int nprobe,
+                                  const int32_t *listids, int32_t *out_ids) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<int64_t>(nq) * k) return;
+    int q = static_cast<int>(i / k);
+    uint32_t o = ord[i];
+    int32_t id = -1;
+    if (o != 0xffffffffu) {
+        const Pair *pp = pairs + static_cast<int64_t>(q) * nprobe;
+        int p = 0;
+        while (p + 1 < nprobe && pp[p + 1].ord_base <= o) p++;
+        // lists of length 0 share an ord_base with their successor: take the last one that fits
+        id = listids[pp[p].row_begin + (o - pp[p].ord_base)];
+    }
+    out_ids[i] = id;
+}
+
+// dst row pos <- src row listids[pos]; one wave per row, float4 lanes
+__global__ __launch_bounds__(kWG) void permute_rows_kernel(const float *src, const float *src_norms, int64_t ld,
+                                                           const int32_t *listids, int64_t n, float *dst,
+                                                           float *dst_norms) {
+    int lane = threadIdx.x & (kWave - 1);
+    int64_t pos = static_cast<int64_t>(blockIdx.x) * kNWave + (threadIdx.x >> 6);
+    if (pos >= n) return;
+    int64_t s = listids[pos];
+    const float4 *sp = reinterpret_cast<const float4 *>(src + s * ld);
+    float4 *dp = reinterpret_cast<float4 *>(dst + pos * ld);
+    for (int i = lane; i < ld / 4; i += kWave) dp[i] = sp[i];
+    if (lane == 0) dst_norms[pos] = src_norms[s];
+}
+
+// compute-centroid (ivf_flat.clj:66-77): f64 sum of the member rows in index order, divided by the
+// count, rounded to f32 for storage; an empty list keeps its previous centroid (:112-114).
+// One workgroup per list; thread t owns columns t, t+256, ...
+__global__ __launch_bounds__(kWG) void centroid_mean_kernel(const float *rows, int64_t ld, int dim,
+                                                            const int64_t *listoff, const int32_t *listids,
+                                                            float *cent) {
+    int l = blockIdx.x;
+    int64_t b = listoff[l], e = listoff[l + 1];
+    if (e <= b) return;
+    for (int c0 = threadIdx.x; c0 < dim; c0 += kWG) {
+        double s = 0.0;
+        for (int64_t i = b; i < e; i++) s = s + static_cast<double>(rows[static_cast<int64_t>(listids[i]) * ld + c0]);
+        cent[static_cast<int64_t>(l) * ld + c0] = static_cast<float>(s / static_cast<double>(e - b));
+    }
+}
+
+__global__ void fill_kernel(float *p, int64_t n, float v) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+static int validate_lists(int64_t n, int32_t nlist, const int64_t *off, const int32_t *ids) {
+    HG_REQUIRE(off[0] == 0 && off[nlist] == n, HNSWGPU_EINVAL, "list_off must start at 0 and end at n");
+    for (int l = 0; l < nlist; l++) HG_REQUIRE(off[l] <= off[l + 1], HNSWGPU_EINVAL, "list_off not monotone");
+    std::vector<uint8_t> seen(static_cast<size_t>(n), 0);
+    for (int64_t i = 0; i < n; i++) {
+        HG_REQUIRE(ids[i] >= 0 && ids[i] < n, HNSWGPU_EINVAL, "list_ids[%lld] out of range", (long long)i);
+        HG_REQUIRE(!seen[ids[i]], HNSWGPU_EINVAL, "row %d is in two lists", ids[i]);
+        seen[ids[i]] = 1;
+    }
+    return 0;
+}
+
+static void free_ivf(hnswgpu_index *idx) {
+    void *ptrs[] = {idx->d_cent, idx->d_cnorms, idx->d_lrows, idx->d_lnorms, idx->d_listoff, idx->d_listids};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    idx->d_cent = idx->d_cnorms = idx->d_lrows = idx->d_lnorms = nullptr;
+    idx->d_listoff = nullptr;
+    idx->d_listids = nullptr;
+    idx->nlist = 0;
+}
+
+// device centroids (nlist x ld) + host lists -> the searchable layout
+static int install_lists(hnswgpu_index *idx, int32_t nlist, const int64_t *off, const int32_t *ids, hipStream_t st) {
+    int64_t n = idx->n;
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_listoff), sizeof(int64_t) * (nlist + 1)));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_listids), sizeof(int32_t) * std::max<int64_t>(n, 1)));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lrows), sizeof(float) * std::max<int64_t>(n, 1) * idx->ld));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lnorms), sizeof(float) * std::max<int64_t>(n, 1)));
+    HG_HIP(hipMemcpyAsync(idx->d_listoff, off, sizeof(int64_t) * (nlist + 1), hipMemcpyHostToDevice, st));
+    if (n > 0) {
+        HG_HIP(hipMemcpyAsync(idx->d_listids, ids, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(permute_rows_kernel, dim3(static_cast<unsigned>((n + kNWave - 1) / kNWave)), dim3(kWG), 0,
+                           st, idx->d_base, idx->d_norms, idx->ld, idx->d_listids, n, idx->d_lrows, idx->d_lnorms);
+        HG_HIP(hipGetLastError());
+    }
+    idx->h_listoff.assign(off, off + nlist + 1);
+    idx->h_listids.assign(ids, ids + n);
+    idx->max_list_len = 0;
+    for (int l = 0; l < nlist; l++) idx->max_list_len = std::max(idx->max_list_len, off[l + 1] - off[l]);
+    idx->nlist = nlist;
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+static int alloc_centroids(hnswgpu_index *idx, int32_t nlist) {
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_cent), sizeof(float) * nlist * idx->ld));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_cnorms), sizeof(float) * nlist));
+    return 0;
+}
+
+static int download_centroids(hnswgpu_index *idx, hipStream_t st) {
+    idx->h_cent.resize(static_cast<size_t>(idx->nlist) * idx->dim);
+    HG_HIP(hipMemcpy2DAsync(idx->h_cent.data(), sizeof(float) * idx->dim, idx->d_cent, sizeof(float) * idx->ld,
+                            sizeof(float) * idx->dim, idx->nlist, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// assignment of every base row to its nearest centroid (ivf_flat.clj:79-90) -> s_ord / s_dist [n]
+static int assign_enqueue(hnswgpu_index *idx, const float *d_cent, const float *d_cnorms, int32_t nlist,
+                          hipStream_t st) {
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = d_cent;
+    a.row_norms = d_cnorms;
+    a.ld = idx->ld;
+    a.nrows_all = nlist;
+    a.Q = idx->d_base;
+    a.qld = idx->ld;
+    a.q_norms = idx->d_norms;
+    a.dim = idx->dim;
+    a.metric = idx->metric;
+    a.pairs = nullptr;
+    a.k = 1;
+    return scan_topk(idx, a, static_cast<int32_t>(idx->n), 1, nlist, st, PROF_ASSIGN);
+}
+
+static void lists_from_assign(const uint32_t *assign, int64_t n, int32_t nlist, std::vector<int64_t> &off,
+                              std::vector<int32_t> &ids) {
+    off.assign(nlist + 1, 0);
+    for (int64_t i = 0; i < n; i++) off[assign[i] + 1]++;
+    for (int l = 0; l < nlist; l++) off[l + 1] += off[l];
+    ids.resize(static_cast<size_t>(n));
+    std::vector<int64_t> cur(off.begin(), off.end() - 1);
+    for (int64_t i = 0; i < n; i++) ids[cur[assign[i]]++] = static_cast<int32_t>(i);  // index order inside a list
+}
+
+// kmeans-plus-plus-init (ivf_flat.clj:32-60), incremental: one streaming min-update pass per new
+// centroid instead of the reference's O(N k^2 D) recomputation (same minima).  The D^2 sampling
+// itself (sequential f64 prefix sum + Random draw, :51-58) runs on the host over the device-computed
+// distances so that its order of additions is the reference's.
+static int kmeanspp_device(hnswgpu_index *idx, int32_t nlist, int64_t seed, std::vector<int32_t> &chosen,
+                           hipStream_t st) {
+    int64_t n = idx->n;
+    JavaRandom rng(seed);
+    HG_TRY(idx->s_misc.ensure(sizeof(float) * n));
+    float *mind = idx->s_misc.as<float>();
+    hipLaunchKernelGGL(fill_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, mind, n, FLT_MAX);
+    HG_HIP(hipGetLastError());
+    std::vector<float> h(static_cast<size_t>(n));
+    chosen.resize(nlist);
+    int32_t cur = rng.next_int(static_cast<int32_t>(n));
+    chosen[0] = cur;
+    for (int c = 1; c < nlist; c++) {
+        ScanArgs a;
+        memset(&a, 0, sizeof(a));
+        a.rows = idx->d_base;
+        a.row_norms = idx->d_norms;
+        a.ld = idx->ld;
+        a.nrows_all = n;
+        a.Q = idx->d_base + static_cast<int64_t>(cur) * idx->ld;
+        a.qld = idx->ld;
+        a.q_norms = idx->d_norms + cur;
+        a.dim = idx->dim;
+        a.metric = idx->metric;
+        a.mode = MODE_MINUPD;
+        a.pairs = nullptr;
+        a.npairs = 1;
+        a.nchunks = plan_chunks(idx->nch, n, 1, &a.chunk_rows);
+        a.k = 1;
+        a.out = mind;
+        HG_TRY(launch_scan(idx->nch, a, st));
+        HG_HIP(hipMemcpyAsync(h.data(), mind, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipStreamSynchronize(st));
+        double sum = 0.0;
+        for (int64_t i = 0; i < n; i++) sum = sum + static_cast<double>(h[i]) * static_cast<double>(h[i]);
+        double r = rng.next_double() * sum;
+        double cum = 0.0;
+        int64_t i = 0;
+        for (;; i++) {
+            double dsq = static_cast<double>(h[i]) * static_cast<double>(h[i]);
+            if (cum + dsq >= r || i == n - 1) break;  // clamped against round-off; the reference would throw
+            cum = cum + dsq;
+        }
+        cur = static_cast<int32_t>(i);
+        chosen[c] = cur;
+    }
+    return 0;
+}
+
+static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
+                              int32_t *d_out_ids, float *d_out_dist, int32_t *d_out_probes, hipStream_t st,
+                              const int32_t *d_given_probes = nullptr) {
+    if (nprobe > idx->nlist && !d_given_probes) nprobe = idx->nlist;
+    // 1. centroid routing (:261-269): top-nprobe of the centroid table, stable on the centroid index
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    HG_TRY(idx->s_pairs.ensure(sizeof(Pair) * static_cast<size_t>(nq) * nprobe));
+    if (d_given_probes) {  // caller-chosen lists (the :turbo mode's random partitions, :271-272); -1 = none
+        hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + 127) / 128), dim3(128), 0, st,
+                           reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff,
+                           idx->s_pairs.as<Pair>(), d_out_probes);
+        HG_HIP(hipGetLastError());
+    } else {
+    a.rows = idx->d_cent;
+    a.row_norms = idx->d_cnorms;
+    a.ld = idx->ld;
+    a.nrows_all = idx->nlist;
+    a.Q = d_Q;
+    a.qld = idx->dim;
+    a.dim = idx->dim;
+    a.metric = idx->metric;
+    a.k = nprobe;
+    HG_TRY(scan_topk(idx, a, nq, 1, idx->nlist, st, -1));
+    hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + 127) / 128), dim3(128), 0, st, idx->s_ord.as<uint32_t>(), nq,
+                       nprobe, idx->d_listoff, idx->s_pairs.as<Pair>(), d_out_probes);
+    HG_HIP(hipGetLastError());
+    }
+    // 2. scan the probed lists (:217-234) and merge (:291-294)
+    memset(&a, 0, sizeof(a));
+    a.rows = idx->d_lrows;
+    a.row_norms = idx->d_lnorms;
+    a.ld = idx->ld;
+    a.Q = d_Q;
+    a.qld = idx->dim;
+    a.dim = idx->dim;
+    a.metric = idx->metric;
+    a.pairs = idx->s_pairs.as<Pair>();
+    a.k = k;
+    HG_TRY(scan_topk(idx, a, nq, nprobe, idx->max_list_len, st, PROF_IVF_SCAN));
+    int64_t cnt = static_cast<int64_t>(nq) * k;
+    hipLaunchKernelGGL(ivf_decode_kernel, dim3(static_cast<unsigned>((cnt + 255) / 256)), dim3(256), 0, st,
+                       idx->s_ord.as<uint32_t>(), nq, k, idx->s_pairs.as<Pair>(), nprobe, idx->d_listids, d_out_ids);
+    HG_HIP(hipGetLastError());
+    HG_HIP(hipMemcpyAsync(d_out_dist, idx->s_dist.p, sizeof(float) * cnt, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+}  // namespace hg
+
+using namespace hg;
+
+extern "C" {
+
+int hnswgpu_set_ivf(hnswgpu_index *idx, const float *centroids, int32_t nlist, const int64_t *list_off,
+                    const int32_t *list_ids) {
+    HG_REQUIRE(idx && centroids && list_off && (list_ids || idx->n == 0), HNSWGPU_EINVAL, "null argument");
+    HG_REQUIRE(nlist >= 1, HNSWGPU_EINVAL, "nlist must be >= 1");
+    HG_TRY(validate_lists(idx->n, nlist, list_off, list_ids));
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    free_ivf(idx);
+    HG_TRY(alloc_centroids(idx, nlist));
+    HG_HIP(hipMemsetAsync(idx->d_cent, 0, sizeof(float) * nlist * idx->ld, st));
+    HG_HIP(hipMemcpy2DAsync(idx->d_cent, sizeof(float) * idx->ld, centroids, sizeof(float) * idx->dim,
+                            sizeof(float) * idx->dim, nlist, hipMemcpyHostToDevice, st));
+    HG_TRY(launch_norms(idx->nch, idx->d_cent, idx->ld, nlist, idx->d_cnorms, st));
+    HG_TRY(install_lists(idx, nlist, list_off, list_ids, st));
+    idx->h_cent.assign(centroids, centroids + static_cast<size_t>(nlist) * idx->dim);
+    return 0;
+}
+
+int hnswgpu_get_ivf(const hnswgpu_index *idx, float *centroids, int64_t *list_off, int32_t *list_ids) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(idx->nlist > 0, HNSWGPU_ESTATE, "index has no IVF lists");
+    if (centroids) memcpy(centroids, idx->h_cent.data(), sizeof(float) * idx->h_cent.size());
+    if (list_off) memcpy(list_off, idx->h_listoff.data(), sizeof(int64_t) * idx->h_listoff.size());
+    if (list_ids && !idx->h_listids.empty())
+        memcpy(list_ids, idx->h_listids.data(), sizeof(int32_t) * idx->h_listids.size());
+    return 0;
+}
+
+int hnswgpu_kmeans_assign(hnswgpu_index *idx, const float *centroids, int32_t nlist, int32_t *out_assign,
+                          float *out_dist) {
+    HG_REQUIRE(idx && centroids && (out_assign || idx->n == 0), HNSWGPU_EINVAL, "null argument");
+    HG_REQUIRE(nlist >= 1, HNSWGPU_EINVAL, "nlist must be >= 1");
+    if (idx->n == 0) return 0;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(idx->s_misc.ensure(sizeof(float) * nlist * idx->ld));
+    HG_TRY(idx->s_misc2.ensure(sizeof(float) * nlist));
+    HG_HIP(hipMemsetAsync(idx->s_misc.p, 0, sizeof(float) * nlist * idx->ld, st));
+    HG_HIP(hipMemcpy2DAsync(idx->s_misc.p, sizeof(float) * idx->ld, centroids, sizeof(float) * idx->dim,
+                            sizeof(float) * idx->dim, nlist, hipMemcpyHostToDevice, st));
+    HG_TRY(launch_norms(idx->nch, idx->s_misc.as<float>(), idx->ld, nlist, idx->s_misc2.as<float>(), st));
+    HG_TRY(assign_enqueue(idx, idx->s_misc.as<float>(), idx->s_misc2.as<float>(), nlist, st));
+    HG_HIP(hipMemcpyAsync(out_assign, idx->s_ord.p, sizeof(int32_t) * idx->n, hipMemcpyDeviceToHost, st));
+    if (out_dist) HG_HIP(hipMemcpyAsync(out_dist, idx->s_dist.p, sizeof(float) * idx->n, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int hnswgpu_kmeanspp(hnswgpu_index *idx, int32_t nlist, int64_t seed, int32_t *out_rows) {
+    HG_REQUIRE(idx && out_rows, HNSWGPU_EINVAL, "null argument");
+    HG_REQUIRE(nlist >= 1 && idx->n >= 1, HNSWGPU_EINVAL, "need nlist >= 1 and a non-empty index");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    std::vector<int32_t> chosen;
+    HG_TRY(kmeanspp_device(idx, nlist, seed, chosen, idx->stream));
+    memcpy(out_rows, chosen.data(), sizeof(int32_t) * nlist);
+    return 0;
+}
+
+int hnswgpu_ivf_build(hnswgpu_index *idx, int32_t nlist, int32_t max_iter, int64_t seed) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(nlist >= 1 && max_iter >= 0, HNSWGPU_EINVAL, "bad nlist / max_iter");
+    HG_REQUIRE(idx->n >= 1, HNSWGPU_ESTATE, "cannot partition an empty index");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    const int64_t n = idx->n;
+    free_ivf(idx);
+    std::vector<int32_t> chosen;
+    HG_TRY(kmeanspp_device(idx, nlist, seed, chosen, st));
+    HG_TRY(alloc_centroids(idx, nlist));
+    for (int c = 0; c < nlist; c++)  // centroids start as copies of data rows (:39,:57)
+        HG_HIP(hipMemcpyAsync(idx->d_cent + static_cast<int64_t>(c) * idx->ld,
+                              idx->d_base + static_cast<int64_t>(chosen[c]) * idx->ld, sizeof(float) * idx->ld,
+                              hipMemcpyDeviceToDevice, st));
+    HG_TRY(launch_norms(idx->nch, idx->d_cent, idx->ld, nlist, idx->d_cnorms, st));
+    std::vector<uint32_t> assign(static_cast<size_t>(n));
+    std::vector<int64_t> off;
+    std::vector<int32_t> ids;
+    HG_TRY(idx->s_misc.ensure(sizeof(int64_t) * (nlist + 1)));
+    HG_TRY(idx->s_misc2.ensure(sizeof(int32_t) * n));
+    for (int it = 0; it <= max_iter; it++) {  // max_iter Lloyd passes (:100-117) + the final assignment (:120-124)
+        HG_TRY(assign_enqueue(idx, idx->d_cent, idx->d_cnorms, nlist, st));
+        HG_HIP(hipMemcpyAsync(assign.data(), idx->s_ord.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipStreamSynchronize(st));
+        lists_from_assign(assign.data(), n, nlist, off, ids);
+        if (it == max_iter) break;
+        HG_HIP(hipMemcpyAsync(idx->s_misc.p, off.data(), sizeof(int64_t) * (nlist + 1), hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(idx->s_misc2.p, ids.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(centroid_mean_kernel, dim3(nlist), dim3(kWG), 0, st, idx->d_base, idx->ld, idx->dim,
+                           idx->s_misc.as<int64_t>(), idx->s_misc2.as<int32_t>(), idx->d_cent);
+        HG_HIP(hipGetLastError());
+        HG_TRY(launch_norms(idx->nch, idx->d_cent, idx->ld, nlist, idx->d_cnorms, st));
+        HG_HIP(hipStreamSynchronize(st));
+    }
+    HG_TRY(install_lists(idx, nlist, off.data(), ids.data(), st));
+    HG_TRY(download_centroids(idx, st));
+    return 0;
+}
+
+static int check_ivf_args(const hnswgpu_index *idx, const void *Q, int32_t nq, int32_t k, int32_t nprobe,
+                          const void *ids, const void *dist) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(nq >= 0 && k >= 1 && nprobe >= 1, HNSWGPU_EINVAL, "need nq >= 0, k >= 1, nprobe >= 1");
+    HG_REQUIRE(k <= 1024 && nprobe <= 1024, HNSWGPU_ELIMIT, "k / nprobe > 1024 is not supported");
+    HG_REQUIRE(nq == 0 || (Q && ids && dist), HNSWGPU_EINVAL, "null argument");
+    HG_REQUIRE(idx->nlist > 0, HNSWGPU_ESTATE, "index has no IVF lists (call hnswgpu_ivf_build / hnswgpu_set_ivf)");
+    return 0;
+}
+
+int hnswgpu_ivf_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
+                           int32_t *d_out_ids, float *d_out_dist, void *stream) {
+    HG_TRY(check_ivf_args(idx, d_Q, nq, k, nprobe, d_out_ids, d_out_dist));
+    if (nq == 0) return 0;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : idx->stream;
+    return ivf_search_enqueue(idx, d_Q, nq, k, nprobe, d_out_ids, d_out_dist, nullptr, st);
+}
+
+int hnswgpu_ivf_search_lists(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t nprobe,
+                             const int32_t *probes, int32_t *out_ids, float *out_dist) {
+    HG_TRY(check_ivf_args(idx, Q, nq, k, nprobe, out_ids, out_dist));
+    if (nq == 0) return 0;
+    HG_REQUIRE(probes, HNSWGPU_EINVAL, "probes is null");
+    for (int64_t i = 0; i < static_cast<int64_t>(nq) * nprobe; i++)
+        HG_REQUIRE(probes[i] >= -1 && probes[i] < idx->nlist, HNSWGPU_EINVAL, "probe list id out of range");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    int64_t cnt = static_cast<int64_t>(nq) * k;
+    HG_TRY(upload_queries(idx, Q, nq, st));
+    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
+    HG_TRY(idx->s_probes.ensure(sizeof(int32_t) * static_cast<size_t>(nq) * nprobe));
+    HG_HIP(hipMemcpyAsync(idx->s_probes.p, probes, sizeof(int32_t) * static_cast<size_t>(nq) * nprobe,
+                          hipMemcpyHostToDevice, st));
+    HG_TRY(ivf_search_enqueue(idx, idx->s_q.as<float>(), nq, k, nprobe, idx->s_ids.as<int32_t>(),
+                              idx->s_outd.as<float>(), nullptr, st, idx->s_probes.as<int32_t>()));
+    HG_HIP(hipMemcpyAsync(out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipMemcpyAsync(out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t nprobe,
+                       int32_t *out_ids, float *out_dist, int32_t *out_probes) {
+    HG_TRY(check_ivf_args(idx, Q, nq, k, nprobe, out_ids, out_dist));
+    if (nq == 0) return 0;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    int32_t np = std::min(nprobe, idx->nlist);
+    int64_t cnt = static_cast<int64_t>(nq) * k;
+    HG_TRY(upload_queries(idx, Q, nq, st));
+    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
+    HG_TRY(idx->s_probes.ensure(sizeof(int32_t) * static_cast<size_t>(nq) * np));
+    HG_TRY(ivf_search_enqueue(idx, idx->s_q.as<float>(), nq, k, np, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(),
+                              idx->s_probes.as<int32_t>(), st));
+    HG_HIP(hipMemcpyAsync(out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipMemcpyAsync(out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
+    if (out_probes) {
+        if (np < nprobe)
+            for (int64_t i = 0; i < static_cast<int64_t>(nq) * nprobe; i++) out_probes[i] = -1;
+        HG_HIP(hipMemcpy2DAsync(out_probes, sizeof(int32_t) * nprobe, idx->s_probes.p, sizeof(int32_t) * np,
+                                sizeof(int32_t) * np, nq, hipMemcpyDeviceToHost, st));
+    }
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // extern "C"

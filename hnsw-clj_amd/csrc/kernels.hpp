@@ -1,0 +1,597 @@
+// kernels.hpp -- gfx950 (MI355X, CDNA4) device code of the hnsw-clj distance engine.
+//
+// One numeric contract for every kernel (oracle/oracle.c section 2 mimics it bit for bit):
+//   lane l of a 64-lane wavefront accumulates elements {256c + 4l + j} (c ascending, j = 0..3) of a
+//   row with one fmaf per element into a single f32 accumulator; the 64 partials are combined by
+//   an xor butterfly with offsets 1,2,4,8,16,32 (x = x + shfl_xor(x, off)); cosine is
+//   1 - dot / (qnorm * rownorm) with correctly rounded mul / div / sub and both norms
+//   sqrt(reduce(v.v)) in the same order; L2 is sqrt(reduce((q-v)^2)); DOT is -dot.
+// Rows are streamed/gathered straight into VGPRs as float4 (16 B/lane, 1 KiB per wave
+// instruction): every row is used once per query, so an LDS round trip would be pure overhead
+// (cdna_hip_programming.md section 5 "GEMV / M <= 16" row).  LDS holds the per-query state instead:
+// candidate lists, visited bitset, per-wave top-k lists.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hg {
+
+constexpr int kWave = 64;
+constexpr int kWG = 256;
+constexpr int kNWave = kWG / kWave;
+constexpr int kMaxDeg = 64;  // M0 = 2M <= 64
+constexpr int kGhost = 32;   // extra list slots for evicted-but-tied candidates (see hnsw kernel)
+
+constexpr int METRIC_COS = 0, METRIC_L2 = 1, METRIC_DOT = 2;
+constexpr int MODE_TOPK = 0, MODE_STORE = 1, MODE_MINUPD = 2;
+
+__device__ __forceinline__ float wave_sum(float x) {
+    x = x + __shfl_xor(x, 1, kWave);
+    x = x + __shfl_xor(x, 2, kWave);
+    x = x + __shfl_xor(x, 4, kWave);
+    x = x + __shfl_xor(x, 8, kWave);
+    x = x + __shfl_xor(x, 16, kWave);
+    x = x + __shfl_xor(x, 32, kWave);
+    return x;
+}
+
+template <int NCH>
+__device__ __forceinline__ void load_query(float4 (&q)[NCH], const float *Q, int dim, int lane) {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        int e = (c * kWave + lane) * 4;
+        q[c].x = e + 0 < dim ? Q[e + 0] : 0.0f;
+        q[c].y = e + 1 < dim ? Q[e + 1] : 0.0f;
+        q[c].z = e + 2 < dim ? Q[e + 2] : 0.0f;
+        q[c].w = e + 3 < dim ? Q[e + 3] : 0.0f;
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void load_row(float4 (&r)[NCH], const float *row, int nvec, int lane, bool valid) {
+    const float4 *rp = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        int i = c * kWave + lane;
+        r[c] = (valid && i < nvec) ? rp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int NCH, bool L2>
+__device__ __forceinline__ float lane_partial(const float4 (&q)[NCH], const float4 (&r)[NCH]) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        if (L2) {
+            float d0 = q[c].x - r[c].x, d1 = q[c].y - r[c].y, d2 = q[c].z - r[c].z, d3 = q[c].w - r[c].w;
+            acc = __builtin_fmaf(d0, d0, acc);
+            acc = __builtin_fmaf(d1, d1, acc);
+            acc = __builtin_fmaf(d2, d2, acc);
+            acc = __builtin_fmaf(d3, d3, acc);
+        } else {
+            acc = __builtin_fmaf(q[c].x, r[c].x, acc);
+            acc = __builtin_fmaf(q[c].y, r[c].y, acc);
+            acc = __builtin_fmaf(q[c].z, r[c].z, acc);
+            acc = __builtin_fmaf(q[c].w, r[c].w, acc);
+        }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float finish_dist(int metric, float s, float qn, float rn) {
+    if (metric == METRIC_L2) return __fsqrt_rn(s);
+    if (metric == METRIC_DOT) return -s;
+    return (qn > 0.0f && rn > 0.0f) ? __fsub_rn(1.0f, __fdiv_rn(s, __fmul_rn(qn, rn))) : 1.0f;
+}
+
+template <int NCH>
+__device__ __forceinline__ float query_norm(const float4 (&q)[NCH]) {
+    return __fsqrt_rn(wave_sum(lane_partial<NCH, false>(q, q)));
+}
+
+// total order on (distance, order) packed in 64 bits; -0 is canonicalised to +0, NaN sorts last
+__device__ __forceinline__ uint64_t make_key(float d, uint32_t ord) {
+    d = d + 0.0f;
+    uint32_t u = __float_as_uint(d);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return (static_cast<uint64_t>(u) << 32) | ord;
+}
+__device__ __forceinline__ float key_dist(uint64_t key) {
+    uint32_t u = static_cast<uint32_t>(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+// Insert `key` (wave-uniform) into the ascending list of `cnt` (<= k) keys kept in LDS by one wave.
+__device__ __forceinline__ void wave_insert(uint64_t *list, int &cnt, int k, uint64_t key, int lane) {
+    int pos = 0;
+    for (int base = 0; base < cnt; base += kWave) {
+        int i = base + lane;
+        bool lt = (i < cnt) && (list[i] < key);
+        pos += __popcll(__ballot(lt));
+    }
+    if (pos >= k) return;
+    int newcnt = cnt + 1 < k ? cnt + 1 : k;
+    for (int top = newcnt - 1; top > pos; top -= kWave) {
+        int i = top - lane;
+        bool act = i > pos;
+        uint64_t v = 0;
+        if (act) v = list[i - 1];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (act) list[i] = v;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) list[pos] = key;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    cnt = newcnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row norms (ivf_flat.clj:171-177): one wave per row.
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(kWG) void row_norms_kernel(const float *rows, int64_t ld, int64_t n, float *out) {
+    int lane = threadIdx.x & (kWave - 1);
+    int64_t row = static_cast<int64_t>(blockIdx.x) * kNWave + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float4 r[NCH];
+    load_row<NCH>(r, rows + row * ld, static_cast<int>(ld / 4), lane, true);
+    float s = wave_sum(lane_partial<NCH, false>(r, r));
+    if (lane == 0) out[row] = __fsqrt_rn(s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scan: for each (query, contiguous row range) pair, stream the rows and either keep the per-wave
+// top-k (MODE_TOPK), store the distances (MODE_STORE) or fold them into a running minimum
+// (MODE_MINUPD).  IVF list scan (ivf_flat.clj:217-234), centroid routing (:261-269), k-means
+// assignment (:79-90), k-means++ seeding (:43-49) and exact kNN (bench.clj:72-84) are all this
+// kernel with different pair tables.
+// ------------------------------------------------------------------------------------------------
+struct Pair {
+    int64_t row_begin, row_end;
+    int32_t q;
+    uint32_t ord_base;
+};
+
+struct ScanArgs {
+    const float *rows;
+    const float *row_norms;
+    int64_t ld;
+    int64_t nrows_all;  // implicit pairs: every query scans rows [0, nrows_all)
+    const float *Q;
+    int64_t qld;
+    const float *q_norms;  // optional precomputed query norms (queries that are base rows)
+    int32_t dim;
+    int32_t metric;
+    int32_t mode;
+    const Pair *pairs;  // nullptr = implicit pairs
+    int32_t npairs;
+    int32_t chunk_rows;
+    int32_t nchunks;
+    int32_t k;
+    uint64_t *partial;  // TOPK: [pair][chunk][wave][k]
+    float *out;         // STORE: out[pair * out_stride + (row - row_begin)]; MINUPD: out[row]
+    int64_t out_stride;
+};
+
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);  // [kNWave][k]
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int64_t bid = blockIdx.x;
+    const int32_t pair = static_cast<int32_t>(bid / a.nchunks);
+    const int32_t chunk = static_cast<int32_t>(bid % a.nchunks);
+    int64_t rb0, rb1;
+    int32_t qi;
+    uint32_t ord_base;
+    if (a.pairs) {
+        Pair p = a.pairs[pair];
+        rb0 = p.row_begin;
+        rb1 = p.row_end;
+        qi = p.q;
+        ord_base = p.ord_base;
+    } else {
+        rb0 = 0;
+        rb1 = a.nrows_all;
+        qi = pair;
+        ord_base = 0;
+    }
+    int64_t r0 = rb0 + static_cast<int64_t>(chunk) * a.chunk_rows;
+    int64_t r1 = r0 + a.chunk_rows < rb1 ? r0 + a.chunk_rows : rb1;
+    uint64_t *mylist = lists + wave * a.k;
+    int cnt = 0;
+    uint64_t thr = ~0ull;
+    if (r0 < r1) {
+        float4 q[NCH];
+        load_query<NCH>(q, a.Q + qi * a.qld, a.dim, lane);
+        float qn = 0.0f;
+        if (a.metric == METRIC_COS) qn = a.q_norms ? a.q_norms[qi] : query_norm<NCH>(q);
+        const int nvec = static_cast<int>(a.ld / 4);
+        for (int64_t base = r0 + wave * RB; base < r1; base += kNWave * RB) {
+            float4 r[RB][NCH];
+#pragma unroll
+            for (int b = 0; b < RB; b++) load_row<NCH>(r[b], a.rows + (base + b) * a.ld, nvec, lane, base + b < r1);
+            float s[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2>(q, r[b]);
+#pragma unroll
+            for (int b = 0; b < RB; b++) s[b] = wave_sum(s[b]);
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                int64_t row = base + b;
+                if (row < r1) {  // wave-uniform
+                    float rn = (a.metric == METRIC_COS) ? a.row_norms[row] : 0.0f;
+                    float d = finish_dist(a.metric, s[b], qn, rn);
+                    if (a.mode == MODE_TOPK) {
+                        uint64_t key = make_key(d, ord_base + static_cast<uint32_t>(row - rb0));
+                        if (key < thr) {
+                            wave_insert(mylist, cnt, a.k, key, lane);
+                            thr = cnt == a.k ? mylist[a.k - 1] : ~0ull;
+                        }
+                    } else if (a.mode == MODE_STORE) {
+                        if (lane == 0) a.out[pair * a.out_stride + (row - rb0)] = d;
+                    } else {
+                        if (lane == 0) {
+                            float o = a.out[row];
+                            if (d < o) a.out[row] = d;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (a.mode == MODE_TOPK) {
+        uint64_t *dst = a.partial + ((static_cast<int64_t>(pair) * a.nchunks + chunk) * kNWave + wave) * a.k;
+        for (int i = lane; i < a.k; i += kWave) dst[i] = i < cnt ? mylist[i] : ~0ull;
+    }
+}
+
+// Merge the partial top-k lists of one query (contiguous keys) into its final ascending top-k.
+// One wave per query.  out_ord / out_dist: [nq][k], padded with 0xffffffff / +inf.
+struct MergeArgs {
+    const uint64_t *partial;
+    int64_t keys_per_query;
+    int32_t nq, k;
+    uint32_t *out_ord;
+    float *out_dist;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Gather-dot: distances from one query to base rows ids[0..m) -- the per-hop neighbour expansion
+// of search-layer-ultra (ultra_fast.clj:185-204) as a stand-alone seam
+// (simd-optimized/batch-cosine-distances, simd_optimized.clj:176-184).
+// ------------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const float *rows;
+    const float *row_norms;
+    int64_t ld;
+    int64_t n;
+    const float *q;
+    int32_t dim;
+    int32_t metric;
+    const int32_t *ids;  // nullptr = 0..m-1
+    int32_t m;
+    float *out;
+};
+
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void gather_dist_kernel(GatherArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    float4 q[NCH];
+    load_query<NCH>(q, a.q, a.dim, lane);
+    float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+    const int nvec = static_cast<int>(a.ld / 4);
+    int j0 = (blockIdx.x * kNWave + wave) * RB;
+    if (j0 >= a.m) return;
+    float4 r[RB][NCH];
+    int64_t rid[RB];
+#pragma unroll
+    for (int b = 0; b < RB; b++) {
+        int j = j0 + b;
+        int64_t id = -1;
+        if (j < a.m) id = a.ids ? a.ids[j] : j;
+        bool ok = id >= 0 && id < a.n;
+        rid[b] = ok ? id : -1;
+        load_row<NCH>(r[b], a.rows + (ok ? id : 0) * a.ld, nvec, lane, ok);
+    }
+#pragma unroll
+    for (int b = 0; b < RB; b++) {
+        float s = wave_sum(lane_partial<NCH, L2>(q, r[b]));
+        if (j0 + b < a.m && lane == 0) {
+            float d = __uint_as_float(0x7fc00000u);  // NaN for an out-of-range id
+            if (rid[b] >= 0) d = finish_dist(a.metric, s, qn, a.metric == METRIC_COS ? a.row_norms[rid[b]] : 0.0f);
+            a.out[j0 + b] = d;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// HNSW traversal: one 256-thread workgroup per query, the whole layered search GPU-resident.
+//
+// Restates search-layer-ultra / search-knn (ultra_fast.clj:151-212, 346-374) with one sorted list:
+//   * `nearest` (max-PQ) and `candidates` (min-PQ) become ONE ascending list in LDS; an entry
+//     carries an "expanded" flag (bit 31 of the id word).  The next candidate is the first
+//     unexpanded entry.  A candidate the reference would still hold after its eviction from
+//     `nearest` can only be expanded if its distance EQUALS the current worst (:175-178 uses <=),
+//     so evicted entries tied with the worst are kept as "ghosts" behind position ef.
+//   * per expansion: <= M0 neighbour ids are read, visited-filtered against an LDS bitset
+//     (HashSet visited, :156) with ballot/popcount compaction, their rows gathered (3 x 1 KiB wave
+//     loads per 768-d row, RB rows in flight per wave), distances reduced with wave shuffles, then
+//     all admitted neighbours are merged into the list in one parallel rank-and-scatter step that
+//     is equivalent to the reference's sequential admit/evict loop (:195-204): an incoming
+//     neighbour is admitted iff fewer than ef of {list, earlier neighbours} are <= it (strict <
+//     against the worst), ties keep admission order.
+//   * levels > 0 use ef = 1 (:373-374); the single survivor seeds the next level.
+// In build mode (q_rows != nullptr) the query is a base row, and the best m entries of every level
+// <= the node's level are emitted for the host-side linker.
+// ------------------------------------------------------------------------------------------------
+struct HnswArgs {
+    const float *rows;
+    const float *row_norms;
+    int64_t ld;
+    int64_t n;
+    int32_t dim;
+    int32_t metric;
+    const float *Q;
+    int64_t qld;
+    const int32_t *q_rows;    // build mode: query q is base row q_rows[q]
+    const int32_t *q_levels;  // build mode: level of the node being inserted
+    int32_t nq;
+    const int32_t *l0_adj;
+    int32_t M0;
+    const int64_t *up_off;
+    const int32_t *up_adj;
+    int32_t M;
+    int32_t entry;
+    int32_t max_level;
+    int32_t ef;   // layer-0 breadth (ef-construction in build mode)
+    int32_t k;    // results per query (M0 in build mode)
+    int32_t cap;  // list capacity = ef + kGhost
+    int32_t nwords;
+    int32_t *out_ids;
+    float *out_dist;
+    int64_t *stats;
+    int32_t *up_out_ids;  // build mode: [nq][up_stride] nearest node of each upper level <= q level
+    float *up_out_dist;
+    int32_t up_stride;
+};
+
+constexpr uint32_t kExpanded = 0x80000000u;
+
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void hnsw_search_kernel(HnswArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint2 *listA = reinterpret_cast<uint2 *>(smem);
+    uint2 *listB = listA + a.cap;
+    int32_t *cand_id = reinterpret_cast<int32_t *>(listB + a.cap);
+    float *cand_d = reinterpret_cast<float *>(cand_id + kMaxDeg);
+    int32_t *cand_P = reinterpret_cast<int32_t *>(cand_d + kMaxDeg);
+    int32_t *sc = cand_P + kMaxDeg;  // scalars
+    uint32_t *bits = reinterpret_cast<uint32_t *>(sc + 16);
+    // sc[0]=cursor sc[1]=ncand sc[2]=nadmit sc[3]=minP sc[4]=worst bits sc[5]=nghost
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+    const int qi = blockIdx.x;
+    const int nvec = static_cast<int>(a.ld / 4);
+
+    const float *qptr = a.q_rows ? a.rows + static_cast<int64_t>(a.q_rows[qi]) * a.ld : a.Q + qi * a.qld;
+    float4 q[NCH];
+    load_query<NCH>(q, qptr, a.dim, lane);
+    float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+    const int qlevel = a.q_levels ? a.q_levels[qi] : -1;
+
+    int64_t n_eval = 0, n_hop = 0;
+    int len = 0;
+    // seed: the entry point (ultra_fast.clj:358-359)
+    {
+        float4 r[NCH];
+        load_row<NCH>(r, a.rows + static_cast<int64_t>(a.entry) * a.ld, nvec, lane, true);
+        float s = wave_sum(lane_partial<NCH, L2>(q, r));
+        float d = finish_dist(a.metric, s, qn, a.metric == METRIC_COS ? a.row_norms[a.entry] : 0.0f);
+        if (tid == 0) listA[0] = make_uint2(__float_as_uint(d + 0.0f), static_cast<uint32_t>(a.entry));
+        len = 1;
+        n_eval = 1;
+    }
+    for (int level = a.max_level; level >= 0; level--) {
+        int ef_l = level > 0 ? 1 : a.ef;
+        // fresh visited set per layer (:156); entries carried from the level above are marked
+        for (int w = tid; w < a.nwords; w += kWG) bits[w] = 0;
+        __syncthreads();
+        if (len > ef_l) len = ef_l;
+        for (int i = tid; i < len; i += kWG) {
+            uint2 e = listA[i];
+            e.y &= ~kExpanded;
+            listA[i] = e;
+            atomicOr(&bits[e.y >> 5], 1u << (e.y & 31));
+        }
+        __syncthreads();
+        int cur_start = 0;
+        const int deg = level == 0 ? a.M0 : a.M;
+        for (;;) {
+            // ---- next candidate: first unexpanded entry
+            if (wave == 0) {
+                int found = -1;
+                for (int base = cur_start; base < len && found < 0; base += kWave) {
+                    int i = base + lane;
+                    bool un = i < len && !(listA[i].y & kExpanded);
+                    uint64_t m = __ballot(un);
+                    if (m) found = base + __ffsll(static_cast<unsigned long long>(m)) - 1;
+                }
+                if (lane == 0) sc[0] = found;
+            }
+            __syncthreads();
+            const int c = sc[0];
+            if (c < 0) break;
+            const uint32_t node = listA[c].y & ~kExpanded;
+            // ---- neighbour ids, visited filter, compaction (wave 0)
+            if (wave == 0) {
+                const int32_t *adj = level == 0 ? a.l0_adj + static_cast<int64_t>(node) * a.M0
+                                                : a.up_adj + (a.up_off[node] + (level - 1)) * a.M;
+                int nb = lane < deg ? adj[lane] : -1;
+                bool fresh = false;
+                if (nb >= 0 && nb < a.n) {
+                    uint32_t bit = 1u << (nb & 31);
+                    uint32_t old = atomicOr(&bits[nb >> 5], bit);
+                    fresh = !(old & bit);
+                }
+                uint64_t m = __ballot(fresh);
+                int pos = __popcll(m & ((1ull << lane) - 1ull));
+                if (fresh) cand_id[pos] = nb;
+                if (lane == 0) {
+                    sc[1] = __popcll(m);
+                    listA[c].y = node | kExpanded;
+                }
+            }
+            __syncthreads();
+            const int nc = sc[1];
+            n_hop++;
+            if (nc == 0) {
+                cur_start = c + 1;
+                continue;
+            }
+            n_eval += nc;
+            // ---- gather rows + distances: wave w takes candidates [w*RB + t*4*RB, +RB)
+            for (int j0 = wave * RB; j0 < nc; j0 += kNWave * RB) {
+                float4 r[RB][NCH];
+                int32_t rid[RB];
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    bool ok = j0 + b < nc;
+                    rid[b] = ok ? cand_id[j0 + b] : 0;
+                    load_row<NCH>(r[b], a.rows + static_cast<int64_t>(rid[b]) * a.ld, nvec, lane, ok);
+                }
+                float s[RB];
+#pragma unroll
+                for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2>(q, r[b]);
+#pragma unroll
+                for (int b = 0; b < RB; b++) s[b] = wave_sum(s[b]);
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    if (j0 + b < nc && lane == 0) {
+                        float rn = a.metric == METRIC_COS ? a.row_norms[rid[b]] : 0.0f;
+                        cand_d[j0 + b] = finish_dist(a.metric, s[b], qn, rn) + 0.0f;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- ranks of the incoming candidates (threads 0..nc-1, all inside wave 0)
+            if (wave == 0) {
+                bool admitted = false;
+                int P = 0x7fffffff;
+                float dj = 0.0f;
+                if (lane < nc) {
+                    dj = cand_d[lane];
+                    int lo = 0, hi = len;  // upper_bound: #entries with d <= dj
+                    while (lo < hi) {
+                        int mid = (lo + hi) >> 1;
+                        if (__uint_as_float(listA[mid].x) <= dj) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    int before = 0, after_less = 0;
+                    for (int j = 0; j < nc; j++) {
+                        float o = cand_d[j];
+                        before += (j < lane && o <= dj) ? 1 : 0;
+                        after_less += (j > lane && o < dj) ? 1 : 0;
+                    }
+                    int r = lo + before;
+                    admitted = r < ef_l;
+                    P = r + after_less;
+                    cand_P[lane] = admitted ? P : -1;
+                }
+                uint64_t am = __ballot(admitted);
+                int minP = admitted ? P : 0x7fffffff;
+                for (int off = 1; off < kWave; off <<= 1) {
+                    int o = __shfl_xor(minP, off, kWave);
+                    minP = o < minP ? o : minP;
+                }
+                if (lane == 0) {
+                    sc[2] = __popcll(am);
+                    sc[3] = minP;
+                    sc[5] = 0;
+                }
+            }
+            __syncthreads();
+            const int nadm = sc[2];
+            if (nadm == 0) {
+                cur_start = c + 1;
+                continue;
+            }
+            // ---- scatter old entries and admitted candidates to their merged positions
+            const int total = len + nadm;
+            for (int i = tid; i < len; i += kWG) {
+                uint2 e = listA[i];
+                float de = __uint_as_float(e.x);
+                int sh = 0;
+                for (int j = 0; j < nc; j++) sh += cand_d[j] < de ? 1 : 0;
+                int P = i + sh;
+                if (P < a.cap) listB[P] = e;
+                if (P == ef_l - 1) sc[4] = e.x;
+            }
+            if (tid < nc) {
+                int P = cand_P[tid];
+                if (P >= 0) {
+                    uint2 e = make_uint2(__float_as_uint(cand_d[tid]), static_cast<uint32_t>(cand_id[tid]));
+                    if (P < a.cap) listB[P] = e;
+                    if (P == ef_l - 1) sc[4] = e.x;
+                }
+            }
+            __syncthreads();
+            int newlen = total;
+            if (total > ef_l) {
+                // ghosts: admitted-at-some-time entries pushed past ef whose distance ties the worst
+                const uint32_t wbits = static_cast<uint32_t>(sc[4]);
+                for (int i = tid; i < len; i += kWG) {
+                    uint2 e = listA[i];
+                    if (e.x == wbits) {
+                        float de = __uint_as_float(e.x);
+                        int sh = 0;
+                        for (int j = 0; j < nc; j++) sh += cand_d[j] < de ? 1 : 0;
+                        if (i + sh >= ef_l && i + sh < a.cap) atomicAdd(&sc[5], 1);
+                    }
+                }
+                if (tid < nc) {
+                    int P = cand_P[tid];
+                    if (P >= ef_l && P < a.cap && __float_as_uint(cand_d[tid]) == wbits) atomicAdd(&sc[5], 1);
+                }
+                __syncthreads();
+                newlen = ef_l + sc[5];
+            }
+            {
+                uint2 *t = listA;
+                listA = listB;
+                listB = t;
+            }
+            len = newlen;
+            const int minP = sc[3];
+            cur_start = minP < c + 1 ? minP : c + 1;
+            __syncthreads();
+        }
+        // ---- level done
+        if (a.q_rows && level > 0 && level <= qlevel && tid == 0) {
+            a.up_out_ids[static_cast<int64_t>(qi) * a.up_stride + (level - 1)] =
+                len > 0 ? static_cast<int32_t>(listA[0].y & ~kExpanded) : -1;
+            a.up_out_dist[static_cast<int64_t>(qi) * a.up_stride + (level - 1)] =
+                len > 0 ? __uint_as_float(listA[0].x) : 0.0f;
+        }
+    }
+    // ---- results: ascending, take k (:362-370; the distances are reused, not recomputed)
+    int real = len < a.ef ? len : a.ef;
+    for (int i = tid; i < a.k; i += kWG) {
+        bool ok = i < real;
+        a.out_ids[static_cast<int64_t>(qi) * a.k + i] = ok ? static_cast<int32_t>(listA[i].y & ~kExpanded) : -1;
+        a.out_dist[static_cast<int64_t>(qi) * a.k + i] = ok ? __uint_as_float(listA[i].x) : __uint_as_float(0x7f800000u);
+    }
+    if (a.stats && tid == 0) {
+        a.stats[2 * static_cast<int64_t>(qi)] = n_eval;
+        a.stats[2 * static_cast<int64_t>(qi) + 1] = n_hop;
+    }
+}
+
+}  // namespace hg

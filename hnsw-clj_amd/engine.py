@@ -1,0 +1,269 @@
+"""Index handle over libhnswgpu.so -- thin, typed wrapper of the C ABI (include/hnswgpu.h).
+
+numpy arrays go through the host-pointer entry points; torch CUDA tensors go through the ``_dev``
+entry points on torch's current stream (zero copy).  Nothing here computes distances on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from ._native import COSINE, DOT, L2, check, lib
+
+METRICS = {"cosine": COSINE, "l2": L2, "euclidean": L2, "dot": DOT, COSINE: COSINE, L2: L2, DOT: DOT}
+PROF_IVF_SCAN, PROF_HNSW, PROF_ASSIGN = 0, 1, 2
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _queries(Q, dim):
+    Q = _f32(Q)
+    if Q.ndim == 1:
+        Q = Q[None, :]
+    if Q.ndim != 2 or Q.shape[1] != dim:
+        raise ValueError("queries must be (nq, %d), got %s" % (dim, Q.shape))
+    return Q
+
+
+class Graph:
+    """Flat HNSW graph (layout documented in include/hnswgpu.h)."""
+
+    def __init__(self, levels, l0_adj, up_off, up_adj, M, entry, max_level):
+        self.levels = np.ascontiguousarray(levels, np.int32)
+        self.l0_adj = np.ascontiguousarray(l0_adj, np.int32)
+        self.up_off = np.ascontiguousarray(up_off, np.int64)
+        self.up_adj = np.ascontiguousarray(up_adj, np.int32)
+        self.M = int(M)
+        self.n = len(self.levels)
+        self.M0 = self.l0_adj.shape[1] if self.l0_adj.ndim == 2 else (self.l0_adj.size // max(self.n, 1))
+        self.entry = int(entry)
+        self.max_level = int(max_level)
+
+
+class Index:
+    """Base vectors resident in HBM + optional HNSW graph and IVF lists."""
+
+    def __init__(self, base, metric="cosine", device=0):
+        self.metric = METRICS[metric]
+        self.device = int(device)
+        self._h = C.c_void_p(None)
+        if hasattr(base, "is_cuda") and base.is_cuda:  # torch tensor already in HBM
+            import torch
+
+            assert base.dtype == torch.float32 and base.dim() == 2
+            base = base.contiguous()
+            self.n, self.dim = int(base.shape[0]), int(base.shape[1])
+            st = torch.cuda.current_stream(base.device).cuda_stream
+            check(lib().hnswgpu_create_dev(base.data_ptr(), self.n, self.dim, self.dim, self.metric,
+                                           base.device.index or 0, st, C.byref(self._h)))
+            self.device = base.device.index or 0
+        else:
+            base = _f32(base)
+            if base.ndim != 2:
+                raise ValueError("base must be (n, dim)")
+            self.n, self.dim = base.shape
+            check(lib().hnswgpu_create(_p(base), self.n, self.dim, self.metric, self.device, C.byref(self._h)))
+
+    # -- lifetime
+    def close(self):
+        if self._h:
+            lib().hnswgpu_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        check(lib().hnswgpu_sync(self._h))
+
+    # -- distance seams
+    def batch_distances(self, q, ids=None, m=None):
+        q = _f32(q).reshape(-1)
+        if len(q) != self.dim:
+            raise ValueError("query has %d elements, index dim is %d" % (len(q), self.dim))
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, np.int32)
+            m = len(ids)
+        elif m is None:
+            m = self.n
+        out = np.empty(m, np.float32)
+        check(lib().hnswgpu_batch_distances(self._h, _p(q), _p(ids), m, _p(out)))
+        return out
+
+    def norms(self):
+        out = np.empty(self.n, np.float32)
+        check(lib().hnswgpu_norms(self._h, _p(out)))
+        return out
+
+    def exact_knn(self, Q, k):
+        Q = _queries(Q, self.dim)
+        ids = np.empty((len(Q), k), np.int32)
+        d = np.empty((len(Q), k), np.float32)
+        check(lib().hnswgpu_exact_knn(self._h, _p(Q), len(Q), k, _p(ids), _p(d)))
+        return ids, d
+
+    # -- HNSW
+    def set_graph(self, g):
+        check(lib().hnswgpu_set_graph(self._h, _p(g.levels), _p(g.l0_adj), g.M0, _p(g.up_off), _p(g.up_adj), g.M,
+                                      g.entry, g.max_level))
+
+    def hnsw_build(self, M=16, ef_construction=200, seed=42):
+        check(lib().hnswgpu_hnsw_build(self._h, M, ef_construction, seed))
+
+    def get_graph(self):
+        M, M0, ent, mx = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        blocks = C.c_int64()
+        check(lib().hnswgpu_graph_sizes(self._h, C.byref(M), C.byref(M0), C.byref(blocks), C.byref(ent),
+                                        C.byref(mx)))
+        levels = np.zeros(self.n, np.int32)
+        l0 = np.full((self.n, M0.value), -1, np.int32)
+        up_off = np.zeros(self.n + 1, np.int64)
+        up = np.full(blocks.value * M.value, -1, np.int32)
+        check(lib().hnswgpu_get_graph(self._h, _p(levels), _p(l0), _p(up_off), _p(up)))
+        return Graph(levels, l0, up_off, up, M.value, ent.value, mx.value)
+
+    def hnsw_search(self, Q, k, ef=0, want_stats=False):
+        Q = _queries(Q, self.dim)
+        ids = np.empty((len(Q), k), np.int32)
+        d = np.empty((len(Q), k), np.float32)
+        stats = np.zeros((len(Q), 2), np.int64) if want_stats else None
+        check(lib().hnswgpu_hnsw_search(self._h, _p(Q), len(Q), k, int(ef or 0), _p(ids), _p(d), _p(stats)))
+        return (ids, d, stats) if want_stats else (ids, d)
+
+    # -- IVF
+    def ivf_build(self, nlist=24, max_iterations=10, seed=42):
+        check(lib().hnswgpu_ivf_build(self._h, nlist, max_iterations, seed))
+
+    def set_ivf(self, centroids, list_off, list_ids):
+        cen = _f32(centroids)
+        off = np.ascontiguousarray(list_off, np.int64)
+        ids = np.ascontiguousarray(list_ids, np.int32)
+        check(lib().hnswgpu_set_ivf(self._h, _p(cen), cen.shape[0], _p(off), _p(ids)))
+
+    @property
+    def nlist(self):
+        nl = C.c_int32()
+        check(lib().hnswgpu_info(self._h, None, None, None, None, C.byref(nl)))
+        return nl.value
+
+    def get_ivf(self):
+        nl = self.nlist
+        cen = np.empty((nl, self.dim), np.float32)
+        off = np.empty(nl + 1, np.int64)
+        ids = np.empty(self.n, np.int32)
+        check(lib().hnswgpu_get_ivf(self._h, _p(cen), _p(off), _p(ids)))
+        return cen, off, ids
+
+    def kmeans_assign(self, centroids):
+        cen = _f32(centroids)
+        a = np.empty(self.n, np.int32)
+        d = np.empty(self.n, np.float32)
+        check(lib().hnswgpu_kmeans_assign(self._h, _p(cen), cen.shape[0], _p(a), _p(d)))
+        return a, d
+
+    def kmeanspp(self, nlist, seed=42):
+        out = np.empty(nlist, np.int32)
+        check(lib().hnswgpu_kmeanspp(self._h, nlist, seed, _p(out)))
+        return out
+
+    def ivf_search(self, Q, k, nprobe, want_probes=False):
+        Q = _queries(Q, self.dim)
+        ids = np.empty((len(Q), k), np.int32)
+        d = np.empty((len(Q), k), np.float32)
+        pr = np.empty((len(Q), nprobe), np.int32) if want_probes else None
+        check(lib().hnswgpu_ivf_search(self._h, _p(Q), len(Q), k, nprobe, _p(ids), _p(d), _p(pr)))
+        return (ids, d, pr) if want_probes else (ids, d)
+
+    def ivf_search_lists(self, Q, k, probes):
+        Q = _queries(Q, self.dim)
+        probes = np.ascontiguousarray(probes, np.int32).reshape(len(Q), -1)
+        ids = np.empty((len(Q), k), np.int32)
+        d = np.empty((len(Q), k), np.float32)
+        check(lib().hnswgpu_ivf_search_lists(self._h, _p(Q), len(Q), k, probes.shape[1], _p(probes), _p(ids), _p(d)))
+        return ids, d
+
+    # -- zero-copy device entry points (torch tensors, torch's current stream)
+    def _dev_args(self, Q, k):
+        import torch
+
+        assert Q.is_cuda and Q.dtype == torch.float32 and Q.dim() == 2 and Q.shape[1] == self.dim
+        Q = Q.contiguous()
+        ids = torch.empty((Q.shape[0], k), dtype=torch.int32, device=Q.device)
+        d = torch.empty((Q.shape[0], k), dtype=torch.float32, device=Q.device)
+        st = torch.cuda.current_stream(Q.device).cuda_stream
+        return Q, ids, d, st
+
+    def hnsw_search_dev(self, Q, k, ef=0, out=None, stats=None):
+        Q, ids, d, st = self._dev_args(Q, k)
+        if out is not None:
+            ids, d = out
+        check(lib().hnswgpu_hnsw_search_dev(self._h, Q.data_ptr(), Q.shape[0], k, int(ef or 0), ids.data_ptr(),
+                                            d.data_ptr(), stats.data_ptr() if stats is not None else None, st))
+        return ids, d
+
+    def ivf_search_dev(self, Q, k, nprobe, out=None):
+        Q, ids, d, st = self._dev_args(Q, k)
+        if out is not None:
+            ids, d = out
+        check(lib().hnswgpu_ivf_search_dev(self._h, Q.data_ptr(), Q.shape[0], k, nprobe, ids.data_ptr(),
+                                           d.data_ptr(), st))
+        return ids, d
+
+    def exact_knn_dev(self, Q, k, out=None):
+        Q, ids, d, st = self._dev_args(Q, k)
+        if out is not None:
+            ids, d = out
+        check(lib().hnswgpu_exact_knn_dev(self._h, Q.data_ptr(), Q.shape[0], k, ids.data_ptr(), d.data_ptr(), st))
+        return ids, d
+
+    # -- measurement
+    def set_profiling(self, on=True):
+        check(lib().hnswgpu_set_profiling(self._h, 1 if on else 0))
+
+    def get_profile(self, which, reset=True):
+        ms, cnt = C.c_double(), C.c_int64()
+        check(lib().hnswgpu_get_profile(self._h, which, C.byref(ms), C.byref(cnt), 1 if reset else 0))
+        return ms.value, cnt.value
+
+
+def pair_distance(metric, a, b, device=0):
+    """(distance-fn a b) on the device: one pair through the same kernel as everything else."""
+    a, b = _f32(a).reshape(-1), _f32(b).reshape(-1)
+    if len(a) != len(b):
+        raise ValueError("vectors differ in length (%d vs %d)" % (len(a), len(b)))
+    out = C.c_float()
+    check(lib().hnswgpu_pair_distance(METRICS[metric], _p(a), _p(b), len(a), device, C.byref(out)))
+    return float(out.value)
+
+
+def merge_topk_dev(ids, dist, out=None):
+    """[nshard][nq][k] torch CUDA tensors of global ids / distances -> merged [nq][k]."""
+    import torch
+
+    assert ids.is_cuda and ids.dtype == torch.int32 and dist.dtype == torch.float32 and ids.dim() == 3
+    ids, dist = ids.contiguous(), dist.contiguous()
+    ns, nq, k = ids.shape
+    oi = torch.empty((nq, k), dtype=torch.int32, device=ids.device) if out is None else out[0]
+    od = torch.empty((nq, k), dtype=torch.float32, device=ids.device) if out is None else out[1]
+    st = torch.cuda.current_stream(ids.device).cuda_stream
+    check(lib().hnswgpu_merge_topk_dev(ids.device.index or 0, ids.data_ptr(), dist.data_ptr(), ns, nq, k,
+                                       oi.data_ptr(), od.data_ptr(), st))
+    return oi, od
+
+
+device_count = _native.device_count

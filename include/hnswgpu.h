@@ -1,0 +1,161 @@
+/*
+ * hnswgpu.h -- C ABI of libhnswgpu.so: the MI355X (gfx950) distance engine behind hnsw-clj's
+ * index/search API.  This header is the drop-in boundary: every entry point names the reference
+ * interface (file:line under damesek/hnsw-clj) it replaces.  INTEGRATION.md shows the Clojure
+ * (Panama FFM / JNI) binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only.  Every function returns 0 on success or a negative
+ *    HNSWGPU_E* code; hnswgpu_last_error() returns a thread-local message.  No exception crosses
+ *    the boundary.
+ *  - Host-pointer entry points: the caller owns every host buffer; the library copies or consumes
+ *    it before returning.  `_dev` entry points take DEVICE pointers (e.g. a torch tensor's
+ *    data_ptr) plus a hipStream_t passed as void* (NULL = the index's own stream); they only
+ *    enqueue work and do not synchronise.
+ *  - Row ids are dense int32 in [0, n); the String-id <-> row table stays on the Clojure side
+ *    (UltraNode.id is a String, src/hnsw/ultra_fast.clj:99).
+ *  - Results are ascending by distance; fewer than k results are padded with id -1 / +inf
+ *    (the reference returns shorter seqs: test/hnsw/core_test.clj:90-96, ultra_fast.clj:349-351).
+ *  - Metrics: COSINE = 1 - dot/(|a||b|), 1.0 when a norm is 0 (ultra_fast.clj:53-95);
+ *    L2 = sqrt(sum (a-b)^2), rooted (ultra_fast.clj:43-51); DOT = -dot (ordering key for
+ *    simd-optimized/dot-product, simd_optimized.clj:283-293).
+ *  - Arithmetic is float32 on the device (the reference is float64): ids identical to the f64
+ *    reference order, distances within 1e-4 relative (BASELINE.json north_star).
+ *  - An index handle is safe for concurrent *_search calls from several host threads (calls are
+ *    serialised on the handle's stream); set_* / build calls must not overlap searches.
+ */
+#ifndef HNSWGPU_H
+#define HNSWGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HNSWGPU_VERSION 100
+
+#define HNSWGPU_COSINE 0
+#define HNSWGPU_L2 1
+#define HNSWGPU_DOT 2
+
+#define HNSWGPU_OK 0
+#define HNSWGPU_EINVAL (-1)   /* bad argument (null pointer, k < 1, dim unsupported ...)       */
+#define HNSWGPU_EHIP (-2)     /* HIP runtime error; message has the hipError string            */
+#define HNSWGPU_ESTATE (-3)   /* index lacks what the call needs (no graph / no IVF lists)      */
+#define HNSWGPU_ENOMEM (-4)   /* host or device allocation failed                               */
+#define HNSWGPU_ELIMIT (-5)   /* a documented limit exceeded (dim > 3072, ef > 4096, k > 1024)  */
+
+typedef struct hnswgpu_index hnswgpu_index;
+
+int hnswgpu_version(void);
+const char *hnswgpu_last_error(void);
+int hnswgpu_device_count(int32_t *count);
+
+/* ---- index lifetime ----------------------------------------------------------------------------
+ * Replaces the data-map of the reference indexes: ConcurrentHashMap<String,UltraNode{double[]}>
+ * (ultra_fast.clj:99-111) / IVFFlatIndex.data-map (ivf_flat.clj:22-27).  `base` is n x dim float32
+ * row-major host memory; it is copied to one contiguous HBM matrix (rows padded to 16 B) and the
+ * per-row norms are precomputed on the device (ivf_flat.clj:171-177, simd_optimized.clj:206-216).
+ * n == 0 is legal (empty index: every search returns no results, ultra_fast.clj:349-351). */
+int hnswgpu_create(const float *base, int64_t n, int32_t dim, int32_t metric, int32_t device,
+                   hnswgpu_index **out);
+/* Same, from a device-resident n x dim matrix with row stride ld floats (copied). */
+int hnswgpu_create_dev(const float *d_base, int64_t n, int32_t dim, int64_t ld, int32_t metric, int32_t device,
+                       void *stream, hnswgpu_index **out);
+int hnswgpu_destroy(hnswgpu_index *idx);
+int hnswgpu_info(const hnswgpu_index *idx, int64_t *n, int32_t *dim, int32_t *metric, int32_t *has_graph,
+                 int32_t *nlist);
+int hnswgpu_sync(hnswgpu_index *idx);
+
+/* ---- distance seams ------------------------------------------------------------------------------
+ * hnswgpu_pair_distance: the :distance-fn signature (fn ^double [^doubles a ^doubles b])
+ *   (ultra_fast.clj:43-95, simd_optimized.clj:145-160,283-293), one pair, computed on the device.
+ * hnswgpu_batch_distances: simd-optimized/batch-cosine-distances, batch-euclidean-distances
+ *   [query vectors] -> distances (simd_optimized.clj:164-184): q vs base rows ids[0..m) (ids NULL =
+ *   rows 0..m-1).  This is the gather-dot used per hop inside HNSW (ultra_fast.clj:185-204).
+ * hnswgpu_norms: simd-optimized/precompute-norms (simd_optimized.clj:206-216).
+ * hnswgpu_exact_knn: bench/compute-exact-knn (src/hnsw/bench.clj:72-84) and
+ *   simd-optimized/top-k-distances (simd_optimized.clj:271-280): brute force over the full base. */
+int hnswgpu_pair_distance(int32_t metric, const float *a, const float *b, int32_t dim, int32_t device, float *out);
+int hnswgpu_batch_distances(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out);
+int hnswgpu_norms(hnswgpu_index *idx, float *out_norms);
+int hnswgpu_exact_knn(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t *out_ids,
+                      float *out_dist);
+int hnswgpu_exact_knn_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t *d_out_ids,
+                          float *d_out_dist, void *stream);
+
+/* ---- HNSW ---------------------------------------------------------------------------------------
+ * Graph layout (what UltraGraph's nodes / neighbor HashSets flatten to, ultra_fast.clj:99-111):
+ *   levels[n]                node level
+ *   l0_adj[n * M0]           layer-0 neighbours, -1 padded, adjacency-array order
+ *   up_off[n + 1]            prefix sum of levels: node i's layers 1..levels[i] are the blocks
+ *                            up_off[i] .. up_off[i+1]-1 of up_adj
+ *   up_adj[up_off[n] * M]    one block of M neighbours (-1 padded) per (node, layer >= 1)
+ *   entry, max_level         entry point and its level
+ * hnswgpu_set_graph uploads a graph built elsewhere (e.g. by the reference's own insert-single);
+ * hnswgpu_hnsw_build builds one on the device (batched insertion; replaces build-index /
+ * insert-batch ultra_fast.clj:303-344); hnswgpu_get_graph exports it in the same layout.
+ * hnswgpu_hnsw_search replaces search-knn (ultra_fast.clj:346-374) for a batch of queries -- the
+ * seam of BatchSearchIndex/search-batch* (api/protocol.clj:58-67) and parallel-search-futures
+ * (helper/parallel_search.clj:15-49).  ef is explicit; the reference's value is max(k, 50)
+ * (ultra_fast.clj:355): pass ef <= 0 to get it.  stats (optional, nq x 2 int64): distance
+ * evaluations and expansions per query. */
+int hnswgpu_set_graph(hnswgpu_index *idx, const int32_t *levels, const int32_t *l0_adj, int32_t M0,
+                      const int64_t *up_off, const int32_t *up_adj, int32_t M, int32_t entry, int32_t max_level);
+int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, int64_t seed);
+int hnswgpu_graph_sizes(const hnswgpu_index *idx, int32_t *M, int32_t *M0, int64_t *up_blocks, int32_t *entry,
+                        int32_t *max_level);
+int hnswgpu_get_graph(const hnswgpu_index *idx, int32_t *levels, int32_t *l0_adj, int64_t *up_off,
+                      int32_t *up_adj);
+int hnswgpu_hnsw_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t ef, int32_t *out_ids,
+                        float *out_dist, int64_t *stats);
+int hnswgpu_hnsw_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t ef,
+                            int32_t *d_out_ids, float *d_out_dist, int64_t *d_stats, void *stream);
+
+/* ---- IVF-FLAT -------------------------------------------------------------------------------------
+ * hnswgpu_ivf_build: build-ivf-flat-index :partition-method :kmeans (ivf_flat.clj:137-211):
+ *   k-means++ seeding with java.util.Random(seed) (:32-60), max_iter Lloyd iterations (:92-131),
+ *   final assignment, inverted lists in index order.  seed 42 is the reference's.
+ * hnswgpu_set_ivf / hnswgpu_get_ivf: import / export centroids (nlist x dim f32), list_off[nlist+1],
+ *   list_ids[n] (row ids in list order).
+ * hnswgpu_kmeans_assign: assign-to-nearest-centroid for every base row (ivf_flat.clj:79-90):
+ *   strict <, lowest index wins ties.
+ * hnswgpu_ivf_search: search-ivf-flat (ivf_flat.clj:236-294) with explicit nprobe for a batch of
+ *   queries: centroid routing (:261-269), brute-force scan of the probed lists with precomputed
+ *   norms (:217-234), merge, take k.  out_probes optional (nq x nprobe list ids). */
+int hnswgpu_ivf_build(hnswgpu_index *idx, int32_t nlist, int32_t max_iter, int64_t seed);
+int hnswgpu_set_ivf(hnswgpu_index *idx, const float *centroids, int32_t nlist, const int64_t *list_off,
+                    const int32_t *list_ids);
+int hnswgpu_get_ivf(const hnswgpu_index *idx, float *centroids, int64_t *list_off, int32_t *list_ids);
+int hnswgpu_kmeans_assign(hnswgpu_index *idx, const float *centroids, int32_t nlist, int32_t *out_assign,
+                          float *out_dist);
+int hnswgpu_kmeanspp(hnswgpu_index *idx, int32_t nlist, int64_t seed, int32_t *out_rows);
+int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t nprobe,
+                       int32_t *out_ids, float *out_dist, int32_t *out_probes);
+int hnswgpu_ivf_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
+                           int32_t *d_out_ids, float *d_out_dist, void *stream);
+/* Same scan with caller-chosen lists instead of centroid routing: probes[nq][nprobe] list ids
+ * (-1 = skip).  This is search-ivf-flat's :use-centroids false path (the :turbo mode's random
+ * partitions, ivf_flat.clj:243-251,271-272) and lightning's partition scan (lightning.clj:144-187). */
+int hnswgpu_ivf_search_lists(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t nprobe,
+                             const int32_t *probes, int32_t *out_ids, float *out_dist);
+
+/* ---- multi-GPU merge --------------------------------------------------------------------------------
+ * Merge `nshard` per-shard top-k lists (what RCCL all-gather delivers) into the global top-k:
+ * the partitioned_hnsw.clj:171-196 gather/sort/take-k step.  d_ids/d_dist: [nshard][nq][k] device
+ * arrays of GLOBAL ids (-1 padded) and distances; ties keep the lower shard first. */
+int hnswgpu_merge_topk_dev(int32_t device, const int32_t *d_ids, const float *d_dist, int32_t nshard, int32_t nq,
+                           int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream);
+
+/* ---- measurement --------------------------------------------------------------------------------------
+ * With profiling on, the dominant kernel of each search call is bracketed by hipEvents on the
+ * launch stream.  which: 0 = IVF list scan, 1 = HNSW traversal, 2 = k-means assignment scan.
+ * Returns the accumulated kernel ms and launch count since the last reset (forces a stream sync). */
+int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
+int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int64_t *launches, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNSWGPU_H */

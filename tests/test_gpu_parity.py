@@ -1,0 +1,367 @@
+"""GPU parity tests: the HIP path (through the C ABI of libhnswgpu.so) against the CPU oracle.
+
+Two bars, both from BASELINE.json's north_star:
+  * vs the oracle's f64 reference-order mode: identical top-k id sets (modulo ties inside the
+    tolerance at the k-th boundary), distances within 1e-4 relative (+1e-6 absolute)  -> util.assert_topk_parity
+  * vs the oracle's device-order f32 mode (a bit-mimic of the kernels' summation order): ids
+    IDENTICAL, distances BIT-identical, traversal counters (distance evaluations, expansions) equal
+    -> util.assert_exact.  This is the bit-exact bar for the index/integer side of the path.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from util import assert_exact, assert_topk_parity, close  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+METRIC_NAMES = {0: "cos", 1: "l2", 2: "dot"}
+
+
+@pytest.fixture(scope="module")
+def eng(native_lib):
+    from hnsw_clj_amd import engine
+
+    assert engine.device_count() >= 1, "no GPU visible"
+    return engine
+
+
+def _data(oracle, n, dim, dist="gaussian", seed=42, **kw):
+    return oracle.generate_dataset(n, dim, dist, seed=seed, **kw).astype(np.float32)
+
+
+# ---- the :distance-fn seam, on the reference's own known answers ------------------------------------
+def test_pair_distance_reference_kats(eng):
+    # test/hnsw/core_test.clj:9-31, test/simple_test.clj:33-41, test/hnsw/graph_test.clj:11-22
+    assert eng.pair_distance("l2", [1, 2, 3], [1, 2, 3]) == 0.0
+    assert eng.pair_distance("l2", [0, 0], [3, 4]) == 5.0
+    assert abs(eng.pair_distance("l2", [1, 2, 3], [4, 5, 6]) - 5.196152422706632) < 1e-5
+    assert 1.73 < eng.pair_distance("l2", [1, 2, 3], [2, 3, 4]) < 1.74
+    assert eng.pair_distance("cosine", [1, 2, 3], [1, 2, 3]) < 1e-3
+    assert abs(eng.pair_distance("cosine", [1, 0], [-1, 0]) - 2.0) < 1e-3
+    assert abs(eng.pair_distance("cosine", [1, 0], [0, 1]) - 1.0) < 1e-3
+    assert abs(eng.pair_distance("cosine", [1, 2, 3], [4, 5, 6]) - 0.025368153802923787) < 1e-6
+    assert eng.pair_distance("cosine", [0, 0, 0], [1, 2, 3]) == 1.0      # zero-norm guard, ultra_fast.clj:92-95
+    assert eng.pair_distance("dot", [1, 2, 3], [4, 5, 6]) == -32.0
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3, 5, 64, 100, 128, 257, 768, 1000, 1536, 3072])
+def test_batch_distances_and_norms(eng, oracle, dim):
+    O = oracle
+    n = 70
+    base = _data(O, n, dim)
+    q = _data(O, 1, dim, seed=43)[0]
+    for metric in (O.COSINE, O.L2, O.DOT):
+        with eng.Index(base, metric) as idx:
+            d = idx.batch_distances(q)
+            want_dev = np.array([O.distance_dev(metric, q, base[i]) for i in range(n)], np.float32)
+            np.testing.assert_array_equal(d.view(np.uint32), want_dev.view(np.uint32))
+            want64 = np.array([O.distance(metric, q, base[i]) for i in range(n)])
+            assert close(d, want64).all()
+            ids = np.array([5, 0, 69, 5, 33], np.int32)                 # gather, with a repeat
+            np.testing.assert_array_equal(idx.batch_distances(q, ids), d[ids])
+            bad = idx.batch_distances(q, np.array([3, n, -1], np.int32))  # out-of-range ids -> NaN, no fault
+            assert bad[0] == d[3] and np.isnan(bad[1]) and np.isnan(bad[2])
+            if metric == O.COSINE:
+                np.testing.assert_array_equal(idx.norms().view(np.uint32), O.norms(base, O.MODE_DEV).view(np.uint32))
+                assert np.allclose(idx.norms(), np.linalg.norm(base.astype(np.float64), axis=1), rtol=1e-6)
+
+
+def test_dim_limit_and_bad_args(eng):
+    with pytest.raises(Exception, match="3072"):
+        eng.Index(np.zeros((2, 3073), np.float32))
+    with eng.Index(np.ones((4, 8), np.float32)) as idx:
+        with pytest.raises(ValueError):
+            idx.batch_distances(np.ones(7, np.float32))
+        with pytest.raises(Exception, match="no graph"):
+            idx.hnsw_search(np.ones(8, np.float32), 2)
+        with pytest.raises(Exception, match="no IVF"):
+            idx.ivf_search(np.ones(8, np.float32), 2, 1)
+        with pytest.raises(Exception, match="k must be"):
+            idx.exact_knn(np.ones(8, np.float32), 0)
+
+
+# ---- exact kNN (bench.clj:72-84) ------------------------------------------------------------------------
+@pytest.mark.parametrize("n,dim,k", [(1, 4, 3), (33, 7, 5), (1000, 128, 10), (5000, 96, 64), (300, 768, 100)])
+def test_exact_knn(eng, oracle, n, dim, k):
+    O = oracle
+    base = _data(O, n, dim)
+    Q = np.vstack([_data(O, 9, dim, seed=43), base[:3]])
+    for metric in (O.COSINE, O.L2, O.DOT):
+        with eng.Index(base, metric) as idx:
+            ids, d = idx.exact_knn(Q, k)
+        oi, od, _ = O.exact_knn(base, Q, k, metric=metric, mode=O.MODE_DEV)
+        assert_exact(ids, d, oi, od, "exact dev n=%d" % n)
+        fi, fd, _ = O.exact_knn(base, Q, k, metric=metric)
+        assert_topk_parity(ids, d, fi, fd, "exact f64 n=%d" % n)
+        if k > n:
+            assert (ids[:, n:] == -1).all() and np.isinf(d[:, n:]).all()
+
+
+# ---- HNSW search on FIXED graphs (the committed golden adjacency) -----------------------------------------
+@pytest.mark.parametrize("name", ["g256x64", "c1000x128"])
+def test_hnsw_search_golden(eng, oracle, name):
+    import make_golden
+
+    O = oracle
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    base, Q = make_golden.inputs(name)
+    for metric, m in METRIC_NAMES.items():
+        g = O.Graph(gold[m + "_levels"], gold[m + "_l0"].astype(np.int32), gold[m + "_up_off"],
+                    gold[m + "_up"].astype(np.int32), 8, int(gold[m + "_entry"]), int(gold[m + "_maxl"]))
+        with eng.Index(base, metric) as idx:
+            idx.set_graph(g)
+            ids, d, st = idx.hnsw_search(Q, 10, 50, want_stats=True)
+            # golden = f64 reference-order results
+            assert_topk_parity(ids, d, gold[m + "_hnsw_ids"], gold[m + "_hnsw_d"], name + " " + m)
+            # device-order oracle: everything identical, including the traversal itself
+            oi, od, ost, _ = O.hnsw_search(base, g, Q, 10, ef=50, metric=metric, mode=O.MODE_DEV)
+            assert_exact(ids, d, oi, od, name + " " + m)
+            np.testing.assert_array_equal(st, ost, err_msg="distance evaluations / expansions differ")
+            # export == import
+            g2 = idx.get_graph()
+            assert np.array_equal(g2.l0_adj, g.l0_adj) and np.array_equal(g2.up_adj, g.up_adj) and g2.entry == g.entry
+
+
+@pytest.mark.parametrize("ef,k", [(1, 1), (10, 10), (50, 10), (200, 10), (333, 100), (1024, 10)])
+def test_hnsw_search_ef_sweep(eng, oracle, ef, k):
+    O = oracle
+    base = _data(O, 3000, 64, "clustered", num_clusters=20, noise_level=0.5)
+    Q = _data(O, 12, 64, "clustered", num_clusters=20, noise_level=0.5, seed=43)
+    g = O.hnsw_build(base, O.COSINE, M=16, ef_construction=100, mode=O.MODE_FAST)
+    with eng.Index(base, "cosine") as idx:
+        idx.set_graph(g)
+        ids, d, st = idx.hnsw_search(Q, k, ef, want_stats=True)
+    oi, od, ost, _ = O.hnsw_search(base, g, Q, k, ef=ef, mode=O.MODE_DEV)
+    assert_exact(ids, d, oi, od, "ef=%d" % ef)
+    np.testing.assert_array_equal(st, ost)
+    fi, fd, _, _ = O.hnsw_search(base, g, Q, k, ef=ef)
+    assert_topk_parity(ids, d, fi, fd, "ef=%d f64" % ef)
+
+
+def test_hnsw_collisions_and_zero_vectors(eng, oracle):
+    """Duplicate rows give exact distance ties (the evicted-but-tied 'ghost' rule of the traversal),
+    zero rows hit the cosine guard."""
+    O = oracle
+    rs = np.random.RandomState(7)
+    uniq = rs.randn(40, 16).astype(np.float32)
+    base = uniq[rs.randint(0, 40, 600)]            # every row has ~15 exact duplicates
+    base[::50] = 0.0
+    Q = np.vstack([uniq[:6], np.zeros((1, 16), np.float32), rs.randn(5, 16).astype(np.float32)])
+    for metric in (O.COSINE, O.L2):
+        g = O.hnsw_build(base, metric, M=6, ef_construction=40, mode=O.MODE_DEV)
+        with eng.Index(base, metric) as idx:
+            idx.set_graph(g)
+            for ef in (1, 5, 20, 64):
+                ids, d, st = idx.hnsw_search(Q, 5, ef, want_stats=True)
+                oi, od, ost, _ = O.hnsw_search(base, g, Q, 5, ef=ef, metric=metric, mode=O.MODE_DEV)
+                assert_exact(ids, d, oi, od, "dups ef=%d metric=%d" % (ef, metric))
+                np.testing.assert_array_equal(st, ost)
+
+
+def test_hnsw_edge_cases(eng, oracle):
+    O = oracle
+    # empty index -> [] (ultra_fast.clj:349-351, core_test.clj:63-68)
+    with eng.Index(np.zeros((0, 3), np.float32)) as idx:
+        idx.hnsw_build()
+        ids, d = idx.hnsw_search([1, 2, 3], 5)
+        assert (ids == -1).all() and np.isinf(d).all()
+    # single vector (core_test.clj:70-78)
+    one = np.array([[1.0, 2.0, 3.0, 4.0]], np.float32)
+    with eng.Index(one) as idx:
+        idx.hnsw_build()
+        ids, d = idx.hnsw_search(one[0], 1)
+        assert ids[0, 0] == 0 and d[0, 0] < 1e-3
+    # k > n (core_test.clj:90-96)
+    five = _data(O, 5, 64)
+    with eng.Index(five) as idx:
+        idx.hnsw_build()
+        ids, d = idx.hnsw_search(five[0], 10)
+        assert (ids[0] >= 0).sum() == 5 and sorted(ids[0][:5].tolist()) == [0, 1, 2, 3, 4]
+    # malformed graphs are rejected, not run
+    with eng.Index(five) as idx:
+        g = O.hnsw_build(five)
+        bad = O.Graph(g.levels, g.l0_adj.copy(), g.up_off, g.up_adj, g.M, g.entry, g.max_level)
+        bad.l0_adj[0, 0] = 99
+        with pytest.raises(Exception, match="out of range"):
+            idx.set_graph(bad)
+
+
+def test_hnsw_build_on_device(eng, oracle):
+    """hnswgpu_hnsw_build: a valid graph (re-importable), reference level distribution, and recall
+    comparable to the oracle's sequential reference-structure build."""
+    O = oracle
+    base = _data(O, 4000, 64, "clustered", num_clusters=30, noise_level=0.6)
+    Q = _data(O, 64, 64, "clustered", num_clusters=30, noise_level=0.6, seed=43)
+    ex, _, _ = O.exact_knn(base, Q, 10, mode=O.MODE_FAST)
+    with eng.Index(base) as idx:
+        idx.hnsw_build(16, 200, 42)
+        g = idx.get_graph()
+        # levels follow floor(-ln U / ln 2) of java.util.Random(42) (ultra_fast.clj:133,143-147)
+        r = O.JavaRandom(42)
+        want = [min(int((1.0 / np.log(2.0)) * -np.log(r.next_double())), 30) for _ in range(4000)]
+        assert g.levels.tolist() == want
+        assert g.levels[g.entry] == g.max_level == max(want)
+        deg = (g.l0_adj >= 0).sum(1)
+        assert deg.min() >= 1 and deg.max() <= 32
+        idx.set_graph(g)  # passes the validator
+        ids, d = idx.hnsw_search(Q, 10, 100)
+        rec_gpu_graph = O.recall(ids, ex)
+        # same graph searched by the oracle gives the same answer
+        oi, od, _, _ = O.hnsw_search(base, g, Q, 10, ef=100, mode=O.MODE_DEV)
+        assert_exact(ids, d, oi, od, "gpu-built graph")
+    g_ref = O.hnsw_build(base, O.COSINE, 16, 200, 42, mode=O.MODE_FAST)
+    ri, _, _, _ = O.hnsw_search(base, g_ref, Q, 10, ef=100, mode=O.MODE_FAST)
+    rec_ref = O.recall(ri, ex)
+    assert rec_gpu_graph >= 0.9 and rec_gpu_graph >= rec_ref - 0.03, (rec_gpu_graph, rec_ref)
+
+
+# ---- IVF-FLAT -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g256x64", "c1000x128"])
+def test_ivf_build_golden(eng, oracle, name):
+    import make_golden
+
+    O = oracle
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    base, Q = make_golden.inputs(name)
+    with eng.Index(base) as idx:
+        np.testing.assert_array_equal(idx.kmeanspp(16), gold["ivf_kpp"])      # same D^2 samples as the f64 path
+        a, d = idx.kmeans_assign(gold["ivf_cent"])
+        oa, od = O.kmeans_assign(base, gold["ivf_cent"].astype(np.float64))
+        flips = np.flatnonzero(a != oa)
+        for i in flips:  # an assignment may only differ where the two best centroids tie within tolerance
+            dd = np.sort([O.distance(O.COSINE, base[i], c) for c in gold["ivf_cent"]])
+            assert dd[1] - dd[0] <= 1e-4 * abs(dd[0]) + 1e-6
+        assert close(d, od).all()
+        idx.ivf_build(16, 10, 42)
+        cen, off, lids = idx.get_ivf()
+        assign = np.empty(len(base), np.int64)
+        for l in range(16):
+            assign[lids[off[l]:off[l + 1]]] = l
+            assert np.all(np.diff(lids[off[l]:off[l + 1]]) > 0)               # index order inside a list
+        assert (assign != gold["ivf_assign"]).mean() <= 0.01
+        if np.array_equal(assign, gold["ivf_assign"]):
+            assert np.allclose(cen, gold["ivf_cent"], rtol=1e-5, atol=1e-6)
+        # search: bit-exact vs the device-order oracle on the engine's own lists / centroids
+        for nprobe, k in [(1, 10), (4, 10), (16, 10), (4, 40)]:
+            ids, dist, pr = idx.ivf_search(Q, k, nprobe, want_probes=True)
+            oi, odist, opr = O.ivf_search(base, cen, off, lids, Q, k, nprobe, mode=O.MODE_DEV)
+            np.testing.assert_array_equal(pr, opr)
+            assert_exact(ids, dist, oi, odist, "ivf nprobe=%d" % nprobe)
+            fi, fd, _ = O.ivf_search(base, cen, off, lids, Q, k, nprobe)
+            assert_topk_parity(ids, dist, fi, fd, "ivf f64 nprobe=%d" % nprobe)
+        # caller-chosen lists (the :turbo path)
+        probes = np.tile(np.array([[3, -1, 7]], np.int32), (len(Q), 1))
+        ids, dist = idx.ivf_search_lists(Q, 5, probes)
+        members = set(lids[off[3]:off[4]].tolist()) | set(lids[off[7]:off[8]].tolist())
+        assert all(i in members for i in ids.ravel() if i >= 0)
+
+
+def test_ivf_ragged_lists_and_full_probe(eng, oracle):
+    """Empty lists, a list holding almost everything, nprobe > nlist, k > candidates."""
+    O = oracle
+    base = _data(O, 700, 48)
+    Q = _data(O, 10, 48, seed=43)
+    rs = np.random.RandomState(3)
+    assign = np.where(rs.rand(700) < 0.8, 2, rs.randint(0, 9, 700))   # list 2 is huge
+    assign[assign == 5] = 6                                          # list 5 is empty
+    cen = _data(O, 9, 48, seed=99)
+    off, lids = O.lists_from_assign(assign, 9)
+    with eng.Index(base) as idx:
+        idx.set_ivf(cen, off, lids)
+        for nprobe, k in [(1, 5), (3, 10), (9, 10), (50, 10), (2, 300)]:
+            ids, d = idx.ivf_search(Q, k, nprobe)
+            oi, od, _ = O.ivf_search(base, cen, off, lids, Q, k, nprobe, mode=O.MODE_DEV)
+            assert_exact(ids, d, oi, od, "ragged nprobe=%d k=%d" % (nprobe, k))
+        # probing every list == exact kNN (size-independent property)
+        ids, d = idx.ivf_search(Q, 10, 9)
+        ei, ed = idx.exact_knn(Q, 10)
+        np.testing.assert_array_equal(np.sort(ids, 1), np.sort(ei, 1))
+        with pytest.raises(Exception, match="two lists"):
+            idx.set_ivf(cen, off, np.zeros_like(lids))
+
+
+# ---- BASELINE.json full-size shapes: size-independent properties --------------------------------------------
+def test_full_size_31k_properties(eng, oracle):
+    """31,173 x 768 (configs[0]/[1]): sortedness, idempotence, self-match, GPU brute force as ground
+    truth for recall, IVF(all lists) == exact."""
+    from hnsw_clj_amd import datagen
+
+    base = datagen.generate_dataset(31173, 768)
+    Q = np.vstack([base[:100], datagen.generate_dataset(100, 768, seed=43)])
+    with eng.Index(base) as idx:
+        ei, ed = idx.exact_knn(Q, 10)
+        assert (ei[:100, 0] == np.arange(100)).all() and (np.abs(ed[:100, 0]) < 1e-5).all()
+        assert (np.diff(ed, axis=1) >= 0).all()
+        idx.hnsw_build(16, 200, 42)
+        ids, d, st = idx.hnsw_search(Q, 10, 200, want_stats=True)
+        ids2, d2 = idx.hnsw_search(Q, 10, 200)
+        assert np.array_equal(ids, ids2) and np.array_equal(d.view(np.uint32), d2.view(np.uint32))
+        assert (np.diff(d, axis=1) >= 0).all() and (ids >= 0).all() and (ids < 31173).all()
+        assert all(len(set(r.tolist())) == 10 for r in ids)
+        assert (ids[:100, 0] == np.arange(100)).all()
+        # every returned distance is the true distance of that id
+        for q in (0, 57, 150):
+            np.testing.assert_array_equal(idx.batch_distances(Q[q], ids[q]).view(np.uint32), d[q].view(np.uint32))
+        assert oracle.recall(ids[:100], ei[:100]) >= 0.9
+        assert st[:, 0].min() > 200 and st[:, 1].min() >= 200
+        idx.ivf_build(24, 2, 42)   # the reference's default nlist (ivf_flat.clj:144); 2 Lloyd passes keep it short
+        ii, dd = idx.ivf_search(Q, 10, 24)
+        np.testing.assert_array_equal(ii, ei)
+        np.testing.assert_array_equal(dd.view(np.uint32), ed.view(np.uint32))
+
+
+def test_merge_topk_dev(eng):
+    import torch
+
+    rs = np.random.RandomState(0)
+    ns, nq, k = 4, 37, 10
+    d = np.sort(rs.rand(ns, nq, k).astype(np.float32), axis=2)
+    ids = rs.randint(0, 1 << 30, (ns, nq, k)).astype(np.int32)
+    ids[1, :, 7:] = -1
+    d[1, :, 7:] = np.inf
+    d[2, 5, 0] = d[0, 5, 0]                        # a cross-shard tie: lower shard first
+    oi, od = eng.merge_topk_dev(torch.from_numpy(ids).cuda(), torch.from_numpy(d).cuda())
+    oi, od = oi.cpu().numpy(), od.cpu().numpy()
+    for q in range(nq):
+        flat = [(d[s, q, r], s * k + r, ids[s, q, r]) for s in range(ns) for r in range(k) if ids[s, q, r] >= 0]
+        flat.sort()
+        assert [x[2] for x in flat[:k]] == oi[q].tolist()
+        assert np.array_equal(np.array([x[0] for x in flat[:k]], np.float32), od[q])
+
+
+# ---- the Python mirror of the reference API (names / shapes / edge cases of core_test.clj) ---------------
+def test_reference_api_mirror(eng, oracle):
+    from hnsw_clj_amd import datagen, ivf_flat, parallel_search, protocol, simd_optimized, ultra_fast
+
+    vecs = datagen.generate_dataset(100, 128)
+    data = datagen.indexed(vecs)                                     # [["vec_0", v] ...]
+    index = ultra_fast.build_index(data, show_progress=False)
+    res = ultra_fast.search_knn(index, vecs[0], 5)                   # core_test.clj:33-47
+    assert len(res) == 5 and all("id" in r and "distance" in r for r in res)
+    assert res[0]["id"] == "vec_0" and res[0]["distance"] < 0.01
+    assert ultra_fast.search_knn(ultra_fast.build_index([], show_progress=False), [1, 2, 3], 5) == []
+    batch = parallel_search.parallel_search_futures(index, list(vecs[:20]), 10, ultra_fast.search_knn, 8)
+    assert len(batch) == 20 and all(len(r) == 10 for r in batch)     # core_test.clj:112-121
+    assert batch[3] == ultra_fast.search_knn(index, vecs[3], 10)
+    assert protocol.GpuHnswIndex(index).search_batch_star(vecs[:3], 4)[2] == ultra_fast.search_knn(index, vecs[2], 4)
+    assert ultra_fast.graph_info(index)["num-elements"] == 100
+    index.close()
+    l2 = ultra_fast.build_index(data, distance_fn=simd_optimized.euclidean_distance, show_progress=False)
+    assert ultra_fast.search_knn(l2, vecs[7], 1)[0] == {"id": "vec_7", "distance": 0.0}
+    l2.close()
+    ivf = ivf_flat.build_index(data, num_partitions=8, show_progress=False)
+    r = ivf_flat.search_knn(ivf, vecs[5], 3, "precise")
+    assert r[0]["id"] == "vec_5" and len(r) == 3
+    assert len(ivf_flat.search_knn(ivf, vecs[5], 3, "turbo")) == 3
+    assert ivf_flat.index_info(ivf)["partitions"] == 8
+    ivf.close()
+    assert simd_optimized.cosine_distance([1, 0], [-1, 0]) == 2.0
+    assert simd_optimized.dot_product([1, 2, 3], [4, 5, 6]) == 32.0
+    bd = simd_optimized.batch_cosine_distances(vecs[0], vecs[:10])
+    assert bd.shape == (10,) and abs(bd[0]) < 1e-6
+    top = simd_optimized.top_k_distances(simd_optimized.euclidean_distance, vecs[0], vecs, 3)
+    assert top[0] == [0, 0.0] and len(top) == 3
