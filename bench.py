@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline benchmark on MI355X.
+
+Metric (BASELINE.json): QPS @ recall@10 >= 0.98 on 31,173 x 768 float32, k = 10 (HNSW, M=16,
+ef_construction=200 -- the protocol of src/hnsw/wip/reproduce_02ms.clj), plus the IVF-FLAT list scan's
+achieved HBM GB/s against the roofline (1M x 768, nlist=1024, nprobe=32).
+
+A "step" is one pass of the hot path over one batch of `--nq` queries already resident in HBM:
+one hnswgpu_hnsw_search_dev launch.  With N > 1 every rank holds a replica of the 31k index and its
+own query batch (the 31k x 768 index fits one GPU, so the queries are what shard: "replicas", no
+collective on the data path); value = all ranks' queries / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+N31K, DIM, K = 31173, 768, 10
+M, EFC = 16, 200
+EF_SWEEP = [50, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096]
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_31k(distribution, seed, n):
+    """S1 of BASELINE.md: java.util.Random-compatible generator (test/data_generator.clj).  'clustered' =
+    256 gaussian centres, noise 0.3, L2-normalised (the stand-in for the normalised sentence
+    embeddings the reference's published run used); 'gaussian' = i.i.d. N(0,1)."""
+    from hnsw_clj_amd import datagen
+
+    if distribution == "manifold":
+        # Latent-manifold stand-in for the normalised sentence embeddings of the published run (the real
+        # data set is not in the repository): x = normalise(W z / sqrt(r) + 0.1 e), z in R^32, all draws from
+        # the java.util.Random-compatible generator.  Intrinsic dimension ~32, no isolated clusters.
+        r = 32
+        z = datagen.generate_dataset(n, r, seed=seed, dtype=np.float64)
+        w = datagen.generate_dataset(r, DIM, seed=7, dtype=np.float64)
+        e = datagen.generate_dataset(n, DIM, seed=seed + 1000, dtype=np.float64)
+        x = z @ w / np.sqrt(r) + 0.1 * e
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        return x.astype(np.float32)
+    if distribution == "clustered":
+        x = datagen.generate_dataset(n, DIM, "clustered", num_clusters=256, noise_level=0.3, seed=seed,
+                                     dtype=np.float64)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        return x.astype(np.float32)
+    return datagen.generate_dataset(n, DIM, distribution, seed=seed)
+
+
+def recall_at_k(ids, truth):
+    """bench.clj:86-92 calc-recall on id sets, averaged over queries (torch, on device)."""
+    hit = (ids.unsqueeze(2) == truth.unsqueeze(1)).any(dim=2).sum(dim=1).float()
+    return float((hit / truth.shape[1]).mean())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nq", type=int, default=10000, help="queries per step per GPU")
+    ap.add_argument("--ef", type=int, default=0, help="0 = first ef of the sweep with recall@10 >= 0.98")
+    ap.add_argument("--dist", default="manifold", choices=["manifold", "clustered", "gaussian", "uniform"])
+    ap.add_argument("--no-ivf", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--ivf-n", type=int, default=1_000_000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from hnsw_clj_amd import engine
+
+    # ------------------------------------------------------------------ HNSW 31k x 768 (configs[1])
+    t0 = time.time()
+    base = make_31k(args.dist, 42, N31K)
+    queries = make_31k(args.dist, 43 + rank, args.nq)            # held-out, per-rank batch
+    log("[rank %d] data %.1fs" % (rank, time.time() - t0))
+    idx = engine.Index(base, "cosine", local_rank)
+    t0 = time.time()
+    idx.hnsw_build(M, EFC, 42)
+    build_s = time.time() - t0
+    log("[rank %d] hnsw build on device %.2fs" % (rank, build_s))
+    Q = torch.from_numpy(queries).to(dev)
+    n_eval = min(1000, args.nq)
+    truth, _ = idx.exact_knn_dev(Q[:n_eval], K)                   # ground truth over the FULL base (bench.clj:72-84)
+    sweep = []
+    ef = args.ef
+    rec = None
+    if ef <= 0:
+        for e in EF_SWEEP:
+            ids, _ = idx.hnsw_search_dev(Q[:n_eval], K, e)
+            r = recall_at_k(ids, truth)
+            sweep.append([e, round(r, 4)])
+            if r >= 0.98:
+                ef, rec = e, r
+                break
+        if ef <= 0:
+            ef, rec = EF_SWEEP[-1], sweep[-1][1]
+    else:
+        ids, _ = idx.hnsw_search_dev(Q[:n_eval], K, ef)
+        rec = recall_at_k(ids, truth)
+    if world > 1:  # every rank times the same ef (rank 0's)
+        t = torch.tensor([ef], device=dev)
+        dist.broadcast(t, 0)
+        ef = int(t.item())
+    # reference protocol: the first 100 base rows as queries (reproduce_02ms.clj:38)
+    Q100 = torch.from_numpy(base[:100]).to(dev)
+    t100, _ = idx.exact_knn_dev(Q100, K)
+    i100, _ = idx.hnsw_search_dev(Q100, K, ef)
+    rec100 = recall_at_k(i100, t100)
+
+    out_ids = torch.empty((args.nq, K), dtype=torch.int32, device=dev)
+    out_d = torch.empty((args.nq, K), dtype=torch.float32, device=dev)
+    stats = torch.zeros((args.nq, 2), dtype=torch.int64, device=dev)
+    idx.hnsw_search_dev(Q, K, ef, out=(out_ids, out_d), stats=stats)
+    torch.cuda.synchronize()
+    evals = float(stats[:, 0].double().mean())
+    hops = float(stats[:, 1].double().mean())
+
+    for _ in range(args.warmup):
+        idx.hnsw_search_dev(Q, K, ef, out=(out_ids, out_d))
+    idx.set_profiling(True)
+    idx.get_profile(engine.PROF_HNSW, reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx.hnsw_search_dev(Q, K, ef, out=(out_ids, out_d))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms, kern_n = idx.get_profile(engine.PROF_HNSW, reset=True)
+    idx.set_profiling(False)
+    qps = world * args.nq * args.steps / elapsed
+    # single-query latency (configs[1] "single-query latency"): one query per launch
+    torch.cuda.synchronize()
+    lat = []
+    for i in range(50):
+        t1 = time.perf_counter()
+        idx.hnsw_search_dev(Q[i:i + 1], K, ef, out=(out_ids[:1], out_d[:1]))
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat = sorted(lat[5:])
+
+    # algorithmic bytes of the traversal: E * 4*D + H * 4*M0 per query
+    hnsw_bytes_q = evals * 4 * DIM + hops * 4 * (2 * M)
+    hnsw_avg_ms = kern_ms / max(kern_n, 1)
+    hnsw_gbs = hnsw_bytes_q * args.nq / (hnsw_avg_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "QPS @ recall@10>=0.98 (31k x 768, k=10); IVF scan achieved HBM GB/s vs roofline",
+        "value": round(qps, 1),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "hnsw.ultra-optimized search-knn, 31,173 x 768 f32 (%s, java.util.Random seed 42), k=10, "
+                        "M=16 ef_construction=200, batched HIP traversal kernel" % args.dist,
+            "queries_per_step_per_gpu": args.nq,
+            "ef_search": ef,
+            "recall_at_10": round(rec, 4),
+            "recall_at_10_first100_base_rows": round(rec100, 4),
+            "ef_sweep": sweep,
+            "parallelism": "replicas x%d (index replicated, queries sharded, no collective)" % world,
+            "hnsw_build_s": round(build_s, 2),
+            "dist_evals_per_query": round(evals, 1),
+            "expansions_per_query": round(hops, 1),
+            "single_query_latency_ms": {"p50": round(lat[len(lat) // 2], 4), "min": round(lat[0], 4),
+                                        "p95": round(lat[int(len(lat) * 0.95)], 4)},
+        },
+        "roofline_hnsw": {"bound": "hbm", "achieved": round(hnsw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(hnsw_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                          "kernel": "hnsw_search_kernel", "avg_launch_ms": round(hnsw_avg_ms, 4),
+                          "note": "31k x 768 = 95.8 MB is Infinity-Cache resident: latency/occupancy bound, not HBM"},
+    }
+
+    # ------------------------------------------------------------------ IVF-FLAT scan roofline (configs[2])
+    if not args.no_ivf and rank == 0:
+        result["roofline"] = ivf_roofline(engine, dev, args)
+    elif rank == 0:
+        result["roofline"] = result["roofline_hnsw"]
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+    if not args.no_cpu and rank == 0 and world == 1:
+        result["cpu_baseline"] = cpu_baseline(idx, base, queries, ef)
+    idx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def ivf_roofline(engine, dev, args):
+    """1M x 768 clustered-normalised, nlist=1024, nprobe=32.  The timed kernel is the
+    list scan (scan_kernel over the probed lists); algorithmic bytes = sum over (query, probed list)
+    pairs of len * (4*D + 4)  [rows + precomputed norms], SURVEY 8(d)."""
+    n, nlist, nprobe = args.ivf_n, 1024, 32
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    centers = torch.randn(nlist, DIM, generator=g, device=dev)
+    which = torch.randint(0, nlist, (n,), generator=g, device=dev)
+    x = centers[which] + 0.3 * torch.randn(n, DIM, generator=g, device=dev)
+    x /= x.norm(dim=1, keepdim=True)
+    g.manual_seed(43)
+    nq_all = 1024
+    qw = torch.randint(0, nlist, (nq_all,), generator=g, device=dev)
+    Qa = centers[qw] + 0.3 * torch.randn(nq_all, DIM, generator=g, device=dev)
+    Qa /= Qa.norm(dim=1, keepdim=True)
+    idx = engine.Index(x, "cosine", dev.index)
+    del x
+    t0 = time.time()
+    idx.ivf_build(nlist, 10, 42)
+    build_s = time.time() - t0
+    log("ivf build (k-means++ + 10 Lloyd on device) %.1fs" % build_s)
+    _, off, _ = idx.get_ivf()
+    lens = np.diff(off)
+    out = {}
+    for nq in (32, 1024):
+        Q = Qa[:nq].contiguous()
+        _, _, probes = idx.ivf_search(Q.cpu().numpy(), K, nprobe, want_probes=True)
+        rows = int(lens[probes.ravel()].sum())
+        uniq = int(lens[np.unique(probes.ravel())].sum())
+        alg_bytes = rows * (4 * DIM + 4)
+        for _ in range(3):
+            idx.ivf_search_dev(Q, K, nprobe)
+        idx.set_profiling(True)
+        idx.get_profile(engine.PROF_IVF_SCAN, reset=True)
+        torch.cuda.synchronize()
+        steps = 20 if nq == 32 else 5
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            idx.ivf_search_dev(Q, K, nprobe)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps
+        ms, cnt = idx.get_profile(engine.PROF_IVF_SCAN, reset=True)
+        idx.set_profiling(False)
+        avg_ms = ms / max(cnt, 1)
+        out[nq] = {"nq": nq, "avg_scan_ms": round(avg_ms, 4), "search_wall_ms": round(wall * 1e3, 4),
+                   "qps": round(nq / wall, 1), "algorithmic_GB": round(alg_bytes / 1e9, 4),
+                   "unique_GB": round(uniq * (4 * DIM + 4) / 1e9, 4),
+                   "achieved_GBs": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
+                   "unique_GBs": round(uniq * (4 * DIM + 4) / (avg_ms * 1e-3) / 1e9, 1)}
+    # recall of the IVF configuration against exact kNN (GPU brute force)
+    ti, _ = idx.exact_knn_dev(Qa[:256].contiguous(), K)
+    ii, _ = idx.ivf_search_dev(Qa[:256].contiguous(), K, nprobe)
+    torch.cuda.synchronize()
+    rec = recall_at_k(ii, ti)
+    idx.close()
+    r = out[32]
+    return {"bound": "hbm", "achieved": r["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(r["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "scan_kernel",
+            "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch" % n,
+            "avg_launch_ms": r["avg_scan_ms"], "algorithmic_bytes_per_launch": int(r["algorithmic_GB"] * 1e9),
+            "unique_bytes_GBs": r["unique_GBs"], "batch_1024": out[1024], "batch_32": out[32],
+            "ivf_recall_at_10": round(rec, 4), "ivf_build_s": round(build_s, 1),
+            "mean_list_len": float(lens.mean()), "max_list_len": int(lens.max())}
+
+
+def cpu_baseline(idx, base, queries, ef):
+    """The oracle (CPU restatement of the reference algorithm, f64, sequential sums) on the same graph,
+    queries, ef and k, driven like parallel-search-futures (one task per query, T = nproc threads).
+    Bounded sample sized for ~10-15 s.  The reference's JVM cannot run here (no JVM in the image)."""
+    from oracle import oracle as O
+
+    g = idx.get_graph()
+    og = O.Graph(g.levels, g.l0_adj, g.up_off, g.up_adj, g.M, g.entry, g.max_level)
+    cores = os.cpu_count() or 1
+    pilot = min(len(queries), 4 * cores)
+    _, _, _, ms = O.hnsw_search(base, og, queries[:pilot], K, ef=ef, nthreads=cores)
+    nq = int(min(400000, max(pilot, 12000.0 * pilot / max(ms, 1e-3))))          # ~12 s of wall time
+    qs = np.resize(queries, (nq, queries.shape[1]))                              # tile the timed queries
+    _, _, _, ms = O.hnsw_search(base, og, qs, K, ef=ef, nthreads=cores)
+    n1 = max(16, min(nq, int(3000.0 / max(ms * cores / nq, 1e-3))))              # ~3 s single thread
+    _, _, _, ms1 = O.hnsw_search(base, og, qs[:n1], K, ef=ef, nthreads=1)
+    _, _, _, msf = O.hnsw_search(base, og, qs, K, ef=ef, mode=O.MODE_FAST, nthreads=cores)
+    return {"value": round(nq / (ms * 1e-3), 1), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": "%d queries (the timed batch, tiled), same graph/ef/k, f64 reference-order oracle, one task per "
+                      "query on %d threads (parallel_search.clj:15-49)" % (nq, cores),
+            "single_thread_qps": round(n1 / (ms1 * 1e-3), 1),
+            "fair_fight_f32_qps": round(nq / (msf * 1e-3), 1),
+            "published_reference": "5,376 QPS, 20 threads, Apple M4, JVM f64 (BENCHMARK_SUMMARY.md:16-17) -- other hardware"}
+
+
+if __name__ == "__main__":
+    main()

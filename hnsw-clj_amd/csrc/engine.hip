@@ -192,6 +192,18 @@ int scan_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_quer
     return 0;
 }
 
+int begin_call(hnswgpu_index *idx, hipStream_t st) {
+    if (idx->ev_valid && idx->ev_stream != st) HG_HIP(hipStreamWaitEvent(st, idx->ev_last, 0));
+    return 0;
+}
+int end_call(hnswgpu_index *idx, hipStream_t st) {
+    if (!idx->ev_last) HG_HIP(hipEventCreateWithFlags(&idx->ev_last, hipEventDisableTiming));
+    HG_HIP(hipEventRecord(idx->ev_last, st));
+    idx->ev_stream = st;
+    idx->ev_valid = true;
+    return 0;
+}
+
 int upload_queries(hnswgpu_index *idx, const float *Q, int32_t nq, hipStream_t st) {
     size_t bytes = sizeof(float) * static_cast<size_t>(nq) * idx->dim;
     HG_TRY(idx->s_q.ensure(bytes));
@@ -334,7 +346,7 @@ int hnswgpu_create_dev(const float *d_base, int64_t n, int32_t dim, int64_t ld, 
     HG_TRY(create_common(n, dim, metric, device, &idx));
     int rc = [&]() -> int {
         HG_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
-        hipStream_t st = stream ? static_cast<hipStream_t>(stream) : idx->stream;
+        hipStream_t st = static_cast<hipStream_t>(stream);
         if (n > 0) {
             HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_base), sizeof(float) * n * idx->ld));
             if (idx->ld != dim) HG_HIP(hipMemsetAsync(idx->d_base, 0, sizeof(float) * n * idx->ld, st));
@@ -367,6 +379,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
             (void)hipEventDestroy(pr.first);
             (void)hipEventDestroy(pr.second);
         }
+    if (idx->ev_last) (void)hipEventDestroy(idx->ev_last);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
     return 0;
@@ -407,6 +420,7 @@ int hnswgpu_batch_distances(hnswgpu_index *idx, const float *q, const int32_t *i
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
     HG_TRY(upload_queries(idx, q, 1, st));
     HG_TRY(idx->s_outd.ensure(sizeof(float) * m));
     GatherArgs g;
@@ -427,6 +441,7 @@ int hnswgpu_batch_distances(hnswgpu_index *idx, const float *q, const int32_t *i
     g.out = idx->s_outd.as<float>();
     HG_TRY(launch_gather(idx->nch, g, st));
     HG_HIP(hipMemcpyAsync(out, g.out, sizeof(float) * m, hipMemcpyDeviceToHost, st));
+    HG_TRY(end_call(idx, st));
     HG_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -489,8 +504,10 @@ int hnswgpu_exact_knn_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int3
     HG_REQUIRE(idx->n > 0, HNSWGPU_ESTATE, "empty index: use the host entry point");
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : idx->stream;
-    return exact_knn_enqueue(idx, d_Q, nq, k, d_out_ids, d_out_dist, st);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(exact_knn_enqueue(idx, d_Q, nq, k, d_out_ids, d_out_dist, st));
+    return end_call(idx, st);
 }
 
 int hnswgpu_exact_knn(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t *out_ids,
@@ -505,12 +522,14 @@ int hnswgpu_exact_knn(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k,
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
     HG_TRY(upload_queries(idx, Q, nq, st));
     HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
     HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
     HG_TRY(exact_knn_enqueue(idx, idx->s_q.as<float>(), nq, k, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(), st));
     HG_HIP(hipMemcpyAsync(out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
     HG_HIP(hipMemcpyAsync(out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
+    HG_TRY(end_call(idx, st));
     HG_HIP(hipStreamSynchronize(st));
     return 0;
 }

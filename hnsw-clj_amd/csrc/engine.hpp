@@ -79,6 +79,10 @@ struct hnswgpu_index {
     float *d_norms = nullptr;
     hipStream_t stream = nullptr;
     std::mutex mu;
+    // cross-stream ordering of the shared scratch buffers: the last call's completion event
+    hipEvent_t ev_last = nullptr;
+    hipStream_t ev_stream = nullptr;
+    bool ev_valid = false;
 
     // HNSW graph (device + host mirror for export)
     bool has_graph = false;
@@ -132,5 +136,10 @@ void prof_begin(hnswgpu_index *idx, int slot, hipStream_t st, hipEvent_t *e0);
 void prof_end(hnswgpu_index *idx, int slot, hipStream_t st, hipEvent_t e0);
 
 int upload_queries(hnswgpu_index *idx, const float *Q, int32_t nq, hipStream_t st);
+
+// Every entry point brackets its device work with these: a call on stream B waits for the previous
+// call's work on stream A before it may reuse the index's scratch buffers.
+int begin_call(hnswgpu_index *idx, hipStream_t st);
+int end_call(hnswgpu_index *idx, hipStream_t st);
 
 }  // namespace hg

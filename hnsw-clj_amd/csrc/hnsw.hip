@@ -218,6 +218,8 @@ int hnswgpu_set_graph(hnswgpu_index *idx, const int32_t *levels, const int32_t *
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
+    HG_HIP(hipDeviceSynchronize());  // nothing may still be traversing the graph that is about to be freed
     free_graph(idx);
     HG_TRY(alloc_graph(idx, M, M0, blocks));
     if (n > 0) {
@@ -285,8 +287,10 @@ int hnswgpu_hnsw_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, in
     HG_REQUIRE(idx->n > 0, HNSWGPU_ESTATE, "empty index: use the host entry point");
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : idx->stream;
-    return search_enqueue(idx, d_Q, nq, k, ef, d_out_ids, d_out_dist, d_stats, st);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(search_enqueue(idx, d_Q, nq, k, ef, d_out_ids, d_out_dist, d_stats, st));
+    return end_call(idx, st);
 }
 
 int hnswgpu_hnsw_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t ef, int32_t *out_ids,
@@ -305,6 +309,7 @@ int hnswgpu_hnsw_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t 
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
     HG_TRY(upload_queries(idx, Q, nq, st));
     HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
     HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
@@ -314,6 +319,7 @@ int hnswgpu_hnsw_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t 
     HG_HIP(hipMemcpyAsync(out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
     HG_HIP(hipMemcpyAsync(out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
     if (stats) HG_HIP(hipMemcpyAsync(stats, idx->s_stats.p, sizeof(int64_t) * 2 * nq, hipMemcpyDeviceToHost, st));
+    HG_TRY(end_call(idx, st));
     HG_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -354,6 +360,8 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
         }
     }
     const int64_t blocks = n > 0 ? g.up_off[n] : 0;
+    HG_TRY(begin_call(idx, st));
+    HG_HIP(hipDeviceSynchronize());
     free_graph(idx);
     HG_TRY(alloc_graph(idx, M, M0, blocks));
     if (n == 0) {

@@ -291,6 +291,8 @@ int hnswgpu_set_ivf(hnswgpu_index *idx, const float *centroids, int32_t nlist, c
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
+    HG_HIP(hipDeviceSynchronize());
     free_ivf(idx);
     HG_TRY(alloc_centroids(idx, nlist));
     HG_HIP(hipMemsetAsync(idx->d_cent, 0, sizeof(float) * nlist * idx->ld, st));
@@ -320,6 +322,7 @@ int hnswgpu_kmeans_assign(hnswgpu_index *idx, const float *centroids, int32_t nl
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
     HG_TRY(idx->s_misc.ensure(sizeof(float) * nlist * idx->ld));
     HG_TRY(idx->s_misc2.ensure(sizeof(float) * nlist));
     HG_HIP(hipMemsetAsync(idx->s_misc.p, 0, sizeof(float) * nlist * idx->ld, st));
@@ -339,6 +342,7 @@ int hnswgpu_kmeanspp(hnswgpu_index *idx, int32_t nlist, int64_t seed, int32_t *o
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     std::vector<int32_t> chosen;
+    HG_TRY(begin_call(idx, idx->stream));
     HG_TRY(kmeanspp_device(idx, nlist, seed, chosen, idx->stream));
     memcpy(out_rows, chosen.data(), sizeof(int32_t) * nlist);
     return 0;
@@ -352,6 +356,8 @@ int hnswgpu_ivf_build(hnswgpu_index *idx, int32_t nlist, int32_t max_iter, int64
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
     const int64_t n = idx->n;
+    HG_TRY(begin_call(idx, st));
+    HG_HIP(hipDeviceSynchronize());
     free_ivf(idx);
     std::vector<int32_t> chosen;
     HG_TRY(kmeanspp_device(idx, nlist, seed, chosen, st));
@@ -401,8 +407,10 @@ int hnswgpu_ivf_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     if (nq == 0) return 0;
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : idx->stream;
-    return ivf_search_enqueue(idx, d_Q, nq, k, nprobe, d_out_ids, d_out_dist, nullptr, st);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(ivf_search_enqueue(idx, d_Q, nq, k, nprobe, d_out_ids, d_out_dist, nullptr, st));
+    return end_call(idx, st);
 }
 
 int hnswgpu_ivf_search_lists(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t nprobe,
@@ -415,6 +423,7 @@ int hnswgpu_ivf_search_lists(hnswgpu_index *idx, const float *Q, int32_t nq, int
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
     int64_t cnt = static_cast<int64_t>(nq) * k;
     HG_TRY(upload_queries(idx, Q, nq, st));
     HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
@@ -437,6 +446,7 @@ int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
     int32_t np = std::min(nprobe, idx->nlist);
     int64_t cnt = static_cast<int64_t>(nq) * k;
     HG_TRY(upload_queries(idx, Q, nq, st));

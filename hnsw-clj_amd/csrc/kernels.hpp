@@ -79,14 +79,15 @@ __device__ __forceinline__ float lane_partial(const float4 (&q)[NCH], const floa
 }
 
 __device__ __forceinline__ float finish_dist(int metric, float s, float qn, float rn) {
-    if (metric == METRIC_L2) return __fsqrt_rn(s);
+    if (metric == METRIC_L2) return __builtin_sqrtf(s);
     if (metric == METRIC_DOT) return -s;
-    return (qn > 0.0f && rn > 0.0f) ? __fsub_rn(1.0f, __fdiv_rn(s, __fmul_rn(qn, rn))) : 1.0f;
+    // IEEE mul / div / sub: built with -ffp-contract=off and correctly rounded f32 divide
+    return (qn > 0.0f && rn > 0.0f) ? 1.0f - s / (qn * rn) : 1.0f;
 }
 
 template <int NCH>
 __device__ __forceinline__ float query_norm(const float4 (&q)[NCH]) {
-    return __fsqrt_rn(wave_sum(lane_partial<NCH, false>(q, q)));
+    return __builtin_sqrtf(wave_sum(lane_partial<NCH, false>(q, q)));
 }
 
 // total order on (distance, order) packed in 64 bits; -0 is canonicalised to +0, NaN sorts last
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(kWG) void row_norms_kernel(const float *rows, int64
     float4 r[NCH];
     load_row<NCH>(r, rows + row * ld, static_cast<int>(ld / 4), lane, true);
     float s = wave_sum(lane_partial<NCH, false>(r, r));
-    if (lane == 0) out[row] = __fsqrt_rn(s);
+    if (lane == 0) out[row] = __builtin_sqrtf(s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -405,6 +406,9 @@ __global__ __launch_bounds__(kWG) void hnsw_search_kernel(HnswArgs a) {
         for (int w = tid; w < a.nwords; w += kWG) bits[w] = 0;
         __syncthreads();
         if (len > ef_l) len = ef_l;
+        // the reference re-evaluates its entry points at every layer (:162-167); the values are
+        // reused here, but counted so that `evals` is the reference's number of distance calls
+        if (level != a.max_level) n_eval += len;
         for (int i = tid; i < len; i += kWG) {
             uint2 e = listA[i];
             e.y &= ~kExpanded;

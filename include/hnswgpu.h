@@ -10,8 +10,9 @@
  *    the boundary.
  *  - Host-pointer entry points: the caller owns every host buffer; the library copies or consumes
  *    it before returning.  `_dev` entry points take DEVICE pointers (e.g. a torch tensor's
- *    data_ptr) plus a hipStream_t passed as void* (NULL = the index's own stream); they only
- *    enqueue work and do not synchronise.
+ *    data_ptr) plus a hipStream_t passed as void* (NULL = HIP's default stream); they only
+ *    enqueue work and do not synchronise.  Calls on different streams are ordered against each
+ *    other with events (they share the index's scratch buffers).
  *  - Row ids are dense int32 in [0, n); the String-id <-> row table stays on the Clojure side
  *    (UltraNode.id is a String, src/hnsw/ultra_fast.clj:99).
  *  - Results are ascending by distance; fewer than k results are padded with id -1 / +inf

@@ -142,7 +142,7 @@ def test_recall_on_1000x128(oracle):
 
 def test_device_order_mode_agrees_with_f64(oracle):
     """The f32 device-order mimic stays within the north-star tolerance of the f64 truth."""
-    from util import assert_topk_parity
+    from util import assert_topk_parity, metric_scale
 
     O = oracle
     base = O.generate_dataset(800, 96).astype(np.float32)
@@ -151,10 +151,11 @@ def test_device_order_mode_agrees_with_f64(oracle):
         g = O.hnsw_build(base, metric, M=8, ef_construction=64)
         a = O.hnsw_search(base, g, Q, 10, metric=metric)
         b = O.hnsw_search(base, g, Q, 10, metric=metric, mode=O.MODE_DEV)
-        assert_topk_parity(b[0], b[1], a[0], a[1], "hnsw metric %d" % metric)
+        sc = metric_scale(metric, Q, base)
+        assert_topk_parity(b[0], b[1], a[0], a[1], "hnsw metric %d" % metric, sc)
         ea = O.exact_knn(base, Q, 10, metric=metric)
         eb = O.exact_knn(base, Q, 10, metric=metric, mode=O.MODE_DEV)
-        assert_topk_parity(eb[0], eb[1], ea[0], ea[1], "exact metric %d" % metric)
+        assert_topk_parity(eb[0], eb[1], ea[0], ea[1], "exact metric %d" % metric, sc)
 
 
 def test_kmeans_semantics(oracle):
