@@ -73,10 +73,19 @@ int launch_scan(int nch, const ScanArgs &a, hipStream_t st) {
     size_t lds = a.mode == MODE_TOPK ? sizeof(uint64_t) * kNWave * a.k : 0;
     HG_REQUIRE(lds <= 64 * 1024, HNSWGPU_ELIMIT, "k too large for the scan kernel (k=%d)", a.k);
     bool l2 = a.metric == METRIC_L2;
-#define CALL(N, R, L) \
-    hipLaunchKernelGGL((scan_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a)
+#define CALL_ROLE(N, R, L, ROLE) \
+    hipLaunchKernelGGL((scan_kernel<N, R, L, ROLE>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a)
+#define CALL(N, R, L)                                          \
+    switch (a.role) {                                          \
+        case ROLE_ROUTE: CALL_ROLE(N, R, L, ROLE_ROUTE); break;   \
+        case ROLE_ASSIGN: CALL_ROLE(N, R, L, ROLE_ASSIGN); break; \
+        case ROLE_SEED: CALL_ROLE(N, R, L, ROLE_SEED); break;     \
+        case ROLE_EXACT: CALL_ROLE(N, R, L, ROLE_EXACT); break;   \
+        default: CALL_ROLE(N, R, L, ROLE_LIST_SCAN); break;       \
+    }
     HG_DISPATCH(nch, l2, CALL);
 #undef CALL
+#undef CALL_ROLE
     HG_HIP(hipGetLastError());
     return 0;
 }
@@ -471,6 +480,7 @@ static int exact_knn_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, i
     a.metric = idx->metric;
     a.pairs = nullptr;
     a.k = k;
+    a.role = ROLE_EXACT;
     HG_TRY(scan_topk(idx, a, nq, 1, idx->n, st, PROF_IVF_SCAN));
     int64_t cnt = static_cast<int64_t>(nq) * k;
     hipLaunchKernelGGL(ord_to_ids_kernel, dim3(static_cast<unsigned>((cnt + 255) / 256)), dim3(256), 0, st,

@@ -163,6 +163,7 @@ static int assign_enqueue(hnswgpu_index *idx, const float *d_cent, const float *
     a.metric = idx->metric;
     a.pairs = nullptr;
     a.k = 1;
+    a.role = ROLE_ASSIGN;
     return scan_topk(idx, a, static_cast<int32_t>(idx->n), 1, nlist, st, PROF_ASSIGN);
 }
 
@@ -205,6 +206,7 @@ static int kmeanspp_device(hnswgpu_index *idx, int32_t nlist, int64_t seed, std:
         a.dim = idx->dim;
         a.metric = idx->metric;
         a.mode = MODE_MINUPD;
+        a.role = ROLE_SEED;
         a.pairs = nullptr;
         a.npairs = 1;
         a.nchunks = plan_chunks(idx->nch, n, 1, &a.chunk_rows);
@@ -252,6 +254,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     a.dim = idx->dim;
     a.metric = idx->metric;
     a.k = nprobe;
+    a.role = ROLE_ROUTE;
     HG_TRY(scan_topk(idx, a, nq, 1, idx->nlist, st, -1));
     hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + 127) / 128), dim3(128), 0, st, idx->s_ord.as<uint32_t>(), nq,
                        nprobe, idx->d_listoff, idx->s_pairs.as<Pair>(), d_out_probes);
@@ -268,6 +271,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     a.metric = idx->metric;
     a.pairs = idx->s_pairs.as<Pair>();
     a.k = k;
+    a.role = ROLE_LIST_SCAN;
     HG_TRY(scan_topk(idx, a, nq, nprobe, idx->max_list_len, st, PROF_IVF_SCAN));
     int64_t cnt = static_cast<int64_t>(nq) * k;
     hipLaunchKernelGGL(ivf_decode_kernel, dim3(static_cast<unsigned>((cnt + 255) / 256)), dim3(256), 0, st,

@@ -173,12 +173,17 @@ struct ScanArgs {
     int32_t chunk_rows;
     int32_t nchunks;
     int32_t k;
+    int32_t role;       // ROLE_* (profiling label only)
     uint64_t *partial;  // TOPK: [pair][chunk][wave][k]
     float *out;         // STORE: out[pair * out_stride + (row - row_begin)]; MINUPD: out[row]
     int64_t out_stride;
 };
 
-template <int NCH, int RB, bool L2>
+// ROLE only names the caller in profiler output (rocprofv3 groups dispatches by kernel name); the
+// code is identical for every role.
+constexpr int ROLE_LIST_SCAN = 0, ROLE_ROUTE = 1, ROLE_ASSIGN = 2, ROLE_SEED = 3, ROLE_EXACT = 4;
+
+template <int NCH, int RB, bool L2, int ROLE>
 __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem);  // [kNWave][k]

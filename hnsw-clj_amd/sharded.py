@@ -36,8 +36,9 @@ class ShardedSearcher:
         gids = torch.where(ids >= 0, ids + self.row_offset, ids)  # local row -> global row id
         all_ids = torch.empty((world,) + tuple(gids.shape), dtype=gids.dtype, device=gids.device)
         all_d = torch.empty((world,) + tuple(d.shape), dtype=d.dtype, device=d.device)
-        dist.all_gather_into_tensor(all_ids, gids.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(all_d, d.contiguous(), group=self.group)
+        # views of one [world, nq, k] buffer: the merge kernel reads the gathered lists in place
+        dist.all_gather(list(all_ids.unbind(0)), gids.contiguous(), group=self.group)
+        dist.all_gather(list(all_d.unbind(0)), d.contiguous(), group=self.group)
         merge = self.merge_fn
         if merge is None:
             if not all_ids.is_cuda:
