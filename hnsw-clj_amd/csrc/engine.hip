@@ -2,6 +2,7 @@
 // libhnswgpu.so (C ABI: include/hnswgpu.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "engine.hpp"
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(kWave) void merge_topk_kernel(MergeArgs a) {
     const uint64_t *in = a.partial + static_cast<int64_t>(q) * a.keys_per_query;
     int cnt = 0;
     uint64_t thr = ~0ull;
+    const bool regk = a.k <= kWave;
+    uint64_t mine = ~0ull;
     for (int64_t base = 0; base < a.keys_per_query; base += kWave) {
         int64_t i = base + lane;
         uint64_t key = i < a.keys_per_query ? in[i] : ~0ull;
@@ -107,10 +110,20 @@ __global__ __launch_bounds__(kWave) void merge_topk_kernel(MergeArgs a) {
             mask &= mask - 1;
             uint64_t kb = __shfl(key, b, kWave);
             if (kb < thr) {
-                wave_insert(list, cnt, a.k, kb, lane);
-                thr = cnt == a.k ? list[a.k - 1] : ~0ull;
+                if (regk) {
+                    wave_insert_reg(mine, cnt, a.k, kb, lane);
+                    thr = wave_kth_reg(mine, a.k);
+                } else {
+                    wave_insert(list, cnt, a.k, kb, lane);
+                    thr = cnt == a.k ? list[a.k - 1] : ~0ull;
+                }
             }
         }
+    }
+    if (regk) {
+        if (lane < a.k) list[lane] = mine;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     for (int i = lane; i < a.k; i += kWave) {
         bool ok = i < cnt;
@@ -165,7 +178,11 @@ int plan_chunks(int nch, int64_t max_rows, int64_t npairs, int32_t *chunk_rows) 
     // every wave; chunk_rows is a multiple of the rows one workgroup consumes per iteration
     const int64_t per_iter = scan_rows_per_iter(nch);
     if (max_rows < 1) max_rows = 1;
-    int64_t target_blocks = 8192;
+    static const int64_t env_blocks = []() {
+        const char *e = getenv("HNSWGPU_SCAN_BLOCKS");  // tuning override
+        return e ? atoll(e) : 0LL;
+    }();
+    int64_t target_blocks = env_blocks > 0 ? env_blocks : 8192;
     int64_t want = (target_blocks + npairs - 1) / (npairs > 0 ? npairs : 1);
     if (want < 1) want = 1;
     int64_t max_chunks = (max_rows + per_iter - 1) / per_iter;

@@ -1,6 +1,7 @@
 // hnsw.hip -- HNSW graph import/export, batched GPU search and batched GPU-assisted build.
 // Reference: src/hnsw/ultra_fast.clj (file:line cited per function).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -16,18 +17,35 @@ static size_t hnsw_lds_bytes(int cap, int nwords) {
 
 constexpr size_t kMaxLds = 160 * 1024;
 
+// tuning override (HNSWGPU_HNSW_NW=1|2|4), read once; 0 = choose by batch size
+static int g_hnsw_nw = []() {
+    const char *e = getenv("HNSWGPU_HNSW_NW");
+    int v = e ? atoi(e) : 0;
+    return (v == 1 || v == 2 || v == 4) ? v : 0;
+}();
+
 int launch_hnsw(int nch, const HnswArgs &a, hipStream_t st) {
     if (a.nq <= 0) return 0;
     size_t lds = hnsw_lds_bytes(a.cap, a.nwords);
     HG_REQUIRE(lds <= kMaxLds, HNSWGPU_ELIMIT,
                "HNSW search state (%zu B: ef=%d, n=%lld) exceeds the 160 KiB LDS of a CU", lds, a.ef, (long long)a.n);
     bool l2 = a.metric == METRIC_L2;
-#define CALL(N, R, L)                                                                                      \
-    do {                                                                                                   \
-        if (lds > 48 * 1024)                                                                               \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<N, R, L>),      \
+    // waves per query.  Measured on 31k x 768, ef 128 (tools/tune_hnsw.py): a query takes 1.1 / 1.4 / 2.0 ms
+    // with 4 / 2 / 1 waves, and a CU holds 3 / 6 / 12 such workgroups (VGPR-limited), so once a batch
+    // exceeds one residency round fewer waves per query win: 10,000 queries run at 601k / 776k / 802k QPS.
+    int nw = g_hnsw_nw > 0 ? g_hnsw_nw : (a.nq > 1536 ? 1 : (a.nq > 768 ? 2 : 4));
+#define CALL_NW(N, R, L, W)                                                                                  \
+    do {                                                                                                     \
+        if (lds > 48 * 1024)                                                                                 \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<N, R, L, W>),     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
-        hipLaunchKernelGGL((hnsw_search_kernel<N, R, L>), dim3(a.nq), dim3(kWG), lds, st, a);              \
+        hipLaunchKernelGGL((hnsw_search_kernel<N, R, L, W>), dim3(a.nq), dim3(W * kWave), lds, st, a);       \
+    } while (0)
+#define CALL(N, R, L)                        \
+    do {                                     \
+        if (nw == 1) CALL_NW(N, R, L, 1);    \
+        else if (nw == 2) CALL_NW(N, R, L, 2); \
+        else CALL_NW(N, R, L, 4);            \
     } while (0)
     switch (nch) {
         case 1: if (l2) CALL(1, 8, true); else CALL(1, 8, false); break;
@@ -40,6 +58,7 @@ int launch_hnsw(int nch, const HnswArgs &a, hipStream_t st) {
         default: set_error("unsupported row length"); return HNSWGPU_ELIMIT;
     }
 #undef CALL
+#undef CALL_NW
     HG_HIP(hipGetLastError());
     return 0;
 }

@@ -130,6 +130,24 @@ __device__ __forceinline__ void wave_insert(uint64_t *list, int &cnt, int k, uin
     cnt = newcnt;
 }
 
+// The same list kept in registers when k <= 64: lane i holds the i-th smallest key (lanes >= cnt hold
+// ~0).  One ballot + one lane shift per insertion instead of an LDS round trip.
+__device__ __forceinline__ void wave_insert_reg(uint64_t &mine, int &cnt, int k, uint64_t key, int lane) {
+    int pos = __popcll(__ballot(mine < key));  // ascending: the smaller keys form a prefix of the lanes
+    if (pos >= k) return;
+    uint32_t lo = static_cast<uint32_t>(mine), hi = static_cast<uint32_t>(mine >> 32);
+    uint32_t ulo = __shfl_up(lo, 1, kWave), uhi = __shfl_up(hi, 1, kWave);
+    uint64_t up = (static_cast<uint64_t>(uhi) << 32) | ulo;
+    mine = lane < pos ? mine : (lane == pos ? key : up);
+    if (lane >= k) mine = ~0ull;
+    cnt = cnt + 1 < k ? cnt + 1 : k;
+}
+__device__ __forceinline__ uint64_t wave_kth_reg(uint64_t mine, int k) {
+    uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(mine), k - 1);
+    uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(mine >> 32), k - 1);
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Row norms (ivf_flat.clj:171-177): one wave per row.
 // ------------------------------------------------------------------------------------------------
@@ -212,6 +230,8 @@ __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
     uint64_t *mylist = lists + wave * a.k;
     int cnt = 0;
     uint64_t thr = ~0ull;
+    const bool regk = a.k <= kWave;  // top-k list in registers (one key per lane) instead of LDS
+    uint64_t mine = ~0ull;
     if (r0 < r1) {
         float4 q[NCH];
         load_query<NCH>(q, a.Q + qi * a.qld, a.dim, lane);
@@ -236,8 +256,13 @@ __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
                     if (a.mode == MODE_TOPK) {
                         uint64_t key = make_key(d, ord_base + static_cast<uint32_t>(row - rb0));
                         if (key < thr) {
-                            wave_insert(mylist, cnt, a.k, key, lane);
-                            thr = cnt == a.k ? mylist[a.k - 1] : ~0ull;
+                            if (regk) {
+                                wave_insert_reg(mine, cnt, a.k, key, lane);
+                                thr = wave_kth_reg(mine, a.k);  // ~0 until the list is full
+                            } else {
+                                wave_insert(mylist, cnt, a.k, key, lane);
+                                thr = cnt == a.k ? mylist[a.k - 1] : ~0ull;
+                            }
                         }
                     } else if (a.mode == MODE_STORE) {
                         if (lane == 0) a.out[pair * a.out_stride + (row - rb0)] = d;
@@ -253,7 +278,11 @@ __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
     }
     if (a.mode == MODE_TOPK) {
         uint64_t *dst = a.partial + ((static_cast<int64_t>(pair) * a.nchunks + chunk) * kNWave + wave) * a.k;
-        for (int i = lane; i < a.k; i += kWave) dst[i] = i < cnt ? mylist[i] : ~0ull;
+        if (regk) {
+            if (lane < a.k) dst[lane] = mine;
+        } else {
+            for (int i = lane; i < a.k; i += kWave) dst[i] = i < cnt ? mylist[i] : ~0ull;
+        }
     }
 }
 
@@ -370,8 +399,11 @@ struct HnswArgs {
 
 constexpr uint32_t kExpanded = 0x80000000u;
 
-template <int NCH, int RB, bool L2>
-__global__ __launch_bounds__(kWG) void hnsw_search_kernel(HnswArgs a) {
+// NW = waves per query: 4 for latency (few queries), 1-2 for throughput (more queries resident per CU;
+// with NW = 1 every barrier is wave-local).  The arithmetic and the traversal are identical for every NW.
+template <int NCH, int RB, bool L2, int NW>
+__global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
+    constexpr int kThreads = NW * kWave;
     extern __shared__ __align__(16) unsigned char smem[];
     uint2 *listA = reinterpret_cast<uint2 *>(smem);
     uint2 *listB = listA + a.cap;
@@ -408,13 +440,13 @@ __global__ __launch_bounds__(kWG) void hnsw_search_kernel(HnswArgs a) {
     for (int level = a.max_level; level >= 0; level--) {
         int ef_l = level > 0 ? 1 : a.ef;
         // fresh visited set per layer (:156); entries carried from the level above are marked
-        for (int w = tid; w < a.nwords; w += kWG) bits[w] = 0;
+        for (int w = tid; w < a.nwords; w += kThreads) bits[w] = 0;
         __syncthreads();
         if (len > ef_l) len = ef_l;
         // the reference re-evaluates its entry points at every layer (:162-167); the values are
         // reused here, but counted so that `evals` is the reference's number of distance calls
         if (level != a.max_level) n_eval += len;
-        for (int i = tid; i < len; i += kWG) {
+        for (int i = tid; i < len; i += kThreads) {
             uint2 e = listA[i];
             e.y &= ~kExpanded;
             listA[i] = e;
@@ -467,7 +499,7 @@ __global__ __launch_bounds__(kWG) void hnsw_search_kernel(HnswArgs a) {
             }
             n_eval += nc;
             // ---- gather rows + distances: wave w takes candidates [w*RB + t*4*RB, +RB)
-            for (int j0 = wave * RB; j0 < nc; j0 += kNWave * RB) {
+            for (int j0 = wave * RB; j0 < nc; j0 += NW * RB) {
                 float4 r[RB][NCH];
                 int32_t rid[RB];
 #pragma unroll
@@ -534,7 +566,7 @@ __global__ __launch_bounds__(kWG) void hnsw_search_kernel(HnswArgs a) {
             }
             // ---- scatter old entries and admitted candidates to their merged positions
             const int total = len + nadm;
-            for (int i = tid; i < len; i += kWG) {
+            for (int i = tid; i < len; i += kThreads) {
                 uint2 e = listA[i];
                 float de = __uint_as_float(e.x);
                 int sh = 0;
@@ -556,7 +588,7 @@ __global__ __launch_bounds__(kWG) void hnsw_search_kernel(HnswArgs a) {
             if (total > ef_l) {
                 // ghosts: admitted-at-some-time entries pushed past ef whose distance ties the worst
                 const uint32_t wbits = static_cast<uint32_t>(sc[4]);
-                for (int i = tid; i < len; i += kWG) {
+                for (int i = tid; i < len; i += kThreads) {
                     uint2 e = listA[i];
                     if (e.x == wbits) {
                         float de = __uint_as_float(e.x);
@@ -592,7 +624,7 @@ __global__ __launch_bounds__(kWG) void hnsw_search_kernel(HnswArgs a) {
     }
     // ---- results: ascending, take k (:362-370; the distances are reused, not recomputed)
     int real = len < a.ef ? len : a.ef;
-    for (int i = tid; i < a.k; i += kWG) {
+    for (int i = tid; i < a.k; i += kThreads) {
         bool ok = i < real;
         a.out_ids[static_cast<int64_t>(qi) * a.k + i] = ok ? static_cast<int32_t>(listA[i].y & ~kExpanded) : -1;
         a.out_dist[static_cast<int64_t>(qi) * a.k + i] = ok ? __uint_as_float(listA[i].x) : __uint_as_float(0x7f800000u);

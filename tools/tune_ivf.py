@@ -1,0 +1,51 @@
+"""Developer tool: time the IVF list scan (1M x 768, nlist 1024, nprobe 32) at several batch sizes.
+usage: [HNSWGPU_SCAN_BLOCKS=N] python tools/tune_ivf.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from hnsw_clj_amd import engine
+
+dev = torch.device("cuda", 0)
+n, nlist, nprobe, D, K = 1_000_000, 1024, 32, 768, 10
+g = torch.Generator(device=dev)
+g.manual_seed(42)
+centers = torch.randn(nlist, D, generator=g, device=dev)
+which = torch.randint(0, nlist, (n,), generator=g, device=dev)
+x = centers[which] + 0.3 * torch.randn(n, D, generator=g, device=dev)
+x /= x.norm(dim=1, keepdim=True)
+g.manual_seed(43)
+qw = torch.randint(0, nlist, (1024,), generator=g, device=dev)
+Qa = centers[qw] + 0.3 * torch.randn(1024, D, generator=g, device=dev)
+Qa /= Qa.norm(dim=1, keepdim=True)
+idx = engine.Index(x, "cosine", 0)
+# cheap lists for tuning: assign to the generating centres (same list-length distribution as k-means)
+a, _ = idx.kmeans_assign(centers.cpu().numpy())
+order = np.argsort(a, kind="stable").astype(np.int32)
+off = np.zeros(nlist + 1, np.int64)
+off[1:] = np.cumsum(np.bincount(a, minlength=nlist))
+idx.set_ivf(centers.cpu().numpy(), off, order)
+lens = np.diff(off)
+for nq in (1, 32, 256, 1024):
+    Q = Qa[:nq].contiguous()
+    _, _, probes = idx.ivf_search(Q.cpu().numpy(), K, nprobe, want_probes=True)
+    alg = int(lens[probes.ravel()].sum()) * (4 * D + 4)
+    for _ in range(3):
+        idx.ivf_search_dev(Q, K, nprobe)
+    idx.set_profiling(True)
+    idx.get_profile(engine.PROF_IVF_SCAN, reset=True)
+    torch.cuda.synchronize()
+    steps = 20 if nq <= 32 else 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        idx.ivf_search_dev(Q, K, nprobe)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    ms, cnt = idx.get_profile(engine.PROF_IVF_SCAN, reset=True)
+    idx.set_profiling(False)
+    print("blocks=%s nq=%4d scan %.4f ms  %.0f GB/s algorithmic   search wall %.4f ms  QPS %.0f" % (
+        os.environ.get("HNSWGPU_SCAN_BLOCKS", "8192"), nq, ms / cnt, alg / (ms / cnt * 1e-3) / 1e9, wall * 1e3, nq / wall))
