@@ -104,7 +104,8 @@ struct hnswgpu_index {
     std::vector<int32_t> h_listids;
 
     // scratch (grown on demand, reused across calls; calls are serialised by `mu`)
-    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2;
+    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2, s_vis;
+    uint32_t vis_gen = 0;  // last generation number handed to an HBM visited slab
 
     // profiling
     bool prof = false;
@@ -122,7 +123,6 @@ int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, 
 int launch_scan(int nch, const ScanArgs &a, hipStream_t st);
 int launch_merge(const MergeArgs &a, hipStream_t st);
 int launch_gather(int nch, const GatherArgs &a, hipStream_t st);
-int launch_hnsw(int nch, const HnswArgs &a, hipStream_t st);
 int scan_rows_per_iter(int nch);  // kNWave * RB
 
 // pick chunking for a scan: returns nchunks, sets chunk_rows

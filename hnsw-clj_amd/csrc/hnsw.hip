@@ -24,22 +24,61 @@ static int g_hnsw_nw = []() {
     return (v == 1 || v == 2 || v == 4) ? v : 0;
 }();
 
-int launch_hnsw(int nch, const HnswArgs &a, hipStream_t st) {
+// Visited-set placement: an LDS bitset while it leaves room for several workgroups per CU, otherwise
+// generation stamps in HBM (4 B per row per resident workgroup; 288 GB makes that cheap).
+constexpr int64_t kLdsVisitedMaxRows = 262144;  // 32 KiB bitset
+static int g_force_vg = []() {
+    const char *e = getenv("HNSWGPU_VIS");  // testing override: "global" forces the HBM stamps
+    return (e && e[0] == 'g') ? 1 : 0;
+}();
+
+int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     if (a.nq <= 0) return 0;
-    size_t lds = hnsw_lds_bytes(a.cap, a.nwords);
-    HG_REQUIRE(lds <= kMaxLds, HNSWGPU_ELIMIT,
-               "HNSW search state (%zu B: ef=%d, n=%lld) exceeds the 160 KiB LDS of a CU", lds, a.ef, (long long)a.n);
-    bool l2 = a.metric == METRIC_L2;
+    const int nch = idx->nch;
+    const bool vg = g_force_vg || a.n > kLdsVisitedMaxRows;
     // waves per query.  Measured on 31k x 768, ef 128 (tools/tune_hnsw.py): a query takes 1.1 / 1.4 / 2.0 ms
     // with 4 / 2 / 1 waves, and a CU holds 3 / 6 / 12 such workgroups (VGPR-limited), so once a batch
     // exceeds one residency round fewer waves per query win: 10,000 queries run at 601k / 776k / 802k QPS.
     int nw = g_hnsw_nw > 0 ? g_hnsw_nw : (a.nq > 1536 ? 1 : (a.nq > 768 ? 2 : 4));
-#define CALL_NW(N, R, L, W)                                                                                  \
+    int grid = a.nq;
+    if (vg) {
+        a.nwords = 0;
+        // one slab of n stamps per workgroup; a persistent grid bounds the slab count
+        const int64_t budget = 16LL << 30;
+        int64_t max_wg = budget / (4 * std::max<int64_t>(a.n, 1));
+        max_wg = std::min<int64_t>(std::max<int64_t>(max_wg, 256), 256 * 12);
+        grid = static_cast<int>(std::min<int64_t>(a.nq, max_wg));
+        size_t need = sizeof(uint32_t) * static_cast<size_t>(a.n) * grid;
+        if (need > idx->s_vis.cap) {
+            HG_TRY(idx->s_vis.ensure(need));
+            HG_HIP(hipMemsetAsync(idx->s_vis.p, 0, idx->s_vis.cap, st));
+            idx->vis_gen = 0;
+        }
+        const int64_t gens = (static_cast<int64_t>(a.nq) + grid - 1) / grid * (a.max_level + 1);
+        if (static_cast<int64_t>(idx->vis_gen) + gens >= 0xfffffff0LL) {
+            HG_HIP(hipMemsetAsync(idx->s_vis.p, 0, idx->s_vis.cap, st));
+            idx->vis_gen = 0;
+        }
+        a.vis = idx->s_vis.as<uint32_t>();
+        a.vis_stride = a.n;
+        a.gen_base = idx->vis_gen;
+        idx->vis_gen += static_cast<uint32_t>(gens);
+    }
+    size_t lds = hnsw_lds_bytes(a.cap, a.nwords);
+    HG_REQUIRE(lds <= kMaxLds, HNSWGPU_ELIMIT,
+               "HNSW search state (%zu B: ef=%d, n=%lld) exceeds the 160 KiB LDS of a CU", lds, a.ef, (long long)a.n);
+    bool l2 = a.metric == METRIC_L2;
+#define CALL_K(N, R, L, W, V)                                                                                \
     do {                                                                                                     \
         if (lds > 48 * 1024)                                                                                 \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<N, R, L, W>),     \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<N, R, L, W, V>),  \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
-        hipLaunchKernelGGL((hnsw_search_kernel<N, R, L, W>), dim3(a.nq), dim3(W * kWave), lds, st, a);       \
+        hipLaunchKernelGGL((hnsw_search_kernel<N, R, L, W, V>), dim3(grid), dim3(W * kWave), lds, st, a);    \
+    } while (0)
+#define CALL_NW(N, R, L, W)          \
+    do {                             \
+        if (vg) CALL_K(N, R, L, W, true); \
+        else CALL_K(N, R, L, W, false);   \
     } while (0)
 #define CALL(N, R, L)                        \
     do {                                     \
@@ -59,6 +98,7 @@ int launch_hnsw(int nch, const HnswArgs &a, hipStream_t st) {
     }
 #undef CALL
 #undef CALL_NW
+#undef CALL_K
     HG_HIP(hipGetLastError());
     return 0;
 }
@@ -117,7 +157,7 @@ static int search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int3
     a.stats = d_stats;
     hipEvent_t e0;
     prof_begin(idx, PROF_HNSW, st, &e0);
-    int rc = launch_hnsw(idx->nch, a, st);
+    int rc = launch_hnsw_idx(idx, a, st);
     prof_end(idx, PROF_HNSW, st, e0);
     return rc;
 }
@@ -446,7 +486,7 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
         a.up_out_ids = d_upids;
         a.up_out_dist = idx->s_misc2.as<float>();
         a.up_stride = maxlv;
-        HG_TRY(launch_hnsw(idx->nch, a, st));
+        HG_TRY(launch_hnsw_idx(idx, a, st));
         HG_HIP(hipMemcpyAsync(h_ids.data(), a.out_ids, sizeof(int32_t) * B * M0, hipMemcpyDeviceToHost, st));
         HG_HIP(hipMemcpyAsync(h_d.data(), a.out_dist, sizeof(float) * B * M0, hipMemcpyDeviceToHost, st));
         HG_HIP(hipMemcpyAsync(h_up.data(), a.up_out_ids, sizeof(int32_t) * B * maxlv, hipMemcpyDeviceToHost, st));

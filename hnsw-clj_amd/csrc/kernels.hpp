@@ -395,13 +395,21 @@ struct HnswArgs {
     int32_t *up_out_ids;  // build mode: [nq][up_stride] nearest node of each upper level <= q level
     float *up_out_dist;
     int32_t up_stride;
+    // visited set in HBM (VG kernels; indexes too large for an LDS bitset): one slab of n generation
+    // stamps per resident workgroup.  A node is visited in the current (query, layer) iff its stamp
+    // equals that pair's generation number; nothing is ever cleared.
+    uint32_t *vis;
+    int64_t vis_stride;
+    uint32_t gen_base;
 };
 
 constexpr uint32_t kExpanded = 0x80000000u;
 
 // NW = waves per query: 4 for latency (few queries), 1-2 for throughput (more queries resident per CU;
-// with NW = 1 every barrier is wave-local).  The arithmetic and the traversal are identical for every NW.
-template <int NCH, int RB, bool L2, int NW>
+// with NW = 1 every barrier is wave-local).  VG = visited set in HBM (generation stamps) instead of
+// the LDS bitset.  The arithmetic and the traversal are identical for every NW / VG.
+// The grid is persistent: workgroup b serves queries b, b + gridDim.x, ...
+template <int NCH, int RB, bool L2, int NW, bool VG>
 __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
     constexpr int kThreads = NW * kWave;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -412,226 +420,241 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
     int32_t *cand_P = reinterpret_cast<int32_t *>(cand_d + kMaxDeg);
     int32_t *sc = cand_P + kMaxDeg;  // scalars
     uint32_t *bits = reinterpret_cast<uint32_t *>(sc + 16);
+    uint32_t *stamps = VG ? a.vis + static_cast<int64_t>(blockIdx.x) * a.vis_stride : nullptr;
     // sc[0]=cursor sc[1]=ncand sc[2]=nadmit sc[3]=minP sc[4]=worst bits sc[5]=nghost
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
-    const int qi = blockIdx.x;
     const int nvec = static_cast<int>(a.ld / 4);
+    uint32_t gen = a.gen_base;
 
-    const float *qptr = a.q_rows ? a.rows + static_cast<int64_t>(a.q_rows[qi]) * a.ld : a.Q + qi * a.qld;
-    float4 q[NCH];
-    load_query<NCH>(q, qptr, a.dim, lane);
-    float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
-    const int qlevel = a.q_levels ? a.q_levels[qi] : -1;
+    for (int qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
+        uint2 *curA = listA, *curB = listB;
+        const float *qptr = a.q_rows ? a.rows + static_cast<int64_t>(a.q_rows[qi]) * a.ld : a.Q + qi * a.qld;
+        float4 q[NCH];
+        load_query<NCH>(q, qptr, a.dim, lane);
+        float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+        const int qlevel = a.q_levels ? a.q_levels[qi] : -1;
 
-    int64_t n_eval = 0, n_hop = 0;
-    int len = 0;
-    // seed: the entry point (ultra_fast.clj:358-359)
-    {
-        float4 r[NCH];
-        load_row<NCH>(r, a.rows + static_cast<int64_t>(a.entry) * a.ld, nvec, lane, true);
-        float s = wave_sum(lane_partial<NCH, L2>(q, r));
-        float d = finish_dist(a.metric, s, qn, a.metric == METRIC_COS ? a.row_norms[a.entry] : 0.0f);
-        if (tid == 0) listA[0] = make_uint2(__float_as_uint(d + 0.0f), static_cast<uint32_t>(a.entry));
-        len = 1;
-        n_eval = 1;
-    }
-    for (int level = a.max_level; level >= 0; level--) {
-        int ef_l = level > 0 ? 1 : a.ef;
-        // fresh visited set per layer (:156); entries carried from the level above are marked
-        for (int w = tid; w < a.nwords; w += kThreads) bits[w] = 0;
-        __syncthreads();
-        if (len > ef_l) len = ef_l;
-        // the reference re-evaluates its entry points at every layer (:162-167); the values are
-        // reused here, but counted so that `evals` is the reference's number of distance calls
-        if (level != a.max_level) n_eval += len;
-        for (int i = tid; i < len; i += kThreads) {
-            uint2 e = listA[i];
-            e.y &= ~kExpanded;
-            listA[i] = e;
-            atomicOr(&bits[e.y >> 5], 1u << (e.y & 31));
+        int64_t n_eval = 0, n_hop = 0;
+        int len = 0;
+        __syncthreads();  // the previous query's result readers are done with the lists
+        // seed: the entry point (ultra_fast.clj:358-359)
+        {
+            float4 r[NCH];
+            load_row<NCH>(r, a.rows + static_cast<int64_t>(a.entry) * a.ld, nvec, lane, true);
+            float s = wave_sum(lane_partial<NCH, L2>(q, r));
+            float d = finish_dist(a.metric, s, qn, a.metric == METRIC_COS ? a.row_norms[a.entry] : 0.0f);
+            if (tid == 0) curA[0] = make_uint2(__float_as_uint(d + 0.0f), static_cast<uint32_t>(a.entry));
+            len = 1;
+            n_eval = 1;
         }
-        __syncthreads();
-        int cur_start = 0;
-        const int deg = level == 0 ? a.M0 : a.M;
-        for (;;) {
-            // ---- next candidate: first unexpanded entry
-            if (wave == 0) {
-                int found = -1;
-                for (int base = cur_start; base < len && found < 0; base += kWave) {
-                    int i = base + lane;
-                    bool un = i < len && !(listA[i].y & kExpanded);
-                    uint64_t m = __ballot(un);
-                    if (m) found = base + __ffsll(static_cast<unsigned long long>(m)) - 1;
-                }
-                if (lane == 0) sc[0] = found;
+        for (int level = a.max_level; level >= 0; level--) {
+            int ef_l = level > 0 ? 1 : a.ef;
+            // fresh visited set per layer (:156); entries carried from the level above are marked
+            if (VG) {
+                gen++;
+            } else {
+                for (int w = tid; w < a.nwords; w += kThreads) bits[w] = 0;
             }
             __syncthreads();
-            const int c = sc[0];
-            if (c < 0) break;
-            const uint32_t node = listA[c].y & ~kExpanded;
-            // ---- neighbour ids, visited filter, compaction (wave 0)
-            if (wave == 0) {
-                const int32_t *adj = level == 0 ? a.l0_adj + static_cast<int64_t>(node) * a.M0
-                                                : a.up_adj + (a.up_off[node] + (level - 1)) * a.M;
-                int nb = lane < deg ? adj[lane] : -1;
-                bool fresh = false;
-                if (nb >= 0 && nb < a.n) {
-                    uint32_t bit = 1u << (nb & 31);
-                    uint32_t old = atomicOr(&bits[nb >> 5], bit);
-                    fresh = !(old & bit);
-                }
-                uint64_t m = __ballot(fresh);
-                int pos = __popcll(m & ((1ull << lane) - 1ull));
-                if (fresh) cand_id[pos] = nb;
-                if (lane == 0) {
-                    sc[1] = __popcll(m);
-                    listA[c].y = node | kExpanded;
-                }
-            }
-            __syncthreads();
-            const int nc = sc[1];
-            n_hop++;
-            if (nc == 0) {
-                cur_start = c + 1;
-                continue;
-            }
-            n_eval += nc;
-            // ---- gather rows + distances: wave w takes candidates [w*RB + t*4*RB, +RB)
-            for (int j0 = wave * RB; j0 < nc; j0 += NW * RB) {
-                float4 r[RB][NCH];
-                int32_t rid[RB];
-#pragma unroll
-                for (int b = 0; b < RB; b++) {
-                    bool ok = j0 + b < nc;
-                    rid[b] = ok ? cand_id[j0 + b] : 0;
-                    load_row<NCH>(r[b], a.rows + static_cast<int64_t>(rid[b]) * a.ld, nvec, lane, ok);
-                }
-                float s[RB];
-#pragma unroll
-                for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2>(q, r[b]);
-#pragma unroll
-                for (int b = 0; b < RB; b++) s[b] = wave_sum(s[b]);
-#pragma unroll
-                for (int b = 0; b < RB; b++) {
-                    if (j0 + b < nc && lane == 0) {
-                        float rn = a.metric == METRIC_COS ? a.row_norms[rid[b]] : 0.0f;
-                        cand_d[j0 + b] = finish_dist(a.metric, s[b], qn, rn) + 0.0f;
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- ranks of the incoming candidates (threads 0..nc-1, all inside wave 0)
-            if (wave == 0) {
-                bool admitted = false;
-                int P = 0x7fffffff;
-                float dj = 0.0f;
-                if (lane < nc) {
-                    dj = cand_d[lane];
-                    int lo = 0, hi = len;  // upper_bound: #entries with d <= dj
-                    while (lo < hi) {
-                        int mid = (lo + hi) >> 1;
-                        if (__uint_as_float(listA[mid].x) <= dj) lo = mid + 1;
-                        else hi = mid;
-                    }
-                    int before = 0, after_less = 0;
-                    for (int j = 0; j < nc; j++) {
-                        float o = cand_d[j];
-                        before += (j < lane && o <= dj) ? 1 : 0;
-                        after_less += (j > lane && o < dj) ? 1 : 0;
-                    }
-                    int r = lo + before;
-                    admitted = r < ef_l;
-                    P = r + after_less;
-                    cand_P[lane] = admitted ? P : -1;
-                }
-                uint64_t am = __ballot(admitted);
-                int minP = admitted ? P : 0x7fffffff;
-                for (int off = 1; off < kWave; off <<= 1) {
-                    int o = __shfl_xor(minP, off, kWave);
-                    minP = o < minP ? o : minP;
-                }
-                if (lane == 0) {
-                    sc[2] = __popcll(am);
-                    sc[3] = minP;
-                    sc[5] = 0;
-                }
-            }
-            __syncthreads();
-            const int nadm = sc[2];
-            if (nadm == 0) {
-                cur_start = c + 1;
-                continue;
-            }
-            // ---- scatter old entries and admitted candidates to their merged positions
-            const int total = len + nadm;
+            if (len > ef_l) len = ef_l;
+            // the reference re-evaluates its entry points at every layer (:162-167); the values are
+            // reused here, but counted so that `evals` is the reference's number of distance calls
+            if (level != a.max_level) n_eval += len;
             for (int i = tid; i < len; i += kThreads) {
-                uint2 e = listA[i];
-                float de = __uint_as_float(e.x);
-                int sh = 0;
-                for (int j = 0; j < nc; j++) sh += cand_d[j] < de ? 1 : 0;
-                int P = i + sh;
-                if (P < a.cap) listB[P] = e;
-                if (P == ef_l - 1) sc[4] = e.x;
-            }
-            if (tid < nc) {
-                int P = cand_P[tid];
-                if (P >= 0) {
-                    uint2 e = make_uint2(__float_as_uint(cand_d[tid]), static_cast<uint32_t>(cand_id[tid]));
-                    if (P < a.cap) listB[P] = e;
-                    if (P == ef_l - 1) sc[4] = e.x;
-                }
+                uint2 e = curA[i];
+                e.y &= ~kExpanded;
+                curA[i] = e;
+                if (VG) atomicExch(&stamps[e.y], gen);
+                else atomicOr(&bits[e.y >> 5], 1u << (e.y & 31));
             }
             __syncthreads();
-            int newlen = total;
-            if (total > ef_l) {
-                // ghosts: admitted-at-some-time entries pushed past ef whose distance ties the worst
-                const uint32_t wbits = static_cast<uint32_t>(sc[4]);
-                for (int i = tid; i < len; i += kThreads) {
-                    uint2 e = listA[i];
-                    if (e.x == wbits) {
-                        float de = __uint_as_float(e.x);
-                        int sh = 0;
-                        for (int j = 0; j < nc; j++) sh += cand_d[j] < de ? 1 : 0;
-                        if (i + sh >= ef_l && i + sh < a.cap) atomicAdd(&sc[5], 1);
+            int cur_start = 0;
+            const int deg = level == 0 ? a.M0 : a.M;
+            for (;;) {
+                // ---- next candidate: first unexpanded entry
+                if (wave == 0) {
+                    int found = -1;
+                    for (int base = cur_start; base < len && found < 0; base += kWave) {
+                        int i = base + lane;
+                        bool un = i < len && !(curA[i].y & kExpanded);
+                        uint64_t m = __ballot(un);
+                        if (m) found = base + __ffsll(static_cast<unsigned long long>(m)) - 1;
                     }
+                    if (lane == 0) sc[0] = found;
+                }
+                __syncthreads();
+                const int c = sc[0];
+                if (c < 0) break;
+                const uint32_t node = curA[c].y & ~kExpanded;
+                // ---- neighbour ids, visited filter, compaction (wave 0)
+                if (wave == 0) {
+                    const int32_t *adj = level == 0 ? a.l0_adj + static_cast<int64_t>(node) * a.M0
+                                                    : a.up_adj + (a.up_off[node] + (level - 1)) * a.M;
+                    int nb = lane < deg ? adj[lane] : -1;
+                    bool fresh = false;
+                    if (nb >= 0 && nb < a.n) {
+                        if (VG) {
+                            fresh = atomicExch(&stamps[nb], gen) != gen;
+                        } else {
+                            uint32_t bit = 1u << (nb & 31);
+                            uint32_t old = atomicOr(&bits[nb >> 5], bit);
+                            fresh = !(old & bit);
+                        }
+                    }
+                    uint64_t m = __ballot(fresh);
+                    int pos = __popcll(m & ((1ull << lane) - 1ull));
+                    if (fresh) cand_id[pos] = nb;
+                    if (lane == 0) {
+                        sc[1] = __popcll(m);
+                        curA[c].y = node | kExpanded;
+                    }
+                }
+                __syncthreads();
+                const int nc = sc[1];
+                n_hop++;
+                if (nc == 0) {
+                    cur_start = c + 1;
+                    continue;
+                }
+                n_eval += nc;
+                // ---- gather rows + distances: wave w takes candidates [w*RB + t*NW*RB, +RB)
+                for (int j0 = wave * RB; j0 < nc; j0 += NW * RB) {
+                    float4 r[RB][NCH];
+                    int32_t rid[RB];
+#pragma unroll
+                    for (int b = 0; b < RB; b++) {
+                        bool ok = j0 + b < nc;
+                        rid[b] = ok ? cand_id[j0 + b] : 0;
+                        load_row<NCH>(r[b], a.rows + static_cast<int64_t>(rid[b]) * a.ld, nvec, lane, ok);
+                    }
+                    float s[RB];
+#pragma unroll
+                    for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2>(q, r[b]);
+#pragma unroll
+                    for (int b = 0; b < RB; b++) s[b] = wave_sum(s[b]);
+#pragma unroll
+                    for (int b = 0; b < RB; b++) {
+                        if (j0 + b < nc && lane == 0) {
+                            float rn = a.metric == METRIC_COS ? a.row_norms[rid[b]] : 0.0f;
+                            cand_d[j0 + b] = finish_dist(a.metric, s[b], qn, rn) + 0.0f;
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- ranks of the incoming candidates (threads 0..nc-1, all inside wave 0)
+                if (wave == 0) {
+                    bool admitted = false;
+                    int P = 0x7fffffff;
+                    float dj = 0.0f;
+                    if (lane < nc) {
+                        dj = cand_d[lane];
+                        int lo = 0, hi = len;  // upper_bound: #entries with d <= dj
+                        while (lo < hi) {
+                            int mid = (lo + hi) >> 1;
+                            if (__uint_as_float(curA[mid].x) <= dj) lo = mid + 1;
+                            else hi = mid;
+                        }
+                        int before = 0, after_less = 0;
+                        for (int j = 0; j < nc; j++) {
+                            float o = cand_d[j];
+                            before += (j < lane && o <= dj) ? 1 : 0;
+                            after_less += (j > lane && o < dj) ? 1 : 0;
+                        }
+                        int r = lo + before;
+                        admitted = r < ef_l;
+                        P = r + after_less;
+                        cand_P[lane] = admitted ? P : -1;
+                    }
+                    uint64_t am = __ballot(admitted);
+                    int minP = admitted ? P : 0x7fffffff;
+                    for (int off = 1; off < kWave; off <<= 1) {
+                        int o = __shfl_xor(minP, off, kWave);
+                        minP = o < minP ? o : minP;
+                    }
+                    if (lane == 0) {
+                        sc[2] = __popcll(am);
+                        sc[3] = minP;
+                        sc[5] = 0;
+                    }
+                }
+                __syncthreads();
+                const int nadm = sc[2];
+                if (nadm == 0) {
+                    cur_start = c + 1;
+                    continue;
+                }
+                // ---- scatter old entries and admitted candidates to their merged positions
+                const int total = len + nadm;
+                for (int i = tid; i < len; i += kThreads) {
+                    uint2 e = curA[i];
+                    float de = __uint_as_float(e.x);
+                    int sh = 0;
+                    for (int j = 0; j < nc; j++) sh += cand_d[j] < de ? 1 : 0;
+                    int P = i + sh;
+                    if (P < a.cap) curB[P] = e;
+                    if (P == ef_l - 1) sc[4] = e.x;
                 }
                 if (tid < nc) {
                     int P = cand_P[tid];
-                    if (P >= ef_l && P < a.cap && __float_as_uint(cand_d[tid]) == wbits) atomicAdd(&sc[5], 1);
+                    if (P >= 0) {
+                        uint2 e = make_uint2(__float_as_uint(cand_d[tid]), static_cast<uint32_t>(cand_id[tid]));
+                        if (P < a.cap) curB[P] = e;
+                        if (P == ef_l - 1) sc[4] = e.x;
+                    }
                 }
                 __syncthreads();
-                newlen = ef_l + sc[5];
+                int newlen = total;
+                if (total > ef_l) {
+                    // ghosts: admitted-at-some-time entries pushed past ef whose distance ties the worst
+                    const uint32_t wbits = static_cast<uint32_t>(sc[4]);
+                    for (int i = tid; i < len; i += kThreads) {
+                        uint2 e = curA[i];
+                        if (e.x == wbits) {
+                            float de = __uint_as_float(e.x);
+                            int sh = 0;
+                            for (int j = 0; j < nc; j++) sh += cand_d[j] < de ? 1 : 0;
+                            if (i + sh >= ef_l && i + sh < a.cap) atomicAdd(&sc[5], 1);
+                        }
+                    }
+                    if (tid < nc) {
+                        int P = cand_P[tid];
+                        if (P >= ef_l && P < a.cap && __float_as_uint(cand_d[tid]) == wbits) atomicAdd(&sc[5], 1);
+                    }
+                    __syncthreads();
+                    newlen = ef_l + sc[5];
+                }
+                {
+                    uint2 *t = curA;
+                    curA = curB;
+                    curB = t;
+                }
+                len = newlen;
+                const int minP = sc[3];
+                cur_start = minP < c + 1 ? minP : c + 1;
+                __syncthreads();
             }
-            {
-                uint2 *t = listA;
-                listA = listB;
-                listB = t;
+            // ---- level done
+            if (a.q_rows && level > 0 && level <= qlevel && tid == 0) {
+                a.up_out_ids[static_cast<int64_t>(qi) * a.up_stride + (level - 1)] =
+                    len > 0 ? static_cast<int32_t>(curA[0].y & ~kExpanded) : -1;
+                a.up_out_dist[static_cast<int64_t>(qi) * a.up_stride + (level - 1)] =
+                    len > 0 ? __uint_as_float(curA[0].x) : 0.0f;
             }
-            len = newlen;
-            const int minP = sc[3];
-            cur_start = minP < c + 1 ? minP : c + 1;
-            __syncthreads();
         }
-        // ---- level done
-        if (a.q_rows && level > 0 && level <= qlevel && tid == 0) {
-            a.up_out_ids[static_cast<int64_t>(qi) * a.up_stride + (level - 1)] =
-                len > 0 ? static_cast<int32_t>(listA[0].y & ~kExpanded) : -1;
-            a.up_out_dist[static_cast<int64_t>(qi) * a.up_stride + (level - 1)] =
-                len > 0 ? __uint_as_float(listA[0].x) : 0.0f;
+        // ---- results: ascending, take k (:362-370; the distances are reused, not recomputed)
+        int real = len < a.ef ? len : a.ef;
+        for (int i = tid; i < a.k; i += kThreads) {
+            bool ok = i < real;
+            a.out_ids[static_cast<int64_t>(qi) * a.k + i] = ok ? static_cast<int32_t>(curA[i].y & ~kExpanded) : -1;
+            a.out_dist[static_cast<int64_t>(qi) * a.k + i] =
+                ok ? __uint_as_float(curA[i].x) : __uint_as_float(0x7f800000u);
         }
-    }
-    // ---- results: ascending, take k (:362-370; the distances are reused, not recomputed)
-    int real = len < a.ef ? len : a.ef;
-    for (int i = tid; i < a.k; i += kThreads) {
-        bool ok = i < real;
-        a.out_ids[static_cast<int64_t>(qi) * a.k + i] = ok ? static_cast<int32_t>(listA[i].y & ~kExpanded) : -1;
-        a.out_dist[static_cast<int64_t>(qi) * a.k + i] = ok ? __uint_as_float(listA[i].x) : __uint_as_float(0x7f800000u);
-    }
-    if (a.stats && tid == 0) {
-        a.stats[2 * static_cast<int64_t>(qi)] = n_eval;
-        a.stats[2 * static_cast<int64_t>(qi) + 1] = n_hop;
+        if (a.stats && tid == 0) {
+            a.stats[2 * static_cast<int64_t>(qi)] = n_eval;
+            a.stats[2 * static_cast<int64_t>(qi) + 1] = n_hop;
+        }
     }
 }
 

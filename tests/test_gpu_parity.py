@@ -220,6 +220,30 @@ def test_hnsw_build_on_device(eng, oracle):
     assert rec_gpu_graph >= 0.9 and rec_gpu_graph >= rec_ref - 0.03, (rec_gpu_graph, rec_ref)
 
 
+def test_hnsw_large_index_hbm_visited(eng, oracle):
+    """n > 262,144 rows: the visited set moves from the LDS bitset to generation stamps in HBM and the
+    grid becomes persistent.  Same traversal, checked bit for bit against the oracle on the same graph."""
+    O = oracle
+    rs = np.random.RandomState(11)
+    z = rs.randn(300_000, 6).astype(np.float32)
+    base = (z @ rs.randn(6, 24).astype(np.float32) + 0.05 * rs.randn(300_000, 24).astype(np.float32))
+    Q = base[rs.randint(0, 300_000, 24)] + 0.01 * rs.randn(24, 24).astype(np.float32)
+    with eng.Index(base, "l2") as idx:
+        idx.hnsw_build(8, 48, 42)
+        g = idx.get_graph()
+        for ef in (1, 40, 200):
+            ids, d, st = idx.hnsw_search(Q, 10, ef, want_stats=True)
+            oi, od, ost, _ = O.hnsw_search(base, g, Q, 10, ef=ef, metric=O.L2, mode=O.MODE_DEV)
+            assert_exact(ids, d, oi, od, "large n ef=%d" % ef)
+            np.testing.assert_array_equal(st, ost)
+        big = np.tile(Q, (200, 1))                       # 4800 queries > resident slabs: persistent loop + reuse
+        ids2, d2 = idx.hnsw_search(big, 10, 40)
+        ids1, d1 = idx.hnsw_search(Q, 10, 40)
+        assert np.array_equal(ids2, np.tile(ids1, (200, 1))) and np.array_equal(d2, np.tile(d1, (200, 1)))
+        ex, _ = idx.exact_knn(Q, 10)
+        assert O.recall(idx.hnsw_search(Q, 10, 200)[0], ex) >= 0.9
+
+
 # ---- IVF-FLAT -----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["g256x64", "c1000x128"])
 def test_ivf_build_golden(eng, oracle, name):
