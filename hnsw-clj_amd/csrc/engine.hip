@@ -5,7 +5,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "engine.hpp"
+#include "tile_kernels.hpp"
 
 namespace hg {
 
@@ -230,6 +233,96 @@ int end_call(hnswgpu_index *idx, hipStream_t st) {
     return 0;
 }
 
+bool tile_path_ok(const hnswgpu_index *idx) { return idx->metric != METRIC_L2 && idx->dim <= kTileMaxDim; }
+
+int tile_mode() {
+    static const int m = []() {
+        const char *e = getenv("HNSWGPU_TILE");
+        return e ? atoi(e) : -1;
+    }();
+    return m;
+}
+
+int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t st) {
+    int64_t blocks = ngroups_bound * a.nchunks;
+    if (blocks <= 0) return 0;
+    HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "tile grid too large");
+    size_t lds = tile_lds_bytes(dim);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_scan_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a);
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_select(const SelectArgs &a, hipStream_t st) {
+    if (a.nq <= 0) return 0;
+    size_t lds = sizeof(uint64_t) * kNWave * a.k;
+    hipLaunchKernelGGL(select_topk_kernel, dim3((a.nq + kNWave - 1) / kNWave), dim3(kWG), lds, st, a);
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+int pad_queries(hnswgpu_index *idx, const float *d_Q, int64_t qld, int32_t nq, hipStream_t st) {
+    HG_TRY(idx->s_qp.ensure(sizeof(float) * static_cast<size_t>(nq) * idx->ld));
+    HG_TRY(idx->s_qn.ensure(sizeof(float) * static_cast<size_t>(nq)));
+    if (idx->ld != idx->dim) HG_HIP(hipMemsetAsync(idx->s_qp.p, 0, sizeof(float) * static_cast<size_t>(nq) * idx->ld, st));
+    HG_HIP(hipMemcpy2DAsync(idx->s_qp.p, sizeof(float) * idx->ld, d_Q, sizeof(float) * qld, sizeof(float) * idx->dim, nq,
+                            hipMemcpyDeviceToDevice, st));
+    return launch_norms(idx->nch, idx->s_qp.as<float>(), idx->ld, nq, idx->s_qn.as<float>(), st);
+}
+
+int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int32_t nq, const float *rows,
+                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot) {
+    HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * k));
+    HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * k));
+    // distance scratch [qb][nrows]; bound it to ~2 GiB by batching the queries
+    int64_t qb = std::max<int64_t>(kTileQ, ((2LL << 30) / (4 * std::max<int64_t>(nrows, 1))) / kTileQ * kTileQ);
+    qb = std::min<int64_t>(qb, (nq + kTileQ - 1) / kTileQ * kTileQ);
+    HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(qb) * nrows));
+    for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+        int32_t nb = static_cast<int32_t>(std::min<int64_t>(qb, nq - q0));
+        TileArgs t;
+        memset(&t, 0, sizeof(t));
+        t.rows = rows;
+        t.row_norms = row_norms;
+        t.ld = idx->ld;
+        t.dim = idx->dim;
+        t.metric = idx->metric;
+        t.Qp = Qp + q0 * idx->ld;
+        t.q_norms = q_norms + q0;
+        t.nrows_all = nrows;
+        t.nq = nb;
+        t.out_stride = nrows;
+        int64_t groups = (nb + kTileQ - 1) / kTileQ;
+        int64_t tiles = (nrows + kTileRows - 1) / kTileRows;
+        int64_t want = std::max<int64_t>(1, std::min<int64_t>(tiles, (2048 + groups - 1) / groups));
+        int64_t cr = ((tiles + want - 1) / want) * kTileRows;
+        t.chunk_rows = static_cast<int32_t>(cr);
+        t.nchunks = static_cast<int32_t>((nrows + cr - 1) / cr);
+        t.out = idx->s_tile.as<float>();
+        hipEvent_t e0;
+        prof_begin(idx, prof_slot, st, &e0);
+        HG_TRY(launch_tile(t, groups, idx->dim, st));
+        prof_end(idx, prof_slot, st, e0);
+        SelectArgs s;
+        memset(&s, 0, sizeof(s));
+        s.dist = t.out;
+        s.stride = nrows;
+        s.cnt_all = nrows;
+        s.nq = nb;
+        s.k = k;
+        s.out_ord = idx->s_ord.as<uint32_t>() + q0 * k;
+        s.out_dist = idx->s_dist.as<float>() + q0 * k;
+        HG_TRY(launch_select(s, st));
+    }
+    return 0;
+}
+
 int upload_queries(hnswgpu_index *idx, const float *Q, int32_t nq, hipStream_t st) {
     size_t bytes = sizeof(float) * static_cast<size_t>(nq) * idx->dim;
     HG_TRY(idx->s_q.ensure(bytes));
@@ -398,7 +491,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf *bufs[] = {&idx->s_q,   &idx->s_partial, &idx->s_ord,   &idx->s_dist, &idx->s_pairs, &idx->s_ids,
-                      &idx->s_outd, &idx->s_probes,  &idx->s_stats, &idx->s_misc, &idx->s_misc2, &idx->s_vis};
+                      &idx->s_outd, &idx->s_probes,  &idx->s_stats, &idx->s_misc, &idx->s_misc2, &idx->s_vis, &idx->s_qp, &idx->s_qn, &idx->s_tile, &idx->s_grp};
     for (DevBuf *b : bufs) b->release();
     for (int s = 0; s < PROF_N; s++)
         for (auto &pr : idx->prof_ev[s]) {
@@ -484,6 +577,18 @@ int hnswgpu_norms(hnswgpu_index *idx, float *out_norms) {
 
 static int exact_knn_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t *d_ids,
                              float *d_dist, hipStream_t st) {
+    const int tm = tile_mode();
+    if (tile_path_ok(idx) && tm != 0 && (tm == 1 || nq >= 16)) {  // many queries share the rows: MFMA tiles
+        HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
+        HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_base, idx->d_norms, idx->n, k,
+                             st, PROF_IVF_SCAN));
+        int64_t cnt = static_cast<int64_t>(nq) * k;
+        hipLaunchKernelGGL(ord_to_ids_kernel, dim3(static_cast<unsigned>((cnt + 255) / 256)), dim3(256), 0, st,
+                           idx->s_ord.as<uint32_t>(), cnt, d_ids);
+        HG_HIP(hipGetLastError());
+        HG_HIP(hipMemcpyAsync(d_dist, idx->s_dist.p, sizeof(float) * cnt, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.rows = idx->d_base;

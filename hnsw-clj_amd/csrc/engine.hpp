@@ -10,6 +10,7 @@
 
 #include "../../include/hnswgpu.h"
 #include "kernels.hpp"
+#include "tile_args.hpp"
 
 namespace hg {
 
@@ -104,7 +105,7 @@ struct hnswgpu_index {
     std::vector<int32_t> h_listids;
 
     // scratch (grown on demand, reused across calls; calls are serialised by `mu`)
-    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2, s_vis;
+    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2, s_vis, s_qp, s_qn, s_tile, s_grp;
     uint32_t vis_gen = 0;  // last generation number handed to an HBM visited slab
 
     // profiling
@@ -136,6 +137,17 @@ void prof_begin(hnswgpu_index *idx, int slot, hipStream_t st, hipEvent_t *e0);
 void prof_end(hnswgpu_index *idx, int slot, hipStream_t st, hipEvent_t e0);
 
 int upload_queries(hnswgpu_index *idx, const float *Q, int32_t nq, hipStream_t st);
+
+// --- tiled (MFMA) scan path -------------------------------------------------------------------------
+bool tile_path_ok(const hnswgpu_index *idx);  // metric != L2 and dim fits the LDS-resident query group
+int tile_mode();                               // HNSWGPU_TILE: -1 auto, 0 never, 1 whenever possible
+int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t st);
+int launch_select(const SelectArgs &a, hipStream_t st);
+// queries (nq x dim, row stride qld) -> s_qp (nq x ld, zero padded) + s_qn (device-order norms)
+int pad_queries(hnswgpu_index *idx, const float *d_Q, int64_t qld, int32_t nq, hipStream_t st);
+// every query against rows [0, nrows): per-query ascending top-k into s_ord / s_dist
+int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int32_t nq, const float *rows,
+                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot);
 
 // Every entry point brackets its device work with these: a call on stream B waits for the previous
 // call's work on stream A before it may reuse the index's scratch buffers.

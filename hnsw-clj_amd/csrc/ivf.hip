@@ -164,6 +164,9 @@ static int assign_enqueue(hnswgpu_index *idx, const float *d_cent, const float *
     a.pairs = nullptr;
     a.k = 1;
     a.role = ROLE_ASSIGN;
+    if (tile_path_ok(idx) && tile_mode() != 0)  // dense X . C^T: every base row against every centroid
+        return tile_topk_all(idx, idx->d_base, idx->d_norms, static_cast<int32_t>(idx->n), d_cent, d_cnorms, nlist, 1, st,
+                             PROF_ASSIGN);
     return scan_topk(idx, a, static_cast<int32_t>(idx->n), 1, nlist, st, PROF_ASSIGN);
 }
 

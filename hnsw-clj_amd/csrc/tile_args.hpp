@@ -1,0 +1,80 @@
+// tile_kernels.hpp -- the batched form of the distance scan for gfx950: when MANY queries share the
+// same rows (a large query batch against IVF lists, every base row against the centroid table in
+// k-means assignment, ground-truth kNN), the per-(query,row) GEMV of scan_kernel re-reads each row once
+// per query.  Here a workgroup keeps a group of up to 32 queries resident in LDS, streams the rows
+// through LDS once, and lets the matrix cores do the reduction over D:
+//     v_mfma_f32_32x32x2_f32  (f32 in, f32 accumulate: exact f32, bit-for-bit a k-ordered fmaf chain --
+//     cdna_hip_programming.md "FP32-input MFMA"), one 32-row x 32-query tile per wave.
+// This is a real reuse win, not a reshaping for its own sake: the row bytes fetched from HBM drop by
+// the group size, and the dot products need no cross-lane shuffles at all.
+//
+// Numeric contract (oracle/oracle.c "MFMA order" mimics it): for a (row, query) pair the accumulator
+// is one f32 fmaf chain over k in the order 8t+j, 8t+4+j (j = 0..3, t ascending) -- lane half 0 of an
+// MFMA carries k = 8t+j, half 1 carries k = 8t+4+j, and the instruction adds half 0's product first.
+// Norms are the same sqrt(reduce(v.v)) values as everywhere else (row_norms_kernel).
+// Cosine and dot only: rooted L2 from |q|^2+|v|^2-2q.v would lose the exact zeros the reference's
+// tests pin, so L2 stays on scan_kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hg {
+
+constexpr int kTileRows = 128;  // rows per tile: 4 waves x 32
+constexpr int kTileQ = 32;      // queries per group (MFMA N)
+constexpr int kTileK = 32;      // K per staging step
+constexpr int kTileLdA = kTileK + 4;  // padded LDS row of the A (rows) tile: conflict-free ds_read_b128
+constexpr int kTileMaxDim = 896;      // queries (32 x (dim+pad)) + 2 A buffers must fit 160 KiB of LDS
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ inline int tile_ldq(int dim) { return ((dim + 63) / 64) * 64 + 4; }
+__host__ inline size_t tile_lds_bytes(int dim) {
+    return sizeof(float) * (static_cast<size_t>(kTileQ) * tile_ldq(dim) + 2 * kTileRows * kTileLdA) +
+           sizeof(float) * kTileQ + sizeof(int64_t) * kTileQ;
+}
+
+struct GroupMember {
+    int32_t q;         // query index
+    int32_t pad;
+    int64_t out_base;  // distances of this (query, segment) go to out[out_base + (row - row_begin)]
+};
+
+struct TileArgs {
+    const float *rows;
+    const float *row_norms;
+    int64_t ld;
+    int32_t dim;
+    int32_t metric;
+    const float *Qp;  // queries padded to stride ld (zero filled), 16-B aligned rows
+    const float *q_norms;
+    // explicit groups (IVF): group g -> segment seg_of[g], members [mem_begin[g], mem_begin[g] + mem_cnt[g])
+    const int32_t *grp_seg;
+    const int32_t *grp_mem_begin;
+    const int32_t *grp_mem_cnt;
+    const int32_t *ngroups;  // device scalar (grid is an upper bound)
+    const GroupMember *members;
+    const int64_t *seg_off;  // row range of segment s = [seg_off[s], seg_off[s+1])
+    // implicit groups (assignment / exact kNN): group g = queries [32g, 32g+32), every group scans rows
+    // [0, nrows_all) and writes out[q * out_stride + row]
+    int64_t nrows_all;
+    int32_t nq;
+    int64_t out_stride;
+    int32_t chunk_rows;  // multiple of kTileRows
+    int32_t nchunks;
+    float *out;
+};
+
+// Per-query top-k over a dense distance array (written by tile_scan_kernel): one wave per query.
+// ord = position in the array = position in the query's concatenated candidate stream.
+struct SelectArgs {
+    const float *dist;     // query q's candidates are dist[q * stride .. + (q_cnt ? q_cnt[q] : cnt_all))
+    const int32_t *q_cnt;
+    int64_t stride;
+    int64_t cnt_all;
+    int32_t nq, k;
+    uint32_t *out_ord;
+    float *out_dist;
+};
+
+}  // namespace hg

@@ -30,6 +30,7 @@
 #define ORC_MODE_F64 0  /* reference order, f64 (the truth)                                  */
 #define ORC_MODE_DEV 1  /* bit-mimic of the HIP kernels' f32 lane/butterfly order            */
 #define ORC_MODE_FAST 2 /* "fair-fight" CPU baseline: f32, 8 partial sums, precomputed norms */
+#define ORC_MODE_MFMA 3 /* bit-mimic of the tiled MFMA scan path (tile_kernels.hpp); norms as DEV      */
 
 /* ------------------------------------------------------------------------------------------ */
 /* 1. Distances, f64, strictly left-to-right                                                  */
@@ -149,6 +150,25 @@ static inline float dev_l2sq(const float *q, const float *v, int n) {
     return dev_reduce64(s);
 }
 float orc_norm_dev(const float *v, int n) { return sqrtf(dev_dot(v, v, n)); }
+
+/* Tiled path (hnsw-clj_amd/csrc/tile_kernels.hpp): v_mfma_f32_32x32x2_f32 is a k-ordered f32 fmaf chain;
+ * the kernel feeds k in the order 8t+j, 8t+4+j (j = 0..3, t ascending). */
+static inline float mfma_dot(const float *q, const float *v, int n) {
+    float acc = 0.0f;
+    for (int t = 0; 8 * t < n; t++)
+        for (int j = 0; j < 4; j++) {
+            int k0 = 8 * t + j, k1 = 8 * t + 4 + j;
+            if (k0 < n) acc = fmaf(v[k0], q[k0], acc);
+            if (k1 < n) acc = fmaf(v[k1], q[k1], acc);
+        }
+    return acc;
+}
+float orc_dist_mfma(int metric, const float *q, const float *v, int n, float qnorm, float vnorm) {
+    float dot = mfma_dot(q, v, n);
+    if (metric == ORC_DOT) return -dot + 0.0f;
+    if (qnorm > 0.0f && vnorm > 0.0f) return 1.0f - dot / (qnorm * vnorm) + 0.0f;
+    return 1.0f;
+}
 /* qnorm / vnorm are orc_norm_dev values (cosine only). */
 float orc_dist_dev(int metric, const float *q, const float *v, int n, float qnorm, float vnorm) {
     if (metric == ORC_L2) return sqrtf(dev_l2sq(q, v, n));
@@ -197,15 +217,17 @@ static void ctx_set_query(dist_ctx *c, const float *q) {
     c->q = q;
     c->qnorm = 0.0f;
     if (c->metric == ORC_COSINE) {
-        if (c->mode == ORC_MODE_DEV) c->qnorm = orc_norm_dev(q, c->dim);
+        if (c->mode == ORC_MODE_DEV || c->mode == ORC_MODE_MFMA) c->qnorm = orc_norm_dev(q, c->dim);
         else if (c->mode == ORC_MODE_FAST) c->qnorm = sqrtf(fast_dot(q, q, c->dim));
     }
 }
 static inline double ctx_dist(const dist_ctx *c, int64_t row) {
     const float *v = c->base + row * (int64_t)c->dim;
     if (c->mode == ORC_MODE_F64) return dist_f64(c->metric, c->q, v, c->dim);
-    if (c->mode == ORC_MODE_DEV)
+    if (c->mode == ORC_MODE_DEV || (c->mode == ORC_MODE_MFMA && c->metric == ORC_L2))
         return (double)orc_dist_dev(c->metric, c->q, v, c->dim, c->qnorm, c->norms ? c->norms[row] : 0.0f);
+    if (c->mode == ORC_MODE_MFMA)
+        return (double)orc_dist_mfma(c->metric, c->q, v, c->dim, c->qnorm, c->norms ? c->norms[row] : 0.0f);
     /* FAST */
     if (c->metric == ORC_L2) return (double)sqrtf(fast_l2sq(c->q, v, c->dim));
     float dot = fast_dot(c->q, v, c->dim);
@@ -218,7 +240,7 @@ static inline double ctx_dist(const dist_ctx *c, int64_t row) {
 void orc_norms(const float *base, int64_t n, int dim, int mode, float *out) {
     for (int64_t i = 0; i < n; i++) {
         const float *v = base + i * dim;
-        if (mode == ORC_MODE_DEV) out[i] = orc_norm_dev(v, dim);
+        if (mode == ORC_MODE_DEV || mode == ORC_MODE_MFMA) out[i] = orc_norm_dev(v, dim);
         else if (mode == ORC_MODE_FAST) out[i] = sqrtf(fast_dot(v, v, dim));
         else { /* src/hnsw/ann/partition/ivf_flat.clj:171-177 (f64), rounded for storage */
             double s = 0.0;
@@ -972,6 +994,35 @@ void orc_kmeans_assign(const float *base, int64_t n, int dim, int metric, const 
     }
 }
 
+/* Same assignment on float32 centroids (what the engine stores) in any arithmetic mode: used to check
+ * hnswgpu_kmeans_assign bit for bit (DEV = scan_kernel order, MFMA = tile_scan_kernel order). */
+void orc_kmeans_assign_f32(const float *base, int64_t n, int dim, int metric, int mode, const float *cent,
+                           int nlist, int32_t *assign, float *best_d) {
+    float *cn = (float *)malloc(sizeof(float) * (size_t)(nlist + 1));
+    orc_norms(cent, nlist, dim, mode, cn);
+    dist_ctx c;
+    c.metric = metric;
+    c.mode = mode;
+    c.dim = dim;
+    c.base = cent;
+    c.norms = cn;
+    for (int64_t i = 0; i < n; i++) {
+        ctx_set_query(&c, base + i * dim);
+        double md = 1.7976931348623157e308;
+        int bi = 0;
+        for (int j = 0; j < nlist; j++) {
+            double d = ctx_dist(&c, j);
+            if (d < md) {
+                md = d;
+                bi = j;
+            }
+        }
+        assign[i] = bi;
+        if (best_d) best_d[i] = (float)md;
+    }
+    free(cn);
+}
+
 /* ivf_flat.clj:32-60 kmeans-plus-plus-init, restated incrementally (min over chosen centroids is
  * kept per row; identical values to recomputing all of them each round as the reference does
  * :43-49).  Random(42) :36.  Returns chosen row indices.  The pick loop (:54-58) is clamped to
@@ -1044,7 +1095,7 @@ void orc_ivf_build(const float *base, int64_t n, int dim, int metric, int nlist,
  * Lists: list_off[nlist+1], list_ids in list order (index order inside a list).
  * centroids are float32 here: the values the engine stores (the reference keeps f64 means).
  * mode: F64 (truth), DEV (device-order mimic; needs norms + cnorms from orc_norms(mode DEV)). */
-void orc_ivf_search(const float *base, int64_t n, int dim, int metric, int mode, const float *norms,
+void orc_ivf_search(const float *base, int64_t n, int dim, int metric, int mode, int scan_mode, const float *norms,
                     const float *centroids, const float *cnorms, int nlist, const int64_t *list_off,
                     const int32_t *list_ids, const float *Q, int nq, int k, int nprobe, int32_t *out_ids,
                     double *out_d, int32_t *out_probes) {
@@ -1067,6 +1118,7 @@ void orc_ivf_search(const float *base, int64_t n, int dim, int metric, int mode,
     cc.base = centroids;
     cc.norms = cnorms;
     cb = cc;
+    cb.mode = scan_mode; /* routing and list scan may run on different kernels (GEMV vs MFMA tiles) */
     cb.base = base;
     cb.norms = norms;
     for (int qi = 0; qi < nq; qi++) {

@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 
 COSINE, L2, DOT = 0, 1, 2
 METRICS = {"cosine": COSINE, "l2": L2, "euclidean": L2, "dot": DOT}
-MODE_F64, MODE_DEV, MODE_FAST = 0, 1, 2
+MODE_F64, MODE_DEV, MODE_FAST, MODE_MFMA = 0, 1, 2, 3
 GAUSSIAN, UNIFORM, UNIT, CLUSTERED = 0, 1, 2, 3
 
 
@@ -72,7 +72,9 @@ def lib():
         _lib.orc_ivf_build.restype = None
         _lib.orc_ivf_build.argtypes = [p, i64, i32, i32, i32, i32, i64, p, p]
         _lib.orc_ivf_search.restype = None
-        _lib.orc_ivf_search.argtypes = [p, i64, i32, i32, i32, p, p, p, i32, p, p, p, i32, i32, i32, p, p, p]
+        _lib.orc_ivf_search.argtypes = [p, i64, i32, i32, i32, i32, p, p, p, i32, p, p, p, i32, i32, i32, p, p, p]
+        _lib.orc_kmeans_assign_f32.restype = None
+        _lib.orc_kmeans_assign_f32.argtypes = [p, i64, i32, i32, i32, p, i32, p, p]
         # java.util.Random
         _lib.jr_init.argtypes = [p, i64]
         _lib.jr_next_int.restype = C.c_int32
@@ -273,6 +275,16 @@ def kmeans_assign(base, centroids, metric=COSINE):
     return a, d
 
 
+def kmeans_assign_f32(base, centroids, metric=COSINE, mode=MODE_DEV):
+    """ivf_flat.clj:79-90 on float32 centroids in a device arithmetic mode -> (assign, dist f32)."""
+    base, cen = _f32(base), _f32(centroids)
+    n, dim = base.shape
+    a = np.zeros(n, np.int32)
+    d = np.zeros(n, np.float32)
+    lib().orc_kmeans_assign_f32(_p(base), n, dim, int(metric), mode, _p(cen), cen.shape[0], _p(a), _p(d))
+    return a, d
+
+
 def kmeanspp(base, nlist, metric=COSINE, seed=42):
     """src/hnsw/ann/partition/ivf_flat.clj:32-60 -> chosen row indices."""
     base = _f32(base)
@@ -301,7 +313,7 @@ def lists_from_assign(assign, nlist):
     return off, order
 
 
-def ivf_search(base, centroids, list_off, list_ids, Q, k, nprobe, metric=COSINE, mode=MODE_F64):
+def ivf_search(base, centroids, list_off, list_ids, Q, k, nprobe, metric=COSINE, mode=MODE_F64, scan_mode=None):
     """src/hnsw/ann/partition/ivf_flat.clj:236-294 with explicit nprobe; centroids float32 (engine storage)."""
     base, Q = _f32(base), _f32(Q)
     if Q.ndim == 1:
@@ -311,6 +323,7 @@ def ivf_search(base, centroids, list_off, list_ids, Q, k, nprobe, metric=COSINE,
     nq = Q.shape[0]
     nlist = cen.shape[0]
     nprobe = min(nprobe, nlist)
+    scan_mode = mode if scan_mode is None else scan_mode
     nr = cn = None
     if mode != MODE_F64 and metric == COSINE:
         nr, cn = norms(base, mode), norms(cen, mode)
@@ -319,6 +332,6 @@ def ivf_search(base, centroids, list_off, list_ids, Q, k, nprobe, metric=COSINE,
     ids = np.full((nq, k), -1, np.int32)
     ds = np.full((nq, k), np.inf, np.float64)
     probes = np.zeros((nq, nprobe), np.int32)
-    lib().orc_ivf_search(_p(base), n, dim, int(metric), mode, _p(nr), _p(cen), _p(cn), nlist, _p(off), _p(lids),
+    lib().orc_ivf_search(_p(base), n, dim, int(metric), mode, scan_mode, _p(nr), _p(cen), _p(cn), nlist, _p(off), _p(lids),
                          _p(Q), nq, k, nprobe, _p(ids), _p(ds), _p(probes))
     return ids, ds, probes

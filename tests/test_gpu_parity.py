@@ -101,6 +101,29 @@ def test_exact_knn(eng, oracle, n, dim, k):
             assert (ids[:, n:] == -1).all() and np.isinf(d[:, n:]).all()
 
 
+@pytest.mark.parametrize("n,dim,nq,k", [(1000, 128, 70, 10), (300, 768, 33, 100), (2500, 100, 64, 5), (129, 8, 16, 3)])
+def test_tiled_mfma_path_exact(eng, oracle, n, dim, nq, k):
+    """Many queries against the same rows run on the MFMA tile kernel (v_mfma_f32_32x32x2_f32); its k-order is
+    mimicked by the oracle's MFMA mode: ids identical, distances bit-identical.  L2 stays on the GEMV kernel."""
+    O = oracle
+    base = _data(O, n, dim)
+    Q = np.vstack([_data(O, nq - 2, dim, seed=43), base[:2]])
+    for metric in (O.COSINE, O.DOT, O.L2):
+        with eng.Index(base, metric) as idx:
+            ids, d = idx.exact_knn(Q, k)
+            mode = O.MODE_DEV if metric == O.L2 else O.MODE_MFMA
+            oi, od, _ = O.exact_knn(base, Q, k, metric=metric, mode=mode)
+            assert_exact(ids, d, oi, od, "tile exact n=%d metric=%d" % (n, metric))
+            fi, fd, _ = O.exact_knn(base, Q, k, metric=metric)
+            assert_topk_parity(ids, d, fi, fd, "tile f64", metric_scale(metric, Q, base))
+            if metric != O.L2:  # k-means assignment = every base row against the centroid table, k = 1
+                cen = _data(O, 37, dim, seed=5)
+                a, ad = idx.kmeans_assign(cen)
+                oa, oad = O.kmeans_assign_f32(base, cen, metric, O.MODE_MFMA)
+                np.testing.assert_array_equal(a, oa)
+                np.testing.assert_array_equal(ad.view(np.uint32), oad.view(np.uint32))
+
+
 # ---- HNSW search on FIXED graphs (the committed golden adjacency) -----------------------------------------
 @pytest.mark.parametrize("name", ["g256x64", "c1000x128"])
 def test_hnsw_search_golden(eng, oracle, name):
@@ -337,8 +360,8 @@ def test_full_size_31k_properties(eng, oracle):
         assert st[:, 0].min() > 200 and st[:, 1].min() >= 200
         idx.ivf_build(24, 2, 42)   # the reference's default nlist (ivf_flat.clj:144); 2 Lloyd passes keep it short
         ii, dd = idx.ivf_search(Q, 10, 24)
-        np.testing.assert_array_equal(ii, ei)
-        np.testing.assert_array_equal(dd.view(np.uint32), ed.view(np.uint32))
+        # the list scan (GEMV order) and the brute force (MFMA tile order) sum in different orders
+        assert_topk_parity(ii, dd, ei, ed, "ivf(all lists) vs exact")
 
 
 def test_merge_topk_dev(eng):
