@@ -176,11 +176,14 @@ void prof_end(hnswgpu_index *idx, int slot, hipStream_t st, hipEvent_t e0) {
     idx->prof_ev[slot].push_back({e0, e1});
 }
 
-int plan_chunks(int nch, int64_t max_rows, int64_t npairs, int32_t *chunk_rows) {
-    // enough workgroups to fill 256 CUs several times over, but no chunk below one loop trip of
-    // every wave; chunk_rows is a multiple of the rows one workgroup consumes per iteration
+int plan_chunks(int nch, int64_t max_rows, int64_t mean_rows, int64_t npairs, int32_t *chunk_rows) {
+    // Enough NON-EMPTY workgroups to fill 256 CUs several times over, but no chunk below one loop trip
+    // of every wave.  The chunk size comes from the MEAN segment length (short lists then simply leave
+    // their trailing chunks empty -- those workgroups exit at once); the chunk count from the longest.
     const int64_t per_iter = scan_rows_per_iter(nch);
     if (max_rows < 1) max_rows = 1;
+    if (mean_rows < 1) mean_rows = 1;
+    if (mean_rows > max_rows) mean_rows = max_rows;
     static const int64_t env_blocks = []() {
         const char *e = getenv("HNSWGPU_SCAN_BLOCKS");  // tuning override
         return e ? atoll(e) : 0LL;
@@ -188,19 +191,20 @@ int plan_chunks(int nch, int64_t max_rows, int64_t npairs, int32_t *chunk_rows) 
     int64_t target_blocks = env_blocks > 0 ? env_blocks : 8192;
     int64_t want = (target_blocks + npairs - 1) / (npairs > 0 ? npairs : 1);
     if (want < 1) want = 1;
-    int64_t max_chunks = (max_rows + per_iter - 1) / per_iter;
+    if (want == 1) mean_rows = max_rows;  // already enough pairs: one workgroup per pair, no empty chunks
+    int64_t max_chunks = (mean_rows + per_iter - 1) / per_iter;
     if (want > max_chunks) want = max_chunks;
-    int64_t cr = (max_rows + want - 1) / want;
+    int64_t cr = (mean_rows + want - 1) / want;
     cr = ((cr + per_iter - 1) / per_iter) * per_iter;
     *chunk_rows = static_cast<int32_t>(cr);
     return static_cast<int>((max_rows + cr - 1) / cr);
 }
 
 int scan_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_query, int64_t max_rows,
-              hipStream_t st, int prof_slot) {
+              hipStream_t st, int prof_slot, int64_t mean_rows) {
     a.mode = MODE_TOPK;
     a.npairs = nq * pairs_per_query;
-    a.nchunks = plan_chunks(idx->nch, max_rows, a.npairs, &a.chunk_rows);
+    a.nchunks = plan_chunks(idx->nch, max_rows, mean_rows > 0 ? mean_rows : max_rows, a.npairs, &a.chunk_rows);
     int64_t keys_per_query = static_cast<int64_t>(pairs_per_query) * a.nchunks * kNWave * a.k;
     HG_TRY(idx->s_partial.ensure(sizeof(uint64_t) * keys_per_query * nq));
     HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * a.k));

@@ -14,7 +14,7 @@ namespace hg {
 // its rows in the query's concatenated candidate stream (ties are broken in that order, which is
 // the order search-ivf-flat concatenates partitions in, ivf_flat.clj:281-294)
 __global__ void probe_pairs_kernel(const uint32_t *ord, int nq, int nprobe, const int64_t *listoff, Pair *pairs,
-                                   int32_t *probes) {
+                                   int32_t *probes, int32_t *qcnt) {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     uint32_t base = 0;
@@ -34,6 +34,47 @@ __global__ void probe_pairs_kernel(const uint32_t *ord, int nq, int nprobe, cons
         base += static_cast<uint32_t>(pr.row_end - pr.row_begin);
         pairs[static_cast<int64_t>(q) * nprobe + p] = pr;
     }
+    if (qcnt) qcnt[q] = static_cast<int32_t>(base);
+}
+
+// ---- grouping of (query, probed list) pairs by list, for the tiled scan --------------------------------
+__global__ void ivf_hist_kernel(const int32_t *probes, int64_t npairs, int32_t *cnt) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < npairs && probes[i] >= 0) atomicAdd(&cnt[probes[i]], 1);
+}
+
+// one thread: lists are few (nlist ~ 1e3) and groups ~ npairs/32 + nlist
+__global__ void ivf_plan_kernel(const int32_t *cnt, int nlist, int32_t *list_mem_begin, int32_t *fill,
+                                int32_t *grp_seg, int32_t *grp_mem_begin, int32_t *grp_mem_cnt, int32_t *ngroups) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int32_t mem = 0, g = 0;
+    for (int l = 0; l < nlist; l++) {
+        int c = cnt[l];
+        list_mem_begin[l] = mem;
+        fill[l] = 0;
+        for (int b = 0; b < c; b += kTileQ) {
+            grp_seg[g] = l;
+            grp_mem_begin[g] = mem + b;
+            grp_mem_cnt[g] = c - b < kTileQ ? c - b : kTileQ;
+            g++;
+        }
+        mem += c;
+    }
+    *ngroups = g;
+}
+
+__global__ void ivf_scatter_kernel(const Pair *pairs, const int32_t *probes, int64_t npairs, int64_t stride,
+                                   const int32_t *list_mem_begin, int32_t *fill, GroupMember *members) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= npairs) return;
+    int l = probes[i];
+    if (l < 0) return;
+    int slot = list_mem_begin[l] + atomicAdd(&fill[l], 1);
+    GroupMember m;
+    m.q = pairs[i].q;
+    m.pad = 0;
+    m.out_base = static_cast<int64_t>(pairs[i].q) * stride + pairs[i].ord_base;
+    members[slot] = m;
 }
 
 __global__ void ivf_decode_kernel(const uint32_t *ord, int nq, int k, const Pair *pairs, int nprobe,
@@ -212,7 +253,7 @@ static int kmeanspp_device(hnswgpu_index *idx, int32_t nlist, int64_t seed, std:
         a.role = ROLE_SEED;
         a.pairs = nullptr;
         a.npairs = 1;
-        a.nchunks = plan_chunks(idx->nch, n, 1, &a.chunk_rows);
+        a.nchunks = plan_chunks(idx->nch, n, n, 1, &a.chunk_rows);
         a.k = 1;
         a.out = mind;
         HG_TRY(launch_scan(idx->nch, a, st));
@@ -234,6 +275,73 @@ static int kmeanspp_device(hnswgpu_index *idx, int32_t nlist, int64_t seed, std:
     return 0;
 }
 
+// Large batches: group the (query, list) pairs by list, keep each group of <= 32 queries resident in LDS
+// and stream the list through the MFMA tile kernel once per group; distances land in a dense
+// per-query candidate array (position = the pair's order key), then one select pass per query.
+static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
+                         const int32_t *d_probes, const int32_t *d_qcnt, hipStream_t st) {
+    const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
+    const int nlist = idx->nlist;
+    const int64_t stride = static_cast<int64_t>(nprobe) * idx->max_list_len;  // candidates per query, upper bound
+    const int64_t gbound = npairs / kTileQ + nlist;                            // sum_l ceil(cnt_l / 32) <= this
+    HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(nq) * stride));  // queries already padded
+    // int32 scratch: cnt[nlist] | list_mem_begin[nlist] | fill[nlist] | grp_seg | grp_mem_begin | grp_mem_cnt | ngroups
+    size_t ints = 3 * static_cast<size_t>(nlist) + 3 * static_cast<size_t>(gbound) + 4;
+    HG_TRY(idx->s_misc.ensure(sizeof(int32_t) * ints));
+    HG_TRY(idx->s_misc2.ensure(sizeof(GroupMember) * static_cast<size_t>(npairs)));
+    int32_t *cnt = idx->s_misc.as<int32_t>();
+    int32_t *lmb = cnt + nlist, *fill = lmb + nlist, *gseg = fill + nlist, *gmb = gseg + gbound, *gmc = gmb + gbound,
+            *ngr = gmc + gbound;
+    HG_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nlist, st));
+    hipLaunchKernelGGL(ivf_hist_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st, d_probes,
+                       npairs, cnt);
+    hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(64), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr);
+    hipLaunchKernelGGL(ivf_scatter_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st,
+                       idx->s_pairs.as<Pair>(), d_probes, npairs, stride, lmb, fill, idx->s_misc2.as<GroupMember>());
+    HG_HIP(hipGetLastError());
+    TileArgs t;
+    memset(&t, 0, sizeof(t));
+    t.rows = idx->d_lrows;
+    t.row_norms = idx->d_lnorms;
+    t.ld = idx->ld;
+    t.dim = idx->dim;
+    t.metric = idx->metric;
+    t.Qp = idx->s_qp.as<float>();
+    t.q_norms = idx->s_qn.as<float>();
+    t.grp_seg = gseg;
+    t.grp_mem_begin = gmb;
+    t.grp_mem_cnt = gmc;
+    t.ngroups = ngr;
+    t.members = idx->s_misc2.as<GroupMember>();
+    t.seg_off = idx->d_listoff;
+    t.nq = nq;
+    // rows per workgroup: whole tiles of 128, enough workgroups to fill the chip
+    int64_t mean = std::max<int64_t>(1, idx->n / std::max(nlist, 1));
+    int64_t est_groups = std::max<int64_t>(1, npairs / kTileQ + nlist / 2);
+    int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows;
+    int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (2048 + est_groups - 1) / est_groups));
+    int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows;
+    t.chunk_rows = static_cast<int32_t>(cr);
+    t.nchunks = static_cast<int32_t>((idx->max_list_len + cr - 1) / cr);
+    t.out = idx->s_tile.as<float>();
+    hipEvent_t e0;
+    prof_begin(idx, PROF_IVF_SCAN, st, &e0);
+    HG_TRY(launch_tile(t, gbound, idx->dim, st));
+    prof_end(idx, PROF_IVF_SCAN, st, e0);
+    HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * k));
+    HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * k));
+    SelectArgs s;
+    memset(&s, 0, sizeof(s));
+    s.dist = t.out;
+    s.q_cnt = d_qcnt;
+    s.stride = stride;
+    s.nq = nq;
+    s.k = k;
+    s.out_ord = idx->s_ord.as<uint32_t>();
+    s.out_dist = idx->s_dist.as<float>();
+    return launch_select(s, st);
+}
+
 static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
                               int32_t *d_out_ids, float *d_out_dist, int32_t *d_out_probes, hipStream_t st,
                               const int32_t *d_given_probes = nullptr) {
@@ -242,10 +350,22 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     HG_TRY(idx->s_pairs.ensure(sizeof(Pair) * static_cast<size_t>(nq) * nprobe));
+    const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
+    // tiled (MFMA) list scan when the batch is large enough for queries to share lists
+    const int tm = tile_mode();
+    const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs >= 4LL * idx->nlist);
+    int32_t *probes_buf = d_out_probes;
+    int32_t *qcnt_buf = nullptr;
+    if (use_tile) {
+        HG_TRY(idx->s_grp.ensure(sizeof(int32_t) * (npairs + nq + 16)));
+        if (!probes_buf) probes_buf = idx->s_grp.as<int32_t>();
+        qcnt_buf = idx->s_grp.as<int32_t>() + npairs;
+        HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
+    }
     if (d_given_probes) {  // caller-chosen lists (the :turbo mode's random partitions, :271-272); -1 = none
         hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + 127) / 128), dim3(128), 0, st,
                            reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff,
-                           idx->s_pairs.as<Pair>(), d_out_probes);
+                           idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf);
         HG_HIP(hipGetLastError());
     } else {
     a.rows = idx->d_cent;
@@ -258,9 +378,13 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     a.metric = idx->metric;
     a.k = nprobe;
     a.role = ROLE_ROUTE;
-    HG_TRY(scan_topk(idx, a, nq, 1, idx->nlist, st, -1));
+    if (use_tile)  // every query against the centroid table on the tile kernel as well
+        HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
+                             nprobe, st, -1));
+    else
+        HG_TRY(scan_topk(idx, a, nq, 1, idx->nlist, st, -1));
     hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + 127) / 128), dim3(128), 0, st, idx->s_ord.as<uint32_t>(), nq,
-                       nprobe, idx->d_listoff, idx->s_pairs.as<Pair>(), d_out_probes);
+                       nprobe, idx->d_listoff, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf);
     HG_HIP(hipGetLastError());
     }
     // 2. scan the probed lists (:217-234) and merge (:291-294)
@@ -275,7 +399,12 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     a.pairs = idx->s_pairs.as<Pair>();
     a.k = k;
     a.role = ROLE_LIST_SCAN;
-    HG_TRY(scan_topk(idx, a, nq, nprobe, idx->max_list_len, st, PROF_IVF_SCAN));
+    if (use_tile) {
+        HG_TRY(ivf_tile_scan(idx, d_Q, nq, k, nprobe, probes_buf, qcnt_buf, st));
+    } else {
+        HG_TRY(scan_topk(idx, a, nq, nprobe, idx->max_list_len, st, PROF_IVF_SCAN,
+                         std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1))));
+    }
     int64_t cnt = static_cast<int64_t>(nq) * k;
     hipLaunchKernelGGL(ivf_decode_kernel, dim3(static_cast<unsigned>((cnt + 255) / 256)), dim3(256), 0, st,
                        idx->s_ord.as<uint32_t>(), nq, k, idx->s_pairs.as<Pair>(), nprobe, idx->d_listids, d_out_ids);

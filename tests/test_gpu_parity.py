@@ -29,6 +29,13 @@ def eng(native_lib):
     return engine
 
 
+def _ivf_mode(O, metric, dim, nq, nprobe, nlist):
+    """Which kernel serves an IVF search (ivf.hip: ivf_search_enqueue): the MFMA tile path once the batch has
+    >= 4 (query, list) pairs per list (cosine / dot, dim <= 896), else the GEMV scan."""
+    tiled = metric != O.L2 and dim <= 896 and nq * min(nprobe, nlist) >= 4 * nlist
+    return O.MODE_MFMA if tiled else O.MODE_DEV
+
+
 def _data(oracle, n, dim, dist="gaussian", seed=42, **kw):
     return oracle.generate_dataset(n, dim, dist, seed=seed, **kw).astype(np.float32)
 
@@ -296,7 +303,8 @@ def test_ivf_build_golden(eng, oracle, name):
         # search: bit-exact vs the device-order oracle on the engine's own lists / centroids
         for nprobe, k in [(1, 10), (4, 10), (16, 10), (4, 40)]:
             ids, dist, pr = idx.ivf_search(Q, k, nprobe, want_probes=True)
-            oi, odist, opr = O.ivf_search(base, cen, off, lids, Q, k, nprobe, mode=O.MODE_DEV)
+            oi, odist, opr = O.ivf_search(base, cen, off, lids, Q, k, nprobe,
+                                          mode=_ivf_mode(O, O.COSINE, base.shape[1], len(Q), nprobe, 16))
             np.testing.assert_array_equal(pr, opr)
             assert_exact(ids, dist, oi, odist, "ivf nprobe=%d" % nprobe)
             fi, fd, _ = O.ivf_search(base, cen, off, lids, Q, k, nprobe)
@@ -306,6 +314,31 @@ def test_ivf_build_golden(eng, oracle, name):
         ids, dist = idx.ivf_search_lists(Q, 5, probes)
         members = set(lids[off[3]:off[4]].tolist()) | set(lids[off[7]:off[8]].tolist())
         assert all(i in members for i in ids.ravel() if i >= 0)
+
+
+def test_ivf_large_batch_tiled_scan(eng, oracle):
+    """nq * nprobe >= 4 * nlist: the (query, list) pairs are grouped by list and scanned by the MFMA tile
+    kernel (routing included).  Bit-exact against the oracle's MFMA-order mode; groups of 32 overflow
+    (one list probed by > 32 queries), empty lists, ragged list lengths."""
+    O = oracle
+    base = _data(O, 3000, 72, "clustered", num_clusters=5, noise_level=0.4)
+    Q = _data(O, 150, 72, "clustered", num_clusters=5, noise_level=0.4, seed=43)
+    for metric in (O.COSINE, O.DOT):
+        with eng.Index(base, metric) as idx:
+            idx.ivf_build(12, 4, 42)
+            cen, off, lids = idx.get_ivf()
+            for nprobe, k in [(4, 10), (12, 3), (1, 70)]:
+                ids, d, pr = idx.ivf_search(Q, k, nprobe, want_probes=True)
+                mode = _ivf_mode(O, metric, 72, 150, nprobe, 12)
+                oi, od, opr = O.ivf_search(base, cen, off, lids, Q, k, nprobe, metric=metric, mode=mode)
+                np.testing.assert_array_equal(pr, opr)
+                assert_exact(ids, d, oi, od, "tiled ivf nprobe=%d metric=%d" % (nprobe, metric))
+                fi, fd, _ = O.ivf_search(base, cen, off, lids, Q, k, nprobe, metric=metric)
+                assert_topk_parity(ids, d, fi, fd, "tiled ivf f64", metric_scale(metric, Q, base))
+            # a small batch of the same queries takes the GEMV path: same ids, distances within tolerance
+            i1, d1 = idx.ivf_search(Q[:2], 10, 4)
+            i2, d2 = idx.ivf_search(Q, 10, 4)
+            assert_topk_parity(i1, d1, i2[:2], d2[:2], "gemv vs tile", metric_scale(metric, Q, base))
 
 
 def test_ivf_ragged_lists_and_full_probe(eng, oracle):
@@ -322,7 +355,7 @@ def test_ivf_ragged_lists_and_full_probe(eng, oracle):
         idx.set_ivf(cen, off, lids)
         for nprobe, k in [(1, 5), (3, 10), (9, 10), (50, 10), (2, 300)]:
             ids, d = idx.ivf_search(Q, k, nprobe)
-            oi, od, _ = O.ivf_search(base, cen, off, lids, Q, k, nprobe, mode=O.MODE_DEV)
+            oi, od, _ = O.ivf_search(base, cen, off, lids, Q, k, nprobe, mode=_ivf_mode(O, O.COSINE, 48, len(Q), nprobe, 9))
             assert_exact(ids, d, oi, od, "ragged nprobe=%d k=%d" % (nprobe, k))
         # probing every list == exact kNN (size-independent property)
         ids, d = idx.ivf_search(Q, 10, 9)
