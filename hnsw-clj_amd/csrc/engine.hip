@@ -258,7 +258,13 @@ int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t s
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a);
+    static const int dbg = []() {
+        const char *e = getenv("HNSWGPU_TILE_DBG");
+        return e ? atoi(e) : 0;
+    }();
+    TileArgs b = a;
+    b.dbg = dbg;
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, b);
     HG_HIP(hipGetLastError());
     return 0;
 }
@@ -307,7 +313,7 @@ int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int
         int64_t want = std::max<int64_t>(1, std::min<int64_t>(tiles, (2048 + groups - 1) / groups));
         int64_t cr = ((tiles + want - 1) / want) * kTileRows;
         t.chunk_rows = static_cast<int32_t>(cr);
-        t.nchunks = static_cast<int32_t>((nrows + cr - 1) / cr);
+        t.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (tiles + cr / kTileRows / 2) / (cr / kTileRows)));
         t.out = idx->s_tile.as<float>();
         hipEvent_t e0;
         prof_begin(idx, prof_slot, st, &e0);

@@ -1,6 +1,7 @@
 // ivf.hip -- IVF-FLAT on the device: k-means++ / Lloyd build, list layout, batched nprobe search.
 // Reference: src/hnsw/ann/partition/ivf_flat.clj (file:line cited per function).
 #include <float.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -43,24 +44,48 @@ __global__ void ivf_hist_kernel(const int32_t *probes, int64_t npairs, int32_t *
     if (i < npairs && probes[i] >= 0) atomicAdd(&cnt[probes[i]], 1);
 }
 
-// one thread: lists are few (nlist ~ 1e3) and groups ~ npairs/32 + nlist
-__global__ void ivf_plan_kernel(const int32_t *cnt, int nlist, int32_t *list_mem_begin, int32_t *fill,
-                                int32_t *grp_seg, int32_t *grp_mem_begin, int32_t *grp_mem_cnt, int32_t *ngroups) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    int32_t mem = 0, g = 0;
-    for (int l = 0; l < nlist; l++) {
-        int c = cnt[l];
-        list_mem_begin[l] = mem;
-        fill[l] = 0;
-        for (int b = 0; b < c; b += kTileQ) {
-            grp_seg[g] = l;
-            grp_mem_begin[g] = mem + b;
-            grp_mem_cnt[g] = c - b < kTileQ ? c - b : kTileQ;
-            g++;
+// One workgroup: exclusive scans over the lists (members, groups of <= 32) in chunks of 1024 lists, then
+// every thread writes the groups of its own list.
+__global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *cnt, int nlist, int32_t *list_mem_begin,
+                                                        int32_t *fill, int32_t *grp_seg, int32_t *grp_mem_begin,
+                                                        int32_t *grp_mem_cnt, int32_t *ngroups) {
+    __shared__ int32_t sm[1024], sg[1024];
+    __shared__ int32_t carry_m, carry_g;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry_m = carry_g = 0;
+    __syncthreads();
+    for (int l0 = 0; l0 < nlist; l0 += 1024) {
+        const int l = l0 + tid;
+        const int c = l < nlist ? cnt[l] : 0;
+        const int ng = (c + kTileQ - 1) / kTileQ;
+        sm[tid] = c;
+        sg[tid] = ng;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
+            int am = tid >= off ? sm[tid - off] : 0, ag = tid >= off ? sg[tid - off] : 0;
+            __syncthreads();
+            sm[tid] += am;
+            sg[tid] += ag;
+            __syncthreads();
         }
-        mem += c;
+        const int mem = carry_m + sm[tid] - c, g0 = carry_g + sg[tid] - ng;
+        if (l < nlist) {
+            list_mem_begin[l] = mem;
+            fill[l] = 0;
+            for (int b = 0, g = g0; b < c; b += kTileQ, g++) {
+                grp_seg[g] = l;
+                grp_mem_begin[g] = mem + b;
+                grp_mem_cnt[g] = c - b < kTileQ ? c - b : kTileQ;
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            carry_m += sm[1023];
+            carry_g += sg[1023];
+        }
+        __syncthreads();
     }
-    *ngroups = g;
+    if (tid == 0) *ngroups = carry_g;
 }
 
 __global__ void ivf_scatter_kernel(const Pair *pairs, const int32_t *probes, int64_t npairs, int64_t stride,
@@ -295,7 +320,7 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     HG_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nlist, st));
     hipLaunchKernelGGL(ivf_hist_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st, d_probes,
                        npairs, cnt);
-    hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(64), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr);
+    hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr);
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st,
                        idx->s_pairs.as<Pair>(), d_probes, npairs, stride, lmb, fill, idx->s_misc2.as<GroupMember>());
     HG_HIP(hipGetLastError());
@@ -319,10 +344,17 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     int64_t mean = std::max<int64_t>(1, idx->n / std::max(nlist, 1));
     int64_t est_groups = std::max<int64_t>(1, npairs / kTileQ + nlist / 2);
     int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows;
-    int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (2048 + est_groups - 1) / est_groups));
+    static const int64_t tgt = []() {
+        const char *e = getenv("HNSWGPU_TILE_WGS");  // tuning override
+        return e ? atoll(e) : 2048LL;
+    }();
+    int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + est_groups - 1) / est_groups));
     int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows;
     t.chunk_rows = static_cast<int32_t>(cr);
-    t.nchunks = static_cast<int32_t>((idx->max_list_len + cr - 1) / cr);
+    {
+        int64_t max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows, tpc = cr / kTileRows;
+        t.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));  // kernel splits per list
+    }
     t.out = idx->s_tile.as<float>();
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);

@@ -31,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __host__ __device__ inline int tile_ldq(int dim) { return ((dim + 63) / 64) * 64 + 4; }
 __host__ inline size_t tile_lds_bytes(int dim) {
     return sizeof(float) * (static_cast<size_t>(kTileQ) * tile_ldq(dim) + 2 * kTileRows * kTileLdA) +
-           sizeof(float) * kTileQ + sizeof(int64_t) * kTileQ;
+           sizeof(float) * kTileQ + sizeof(int64_t) * kTileQ + sizeof(float) * kTileRows;
 }
 
 struct GroupMember {
@@ -63,6 +63,7 @@ struct TileArgs {
     int32_t chunk_rows;  // multiple of kTileRows
     int32_t nchunks;
     float *out;
+    int32_t dbg;  // developer ablation switches (HNSWGPU_TILE_DBG); 0 in production
 };
 
 // Per-query top-k over a dense distance array (written by tile_scan_kernel): one wave per query.

@@ -13,6 +13,7 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
     float *As = Bs + kTileQ * ldq;                               // [2][128][36] streamed row tiles
     float *qn_s = As + 2 * kTileRows * kTileLdA;                 // [32]
     int64_t *ob_s = reinterpret_cast<int64_t *>(qn_s + kTileQ);  // [32] output bases (-1 = empty slot)
+    float *rn_s = reinterpret_cast<float *>(ob_s + kTileQ);      // [128] row norms of the current tile
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
@@ -32,8 +33,16 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
         rb1 = a.nrows_all;
         cnt = a.nq - g * kTileQ < kTileQ ? a.nq - g * kTileQ : kTileQ;
     }
-    const int64_t r0 = rb0 + static_cast<int64_t>(chunk) * a.chunk_rows;
-    const int64_t r1 = r0 + a.chunk_rows < rb1 ? r0 + a.chunk_rows : rb1;
+    // split THIS segment evenly into round(tiles / tiles_per_chunk) chunks of whole tiles (no tiny tail chunk
+    // that would reload the query group for a handful of rows); a.nchunks is the bound for the longest segment
+    const int64_t tiles = (rb1 - rb0 + kTileRows - 1) / kTileRows;
+    const int64_t tpc = a.chunk_rows / kTileRows;
+    int64_t nch = (tiles + tpc / 2) / tpc;
+    nch = nch < 1 ? 1 : (nch > a.nchunks ? a.nchunks : nch);
+    if (chunk >= nch) return;
+    const int64_t per = (tiles + nch - 1) / nch * kTileRows;
+    const int64_t r0 = rb0 + static_cast<int64_t>(chunk) * per;
+    const int64_t r1 = r0 + per < rb1 ? r0 + per : rb1;
     if (r0 >= r1 || cnt <= 0) return;
 
     // ---- resident query group -> LDS (zero rows for empty slots)
@@ -76,19 +85,25 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-        // stage K-step 0
-        float4 st[4];
-        auto stage_load = [&](int ks) {
+        // Row tiles are staged global -> registers -> LDS two K-steps ahead (two register sets, two LDS
+        // buffers): with one workgroup per CU a single step of look-ahead leaves the HBM latency exposed.
+        float4 stA[4], stB[4];
+        // unconditional loads from clamped addresses (rows past the segment end feed outputs that are never
+        // stored; columns past the row end are zeroed by a select): no branches, so the compiler can keep
+        // the younger register set's loads in flight behind a counted vmcnt
+        auto stage_load = [&](float4 (&st)[4], int ks) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 int f = tid + kWG * u;
                 int row = f >> 3, c4 = ks * (kTileK / 4) + (f & 7);
                 int64_t gr = t0 + row;
-                st[u] = (gr < r1 && c4 < nvec) ? reinterpret_cast<const float4 *>(a.rows + gr * a.ld)[c4]
-                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                gr = gr < r1 ? gr : r1 - 1;
+                int c4c = c4 < nvec ? c4 : nvec - 1;
+                float4 v = reinterpret_cast<const float4 *>(a.rows + gr * a.ld)[c4c];
+                st[u] = c4 < nvec ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        auto stage_store = [&](int buf) {
+        auto stage_store = [&](const float4 (&st)[4], int buf) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 int f = tid + kWG * u;
@@ -96,38 +111,57 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
                 *reinterpret_cast<float4 *>(As + (buf * kTileRows + row) * kTileLdA + c) = st[u];
             }
         };
-        stage_load(0);
-        stage_store(0);
-        __syncthreads();
-        for (int ks = 0; ks < nk; ks++) {
-            const int buf = ks & 1;
-            if (ks + 1 < nk) stage_load(ks + 1);
+        auto compute = [&](int ks, int buf) {
             const float *Ab = As + (buf * kTileRows + wave * 32 + li) * kTileLdA + 4 * half;
             const float *Bb = Bs + li * ldq + ks * kTileK + 4 * half;
+            float4 av[kTileK / 8], bv[kTileK / 8];
 #pragma unroll
             for (int t = 0; t < kTileK / 8; t++) {
-                float4 av = *reinterpret_cast<const float4 *>(Ab + 8 * t);
-                float4 bv = *reinterpret_cast<const float4 *>(Bb + 8 * t);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+                av[t] = *reinterpret_cast<const float4 *>(Ab + 8 * t);
+                bv[t] = *reinterpret_cast<const float4 *>(Bb + 8 * t);
             }
-            if (ks + 1 < nk) stage_store(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the 8 LDS reads ahead of the MFMA chain
+            if (a.dbg & 1) {
+                asm volatile("" ::"v"(av[0].x), "v"(bv[0].x), "v"(av[3].w), "v"(bv[3].w));
+                return;
+            }
+#pragma unroll
+            for (int t = 0; t < kTileK / 8; t++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bv[t].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv[t].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, bv[t].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bv[t].w, acc, 0, 0, 0);
+            }
+        };
+        // this tile's row norms -> LDS now; they are needed only after the K loop (a per-element global load
+        // in the epilogue would cost one exposed memory round trip per accumulator register)
+        if (tid < kTileRows) rn_s[tid] = (a.metric == METRIC_COS && t0 + tid < r1) ? a.row_norms[t0 + tid] : 0.0f;
+        stage_load(stA, 0);
+        stage_store(stA, 0);
+        if (nk > 1) stage_load(stA, 1);
+        if (nk > 2) stage_load(stB, 2);
+        __syncthreads();
+        for (int ks = 0; ks < nk; ks += 2) {
+            compute(ks, 0);  // stA holds K-step ks+1
+            if (ks + 1 < nk) stage_store(stA, 1);
+            if (ks + 3 < nk && !(a.dbg & 2)) stage_load(stA, ks + 3);
+            __syncthreads();
+            if (ks + 1 >= nk) break;
+            compute(ks + 1, 1);  // stB holds K-step ks+2
+            if (ks + 2 < nk) stage_store(stB, 0);
+            if (ks + 4 < nk && !(a.dbg & 2)) stage_load(stB, ks + 4);
             __syncthreads();
         }
         // ---- epilogue: D[row i][query col]: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         const int64_t ob = ob_s[li];
         const float qn = qn_s[li];
-        if (ob >= 0) {
+        if (ob >= 0 && !(a.dbg & 4)) {
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 int i = (reg & 3) + 8 * (reg >> 2) + 4 * half;
                 int64_t gr = t0 + wave * 32 + i;
-                if (gr < r1) {
-                    float rn = a.metric == METRIC_COS ? a.row_norms[gr] : 0.0f;
-                    a.out[ob + (gr - rb0)] = finish_dist(a.metric, acc[reg], qn, rn) + 0.0f;
-                }
+                float dv = finish_dist(a.metric, acc[reg], qn, rn_s[wave * 32 + i]) + 0.0f;
+                if (gr < r1) a.out[ob + (gr - rb0)] = dv;
             }
         }
         __syncthreads();
@@ -147,21 +181,31 @@ __global__ __launch_bounds__(kWG) void select_topk_kernel(SelectArgs a) {
     uint64_t thr = ~0ull;
     const bool regk = a.k <= kWave;
     uint64_t mine = ~0ull;
-    for (int64_t base = 0; base < n; base += kWave) {
-        int64_t i = base + lane;
-        uint64_t key = i < n ? make_key(in[i], static_cast<uint32_t>(i)) : ~0ull;
-        uint64_t mask = __ballot(key < thr);
-        while (mask) {
-            int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
-            mask &= mask - 1;
-            uint64_t kb = __shfl(key, b, kWave);
-            if (kb < thr) {
-                if (regk) {
-                    wave_insert_reg(mine, cnt, a.k, kb, lane);
-                    thr = wave_kth_reg(mine, a.k);
-                } else {
-                    wave_insert(list, cnt, a.k, kb, lane);
-                    thr = cnt == a.k ? list[a.k - 1] : ~0ull;
+    constexpr int U = 8;  // 8 independent 64-wide loads in flight per iteration (one latency per 512 candidates)
+    for (int64_t base = 0; base < n; base += U * kWave) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int64_t i = base + u * kWave + lane;
+            v[u] = i < n ? in[i] : __uint_as_float(0x7fc00000u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int64_t i = base + u * kWave + lane;
+            uint64_t key = i < n ? make_key(v[u], static_cast<uint32_t>(i)) : ~0ull;
+            uint64_t mask = __ballot(key < thr);
+            while (mask) {
+                int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+                mask &= mask - 1;
+                uint64_t kb = __shfl(key, b, kWave);
+                if (kb < thr) {
+                    if (regk) {
+                        wave_insert_reg(mine, cnt, a.k, kb, lane);
+                        thr = wave_kth_reg(mine, a.k);
+                    } else {
+                        wave_insert(list, cnt, a.k, kb, lane);
+                        thr = cnt == a.k ? list[a.k - 1] : ~0ull;
+                    }
                 }
             }
         }

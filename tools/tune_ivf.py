@@ -24,12 +24,20 @@ Qa = centers[qw] + 0.3 * torch.randn(1024, D, generator=g, device=dev)
 Qa /= Qa.norm(dim=1, keepdim=True)
 idx = engine.Index(x, "cosine", 0)
 # cheap lists for tuning: assign to the generating centres (same list-length distribution as k-means)
-a, _ = idx.kmeans_assign(centers.cpu().numpy())
-order = np.argsort(a, kind="stable").astype(np.int32)
-off = np.zeros(nlist + 1, np.int64)
-off[1:] = np.cumsum(np.bincount(a, minlength=nlist))
-idx.set_ivf(centers.cpu().numpy(), off, order)
+import os
+if os.environ.get("REAL_KMEANS"):
+    idx.ivf_build(nlist, 10, 42)
+    cen_, off, order = idx.get_ivf()
+else:
+  a, _ = idx.kmeans_assign(centers.cpu().numpy())
+  if os.environ.get("MERGE_PAIRS"):   # skewed synthetic lists: clusters 2l and 2l+1 share list 2l, list 2l+1 is empty
+      a = (a // 2) * 2
+  order = np.argsort(a, kind="stable").astype(np.int32)
+  off = np.zeros(nlist + 1, np.int64)
+  off[1:] = np.cumsum(np.bincount(a, minlength=nlist))
+  idx.set_ivf(centers.cpu().numpy(), off, order)
 lens = np.diff(off)
+print("list len mean %.0f max %d min %d" % (lens.mean(), lens.max(), lens.min()))
 for nq in (1, 32, 256, 1024):
     Q = Qa[:nq].contiguous()
     _, _, probes = idx.ivf_search(Q.cpu().numpy(), K, nprobe, want_probes=True)
