@@ -68,6 +68,10 @@ def recall_at_k(ids, truth):
 
 
 def main():
+    # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL's version banner
+    # does) are sent to stderr for the duration of the run
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -78,6 +82,8 @@ def main():
     ap.add_argument("--no-ivf", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--ivf-n", type=int, default=1_000_000)
+    ap.add_argument("--sharded", action="store_true", help="also run the row-sharded IVF search (always on for N > 1)")
+    ap.add_argument("--shard-rows", type=int, default=1_250_000, help="rows per GPU of the sharded IVF index")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,8 +91,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    if world > 1 or args.sharded:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29517"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from hnsw_clj_amd import engine
@@ -214,15 +222,24 @@ def main():
     elif rank == 0:
         result["roofline"] = result["roofline_hnsw"]
 
+    # ------------------------------------------------------------------ row-sharded IVF over RCCL (configs[3])
+    if world > 1 or args.sharded:
+        try:
+            sh = sharded_ivf(engine, dev, rank, world, args)
+        except Exception as e:  # never let the secondary measurement take the headline number down
+            sh = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            result["sharded_ivf"] = sh
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if not args.no_cpu and rank == 0 and world == 1:
         result["cpu_baseline"] = cpu_baseline(idx, base, queries, ef)
     idx.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
 
 
 def ivf_roofline(engine, dev, args):
@@ -305,6 +322,56 @@ def ivf_roofline(engine, dev, args):
                              "algorithmic_GBs": b["achieved_GBs"], "unique_GB": b["unique_GB"]},
             "ivf_recall_at_10": round(rec, 4), "ivf_build_s": round(build_s, 1),
             "mean_list_len": float(lens.mean()), "max_list_len": int(lens.max())}
+
+
+def sharded_ivf(engine, dev, rank, world, args):
+    """BASELINE.json configs[3]: 768-d index row-sharded over the GPUs (1.25M rows per GPU = 10M x 768 on 8),
+    batch = 1024 queries replicated on every rank, per-shard IVF search (nlist 1024, nprobe 32, k 10), ONE
+    all-gather of the per-shard top-k over RCCL/xGMI and a merge kernel on every rank.  Weak scaling in rows."""
+    from hnsw_clj_amd.sharded import ShardedSearcher
+
+    n, nlist, nprobe, nq = args.shard_rows, 1024, 32, 1024
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)                                   # the cluster centres are global
+    centers = torch.randn(nlist, DIM, generator=g, device=dev)
+    g.manual_seed(1000 + rank)                         # every shard draws its own rows
+    which = torch.randint(0, nlist, (n,), generator=g, device=dev)
+    x = centers[which] + 0.3 * torch.randn(n, DIM, generator=g, device=dev)
+    x /= x.norm(dim=1, keepdim=True)
+    g.manual_seed(43)                                  # the same query batch on every rank
+    qw = torch.randint(0, nlist, (nq,), generator=g, device=dev)
+    Q = centers[qw] + 0.3 * torch.randn(nq, DIM, generator=g, device=dev)
+    Q /= Q.norm(dim=1, keepdim=True)
+    idx = engine.Index(x, "cosine", dev.index)
+    del x
+    t0 = time.time()
+    idx.ivf_build(nlist, 10, 42)
+    build_s = time.time() - t0
+    s = ShardedSearcher(lambda q, k: idx.ivf_search_dev(q, k, nprobe), rank * n)
+    for _ in range(3):
+        ids, d = s.search(Q, K)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    steps = 10
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ids, d = s.search(Q, K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    # sanity: merged ids are global row ids of the right range, distances ascending
+    ok = bool((ids >= 0).all() and (ids < world * n).all() and (d[:, 1:] >= d[:, :-1]).all())
+    idx.close()
+    return {"workload": "hnsw.ivf-flat %d x 768 row-sharded over %d GPU(s) (%d rows each), batch 1024, nlist 1024/shard, "
+                        "nprobe 32, all-gather of per-shard top-10 + merge" % (world * n, world, n),
+            "qps": round(nq * steps / el, 1), "ms_per_batch": round(el / steps * 1e3, 3), "valid": ok,
+            "ivf_build_s_per_shard": round(build_s, 1), "collective": "all_gather of %d B per rank" % (nq * K * 8)}
 
 
 def cpu_baseline(idx, base, queries, ef):
