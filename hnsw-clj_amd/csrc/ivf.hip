@@ -149,6 +149,26 @@ __global__ __launch_bounds__(kWG) void centroid_mean_kernel(const float *rows, i
     }
 }
 
+// sum of d^2 over blocks of kSampleBlock elements in f64 (fixed reduction order): the D^2 sampling of
+// k-means++ then needs only these partial sums plus ONE block of distances on the host
+constexpr int kSampleBlock = 4096;
+__global__ __launch_bounds__(kWG) void block_sumsq_kernel(const float *d, int64_t n, double *out) {
+    __shared__ double sm[kWG];
+    const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kSampleBlock;
+    double s = 0.0;
+    for (int i = 0; i < kSampleBlock / kWG; i++) {
+        int64_t j = b0 + static_cast<int64_t>(threadIdx.x) * (kSampleBlock / kWG) + i;
+        if (j < n) s = s + static_cast<double>(d[j]) * static_cast<double>(d[j]);
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = kWG / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sm[threadIdx.x] = sm[threadIdx.x] + sm[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+}
+
 __global__ void fill_kernel(float *p, int64_t n, float v) {
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -258,7 +278,11 @@ static int kmeanspp_device(hnswgpu_index *idx, int32_t nlist, int64_t seed, std:
     float *mind = idx->s_misc.as<float>();
     hipLaunchKernelGGL(fill_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, mind, n, FLT_MAX);
     HG_HIP(hipGetLastError());
-    std::vector<float> h(static_cast<size_t>(n));
+    const int64_t nb = (n + kSampleBlock - 1) / kSampleBlock;
+    HG_TRY(idx->s_misc2.ensure(sizeof(double) * nb));
+    double *d_bs = idx->s_misc2.as<double>();
+    std::vector<double> bs(static_cast<size_t>(nb));
+    std::vector<float> h(kSampleBlock);
     chosen.resize(nlist);
     int32_t cur = rng.next_int(static_cast<int32_t>(n));
     chosen[0] = cur;
@@ -282,17 +306,35 @@ static int kmeanspp_device(hnswgpu_index *idx, int32_t nlist, int64_t seed, std:
         a.k = 1;
         a.out = mind;
         HG_TRY(launch_scan(idx->nch, a, st));
-        HG_HIP(hipMemcpyAsync(h.data(), mind, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(block_sumsq_kernel, dim3(static_cast<unsigned>(nb)), dim3(kWG), 0, st, mind, n, d_bs);
+        HG_HIP(hipGetLastError());
+        HG_HIP(hipMemcpyAsync(bs.data(), d_bs, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
         HG_HIP(hipStreamSynchronize(st));
+        // (loop [i 0 cumsum 0.0] (if (>= (+ cumsum dist-sq) r) pick i ...)) :54-58, two-level: whole blocks are
+        // skipped by their partial sums, the block that holds r is walked element by element
         double sum = 0.0;
-        for (int64_t i = 0; i < n; i++) sum = sum + static_cast<double>(h[i]) * static_cast<double>(h[i]);
-        double r = rng.next_double() * sum;
+        for (int64_t b = 0; b < nb; b++) sum = sum + bs[b];
+        const double r = rng.next_double() * sum;
         double cum = 0.0;
-        int64_t i = 0;
-        for (;; i++) {
-            double dsq = static_cast<double>(h[i]) * static_cast<double>(h[i]);
-            if (cum + dsq >= r || i == n - 1) break;  // clamped against round-off; the reference would throw
-            cum = cum + dsq;
+        int64_t i = n - 1;  // clamped against round-off; the reference would throw
+        bool found = false;
+        for (int64_t b = 0; b < nb && !found; b++) {
+            if (cum + bs[b] < r && b + 1 < nb) {
+                cum = cum + bs[b];
+                continue;
+            }
+            const int64_t b0 = b * kSampleBlock, cnt = std::min<int64_t>(kSampleBlock, n - b0);
+            HG_HIP(hipMemcpyAsync(h.data(), mind + b0, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
+            HG_HIP(hipStreamSynchronize(st));
+            for (int64_t j = 0; j < cnt; j++) {
+                double dsq = static_cast<double>(h[j]) * static_cast<double>(h[j]);
+                if (cum + dsq >= r) {
+                    i = b0 + j;
+                    found = true;
+                    break;
+                }
+                cum = cum + dsq;
+            }
         }
         cur = static_cast<int32_t>(i);
         chosen[c] = cur;
