@@ -184,6 +184,26 @@ struct HostGraph {
         return &up[static_cast<size_t>(blk) * (M + 1)];
     }
 
+    // rows whose adjacency changed since the last upload (device copy is patched incrementally)
+    std::vector<int32_t> dirty0;
+    std::vector<int64_t> dirtyu;
+    std::vector<uint8_t> flag0, flagu;
+
+    void mark(int32_t node, int lc) {
+        if (lc == 0) {
+            if (!flag0[node]) {
+                flag0[node] = 1;
+                dirty0.push_back(node);
+            }
+        } else {
+            int64_t blk = up_off[node] + (lc - 1);
+            if (!flagu[blk]) {
+                flagu[blk] = 1;
+                dirtyu.push_back(blk);
+            }
+        }
+    }
+
     // one direction of "Connect bidirectionally" (ultra_fast.clj:255-266) + prune-connections-ultra
     // (:279-299): an over-full list keeps its m closest by (distance, insertion order).  Edge
     // distances are stored with the edges, so pruning needs no distance evaluation.
@@ -197,31 +217,70 @@ struct HostGraph {
         a[*cnt] = to;
         d[*cnt] = dist;
         (*cnt)++;
-        if (*cnt > m) {
-            int worst = 0;  // stable sort + take m == drop the last of the largest
-            for (int i = 1; i < *cnt; i++)
-                if (d[i] >= d[worst]) worst = i;
-            // keep the survivors in (distance, order) order like sort-by would
-            std::vector<std::pair<float, int>> o;
-            o.reserve(*cnt);
-            for (int i = 0; i < *cnt; i++)
-                if (i != worst) o.push_back({d[i], i});
-            std::stable_sort(o.begin(), o.end(),
-                             [](const std::pair<float, int> &x, const std::pair<float, int> &y) { return x.first < y.first; });
-            std::vector<int32_t> na(m);
-            std::vector<float> nd(m);
+        mark(from, lc);
+        if (*cnt > m) {  // (take max-conns (sort-by dist connections)): stable sort, drop the last
+            int ord[kMaxDeg + 1];
+            const int c = *cnt;
+            for (int i = 0; i < c; i++) ord[i] = i;
+            std::stable_sort(ord, ord + c, [&](int x, int y) { return d[x] < d[y]; });
+            int32_t na[kMaxDeg + 1];
+            float nd[kMaxDeg + 1];
             for (int i = 0; i < m; i++) {
-                na[i] = a[o[i].second];
-                nd[i] = d[o[i].second];
+                na[i] = a[ord[i]];
+                nd[i] = d[ord[i]];
             }
             for (int i = 0; i < m; i++) {
                 a[i] = na[i];
                 d[i] = nd[i];
             }
+            a[m] = -1;
             *cnt = m;
         }
     }
 };
+
+// dst[ids[i] * width + j] = packed[i * width + j]
+__global__ void scatter_rows_kernel(int32_t *dst, int width, const int64_t *ids, const int32_t *packed, int64_t count) {
+    int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= count * width) return;
+    int64_t i = t / width;
+    int j = static_cast<int>(t % width);
+    dst[ids[i] * width + j] = packed[t];
+}
+
+// patch the device adjacency with the rows that changed (full arrays are never re-sent)
+static int upload_dirty(hnswgpu_index *idx, HostGraph &g, hipStream_t st, std::vector<int32_t> &pack,
+                        std::vector<int64_t> &ids) {
+    for (int pass = 0; pass < 2; pass++) {
+        const int width = pass == 0 ? g.M0 : g.M;
+        const int64_t cnt = pass == 0 ? static_cast<int64_t>(g.dirty0.size()) : static_cast<int64_t>(g.dirtyu.size());
+        if (cnt == 0) continue;
+        pack.resize(static_cast<size_t>(cnt) * width);
+        ids.resize(static_cast<size_t>(cnt));
+        for (int64_t i = 0; i < cnt; i++) {
+            int64_t row = pass == 0 ? g.dirty0[i] : g.dirtyu[i];
+            ids[i] = row;
+            const int32_t *src = pass == 0 ? &g.l0[row * (g.M0 + 1)] : &g.up[row * (g.M + 1)];
+            const int have = pass == 0 ? g.l0_cnt[row] : g.up_cnt[row];
+            for (int j = 0; j < width; j++) pack[i * width + j] = j < have ? src[j] : -1;
+            if (pass == 0) g.flag0[row] = 0;
+            else g.flagu[row] = 0;
+        }
+        HG_TRY(idx->s_partial.ensure(sizeof(int32_t) * pack.size() + sizeof(int64_t) * ids.size() + 64));
+        int64_t *d_ids = idx->s_partial.as<int64_t>();
+        int32_t *d_pack = reinterpret_cast<int32_t *>(d_ids + cnt);
+        HG_HIP(hipMemcpyAsync(d_ids, ids.data(), sizeof(int64_t) * cnt, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(d_pack, pack.data(), sizeof(int32_t) * pack.size(), hipMemcpyHostToDevice, st));
+        int64_t total = cnt * width;
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
+                           pass == 0 ? idx->d_l0 : idx->d_upadj, width, d_ids, d_pack, cnt);
+        HG_HIP(hipGetLastError());
+        HG_HIP(hipStreamSynchronize(st));  // pack / ids are reused by the next pass
+        if (pass == 0) g.dirty0.clear();
+        else g.dirtyu.clear();
+    }
+    return 0;
+}
 
 static int upload_graph(hnswgpu_index *idx, const HostGraph &g, hipStream_t st, std::vector<int32_t> &tmp0,
                         std::vector<int32_t> &tmpu) {
@@ -444,7 +503,7 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
     HG_HIP(hipMemcpyAsync(idx->d_levels, g.levels.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
     HG_HIP(hipMemcpyAsync(idx->d_upoff, g.up_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
 
-    const int64_t maxB = 2048;
+    const int64_t maxB = 16384;  // scratch sizing; the batch actually used grows with the graph (see below)
     const int ef = ef_construction;
     HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * maxB * M0));
     HG_TRY(idx->s_outd.ensure(sizeof(float) * maxB * M0));
@@ -456,12 +515,20 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
     std::vector<int32_t> h_ids(maxB * M0), h_up(maxB * maxlv), h_qrows(maxB), h_qlev(maxB), tmp0, tmpu;
     std::vector<float> h_d(maxB * M0), h_upd(maxB * maxlv);
 
+    g.flag0.assign(n, 0);
+    g.flagu.assign(std::max<int64_t>(blocks, 1), 0);
+    std::vector<int32_t> pack;
+    std::vector<int64_t> pack_ids;
+    HG_HIP(hipMemsetAsync(idx->d_l0, 0xff, sizeof(int32_t) * n * M0, st));
+    HG_HIP(hipMemsetAsync(idx->d_upadj, 0xff, sizeof(int32_t) * std::max<int64_t>(blocks, 1) * M, st));
     g.entry = 0;  // first element becomes the entry point (:229-231)
     g.top = g.levels[0];
     int64_t done = 1;
     while (done < n) {
-        int64_t B = std::min<int64_t>({maxB, std::max<int64_t>(1, done / 8), n - done});
-        HG_TRY(upload_graph(idx, g, st, tmp0, tmpu));
+        // a batch never exceeds 1/8 of the graph it is searched against; beyond 2048 it grows slowly (1/64)
+        // so that big indexes amortise the per-batch round trip without starving early quality
+        int64_t B = std::min<int64_t>({maxB, std::max<int64_t>(1, done / 8), 2048 + done / 64, n - done});
+        HG_TRY(upload_dirty(idx, g, st, pack, pack_ids));
         for (int64_t b = 0; b < B; b++) {
             h_qrows[b] = static_cast<int32_t>(done + b);
             h_qlev[b] = g.levels[done + b];
