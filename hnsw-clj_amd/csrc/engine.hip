@@ -94,43 +94,104 @@ int launch_scan(int nch, const ScanArgs &a, hipStream_t st) {
     return 0;
 }
 
-__global__ __launch_bounds__(kWave) void merge_topk_kernel(MergeArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint64_t *list = reinterpret_cast<uint64_t *>(smem);
-    const int lane = threadIdx.x;
-    const int q = blockIdx.x;
-    const uint64_t *in = a.partial + static_cast<int64_t>(q) * a.keys_per_query;
-    int cnt = 0;
+// One workgroup of W waves per query: every wave folds a contiguous slice of the query's partial keys into
+// its own ascending top-k (registers when k <= 64, LDS otherwise), then wave 0 folds the W lists.
+// (A single wave scanning ~45k keys made the merge the longest kernel of a one-query IVF search.)
+__device__ __forceinline__ void fold_keys(const uint64_t *in, int64_t n, int k, bool regk, uint64_t *list, int lane,
+                                          uint64_t &mine, int &cnt) {
     uint64_t thr = ~0ull;
-    const bool regk = a.k <= kWave;
-    uint64_t mine = ~0ull;
-    for (int64_t base = 0; base < a.keys_per_query; base += kWave) {
-        int64_t i = base + lane;
-        uint64_t key = i < a.keys_per_query ? in[i] : ~0ull;
-        uint64_t mask = __ballot(key < thr);
-        while (mask) {
-            int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
-            mask &= mask - 1;
-            uint64_t kb = __shfl(key, b, kWave);
-            if (kb < thr) {
-                if (regk) {
-                    wave_insert_reg(mine, cnt, a.k, kb, lane);
-                    thr = wave_kth_reg(mine, a.k);
-                } else {
-                    wave_insert(list, cnt, a.k, kb, lane);
-                    thr = cnt == a.k ? list[a.k - 1] : ~0ull;
+    constexpr int U = 4;
+    for (int64_t base = 0; base < n; base += U * kWave) {
+        uint64_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int64_t i = base + u * kWave + lane;
+            key[u] = i < n ? in[i] : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint64_t mask = __ballot(key[u] < thr);
+            while (mask) {
+                int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+                mask &= mask - 1;
+                uint64_t kb = __shfl(key[u], b, kWave);
+                if (kb < thr) {
+                    if (regk) {
+                        wave_insert_reg(mine, cnt, k, kb, lane);
+                        thr = wave_kth_reg(mine, k);
+                    } else {
+                        wave_insert(list, cnt, k, kb, lane);
+                        thr = cnt == k ? list[k - 1] : ~0ull;
+                    }
                 }
             }
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void merge_topk_kernel(MergeArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);  // [W][k]
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int W = blockDim.x >> 6;
+    const int q = blockIdx.x;
+    const uint64_t *in = a.partial + static_cast<int64_t>(q) * a.keys_per_query;
+    const bool regk = a.k <= kWave;
+    const int64_t slice = (a.keys_per_query + W - 1) / W;
+    const int64_t s0 = wave * slice;
+    const int64_t sn = s0 + slice < a.keys_per_query ? slice : (a.keys_per_query > s0 ? a.keys_per_query - s0 : 0);
+    uint64_t *list = lists + static_cast<size_t>(wave) * a.k;
+    uint64_t mine = ~0ull;
+    int cnt = 0;
+    fold_keys(in + s0, sn, a.k, regk, list, lane, mine, cnt);
     if (regk) {
         if (lane < a.k) list[lane] = mine;
+    } else {
+        for (int i = cnt + lane; i < a.k; i += kWave) list[i] = ~0ull;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    if (W > 1) {  // second level: W * k keys (sentinels included) -> final list behind the W slots
+        uint64_t *fin = lists + static_cast<size_t>(W) * a.k;
+        const int tot = W * a.k;
+        uint64_t thr = ~0ull;
+        mine = ~0ull;
+        cnt = 0;
+        for (int base = 0; base < tot; base += kWave) {
+            const int i = base + lane;
+            const uint64_t key = i < tot ? lists[i] : ~0ull;
+            uint64_t mask = __ballot(key < thr);
+            while (mask) {
+                int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+                mask &= mask - 1;
+                uint64_t kb = __shfl(key, b, kWave);
+                if (kb < thr) {
+                    if (regk) {
+                        wave_insert_reg(mine, cnt, a.k, kb, lane);
+                        thr = wave_kth_reg(mine, a.k);
+                    } else {
+                        wave_insert(fin, cnt, a.k, kb, lane);
+                        thr = cnt == a.k ? fin[a.k - 1] : ~0ull;
+                    }
+                }
+            }
+        }
+        if (regk) {
+            if (lane < a.k) fin[lane] = mine;
+        } else {
+            for (int i = cnt + lane; i < a.k; i += kWave) fin[i] = ~0ull;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        list = fin;
+    } else {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
     for (int i = lane; i < a.k; i += kWave) {
-        bool ok = i < cnt;
-        uint64_t key = ok ? list[i] : ~0ull;
+        uint64_t key = list[i];
+        bool ok = key != ~0ull;
         a.out_ord[static_cast<int64_t>(q) * a.k + i] = ok ? static_cast<uint32_t>(key) : 0xffffffffu;
         a.out_dist[static_cast<int64_t>(q) * a.k + i] = ok ? key_dist(key) : __uint_as_float(0x7f800000u);
     }
@@ -138,8 +199,21 @@ __global__ __launch_bounds__(kWave) void merge_topk_kernel(MergeArgs a) {
 
 int launch_merge(const MergeArgs &a, hipStream_t st) {
     if (a.nq <= 0) return 0;
-    size_t lds = sizeof(uint64_t) * a.k;
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(a.nq), dim3(kWave), lds, st, a);
+    // waves per query: ~2048 keys per wave, but never more workgroup-waves than the batch needs to fill the chip
+    int64_t w = std::min<int64_t>(16, std::max<int64_t>(1, a.keys_per_query / 2048));
+    while (w > 1 && static_cast<int64_t>(a.nq) * w > 8192) w /= 2;
+    if (const char *e = getenv("HNSWGPU_MERGE_W")) w = std::max(1, atoi(e));
+    size_t lds = sizeof(uint64_t) * (w + 1) * a.k;
+    HG_REQUIRE(lds <= 150 * 1024, HNSWGPU_ELIMIT, "k too large for the merge kernel");
+    if (lds > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_topk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(a.nq), dim3(static_cast<unsigned>(w * kWave)), lds, st, a);
     HG_HIP(hipGetLastError());
     return 0;
 }

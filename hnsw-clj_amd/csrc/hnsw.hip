@@ -11,8 +11,9 @@
 
 namespace hg {
 
-static size_t hnsw_lds_bytes(int cap, int nwords) {
-    return sizeof(uint2) * 2 * cap + sizeof(int32_t) * 3 * kMaxDeg + sizeof(int32_t) * 16 + sizeof(uint32_t) * nwords;
+static size_t hnsw_lds_bytes(int cap, int nwords, int nw) {
+    return sizeof(uint2) * 2 * cap + sizeof(int32_t) * 3 * kMaxDeg + sizeof(int32_t) * 16 + sizeof(int32_t) * nw * kWave +
+           sizeof(int32_t) * cap + sizeof(uint32_t) * nwords;
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
@@ -64,7 +65,7 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
         a.gen_base = idx->vis_gen;
         idx->vis_gen += static_cast<uint32_t>(gens);
     }
-    size_t lds = hnsw_lds_bytes(a.cap, a.nwords);
+    size_t lds = hnsw_lds_bytes(a.cap, a.nwords, nw);
     HG_REQUIRE(lds <= kMaxLds, HNSWGPU_ELIMIT,
                "HNSW search state (%zu B: ef=%d, n=%lld) exceeds the 160 KiB LDS of a CU", lds, a.ef, (long long)a.n);
     bool l2 = a.metric == METRIC_L2;

@@ -25,11 +25,18 @@ constexpr int kGhost = 32;   // extra list slots for evicted-but-tied candidates
 constexpr int METRIC_COS = 0, METRIC_L2 = 1, METRIC_DOT = 2;
 constexpr int MODE_TOPK = 0, MODE_STORE = 1, MODE_MINUPD = 2;
 
+// xor butterfly 1,2,4,8,16,32.  The first four steps are DPP moves (no LDS crossbar trip): after the
+// xor-1 / xor-2 steps every lane of a quad holds the quad's sum, so row_half_mirror / row_mirror pair the
+// same partial sums the xor-4 / xor-8 steps would (float add is commutative: bit-identical results).
 __device__ __forceinline__ float wave_sum(float x) {
-    x = x + __shfl_xor(x, 1, kWave);
-    x = x + __shfl_xor(x, 2, kWave);
-    x = x + __shfl_xor(x, 4, kWave);
-    x = x + __shfl_xor(x, 8, kWave);
+    int v = __float_as_int(x);
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    v = __float_as_int(x);
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    v = __float_as_int(x);
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v = __float_as_int(x);
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));  // row_mirror
     x = x + __shfl_xor(x, 16, kWave);
     x = x + __shfl_xor(x, 32, kWave);
     return x;
@@ -240,6 +247,8 @@ __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
         const int nvec = static_cast<int>(a.ld / 4);
         for (int64_t base = r0 + wave * RB; base < r1; base += kNWave * RB) {
             float4 r[RB][NCH];
+            // lane b fetches row b's precomputed norm with the rows, not after the reduction
+            const float myrn = (a.metric == METRIC_COS && lane < RB && base + lane < r1) ? a.row_norms[base + lane] : 0.0f;
 #pragma unroll
             for (int b = 0; b < RB; b++) load_row<NCH>(r[b], a.rows + (base + b) * a.ld, nvec, lane, base + b < r1);
             float s[RB];
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
             for (int b = 0; b < RB; b++) {
                 int64_t row = base + b;
                 if (row < r1) {  // wave-uniform
-                    float rn = (a.metric == METRIC_COS) ? a.row_norms[row] : 0.0f;
+                    float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), b));
                     float d = finish_dist(a.metric, s[b], qn, rn);
                     if (a.mode == MODE_TOPK) {
                         uint64_t key = make_key(d, ord_base + static_cast<uint32_t>(row - rb0));
@@ -419,7 +428,9 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
     float *cand_d = reinterpret_cast<float *>(cand_id + kMaxDeg);
     int32_t *cand_P = reinterpret_cast<int32_t *>(cand_d + kMaxDeg);
     int32_t *sc = cand_P + kMaxDeg;  // scalars
-    uint32_t *bits = reinterpret_cast<uint32_t *>(sc + 16);
+    int32_t *part = sc + 16;         // [NW][64] per-wave partial counts of the merge
+    int32_t *posA = part + NW * kWave;  // [cap] merged position of every list entry
+    uint32_t *bits = reinterpret_cast<uint32_t *>(posA + a.cap);
     uint32_t *stamps = VG ? a.vis + static_cast<int64_t>(blockIdx.x) * a.vis_stride : nullptr;
     // sc[0]=cursor sc[1]=ncand sc[2]=nadmit sc[3]=minP sc[4]=worst bits sc[5]=nghost
     const int tid = threadIdx.x;
@@ -473,7 +484,8 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
             int cur_start = 0;
             const int deg = level == 0 ? a.M0 : a.M;
             for (;;) {
-                // ---- next candidate: first unexpanded entry
+                // ---- wave 0: next candidate (first unexpanded entry), its neighbour ids, visited filter,
+                //      compaction.  One barrier for all of it.
                 if (wave == 0) {
                     int found = -1;
                     for (int base = cur_start; base < len && found < 0; base += kWave) {
@@ -482,90 +494,112 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                         uint64_t m = __ballot(un);
                         if (m) found = base + __ffsll(static_cast<unsigned long long>(m)) - 1;
                     }
-                    if (lane == 0) sc[0] = found;
+                    int ncand = 0;
+                    if (found >= 0) {
+                        const uint32_t node = curA[found].y & ~kExpanded;
+                        const int32_t *adj = level == 0 ? a.l0_adj + static_cast<int64_t>(node) * a.M0
+                                                        : a.up_adj + (a.up_off[node] + (level - 1)) * a.M;
+                        int nb = lane < deg ? adj[lane] : -1;
+                        bool fresh = false;
+                        if (nb >= 0 && nb < a.n) {
+                            if (VG) {
+                                fresh = atomicExch(&stamps[nb], gen) != gen;
+                            } else {
+                                uint32_t bit = 1u << (nb & 31);
+                                uint32_t old = atomicOr(&bits[nb >> 5], bit);
+                                fresh = !(old & bit);
+                            }
+                        }
+                        uint64_t m = __ballot(fresh);
+                        int pos = __popcll(m & ((1ull << lane) - 1ull));
+                        if (fresh) cand_id[pos] = nb;
+                        ncand = __popcll(m);
+                        if (lane == 0) curA[found].y = node | kExpanded;
+                    }
+                    if (lane == 0) {
+                        sc[0] = found;
+                        sc[1] = ncand;
+                    }
                 }
                 __syncthreads();
                 const int c = sc[0];
                 if (c < 0) break;
-                const uint32_t node = curA[c].y & ~kExpanded;
-                // ---- neighbour ids, visited filter, compaction (wave 0)
-                if (wave == 0) {
-                    const int32_t *adj = level == 0 ? a.l0_adj + static_cast<int64_t>(node) * a.M0
-                                                    : a.up_adj + (a.up_off[node] + (level - 1)) * a.M;
-                    int nb = lane < deg ? adj[lane] : -1;
-                    bool fresh = false;
-                    if (nb >= 0 && nb < a.n) {
-                        if (VG) {
-                            fresh = atomicExch(&stamps[nb], gen) != gen;
-                        } else {
-                            uint32_t bit = 1u << (nb & 31);
-                            uint32_t old = atomicOr(&bits[nb >> 5], bit);
-                            fresh = !(old & bit);
-                        }
-                    }
-                    uint64_t m = __ballot(fresh);
-                    int pos = __popcll(m & ((1ull << lane) - 1ull));
-                    if (fresh) cand_id[pos] = nb;
-                    if (lane == 0) {
-                        sc[1] = __popcll(m);
-                        curA[c].y = node | kExpanded;
-                    }
-                }
-                __syncthreads();
                 const int nc = sc[1];
                 n_hop++;
                 if (nc == 0) {
                     cur_start = c + 1;
+                    __syncthreads();  // sc[0] / sc[1] are rewritten by wave 0 right away
                     continue;
                 }
                 n_eval += nc;
                 // ---- gather rows + distances: wave w takes candidates [w*RB + t*NW*RB, +RB)
                 for (int j0 = wave * RB; j0 < nc; j0 += NW * RB) {
                     float4 r[RB][NCH];
-                    int32_t rid[RB];
+                    // lane b fetches candidate b's id and precomputed norm up front, so that the norm's memory
+                    // round trip overlaps the row gather instead of following the reduction
+                    const int myj = j0 + lane;
+                    const int32_t myid = (lane < RB && myj < nc) ? cand_id[myj] : 0;
+                    const float myrn = (a.metric == METRIC_COS && lane < RB && myj < nc) ? a.row_norms[myid] : 0.0f;
 #pragma unroll
                     for (int b = 0; b < RB; b++) {
-                        bool ok = j0 + b < nc;
-                        rid[b] = ok ? cand_id[j0 + b] : 0;
-                        load_row<NCH>(r[b], a.rows + static_cast<int64_t>(rid[b]) * a.ld, nvec, lane, ok);
+                        const int32_t rid = __builtin_amdgcn_readlane(myid, b);
+                        load_row<NCH>(r[b], a.rows + static_cast<int64_t>(rid) * a.ld, nvec, lane, j0 + b < nc);
                     }
                     float s[RB];
 #pragma unroll
                     for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2>(q, r[b]);
 #pragma unroll
                     for (int b = 0; b < RB; b++) s[b] = wave_sum(s[b]);
+                    float mine = 0.0f;  // lane b keeps candidate b's reduced sum
 #pragma unroll
-                    for (int b = 0; b < RB; b++) {
-                        if (j0 + b < nc && lane == 0) {
-                            float rn = a.metric == METRIC_COS ? a.row_norms[rid[b]] : 0.0f;
-                            cand_d[j0 + b] = finish_dist(a.metric, s[b], qn, rn) + 0.0f;
-                        }
-                    }
+                    for (int b = 0; b < RB; b++) mine = lane == b ? s[b] : mine;
+                    if (lane < RB && myj < nc) cand_d[myj] = finish_dist(a.metric, mine, qn, myrn) + 0.0f;
                 }
                 __syncthreads();
-                // ---- ranks of the incoming candidates (threads 0..nc-1, all inside wave 0)
+                // ---- merge, step 1 (all waves): every list entry counts the candidates that go before it
+                //      (its shift), every candidate counts the list entries that stay before it.  The
+                //      candidate distances sit one per lane and are broadcast with v_readlane.
+                const float cdist = lane < nc ? cand_d[lane] : 0.0f;
+                const int cbits = __float_as_int(cdist);
+                int cntA = 0;  // lane j: # list entries (of this wave's share) with d <= d_j
+                for (int base = 0; base < len; base += kThreads) {
+                    const int i = base + tid;
+                    const bool valid = i < len;
+                    const float de = valid ? __uint_as_float(curA[i].x) : 0.0f;
+                    int sh = 0;
+                    for (int j = 0; j < nc; j++) {
+                        const float dj = __int_as_float(__builtin_amdgcn_readlane(cbits, j));
+                        sh += (dj < de) ? 1 : 0;
+                        const int below = __popcll(__ballot(valid && de <= dj));
+                        cntA += (lane == j) ? below : 0;
+                    }
+                    if (valid) {
+                        const int P = i + sh;
+                        posA[i] = P;
+                        if (P == ef_l - 1) sc[4] = static_cast<int32_t>(curA[i].x);
+                    }
+                }
+                if (lane < nc) part[wave * kWave + lane] = cntA;
+                __syncthreads();
+                // ---- merge, step 2 (wave 0): rank, admission and final position of every candidate
                 if (wave == 0) {
                     bool admitted = false;
                     int P = 0x7fffffff;
-                    float dj = 0.0f;
+                    int before = 0, after_less = 0;
+                    for (int j = 0; j < nc; j++) {
+                        const float o = __int_as_float(__builtin_amdgcn_readlane(cbits, j));
+                        before += (j < lane && o <= cdist) ? 1 : 0;
+                        after_less += (j > lane && o < cdist) ? 1 : 0;
+                    }
                     if (lane < nc) {
-                        dj = cand_d[lane];
-                        int lo = 0, hi = len;  // upper_bound: #entries with d <= dj
-                        while (lo < hi) {
-                            int mid = (lo + hi) >> 1;
-                            if (__uint_as_float(curA[mid].x) <= dj) lo = mid + 1;
-                            else hi = mid;
-                        }
-                        int before = 0, after_less = 0;
-                        for (int j = 0; j < nc; j++) {
-                            float o = cand_d[j];
-                            before += (j < lane && o <= dj) ? 1 : 0;
-                            after_less += (j > lane && o < dj) ? 1 : 0;
-                        }
-                        int r = lo + before;
+                        int below = 0;
+#pragma unroll
+                        for (int w = 0; w < NW; w++) below += part[w * kWave + lane];
+                        const int r = below + before;
                         admitted = r < ef_l;
                         P = r + after_less;
                         cand_P[lane] = admitted ? P : -1;
+                        if (admitted && P == ef_l - 1) sc[4] = cbits;
                     }
                     uint64_t am = __ballot(admitted);
                     int minP = admitted ? P : 0x7fffffff;
@@ -585,46 +619,37 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                     cur_start = c + 1;
                     continue;
                 }
-                // ---- scatter old entries and admitted candidates to their merged positions
+                // ---- merge, step 3 (all waves): scatter to the merged positions; entries pushed past ef whose
+                //      distance ties the new worst stay as ghosts
                 const int total = len + nadm;
-                for (int i = tid; i < len; i += kThreads) {
-                    uint2 e = curA[i];
-                    float de = __uint_as_float(e.x);
-                    int sh = 0;
-                    for (int j = 0; j < nc; j++) sh += cand_d[j] < de ? 1 : 0;
-                    int P = i + sh;
-                    if (P < a.cap) curB[P] = e;
-                    if (P == ef_l - 1) sc[4] = e.x;
-                }
-                if (tid < nc) {
-                    int P = cand_P[tid];
-                    if (P >= 0) {
-                        uint2 e = make_uint2(__float_as_uint(cand_d[tid]), static_cast<uint32_t>(cand_id[tid]));
+                const bool full = total > ef_l;
+                const uint32_t wbits = static_cast<uint32_t>(sc[4]);
+                int ghosts = 0;
+                for (int base = 0; base < len; base += kThreads) {
+                    const int i = base + tid;
+                    bool gh = false;
+                    if (i < len) {
+                        const uint2 e = curA[i];
+                        const int P = posA[i];
                         if (P < a.cap) curB[P] = e;
-                        if (P == ef_l - 1) sc[4] = e.x;
+                        gh = full && P >= ef_l && P < a.cap && e.x == wbits;
                     }
+                    ghosts += __popcll(__ballot(gh));
                 }
-                __syncthreads();
-                int newlen = total;
-                if (total > ef_l) {
-                    // ghosts: admitted-at-some-time entries pushed past ef whose distance ties the worst
-                    const uint32_t wbits = static_cast<uint32_t>(sc[4]);
-                    for (int i = tid; i < len; i += kThreads) {
-                        uint2 e = curA[i];
-                        if (e.x == wbits) {
-                            float de = __uint_as_float(e.x);
-                            int sh = 0;
-                            for (int j = 0; j < nc; j++) sh += cand_d[j] < de ? 1 : 0;
-                            if (i + sh >= ef_l && i + sh < a.cap) atomicAdd(&sc[5], 1);
+                {
+                    bool gh = false;
+                    if (tid < nc) {
+                        const int P = cand_P[tid];
+                        if (P >= 0) {
+                            if (P < a.cap) curB[P] = make_uint2(static_cast<uint32_t>(cbits), static_cast<uint32_t>(cand_id[tid]));
+                            gh = full && P >= ef_l && P < a.cap && static_cast<uint32_t>(cbits) == wbits;
                         }
                     }
-                    if (tid < nc) {
-                        int P = cand_P[tid];
-                        if (P >= ef_l && P < a.cap && __float_as_uint(cand_d[tid]) == wbits) atomicAdd(&sc[5], 1);
-                    }
-                    __syncthreads();
-                    newlen = ef_l + sc[5];
+                    if (wave == 0) ghosts += __popcll(__ballot(gh));
                 }
+                if (lane == 0 && ghosts) atomicAdd(&sc[5], ghosts);
+                __syncthreads();
+                const int newlen = full ? ef_l + sc[5] : total;
                 {
                     uint2 *t = curA;
                     curA = curB;
@@ -633,7 +658,6 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                 len = newlen;
                 const int minP = sc[3];
                 cur_start = minP < c + 1 ? minP : c + 1;
-                __syncthreads();
             }
             // ---- level done
             if (a.q_rows && level > 0 && level <= qlevel && tid == 0) {

@@ -341,6 +341,25 @@ def test_ivf_large_batch_tiled_scan(eng, oracle):
             assert_topk_parity(i1, d1, i2[:2], d2[:2], "gemv vs tile", metric_scale(metric, Q, base))
 
 
+@pytest.mark.parametrize("k", [10, 100])
+def test_ivf_single_query_many_partials(eng, oracle, k):
+    """One query against long lists: the scan is cut into many chunks, so the per-query merge folds tens of
+    thousands of partial keys with several waves (two-level merge), for k in registers (<= 64) and in LDS."""
+    O = oracle
+    base = _data(O, 20000, 32)
+    Q = _data(O, 3, 32, seed=43)
+    with eng.Index(base) as idx:
+        idx.ivf_build(16, 3, 42)
+        cen, off, lids = idx.get_ivf()
+        for nq in (1, 3):
+            ids, d = idx.ivf_search(Q[:nq], k, 16)
+            oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, 16, mode=_ivf_mode(O, O.COSINE, 32, nq, 16, 16))
+            assert_exact(ids, d, oi, od, "many partials nq=%d k=%d" % (nq, k))
+        ei, ed = idx.exact_knn(Q[:1], k)           # probing every list == brute force (GEMV order on both sides)
+        ids, d = idx.ivf_search(Q[:1], k, 16)
+        assert_exact(ids, d, ei, ed, "ivf(all lists) == exact")
+
+
 def test_ivf_ragged_lists_and_full_probe(eng, oracle):
     """Empty lists, a list holding almost everything, nprobe > nlist, k > candidates."""
     O = oracle
