@@ -59,10 +59,13 @@ _SIGS = {
     "hnswgpu_get_ivf": ["p", "p", "p", "p"],
     "hnswgpu_kmeans_assign": ["p", "p", "i32", "p", "p"],
     "hnswgpu_kmeanspp": ["p", "i32", "i64", "p"],
+    "hnswgpu_list_means": ["p", "i32", "p", "p", "p"],
     "hnswgpu_ivf_search": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
     "hnswgpu_ivf_search_dev": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
     "hnswgpu_ivf_search_lists": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
     "hnswgpu_merge_topk_dev": ["i32", "p", "p", "i32", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_save": ["p", "p"],
+    "hnswgpu_load": ["p", "i32", "p"],
     "hnswgpu_set_profiling": ["p", "i32"],
     "hnswgpu_get_profile": ["p", "i32", "p", "p", "i32"],
 }

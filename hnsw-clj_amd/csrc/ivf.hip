@@ -546,6 +546,32 @@ int hnswgpu_kmeans_assign(hnswgpu_index *idx, const float *centroids, int32_t nl
     return 0;
 }
 
+int hnswgpu_list_means(hnswgpu_index *idx, int32_t nlist, const int64_t *list_off, const int32_t *list_ids,
+                       float *out_centroids) {
+    HG_REQUIRE(idx && list_off && (list_ids || idx->n == 0) && out_centroids, HNSWGPU_EINVAL, "null argument");
+    HG_REQUIRE(nlist >= 1, HNSWGPU_EINVAL, "nlist must be >= 1");
+    HG_TRY(validate_lists(idx->n, nlist, list_off, list_ids));
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(idx->s_misc.ensure(sizeof(int64_t) * (nlist + 1)));
+    HG_TRY(idx->s_misc2.ensure(sizeof(int32_t) * std::max<int64_t>(idx->n, 1)));
+    HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(nlist) * idx->ld));
+    HG_HIP(hipMemsetAsync(idx->s_tile.p, 0, sizeof(float) * static_cast<size_t>(nlist) * idx->ld, st));  // empty list -> zero vector
+    HG_HIP(hipMemcpyAsync(idx->s_misc.p, list_off, sizeof(int64_t) * (nlist + 1), hipMemcpyHostToDevice, st));
+    if (idx->n > 0)
+        HG_HIP(hipMemcpyAsync(idx->s_misc2.p, list_ids, sizeof(int32_t) * idx->n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(centroid_mean_kernel, dim3(nlist), dim3(kWG), 0, st, idx->d_base, idx->ld, idx->dim,
+                       idx->s_misc.as<int64_t>(), idx->s_misc2.as<int32_t>(), idx->s_tile.as<float>());
+    HG_HIP(hipGetLastError());
+    HG_HIP(hipMemcpy2DAsync(out_centroids, sizeof(float) * idx->dim, idx->s_tile.p, sizeof(float) * idx->ld,
+                            sizeof(float) * idx->dim, nlist, hipMemcpyDeviceToHost, st));
+    HG_TRY(end_call(idx, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 int hnswgpu_kmeanspp(hnswgpu_index *idx, int32_t nlist, int64_t seed, int32_t *out_rows) {
     HG_REQUIRE(idx && out_rows, HNSWGPU_EINVAL, "null argument");
     HG_REQUIRE(nlist >= 1 && idx->n >= 1, HNSWGPU_EINVAL, "need nlist >= 1 and a non-empty index");

@@ -70,6 +70,27 @@ class Index:
             self.n, self.dim = base.shape
             check(lib().hnswgpu_create(_p(base), self.n, self.dim, self.metric, self.device, C.byref(self._h)))
 
+    @classmethod
+    def load(cls, path, device=0):
+        """hnswgpu_load: base + graph + IVF lists from one flat binary file."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(None)
+        self.device = int(device)
+        check(lib().hnswgpu_load(str(path).encode(), self.device, C.byref(self._h)))
+        n, dim, metric = C.c_int64(), C.c_int32(), C.c_int32()
+        check(lib().hnswgpu_info(self._h, C.byref(n), C.byref(dim), C.byref(metric), None, None))
+        self.n, self.dim, self.metric = n.value, dim.value, metric.value
+        return self
+
+    def save(self, path):
+        check(lib().hnswgpu_save(self._h, str(path).encode()))
+
+    @property
+    def has_graph(self):
+        g = C.c_int32()
+        check(lib().hnswgpu_info(self._h, None, None, None, C.byref(g), None))
+        return bool(g.value)
+
     # -- lifetime
     def close(self):
         if self._h:
@@ -175,6 +196,13 @@ class Index:
         d = np.empty(self.n, np.float32)
         check(lib().hnswgpu_kmeans_assign(self._h, _p(cen), cen.shape[0], _p(a), _p(d)))
         return a, d
+
+    def list_means(self, list_off, list_ids):
+        off = np.ascontiguousarray(list_off, np.int64)
+        ids = np.ascontiguousarray(list_ids, np.int32)
+        out = np.empty((len(off) - 1, self.dim), np.float32)
+        check(lib().hnswgpu_list_means(self._h, len(off) - 1, _p(off), _p(ids), _p(out)))
+        return out
 
     def kmeanspp(self, nlist, seed=42):
         out = np.empty(nlist, np.int32)

@@ -132,6 +132,10 @@ int hnswgpu_get_ivf(const hnswgpu_index *idx, float *centroids, int64_t *list_of
 int hnswgpu_kmeans_assign(hnswgpu_index *idx, const float *centroids, int32_t nlist, int32_t *out_assign,
                           float *out_dist);
 int hnswgpu_kmeanspp(hnswgpu_index *idx, int32_t nlist, int64_t seed, int32_t *out_rows);
+/* compute-centroid (ivf_flat.clj:66-77, lightning.clj:24-35) for caller-given lists: f64 mean in list order,
+ * stored f32; an empty list yields the zero vector (lightning.clj:118-120). */
+int hnswgpu_list_means(hnswgpu_index *idx, int32_t nlist, const int64_t *list_off, const int32_t *list_ids,
+                       float *out_centroids);
 int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t nprobe,
                        int32_t *out_ids, float *out_dist, int32_t *out_probes);
 int hnswgpu_ivf_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
@@ -148,6 +152,14 @@ int hnswgpu_ivf_search_lists(hnswgpu_index *idx, const float *Q, int32_t nq, int
  * arrays of GLOBAL ids (-1 padded) and distances; ties keep the lower shard first. */
 int hnswgpu_merge_topk_dev(int32_t device, const int32_t *d_ids, const float *d_dist, int32_t nshard, int32_t nq,
                            int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream);
+
+/* ---- persistence ------------------------------------------------------------------------------------------
+ * One flat binary file (header + plain arrays; layout in hnsw-clj_amd/csrc/persist.hip) with the base
+ * vectors, the graph and the IVF lists -- replaces helper/index-io's save-index / load-index, an EDN
+ * pr-str of every node (src/hnsw/helper/index_io.clj:10-80) and api/save, api/load-index which throw
+ * (src/hnsw/api.clj:40-50).  String ids are the caller's to store.  load re-validates the graph. */
+int hnswgpu_save(hnswgpu_index *idx, const char *path);
+int hnswgpu_load(const char *path, int32_t device, hnswgpu_index **out);
 
 /* ---- measurement --------------------------------------------------------------------------------------
  * With profiling on, the dominant kernel of each search call is bracketed by hipEvents on the

@@ -416,6 +416,51 @@ def test_full_size_31k_properties(eng, oracle):
         assert_topk_parity(ii, dd, ei, ed, "ivf(all lists) vs exact")
 
 
+def test_persistence_and_lightning(eng, oracle, tmp_path):
+    """Binary index file (replaces helper/index_io.clj's EDN): save -> load gives the same ids and the same
+    bits; damaged files are rejected.  Lightning partitions reuse the list-scan kernel."""
+    from hnsw_clj_amd import datagen, index_io, ivf_flat, lightning, ultra_fast
+
+    vecs = datagen.generate_dataset(600, 40)
+    data = datagen.indexed(vecs)
+    g = ultra_fast.build_index(data, show_progress=False)
+    path = str(tmp_path / "index.bin")
+    index_io.save_index(g, path)
+    assert index_io.index_exists(path) and os.path.getsize(path) < 600 * (40 * 4 + 33 * 4 + 200)
+    g2 = index_io.load_index(path, ultra_fast.cosine_distance_ultra)
+    for q in vecs[:5]:
+        assert ultra_fast.search_knn(g, q, 7) == ultra_fast.search_knn(g2, q, 7)      # integration_test.clj:68-78 intent
+    assert index_io.load_index(str(tmp_path / "nope.bin"), ultra_fast.cosine_distance_ultra) is None
+    with pytest.raises(ValueError, match="metric"):
+        index_io.load_index(path, ultra_fast.euclidean_distance_ultra)
+    raw = bytearray(open(path, "rb").read())
+    raw[64 + 600 * 40 * 4 + 600 * 4 + 8] = 0x7f                                       # an edge pointing far outside
+    raw[64 + 600 * 40 * 4 + 600 * 4 + 11] = 0x7f
+    open(str(tmp_path / "bad.bin"), "wb").write(raw)
+    with pytest.raises(Exception, match="out of range"):
+        eng.Index.load(str(tmp_path / "bad.bin"))
+    with pytest.raises(Exception, match="truncated"):
+        open(str(tmp_path / "short.bin"), "wb").write(raw[:5000])
+        eng.Index.load(str(tmp_path / "short.bin"))
+    g.close(), g2.close()
+    ivf = ivf_flat.build_index(data, num_partitions=6, show_progress=False)
+    index_io.save_index(ivf, path)
+    ivf2 = index_io.load_index(path)
+    assert ivf_flat.search_knn(ivf, vecs[3], 5, "precise") == ivf_flat.search_knn(ivf2, vecs[3], 5, "precise")
+    ivf.close(), ivf2.close()
+    li = lightning.build_index(data, num_partitions=24, show_progress=False, seed=1)
+    _, off, lids = li.index.get_ivf()
+    assert np.diff(off).max() == 25 and sorted(lids.tolist()) == list(range(600))     # equal random slices
+    r = lightning.search_knn(li, vecs[9], 3, "precise")
+    assert len(r) == 3 and all(len(x) == 2 for x in r)
+    full = lightning.search_lightning(li, vecs[9], 3, search_percent=1.0)
+    assert full[0][0] == "vec_9" and abs(full[0][1]) < 1e-6
+    cen = li.index.list_means(off, lids)
+    want = np.stack([vecs[lids[off[l]:off[l + 1]]].astype(np.float64).mean(0) for l in range(24)])
+    assert np.allclose(cen, want, rtol=1e-6, atol=1e-7)
+    li.close()
+
+
 def test_merge_topk_dev(eng):
     import torch
 
