@@ -365,8 +365,9 @@ int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int
     HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * k));
     HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * k));
     // distance scratch [qb][nrows]; bound it to ~2 GiB by batching the queries
-    int64_t qb = std::max<int64_t>(kTileQ, ((2LL << 30) / (4 * std::max<int64_t>(nrows, 1))) / kTileQ * kTileQ);
-    qb = std::min<int64_t>(qb, (nq + kTileQ - 1) / kTileQ * kTileQ);
+    const int tq = tile_tq(idx->dim);
+    int64_t qb = std::max<int64_t>(tq, ((2LL << 30) / (4 * std::max<int64_t>(nrows, 1))) / tq * tq);
+    qb = std::min<int64_t>(qb, (nq + tq - 1) / tq * tq);
     HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(qb) * nrows));
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         int32_t nb = static_cast<int32_t>(std::min<int64_t>(qb, nq - q0));
@@ -382,7 +383,7 @@ int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int
         t.nrows_all = nrows;
         t.nq = nb;
         t.out_stride = nrows;
-        int64_t groups = (nb + kTileQ - 1) / kTileQ;
+        int64_t groups = (nb + tq - 1) / tq;
         int64_t tiles = (nrows + kTileRows - 1) / kTileRows;
         int64_t want = std::max<int64_t>(1, std::min<int64_t>(tiles, (2048 + groups - 1) / groups));
         int64_t cr = ((tiles + want - 1) / want) * kTileRows;

@@ -48,7 +48,7 @@ __global__ void ivf_hist_kernel(const int32_t *probes, int64_t npairs, int32_t *
 // every thread writes the groups of its own list.
 __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *cnt, int nlist, int32_t *list_mem_begin,
                                                         int32_t *fill, int32_t *grp_seg, int32_t *grp_mem_begin,
-                                                        int32_t *grp_mem_cnt, int32_t *ngroups) {
+                                                        int32_t *grp_mem_cnt, int32_t *ngroups, int tq) {
     __shared__ int32_t sm[1024], sg[1024];
     __shared__ int32_t carry_m, carry_g;
     const int tid = threadIdx.x;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *cnt, int 
     for (int l0 = 0; l0 < nlist; l0 += 1024) {
         const int l = l0 + tid;
         const int c = l < nlist ? cnt[l] : 0;
-        const int ng = (c + kTileQ - 1) / kTileQ;
+        const int ng = (c + tq - 1) / tq;
         sm[tid] = c;
         sg[tid] = ng;
         __syncthreads();
@@ -72,10 +72,10 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *cnt, int 
         if (l < nlist) {
             list_mem_begin[l] = mem;
             fill[l] = 0;
-            for (int b = 0, g = g0; b < c; b += kTileQ, g++) {
+            for (int b = 0, g = g0; b < c; b += tq, g++) {
                 grp_seg[g] = l;
                 grp_mem_begin[g] = mem + b;
-                grp_mem_cnt[g] = c - b < kTileQ ? c - b : kTileQ;
+                grp_mem_cnt[g] = c - b < tq ? c - b : tq;
             }
         }
         __syncthreads();
@@ -350,7 +350,8 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
     const int nlist = idx->nlist;
     const int64_t stride = static_cast<int64_t>(nprobe) * idx->max_list_len;  // candidates per query, upper bound
-    const int64_t gbound = npairs / kTileQ + nlist;                            // sum_l ceil(cnt_l / 32) <= this
+    const int tq = tile_tq(idx->dim);
+    const int64_t gbound = npairs / tq + nlist;                                // sum_l ceil(cnt_l / tq) <= this
     HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(nq) * stride));  // queries already padded
     // int32 scratch: cnt[nlist] | list_mem_begin[nlist] | fill[nlist] | grp_seg | grp_mem_begin | grp_mem_cnt | ngroups
     size_t ints = 3 * static_cast<size_t>(nlist) + 3 * static_cast<size_t>(gbound) + 4;
@@ -362,7 +363,7 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     HG_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nlist, st));
     hipLaunchKernelGGL(ivf_hist_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st, d_probes,
                        npairs, cnt);
-    hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr);
+    hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr, tq);
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st,
                        idx->s_pairs.as<Pair>(), d_probes, npairs, stride, lmb, fill, idx->s_misc2.as<GroupMember>());
     HG_HIP(hipGetLastError());
@@ -384,7 +385,7 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     t.nq = nq;
     // rows per workgroup: whole tiles of 128, enough workgroups to fill the chip
     int64_t mean = std::max<int64_t>(1, idx->n / std::max(nlist, 1));
-    int64_t est_groups = std::max<int64_t>(1, npairs / kTileQ + nlist / 2);
+    int64_t est_groups = std::max<int64_t>(1, npairs / tq + nlist / 2);
     int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows;
     static const int64_t tgt = []() {
         const char *e = getenv("HNSWGPU_TILE_WGS");  // tuning override

@@ -21,16 +21,18 @@
 namespace hg {
 
 constexpr int kTileRows = 128;  // rows per tile: 4 waves x 32
-constexpr int kTileQ = 32;      // queries per group (MFMA N)
+constexpr int kTileQ = 32;      // MFMA N: queries per group for dim <= 896 (16 up to 1792, 8 up to 3072: LDS)
 constexpr int kTileK = 32;      // K per staging step
 constexpr int kTileLdA = kTileK + 4;  // padded LDS row of the A (rows) tile: conflict-free ds_read_b128
-constexpr int kTileMaxDim = 896;      // queries (32 x (dim+pad)) + 2 A buffers must fit 160 KiB of LDS
+constexpr int kTileMaxDim = 3072;     // group size shrinks with dim so that tq x (dim+pad) floats stay < 100 KiB
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __host__ __device__ inline int tile_ldq(int dim) { return ((dim + 63) / 64) * 64 + 4; }
+// queries resident per workgroup: the 32-column MFMA tile is filled fully, half or a quarter
+__host__ __device__ inline int tile_tq(int dim) { return dim <= 896 ? 32 : (dim <= 1792 ? 16 : 8); }
 __host__ inline size_t tile_lds_bytes(int dim) {
-    return sizeof(float) * (static_cast<size_t>(kTileQ) * tile_ldq(dim) + 2 * kTileRows * kTileLdA) +
+    return sizeof(float) * (static_cast<size_t>(tile_tq(dim)) * tile_ldq(dim) + 2 * kTileRows * kTileLdA) +
            sizeof(float) * kTileQ + sizeof(int64_t) * kTileQ + sizeof(float) * kTileRows;
 }
 
@@ -55,7 +57,7 @@ struct TileArgs {
     const int32_t *ngroups;  // device scalar (grid is an upper bound)
     const GroupMember *members;
     const int64_t *seg_off;  // row range of segment s = [seg_off[s], seg_off[s+1])
-    // implicit groups (assignment / exact kNN): group g = queries [32g, 32g+32), every group scans rows
+    // implicit groups (assignment / exact kNN): group g = queries [tq*g, tq*g + tq), every group scans rows
     // [0, nrows_all) and writes out[q * out_stride + row]
     int64_t nrows_all;
     int32_t nq;

@@ -9,8 +9,9 @@ namespace hg {
 __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ldq = tile_ldq(a.dim);
-    float *Bs = reinterpret_cast<float *>(smem);                 // [32][ldq]   resident query group
-    float *As = Bs + kTileQ * ldq;                               // [2][128][36] streamed row tiles
+    const int tq = tile_tq(a.dim);                               // queries resident in LDS (32 / 16 / 8)
+    float *Bs = reinterpret_cast<float *>(smem);                 // [tq][ldq]   resident query group
+    float *As = Bs + tq * ldq;                               // [2][128][36] streamed row tiles
     float *qn_s = As + 2 * kTileRows * kTileLdA;                 // [32]
     int64_t *ob_s = reinterpret_cast<int64_t *>(qn_s + kTileQ);  // [32] output bases (-1 = empty slot)
     float *rn_s = reinterpret_cast<float *>(ob_s + kTileQ);      // [128] row norms of the current tile
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
     } else {
         rb0 = 0;
         rb1 = a.nrows_all;
-        cnt = a.nq - g * kTileQ < kTileQ ? a.nq - g * kTileQ : kTileQ;
+        cnt = a.nq - g * tq < tq ? a.nq - g * tq : tq;
     }
     // split THIS segment evenly into round(tiles / tiles_per_chunk) chunks of whole tiles (no tiny tail chunk
     // that would reload the query group for a handful of rows); a.nchunks is the bound for the longest segment
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
                 qi = m.q;
                 ob = m.out_base;
             } else {
-                qi = g * kTileQ + tid;
+                qi = g * tq + tid;
                 ob = static_cast<int64_t>(qi) * a.out_stride;
             }
             qn = a.q_norms ? a.q_norms[qi] : 0.0f;
@@ -69,11 +70,11 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
     }
     const int nvec = static_cast<int>(a.ld / 4);
     const int nk = (a.dim + kTileK - 1) / kTileK;
-    for (int f = tid; f < kTileQ * (nk * kTileK / 4); f += kWG) {
+    for (int f = tid; f < tq * (nk * kTileK / 4); f += kWG) {
         int slot = f / (nk * kTileK / 4), c4 = f % (nk * kTileK / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (slot < cnt && c4 < nvec) {
-            int qi = a.members ? a.members[a.grp_mem_begin[g] + slot].q : g * kTileQ + slot;
+            int qi = a.members ? a.members[a.grp_mem_begin[g] + slot].q : g * tq + slot;
             v = reinterpret_cast<const float4 *>(a.Qp + static_cast<int64_t>(qi) * a.ld)[c4];
         }
         *reinterpret_cast<float4 *>(Bs + slot * ldq + 4 * c4) = v;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
         };
         auto compute = [&](int ks, int buf) {
             const float *Ab = As + (buf * kTileRows + wave * 32 + li) * kTileLdA + 4 * half;
-            const float *Bb = Bs + li * ldq + ks * kTileK + 4 * half;
+            const float *Bb = Bs + (li & (tq - 1)) * ldq + ks * kTileK + 4 * half;  // columns >= tq repeat, unused
             float4 av[kTileK / 8], bv[kTileK / 8];
 #pragma unroll
             for (int t = 0; t < kTileK / 8; t++) {
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
             __syncthreads();
         }
         // ---- epilogue: D[row i][query col]: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-        const int64_t ob = ob_s[li];
+        const int64_t ob = li < tq ? ob_s[li] : -1;
         const float qn = qn_s[li];
         if (ob >= 0 && !(a.dbg & 4)) {
 #pragma unroll

@@ -31,8 +31,8 @@ def eng(native_lib):
 
 def _ivf_mode(O, metric, dim, nq, nprobe, nlist):
     """Which kernel serves an IVF search (ivf.hip: ivf_search_enqueue): the MFMA tile path once the batch has
-    >= 4 (query, list) pairs per list (cosine / dot, dim <= 896), else the GEMV scan."""
-    tiled = metric != O.L2 and dim <= 896 and nq * min(nprobe, nlist) >= 4 * nlist
+    >= 4 (query, list) pairs per list (cosine / dot), else the GEMV scan."""
+    tiled = metric != O.L2 and dim <= 3072 and nq * min(nprobe, nlist) >= 4 * nlist
     return O.MODE_MFMA if tiled else O.MODE_DEV
 
 
@@ -108,7 +108,8 @@ def test_exact_knn(eng, oracle, n, dim, k):
             assert (ids[:, n:] == -1).all() and np.isinf(d[:, n:]).all()
 
 
-@pytest.mark.parametrize("n,dim,nq,k", [(1000, 128, 70, 10), (300, 768, 33, 100), (2500, 100, 64, 5), (129, 8, 16, 3)])
+@pytest.mark.parametrize("n,dim,nq,k", [(1000, 128, 70, 10), (300, 768, 33, 100), (2500, 100, 64, 5), (129, 8, 16, 3),
+                                       (260, 1536, 21, 5), (140, 3072, 17, 3), (200, 900, 40, 4)])
 def test_tiled_mfma_path_exact(eng, oracle, n, dim, nq, k):
     """Many queries against the same rows run on the MFMA tile kernel (v_mfma_f32_32x32x2_f32); its k-order is
     mimicked by the oracle's MFMA mode: ids identical, distances bit-identical.  L2 stays on the GEMV kernel."""
