@@ -1,0 +1,77 @@
+"""Developer tool: BASELINE.json configs[3]/[4] at their per-GPU size on ONE MI355X.
+  python tools/scale_check.py hnsw   -> 1.25M x 1536 cosine HNSW (one GPU's shard of 10M x 1536), ef_search 256
+  python tools/scale_check.py ivf    -> 10M x 768 IVF-FLAT nlist 1024 nprobe 32, batch 1024"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from hnsw_clj_amd import engine
+
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev)
+g.manual_seed(1)
+
+
+def manifold(n, dim, r=48, noise=0.1, chunk=250_000):
+    w = torch.randn(r, dim, generator=g, device=dev)
+    out = torch.empty(n, dim, device=dev)
+    for i in range(0, n, chunk):
+        m = min(chunk, n - i)
+        x = torch.randn(m, r, generator=g, device=dev) @ w / r ** 0.5 + noise * torch.randn(m, dim, generator=g, device=dev)
+        out[i:i + m] = x / x.norm(dim=1, keepdim=True)
+    return out, w
+
+
+if sys.argv[1] == "hnsw":
+    n, dim = 1_250_000, 1536
+    x, w = manifold(n, dim)
+    idx = engine.Index(x, "cosine", 0)
+    t = time.time()
+    idx.hnsw_build(16, 200, 42)
+    print("HNSW build %d x %d: %.1f s (%.0f vectors/s)" % (n, dim, time.time() - t, n / (time.time() - t)), flush=True)
+    Q = x[:4096] + 0.02 * torch.randn(4096, dim, generator=g, device=dev)
+    Q = (Q / Q.norm(dim=1, keepdim=True)).contiguous()
+    ti, _ = idx.exact_knn_dev(Q[:512], 10)
+    for ef in (64, 128, 256):
+        ids, _ = idx.hnsw_search_dev(Q, 10, ef)
+        torch.cuda.synchronize()
+        t = time.time()
+        ids, _ = idx.hnsw_search_dev(Q, 10, ef)
+        torch.cuda.synchronize()
+        dt = time.time() - t
+        print("  ef %3d  recall@10 %.4f  %d queries in %.2f ms = %.0f QPS" % (ef, bench.recall_at_k(ids[:512], ti), len(Q), dt * 1e3, len(Q) / dt), flush=True)
+else:
+    n, dim, nlist = 10_000_000, 768, 1024
+    cen = torch.randn(nlist, dim, generator=g, device=dev)
+    x = torch.empty(n, dim, device=dev)
+    for i in range(0, n, 500_000):
+        wch = torch.randint(0, nlist, (500_000,), generator=g, device=dev)
+        y = cen[wch] + 0.3 * torch.randn(500_000, dim, generator=g, device=dev)
+        x[i:i + 500_000] = y / y.norm(dim=1, keepdim=True)
+    idx = engine.Index(x, "cosine", 0)
+    del x
+    t = time.time()
+    idx.ivf_build(nlist, 10, 42)
+    print("IVF build %d x %d nlist %d: %.1f s" % (n, dim, nlist, time.time() - t), flush=True)
+    qw = torch.randint(0, nlist, (1024,), generator=g, device=dev)
+    Q = cen[qw] + 0.3 * torch.randn(1024, dim, generator=g, device=dev)
+    Q = (Q / Q.norm(dim=1, keepdim=True)).contiguous()
+    for nq in (1, 32, 1024):
+        q = Q[:nq].contiguous()
+        for _ in range(2):
+            idx.ivf_search_dev(q, 10, 32)
+        torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(5):
+            ids, _ = idx.ivf_search_dev(q, 10, 32)
+        torch.cuda.synchronize()
+        dt = (time.time() - t) / 5
+        print("  batch %4d: %.3f ms per batch = %.0f QPS" % (nq, dt * 1e3, nq / dt), flush=True)
+    ti, _ = idx.exact_knn_dev(Q[:64].contiguous(), 10)
+    ids, _ = idx.ivf_search_dev(Q[:64].contiguous(), 10, 32)
+    torch.cuda.synchronize()
+    print("  recall@10 vs exact: %.4f" % bench.recall_at_k(ids, ti))
