@@ -251,6 +251,53 @@ def test_hnsw_build_on_device(eng, oracle):
     assert rec_gpu_graph >= 0.9 and rec_gpu_graph >= rec_ref - 0.03, (rec_gpu_graph, rec_ref)
 
 
+def test_randomised_differential(eng, oracle):
+    """40 random configurations (size, dim, metric, M, ef, k, nlist, nprobe, batch): every search entry point of
+    the C ABI against the oracle's matching device-order mode, bit for bit."""
+    O = oracle
+    rs = np.random.RandomState(2026)
+    for case in range(40):
+        n = int(rs.choice([3, 17, 64, 200, 777, 1500]))
+        dim = int(rs.choice([1, 2, 7, 16, 33, 96, 130, 260, 400]))
+        metric = int(rs.choice([O.COSINE, O.L2, O.DOT]))
+        dist = str(rs.choice(["gaussian", "uniform", "clustered"]))
+        base = _data(O, n, dim, dist, seed=100 + case, num_clusters=4, noise_level=0.3)
+        if rs.rand() < 0.3:
+            base[rs.randint(0, n, max(1, n // 10))] = base[0]            # duplicates -> exact ties
+        nq = int(rs.choice([1, 2, 5, 19, 40]))
+        Q = np.vstack([_data(O, nq, dim, dist, seed=500 + case, num_clusters=4, noise_level=0.3)])
+        Q[0] = base[min(1, n - 1)]
+        k = int(rs.choice([1, 3, 10, 70]))
+        tag = "case %d n=%d dim=%d metric=%d nq=%d k=%d" % (case, n, dim, metric, nq, k)
+        with eng.Index(base, metric) as idx:
+            # HNSW on an oracle-built graph
+            M = int(rs.choice([2, 5, 16]))
+            g = O.hnsw_build(base, metric, M=M, ef_construction=int(rs.choice([8, 40])), seed=case, mode=O.MODE_DEV)
+            idx.set_graph(g)
+            ef = int(rs.choice([1, 7, 50, 300]))
+            ids, d, st = idx.hnsw_search(Q, k, ef, want_stats=True)
+            oi, od, ost, _ = O.hnsw_search(base, g, Q, k, ef=max(ef, k), metric=metric, mode=O.MODE_DEV)
+            assert_exact(ids, d, oi, od, tag + " hnsw ef=%d M=%d" % (ef, M))
+            np.testing.assert_array_equal(st, ost, err_msg=tag)
+            # exact kNN (tile path from 16 queries on, cosine / dot)
+            ids, d = idx.exact_knn(Q, k)
+            mode = O.MODE_MFMA if (metric != O.L2 and nq >= 16) else O.MODE_DEV
+            oi, od, _ = O.exact_knn(base, Q, k, metric=metric, mode=mode)
+            assert_exact(ids, d, oi, od, tag + " exact")
+            # IVF on random lists
+            nlist = int(rs.choice([1, 3, 8, 20]))
+            assign = rs.randint(0, nlist, n)
+            off, lids = O.lists_from_assign(assign, nlist)
+            cen = _data(O, nlist, dim, seed=900 + case)
+            idx.set_ivf(cen, off, lids)
+            nprobe = int(rs.choice([1, 2, nlist, nlist + 3]))
+            ids, d, pr = idx.ivf_search(Q, k, nprobe, want_probes=True)
+            oi, od, opr = O.ivf_search(base, cen, off, lids, Q, k, nprobe, metric=metric,
+                                       mode=_ivf_mode(O, metric, dim, nq, nprobe, nlist))
+            np.testing.assert_array_equal(pr[:, :min(nprobe, nlist)], opr, err_msg=tag + " probes")
+            assert_exact(ids, d, oi, od, tag + " ivf nlist=%d nprobe=%d" % (nlist, nprobe))
+
+
 def test_hnsw_large_index_hbm_visited(eng, oracle):
     """n > 262,144 rows: the visited set moves from the LDS bitset to generation stamps in HBM and the
     grid becomes persistent.  Same traversal, checked bit for bit against the oracle on the same graph."""
