@@ -28,6 +28,10 @@ import os
 if os.environ.get("REAL_KMEANS"):
     idx.ivf_build(nlist, 10, 42)
     cen_, off, order = idx.get_ivf()
+    if os.environ.get("REAL_KMEANS") == "fresh":   # same lists installed into a fresh handle (fresh allocations)
+        idx.close()
+        idx = engine.Index(x, "cosine", 0)
+        idx.set_ivf(cen_, off, order)
 else:
   a, _ = idx.kmeans_assign(centers.cpu().numpy())
   if os.environ.get("MERGE_PAIRS"):   # skewed synthetic lists: clusters 2l and 2l+1 share list 2l, list 2l+1 is empty
@@ -40,6 +44,10 @@ lens = np.diff(off)
 print("list len mean %.0f max %d min %d" % (lens.mean(), lens.max(), lens.min()))
 for nq in (1, 32, 256, 1024):
     Q = Qa[:nq].contiguous()
+    if os.environ.get("SAMEQ"):          # every query identical: all pairs of a rank stream the same list at once
+        Q = Qa[:1].repeat(nq, 1).contiguous()
+    if os.environ.get("GROUPQ"):         # queries in groups of 4 identical ones
+        Q = Qa[:max(1, nq // 4)].repeat_interleave(4, 0)[:nq].contiguous()
     _, _, probes = idx.ivf_search(Q.cpu().numpy(), K, nprobe, want_probes=True)
     alg = int(lens[probes.ravel()].sum()) * (4 * D + 4)
     for _ in range(3):
