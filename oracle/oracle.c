@@ -1088,6 +1088,68 @@ void orc_ivf_build(const float *base, int64_t n, int dim, int metric, int nlist,
     free(cnt);
 }
 
+/* The same build in the engine's arithmetic (used to check hnswgpu_ivf_build / hnswgpu_kmeanspp bit for bit at
+ * sizes where f32-vs-f64 rounding would flip a D^2 sample or an assignment): seeding distances in
+ * `seed_mode` (the GEMV scan kernel: DEV), assignment distances in `assign_mode` (MFMA tile kernel for
+ * cosine / dot, DEV for L2), centroids = f64 means in index order rounded to f32, D^2 sampling over the f32
+ * distances in the reference's sequential f64 order. */
+void orc_ivf_build_dev(const float *base, int64_t n, int dim, int metric, int seed_mode, int assign_mode, int nlist,
+                       int iters, int64_t seed, int32_t *chosen, float *centroids, int32_t *assign) {
+    jrandom rng;
+    jr_init(&rng, seed);
+    float *mind = (float *)malloc(sizeof(float) * (size_t)n);
+    float *bnorm = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+    orc_norms(base, n, dim, seed_mode, bnorm);
+    for (int64_t i = 0; i < n; i++) mind[i] = 3.402823466e+38f;
+    dist_ctx c;
+    c.metric = metric;
+    c.mode = seed_mode;
+    c.dim = dim;
+    c.base = base;
+    c.norms = bnorm;
+    int32_t cur = jr_next_int_bound(&rng, (int32_t)n);
+    chosen[0] = cur;
+    for (int k = 1; k < nlist; k++) {
+        ctx_set_query(&c, base + (int64_t)cur * dim); /* the new centroid is the query of the streaming pass */
+        double sum = 0.0;
+        for (int64_t i = 0; i < n; i++) {
+            float d = (float)ctx_dist(&c, i);
+            if (d < mind[i]) mind[i] = d;
+            sum = sum + (double)mind[i] * (double)mind[i];
+        }
+        double r = jr_next_double(&rng) * sum, cum = 0.0;
+        int64_t i = 0;
+        for (;; i++) {
+            double dsq = (double)mind[i] * (double)mind[i];
+            if (cum + dsq >= r || i == n - 1) break;
+            cum = cum + dsq;
+        }
+        cur = (int32_t)i;
+        chosen[k] = cur;
+    }
+    for (int k = 0; k < nlist; k++) memcpy(centroids + (int64_t)k * dim, base + (int64_t)chosen[k] * dim, sizeof(float) * (size_t)dim);
+    double *acc = (double *)malloc(sizeof(double) * (size_t)nlist * dim);
+    int64_t *cnt = (int64_t *)malloc(sizeof(int64_t) * (size_t)nlist);
+    for (int it = 0; it <= iters; it++) {
+        orc_kmeans_assign_f32(base, n, dim, metric, assign_mode, centroids, nlist, assign, NULL);
+        if (it == iters) break;
+        memset(acc, 0, sizeof(double) * (size_t)nlist * dim);
+        memset(cnt, 0, sizeof(int64_t) * (size_t)nlist);
+        for (int64_t i = 0; i < n; i++) {
+            double *a = acc + (int64_t)assign[i] * dim;
+            for (int j = 0; j < dim; j++) a[j] = a[j] + (double)base[i * dim + j];
+            cnt[assign[i]]++;
+        }
+        for (int k = 0; k < nlist; k++)
+            if (cnt[k] > 0)
+                for (int j = 0; j < dim; j++) centroids[(int64_t)k * dim + j] = (float)(acc[(int64_t)k * dim + j] / (double)cnt[k]);
+    }
+    free(mind);
+    free(bnorm);
+    free(acc);
+    free(cnt);
+}
+
 /* ivf_flat.clj:236-294 search-ivf-flat with an explicit nprobe (:249-251 path) and centroid
  * routing (:261-269); per list search-partition (:217-234): cosine from dot / (qnorm * vnorm)
  * with precomputed norms (:171-177, 275-278), stable sort, take 2k; merge by stable sort, take k

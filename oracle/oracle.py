@@ -73,6 +73,8 @@ def lib():
         _lib.orc_ivf_build.argtypes = [p, i64, i32, i32, i32, i32, i64, p, p]
         _lib.orc_ivf_search.restype = None
         _lib.orc_ivf_search.argtypes = [p, i64, i32, i32, i32, i32, p, p, p, i32, p, p, p, i32, i32, i32, p, p, p]
+        _lib.orc_ivf_build_dev.restype = None
+        _lib.orc_ivf_build_dev.argtypes = [p, i64, i32, i32, i32, i32, i32, i32, i64, p, p, p]
         _lib.orc_kmeans_assign_f32.restype = None
         _lib.orc_kmeans_assign_f32.argtypes = [p, i64, i32, i32, i32, p, i32, p, p]
         # java.util.Random
@@ -301,6 +303,19 @@ def ivf_build(base, nlist=24, max_iterations=10, metric=COSINE, seed=42):
     a = np.zeros(n, np.int32)
     lib().orc_ivf_build(_p(base), n, dim, int(metric), nlist, max_iterations, int(seed), _p(cen), _p(a))
     return cen, a
+
+
+def ivf_build_dev(base, nlist=24, max_iterations=10, metric=COSINE, seed=42):
+    """The IVF build in the engine's own arithmetic (see orc_ivf_build_dev) -> (chosen rows, centroids f32, assign)."""
+    base = _f32(base)
+    n, dim = base.shape
+    chosen = np.zeros(nlist, np.int32)
+    cen = np.zeros((nlist, dim), np.float32)
+    a = np.zeros(n, np.int32)
+    assign_mode = MODE_DEV if metric == L2 else MODE_MFMA
+    lib().orc_ivf_build_dev(_p(base), n, dim, int(metric), MODE_DEV, assign_mode, nlist, max_iterations, int(seed),
+                            _p(chosen), _p(cen), _p(a))
+    return chosen, cen, a
 
 
 def lists_from_assign(assign, nlist):

@@ -364,6 +364,25 @@ def test_ivf_build_golden(eng, oracle, name):
         assert all(i in members for i in ids.ravel() if i >= 0)
 
 
+@pytest.mark.parametrize("n,dim,nlist,metric", [(6000, 48, 40, 0), (3000, 100, 17, 2), (2500, 32, 12, 1)])
+def test_ivf_build_exact_in_engine_arithmetic(eng, oracle, n, dim, nlist, metric):
+    """hnswgpu_ivf_build against the oracle's restatement of the SAME arithmetic (f32 distances in kernel order,
+    f64 means, sequential f64 D^2 sampling): identical k-means++ picks, identical assignments, bit-identical
+    centroids -- at a size where f64-vs-f32 rounding would already flip the odd assignment."""
+    O = oracle
+    base = _data(O, n, dim, "clustered", num_clusters=9, noise_level=0.5)
+    chosen, cen, assign = O.ivf_build_dev(base, nlist, 4, metric, 42)
+    with eng.Index(base, metric) as idx:
+        np.testing.assert_array_equal(idx.kmeanspp(nlist, 42), chosen)
+        idx.ivf_build(nlist, 4, 42)
+        gc, off, lids = idx.get_ivf()
+        got = np.empty(n, np.int32)
+        for l in range(nlist):
+            got[lids[off[l]:off[l + 1]]] = l
+        np.testing.assert_array_equal(got, assign)
+        np.testing.assert_array_equal(gc.view(np.uint32), cen.view(np.uint32))
+
+
 def test_ivf_large_batch_tiled_scan(eng, oracle):
     """nq * nprobe >= 4 * nlist: the (query, list) pairs are grouped by list and scanned by the MFMA tile
     kernel (routing included).  Bit-exact against the oracle's MFMA-order mode; groups of 32 overflow
