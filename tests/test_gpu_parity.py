@@ -528,6 +528,82 @@ def test_persistence_and_lightning(eng, oracle, tmp_path):
     li.close()
 
 
+def test_concurrent_searches_from_host_threads(eng, oracle):
+    """core_test.clj:112-121: 20 concurrent searches on one index all return 10 results -- here from 20 host
+    threads through the C ABI (ctypes drops the GIL), and every result equals the serial one."""
+    import threading
+
+    O = oracle
+    base = _data(O, 3000, 64)
+    Q = _data(O, 20, 64, seed=43)
+    with eng.Index(base) as idx:
+        idx.hnsw_build(16, 100, 42)
+        idx.ivf_build(8, 2, 42)
+        want_h = [idx.hnsw_search(q, 10, 64) for q in Q]
+        want_i = [idx.ivf_search(q, 10, 4) for q in Q]
+        got_h, got_i, errs = [None] * 20, [None] * 20, []
+
+        def work(t):
+            try:
+                for _ in range(5):
+                    got_h[t] = idx.hnsw_search(Q[t], 10, 64)
+                    got_i[t] = idx.ivf_search(Q[t], 10, 4)
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(20)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs
+        for t in range(20):
+            assert (got_h[t][0] >= 0).sum() == 10
+            assert np.array_equal(got_h[t][0], want_h[t][0]) and np.array_equal(got_h[t][1], want_h[t][1])
+            assert np.array_equal(got_i[t][0], want_i[t][0]) and np.array_equal(got_i[t][1], want_i[t][1])
+
+
+def test_full_size_ivf_1m_properties(eng):
+    """BASELINE.json configs[2] at full size (1M x 768, nlist 1024, nprobe 32): size-independent properties.
+    Sorted output, idempotence, ids valid and unique, returned distances are the rows' true distances, probing
+    every list reproduces GPU brute force, both scan kernels (GEMV for small batches, MFMA tiles for large) agree
+    within tolerance, lists partition the rows, recall of the configuration."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    n, nlist = 1_000_000, 1024
+    cen = torch.randn(nlist, 768, generator=g, device=dev)
+    x = cen[torch.randint(0, nlist, (n,), generator=g, device=dev)] + 0.3 * torch.randn(n, 768, generator=g, device=dev)
+    x /= x.norm(dim=1, keepdim=True)
+    Q = (x[:160] + 0.05 * torch.randn(160, 768, generator=g, device=dev))
+    Q = (Q / Q.norm(dim=1, keepdim=True)).contiguous()
+    with eng.Index(x, "cosine") as idx:
+        idx.ivf_build(nlist, 3, 42)
+        _, off, lids = idx.get_ivf()
+        assert off[0] == 0 and off[-1] == n and np.array_equal(np.sort(lids), np.arange(n, dtype=np.int32))
+        big_i, big_d = idx.ivf_search_dev(Q, 10, 32)                       # 160 * 32 >= 4 * 1024: MFMA tile path
+        big_i2, big_d2 = idx.ivf_search_dev(Q, 10, 32)
+        torch.cuda.synchronize()
+        assert torch.equal(big_i, big_i2) and torch.equal(big_d, big_d2)
+        bi, bd = big_i.cpu().numpy(), big_d.cpu().numpy()
+        assert (np.diff(bd, axis=1) >= 0).all() and (bi >= 0).all() and (bi < n).all()
+        assert all(len(set(r.tolist())) == 10 for r in bi)
+        small_i, small_d = idx.ivf_search_dev(Q[:8].contiguous(), 10, 32)  # GEMV path
+        torch.cuda.synchronize()
+        assert_topk_parity(small_i.cpu().numpy(), small_d.cpu().numpy(), bi[:8], bd[:8], "gemv vs tile at 1M")
+        qh = Q.cpu().numpy()
+        for r in (0, 77):
+            true = idx.batch_distances(qh[r], bi[r])
+            assert close(bd[r], true).all()
+        ei, ed = idx.exact_knn_dev(Q[:32].contiguous(), 10)
+        torch.cuda.synchronize()
+        ei, ed = ei.cpu().numpy(), ed.cpu().numpy()
+        hit = np.mean([len(set(bi[r]) & set(ei[r])) / 10 for r in range(32)])
+        assert hit >= 0.95, hit
+        ai, ad = idx.ivf_search(qh[:2], 10, nlist)                         # every list probed == brute force
+        assert_topk_parity(ai, ad, ei[:2], ed[:2], "ivf(all lists) vs exact at 1M")
+
+
 def test_merge_topk_dev(eng):
     import torch
 
