@@ -321,6 +321,8 @@ int tile_mode() {
     return m;
 }
 
+unsigned long long *g_tile_dbg_buf = nullptr;  // set through hnswgpu_debug_set_tile_stamps (diagnostics only)
+
 int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t st) {
     int64_t blocks = ngroups_bound * a.nchunks;
     if (blocks <= 0) return 0;
@@ -338,6 +340,7 @@ int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t s
     }();
     TileArgs b = a;
     b.dbg = dbg;
+    b.dbg_buf = g_tile_dbg_buf;
     hipLaunchKernelGGL(tile_scan_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, b);
     HG_HIP(hipGetLastError());
     return 0;
@@ -761,6 +764,11 @@ int hnswgpu_merge_topk_dev(int32_t device, const int32_t *d_ids, const float *d_
     hipLaunchKernelGGL(merge_shards_kernel, dim3(nq), dim3(kWave), sizeof(uint64_t) * k,
                        static_cast<hipStream_t>(stream), d_ids, d_dist, nshard, nq, k, d_out_ids, d_out_dist);
     HG_HIP(hipGetLastError());
+    return 0;
+}
+
+int hnswgpu_debug_set_tile_stamps(void *device_buffer) {
+    hg::g_tile_dbg_buf = static_cast<unsigned long long *>(device_buffer);
     return 0;
 }
 

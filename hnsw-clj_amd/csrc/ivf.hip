@@ -48,27 +48,35 @@ __global__ void ivf_hist_kernel(const int32_t *probes, int64_t npairs, int32_t *
 // every thread writes the groups of its own list.
 __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *cnt, int nlist, int32_t *list_mem_begin,
                                                         int32_t *fill, int32_t *grp_seg, int32_t *grp_mem_begin,
-                                                        int32_t *grp_mem_cnt, int32_t *ngroups, int tq) {
-    __shared__ int32_t sm[1024], sg[1024];
-    __shared__ int32_t carry_m, carry_g;
+                                                        int32_t *grp_mem_cnt, int32_t *ngroups, int tq,
+                                                        const int64_t *list_off, int64_t chunk_rows, int max_chunks,
+                                                        int32_t *wi_group, int32_t *wi_chunk, int32_t *nitems) {
+    __shared__ int32_t sm[1024], sg[1024], sw[1024];
+    __shared__ int32_t carry_m, carry_g, carry_w;
     const int tid = threadIdx.x;
-    if (tid == 0) carry_m = carry_g = 0;
+    if (tid == 0) carry_m = carry_g = carry_w = 0;
     __syncthreads();
     for (int l0 = 0; l0 < nlist; l0 += 1024) {
         const int l = l0 + tid;
         const int c = l < nlist ? cnt[l] : 0;
         const int ng = (c + tq - 1) / tq;
+        const int64_t rows = l < nlist ? list_off[l + 1] - list_off[l] : 0;
+        const int nch = (ng > 0 && rows > 0) ? static_cast<int>(tile_nchunks(rows, chunk_rows, max_chunks)) : 0;
+        const int nw = ng * nch;  // work items of this list: every group x every chunk
         sm[tid] = c;
         sg[tid] = ng;
+        sw[tid] = nw;
         __syncthreads();
         for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
-            int am = tid >= off ? sm[tid - off] : 0, ag = tid >= off ? sg[tid - off] : 0;
+            int am = tid >= off ? sm[tid - off] : 0, ag = tid >= off ? sg[tid - off] : 0, aw = tid >= off ? sw[tid - off] : 0;
             __syncthreads();
             sm[tid] += am;
             sg[tid] += ag;
+            sw[tid] += aw;
             __syncthreads();
         }
         const int mem = carry_m + sm[tid] - c, g0 = carry_g + sg[tid] - ng;
+        int w = carry_w + sw[tid] - nw;
         if (l < nlist) {
             list_mem_begin[l] = mem;
             fill[l] = 0;
@@ -76,16 +84,24 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *cnt, int 
                 grp_seg[g] = l;
                 grp_mem_begin[g] = mem + b;
                 grp_mem_cnt[g] = c - b < tq ? c - b : tq;
+                for (int ch = 0; ch < nch; ch++, w++) {
+                    wi_group[w] = g;
+                    wi_chunk[w] = ch;
+                }
             }
         }
         __syncthreads();
         if (tid == 1023) {
             carry_m += sm[1023];
             carry_g += sg[1023];
+            carry_w += sw[1023];
         }
         __syncthreads();
     }
-    if (tid == 0) *ngroups = carry_g;
+    if (tid == 0) {
+        *ngroups = carry_g;
+        *nitems = carry_w;
+    }
 }
 
 __global__ void ivf_scatter_kernel(const Pair *pairs, const int32_t *probes, int64_t npairs, int64_t stride,
@@ -353,17 +369,32 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     const int tq = tile_tq(idx->dim);
     const int64_t gbound = npairs / tq + nlist;                                // sum_l ceil(cnt_l / tq) <= this
     HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(nq) * stride));  // queries already padded
-    // int32 scratch: cnt[nlist] | list_mem_begin[nlist] | fill[nlist] | grp_seg | grp_mem_begin | grp_mem_cnt | ngroups
-    size_t ints = 3 * static_cast<size_t>(nlist) + 3 * static_cast<size_t>(gbound) + 4;
+    // rows per workgroup: whole tiles of 128, enough workgroups to fill the chip; the device splits every list
+    int64_t mean = std::max<int64_t>(1, idx->n / std::max(nlist, 1));
+    int64_t est_groups = std::max<int64_t>(1, npairs / tq + nlist / 2);
+    int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows;
+    static const int64_t tgt = []() {
+        const char *e = getenv("HNSWGPU_TILE_WGS");  // tuning override
+        return e ? atoll(e) : 2048LL;
+    }();
+    int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + est_groups - 1) / est_groups));
+    const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows;
+    const int64_t max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows, tpc = cr / kTileRows;
+    const int32_t max_chunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
+    const int64_t wbound = gbound * max_chunks;
+    // int32 scratch: cnt | list_mem_begin | fill [nlist each] | grp_seg | grp_mem_begin | grp_mem_cnt [gbound each] |
+    //                wi_group | wi_chunk [wbound each] | ngroups | nitems
+    size_t ints = 3 * static_cast<size_t>(nlist) + 3 * static_cast<size_t>(gbound) + 2 * static_cast<size_t>(wbound) + 4;
     HG_TRY(idx->s_misc.ensure(sizeof(int32_t) * ints));
     HG_TRY(idx->s_misc2.ensure(sizeof(GroupMember) * static_cast<size_t>(npairs)));
     int32_t *cnt = idx->s_misc.as<int32_t>();
     int32_t *lmb = cnt + nlist, *fill = lmb + nlist, *gseg = fill + nlist, *gmb = gseg + gbound, *gmc = gmb + gbound,
-            *ngr = gmc + gbound;
+            *wig = gmc + gbound, *wic = wig + wbound, *ngr = wic + wbound, *nit = ngr + 1;
     HG_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nlist, st));
     hipLaunchKernelGGL(ivf_hist_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st, d_probes,
                        npairs, cnt);
-    hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr, tq);
+    hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr, tq,
+                       idx->d_listoff, cr, max_chunks, wig, wic, nit);
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st,
                        idx->s_pairs.as<Pair>(), d_probes, npairs, stride, lmb, fill, idx->s_misc2.as<GroupMember>());
     HG_HIP(hipGetLastError());
@@ -383,21 +414,11 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     t.members = idx->s_misc2.as<GroupMember>();
     t.seg_off = idx->d_listoff;
     t.nq = nq;
-    // rows per workgroup: whole tiles of 128, enough workgroups to fill the chip
-    int64_t mean = std::max<int64_t>(1, idx->n / std::max(nlist, 1));
-    int64_t est_groups = std::max<int64_t>(1, npairs / tq + nlist / 2);
-    int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows;
-    static const int64_t tgt = []() {
-        const char *e = getenv("HNSWGPU_TILE_WGS");  // tuning override
-        return e ? atoll(e) : 2048LL;
-    }();
-    int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + est_groups - 1) / est_groups));
-    int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows;
+    t.wi_group = wig;
+    t.wi_chunk = wic;
+    t.nitems = nit;
     t.chunk_rows = static_cast<int32_t>(cr);
-    {
-        int64_t max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows, tpc = cr / kTileRows;
-        t.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));  // kernel splits per list
-    }
+    t.nchunks = max_chunks;
     t.out = idx->s_tile.as<float>();
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);

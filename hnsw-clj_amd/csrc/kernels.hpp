@@ -215,8 +215,11 @@ __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int64_t bid = blockIdx.x;
-    const int32_t pair = static_cast<int32_t>(bid / a.nchunks);
-    const int32_t chunk = static_cast<int32_t>(bid % a.nchunks);
+    // chunk-major: every pair's chunk 0 first, then chunk 1, ...  Chunks past a short list's end are empty
+    // workgroups; this order keeps them at the END of the dispatch instead of interleaved with working ones
+    // (interleaved idle workgroups cost the tile kernel half its CU occupancy on k-means lists).
+    const int32_t pair = static_cast<int32_t>(bid % a.npairs);
+    const int32_t chunk = static_cast<int32_t>(bid / a.npairs);
     int64_t rb0, rb1;
     int32_t qi;
     uint32_t ord_base;

@@ -31,6 +31,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __host__ __device__ inline int tile_ldq(int dim) { return ((dim + 63) / 64) * 64 + 4; }
 // queries resident per workgroup: the 32-column MFMA tile is filled fully, half or a quarter
 __host__ __device__ inline int tile_tq(int dim) { return dim <= 896 ? 32 : (dim <= 1792 ? 16 : 8); }
+// chunks a segment of `rows` rows is cut into: round(tiles / tiles_per_chunk), at least 1, at most max_chunks
+__host__ __device__ inline int64_t tile_nchunks(int64_t rows, int64_t chunk_rows, int64_t max_chunks) {
+    const int64_t tiles = (rows + 127) / 128, tpc = chunk_rows / 128;
+    int64_t nch = (tiles + tpc / 2) / tpc;
+    return nch < 1 ? 1 : (nch > max_chunks ? max_chunks : nch);
+}
 __host__ inline size_t tile_lds_bytes(int dim) {
     return sizeof(float) * (static_cast<size_t>(tile_tq(dim)) * tile_ldq(dim) + 2 * kTileRows * kTileLdA) +
            sizeof(float) * kTileQ + sizeof(int64_t) * kTileQ + sizeof(float) * kTileRows;
@@ -55,6 +61,12 @@ struct TileArgs {
     const int32_t *grp_mem_begin;
     const int32_t *grp_mem_cnt;
     const int32_t *ngroups;  // device scalar (grid is an upper bound)
+    // explicit mode: dense work list built on the device -- workgroup b serves chunk wi_chunk[b] of group
+    // wi_group[b] for b < *nitems and exits otherwise, so every idle workgroup sits at the END of the grid.
+    // (Interleaved empty workgroups halve the CU occupancy: each needs the whole 136 KiB LDS slot of a CU.)
+    const int32_t *wi_group;
+    const int32_t *wi_chunk;
+    const int32_t *nitems;
     const GroupMember *members;
     const int64_t *seg_off;  // row range of segment s = [seg_off[s], seg_off[s+1])
     // implicit groups (assignment / exact kNN): group g = queries [tq*g, tq*g + tq), every group scans rows
@@ -66,6 +78,7 @@ struct TileArgs {
     int32_t nchunks;
     float *out;
     int32_t dbg;  // developer ablation switches (HNSWGPU_TILE_DBG); 0 in production
+    unsigned long long *dbg_buf;  // diagnostic builds only: per-workgroup {start, end, hw id, tiles} stamps
 };
 
 // Per-query top-k over a dense distance array (written by tile_scan_kernel): one wave per query.

@@ -18,8 +18,15 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
-    const int g = blockIdx.x / a.nchunks;
-    const int chunk = blockIdx.x % a.nchunks;
+    int g, chunk;
+    if (a.members) {
+        if (static_cast<int>(blockIdx.x) >= *a.nitems) return;
+        g = a.wi_group[blockIdx.x];
+        chunk = a.wi_chunk[blockIdx.x];
+    } else {
+        g = blockIdx.x / a.nchunks;
+        chunk = blockIdx.x % a.nchunks;
+    }
 
     int64_t rb0, rb1;
     int cnt;
@@ -37,14 +44,14 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
     // split THIS segment evenly into round(tiles / tiles_per_chunk) chunks of whole tiles (no tiny tail chunk
     // that would reload the query group for a handful of rows); a.nchunks is the bound for the longest segment
     const int64_t tiles = (rb1 - rb0 + kTileRows - 1) / kTileRows;
-    const int64_t tpc = a.chunk_rows / kTileRows;
-    int64_t nch = (tiles + tpc / 2) / tpc;
-    nch = nch < 1 ? 1 : (nch > a.nchunks ? a.nchunks : nch);
+    const int64_t nch = tile_nchunks(rb1 - rb0, a.chunk_rows, a.nchunks);
     if (chunk >= nch) return;
     const int64_t per = (tiles + nch - 1) / nch * kTileRows;
     const int64_t r0 = rb0 + static_cast<int64_t>(chunk) * per;
     const int64_t r1 = r0 + per < rb1 ? r0 + per : rb1;
     if (r0 >= r1 || cnt <= 0) return;
+    unsigned long long t_start = 0;
+    if (a.dbg_buf) t_start = __builtin_amdgcn_s_memrealtime();
 
     // ---- resident query group -> LDS (zero rows for empty slots)
     if (tid < kTileQ) {
@@ -166,6 +173,13 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
             }
         }
         __syncthreads();
+    }
+    if (a.dbg_buf && tid == 0) {  // diagnostics only: when and where this workgroup ran
+        unsigned long long *o = a.dbg_buf + 4ull * blockIdx.x;
+        o[0] = t_start;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = __builtin_amdgcn_s_getreg(0x1804);  // HW_REG_HW_ID
+        o[3] = static_cast<unsigned long long>((r1 - r0 + kTileRows - 1) / kTileRows) | (static_cast<unsigned long long>(cnt) << 32);
     }
 }
 
