@@ -341,7 +341,7 @@ int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t s
     TileArgs b = a;
     b.dbg = dbg;
     b.dbg_buf = g_tile_dbg_buf;
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, b);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, b);
     HG_HIP(hipGetLastError());
     return 0;
 }

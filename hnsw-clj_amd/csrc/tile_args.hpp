@@ -20,7 +20,9 @@
 
 namespace hg {
 
-constexpr int kTileRows = 128;  // rows per tile: 4 waves x 32
+constexpr int kTileWaves = 8;    // waves per workgroup (two per SIMD), each owns 32 rows of a tile
+constexpr int kTileThreads = kTileWaves * 64;
+constexpr int kTileRows = 32 * kTileWaves;  // rows per tile
 constexpr int kTileQ = 32;      // MFMA N: queries per group for dim <= 896 (16 up to 1792, 8 up to 3072: LDS)
 constexpr int kTileK = 32;      // K per staging step
 constexpr int kTileLdA = kTileK + 4;  // padded LDS row of the A (rows) tile: conflict-free ds_read_b128
@@ -33,12 +35,12 @@ __host__ __device__ inline int tile_ldq(int dim) { return ((dim + 63) / 64) * 64
 __host__ __device__ inline int tile_tq(int dim) { return dim <= 896 ? 32 : (dim <= 1792 ? 16 : 8); }
 // chunks a segment of `rows` rows is cut into: round(tiles / tiles_per_chunk), at least 1, at most max_chunks
 __host__ __device__ inline int64_t tile_nchunks(int64_t rows, int64_t chunk_rows, int64_t max_chunks) {
-    const int64_t tiles = (rows + 127) / 128, tpc = chunk_rows / 128;
+    const int64_t tiles = (rows + kTileRows - 1) / kTileRows, tpc = chunk_rows / kTileRows;
     int64_t nch = (tiles + tpc / 2) / tpc;
     return nch < 1 ? 1 : (nch > max_chunks ? max_chunks : nch);
 }
 __host__ inline size_t tile_lds_bytes(int dim) {
-    return sizeof(float) * (static_cast<size_t>(tile_tq(dim)) * tile_ldq(dim) + 2 * kTileRows * kTileLdA) +
+    return sizeof(float) * (static_cast<size_t>(tile_tq(dim)) * tile_ldq(dim) + kTileRows * kTileLdA) +
            sizeof(float) * kTileQ + sizeof(int64_t) * kTileQ + sizeof(float) * kTileRows;
 }
 

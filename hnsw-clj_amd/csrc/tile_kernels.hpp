@@ -6,15 +6,19 @@
 
 namespace hg {
 
-__global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
+// Eight waves per workgroup (two per SIMD).  Every wave owns 32 rows of the 256-row tile and stages ITS rows
+// global -> registers (two K-steps ahead) -> a wave-private LDS slab, so the K loop has no workgroup barrier at
+// all: the only shared LDS data, the resident query group, is read-only.  With two independent instruction
+// streams per SIMD, one wave's LDS / memory waits hide under the other wave's MFMA chain.
+__global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ldq = tile_ldq(a.dim);
     const int tq = tile_tq(a.dim);                               // queries resident in LDS (32 / 16 / 8)
-    float *Bs = reinterpret_cast<float *>(smem);                 // [tq][ldq]   resident query group
-    float *As = Bs + tq * ldq;                               // [2][128][36] streamed row tiles
-    float *qn_s = As + 2 * kTileRows * kTileLdA;                 // [32]
+    float *Bs = reinterpret_cast<float *>(smem);                 // [tq][ldq]     resident query group
+    float *As = Bs + tq * ldq;                                   // [8][32][36]   wave-private row slabs
+    float *qn_s = As + kTileRows * kTileLdA;                     // [32]
     int64_t *ob_s = reinterpret_cast<int64_t *>(qn_s + kTileQ);  // [32] output bases (-1 = empty slot)
-    float *rn_s = reinterpret_cast<float *>(ob_s + kTileQ);      // [128] row norms of the current tile
+    float *rn_s = reinterpret_cast<float *>(ob_s + kTileQ);      // [256] row norms of the current tile
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
@@ -55,10 +59,9 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
 
     // ---- resident query group -> LDS (zero rows for empty slots)
     if (tid < kTileQ) {
-        int64_t ob = -1;
-        float qn = 0.0f;
         if (tid < cnt) {
             int qi;
+            int64_t ob;
             if (a.members) {
                 GroupMember m = a.members[a.grp_mem_begin[g] + tid];
                 qi = m.q;
@@ -67,9 +70,8 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
                 qi = g * tq + tid;
                 ob = static_cast<int64_t>(qi) * a.out_stride;
             }
-            qn = a.q_norms ? a.q_norms[qi] : 0.0f;
             ob_s[tid] = ob;
-            qn_s[tid] = qn;
+            qn_s[tid] = a.q_norms ? a.q_norms[qi] : 0.0f;
         } else {
             ob_s[tid] = -1;
             qn_s[tid] = 0.0f;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
     }
     const int nvec = static_cast<int>(a.ld / 4);
     const int nk = (a.dim + kTileK - 1) / kTileK;
-    for (int f = tid; f < tq * (nk * kTileK / 4); f += kWG) {
+    for (int f = tid; f < tq * (nk * kTileK / 4); f += kTileThreads) {
         int slot = f / (nk * kTileK / 4), c4 = f % (nk * kTileK / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (slot < cnt && c4 < nvec) {
@@ -86,23 +88,24 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
         }
         *reinterpret_cast<float4 *>(Bs + slot * ldq + 4 * c4) = v;
     }
-    __syncthreads();
+    __syncthreads();  // the only workgroup barrier: the query group is complete
 
     const int half = lane >> 5, li = lane & 31;
-    for (int64_t t0 = r0; t0 < r1; t0 += kTileRows) {
+    float *Aw = As + wave * 32 * kTileLdA;  // this wave's slab: 32 rows x 32 floats (+4 pad)
+    float *rnw = rn_s + wave * 32;
+    const int64_t ob = li < tq ? ob_s[li] : -1;
+    const float qn = li < tq ? qn_s[li] : 0.0f;
+    for (int64_t t0 = r0 + wave * 32; t0 < r1; t0 += kTileRows) {  // this wave's 32 rows of every 256-row tile
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-        // Row tiles are staged global -> registers -> LDS two K-steps ahead (two register sets, two LDS
-        // buffers): with one workgroup per CU a single step of look-ahead leaves the HBM latency exposed.
         float4 stA[4], stB[4];
         // unconditional loads from clamped addresses (rows past the segment end feed outputs that are never
-        // stored; columns past the row end are zeroed by a select): no branches, so the compiler can keep
-        // the younger register set's loads in flight behind a counted vmcnt
+        // stored; columns past the row end are zeroed by a select): no branches, counted vmcnt possible
         auto stage_load = [&](float4 (&st)[4], int ks) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                int f = tid + kWG * u;
+                int f = lane + kWave * u;
                 int row = f >> 3, c4 = ks * (kTileK / 4) + (f & 7);
                 int64_t gr = t0 + row;
                 gr = gr < r1 ? gr : r1 - 1;
@@ -111,16 +114,15 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
                 st[u] = c4 < nvec ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        auto stage_store = [&](const float4 (&st)[4], int buf) {
+        auto stage_store = [&](const float4 (&st)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                int f = tid + kWG * u;
-                int row = f >> 3, c = (f & 7) * 4;
-                *reinterpret_cast<float4 *>(As + (buf * kTileRows + row) * kTileLdA + c) = st[u];
+                int f = lane + kWave * u;
+                *reinterpret_cast<float4 *>(Aw + (f >> 3) * kTileLdA + (f & 7) * 4) = st[u];
             }
         };
-        auto compute = [&](int ks, int buf) {
-            const float *Ab = As + (buf * kTileRows + wave * 32 + li) * kTileLdA + 4 * half;
+        auto compute = [&](int ks) {
+            const float *Ab = Aw + li * kTileLdA + 4 * half;
             const float *Bb = Bs + (li & (tq - 1)) * ldq + ks * kTileK + 4 * half;  // columns >= tq repeat, unused
             float4 av[kTileK / 8], bv[kTileK / 8];
 #pragma unroll
@@ -141,45 +143,43 @@ __global__ __launch_bounds__(kWG) void tile_scan_kernel(TileArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bv[t].w, acc, 0, 0, 0);
             }
         };
-        // this tile's row norms -> LDS now; they are needed only after the K loop (a per-element global load
-        // in the epilogue would cost one exposed memory round trip per accumulator register)
-        if (tid < kTileRows) rn_s[tid] = (a.metric == METRIC_COS && t0 + tid < r1) ? a.row_norms[t0 + tid] : 0.0f;
+        // this wave's row norms -> its LDS slot now; they are needed only after the K loop
+        if (lane < 32) rnw[lane] = (a.metric == METRIC_COS && t0 + lane < r1) ? a.row_norms[t0 + lane] : 0.0f;
         stage_load(stA, 0);
-        stage_store(stA, 0);
+        stage_store(stA);
         if (nk > 1) stage_load(stA, 1);
         if (nk > 2) stage_load(stB, 2);
-        __syncthreads();
+        // wave-private slab: LDS operations of one wave execute in issue order, so the reads of a K-step see the
+        // stores before them and the stores of the next K-step land after these reads
         for (int ks = 0; ks < nk; ks += 2) {
-            compute(ks, 0);  // stA holds K-step ks+1
-            if (ks + 1 < nk) stage_store(stA, 1);
+            compute(ks);  // stA holds K-step ks+1
+            if (ks + 1 < nk) stage_store(stA);
             if (ks + 3 < nk && !(a.dbg & 2)) stage_load(stA, ks + 3);
-            __syncthreads();
             if (ks + 1 >= nk) break;
-            compute(ks + 1, 1);  // stB holds K-step ks+2
-            if (ks + 2 < nk) stage_store(stB, 0);
+            compute(ks + 1);  // stB holds K-step ks+2
+            if (ks + 2 < nk) stage_store(stB);
             if (ks + 4 < nk && !(a.dbg & 2)) stage_load(stB, ks + 4);
-            __syncthreads();
         }
         // ---- epilogue: D[row i][query col]: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-        const int64_t ob = li < tq ? ob_s[li] : -1;
-        const float qn = qn_s[li];
         if (ob >= 0 && !(a.dbg & 4)) {
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 int i = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                int64_t gr = t0 + wave * 32 + i;
-                float dv = finish_dist(a.metric, acc[reg], qn, rn_s[wave * 32 + i]) + 0.0f;
+                int64_t gr = t0 + i;
+                float dv = finish_dist(a.metric, acc[reg], qn, rnw[i]) + 0.0f;
                 if (gr < r1) a.out[ob + (gr - rb0)] = dv;
             }
         }
-        __syncthreads();
     }
-    if (a.dbg_buf && tid == 0) {  // diagnostics only: when and where this workgroup ran
-        unsigned long long *o = a.dbg_buf + 4ull * blockIdx.x;
-        o[0] = t_start;
-        o[1] = __builtin_amdgcn_s_memrealtime();
-        o[2] = __builtin_amdgcn_s_getreg(0x1804);  // HW_REG_HW_ID
-        o[3] = static_cast<unsigned long long>((r1 - r0 + kTileRows - 1) / kTileRows) | (static_cast<unsigned long long>(cnt) << 32);
+    if (a.dbg_buf) {  // diagnostics only: when and where this workgroup ran
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long *o = a.dbg_buf + 4ull * blockIdx.x;
+            o[0] = t_start;
+            o[1] = __builtin_amdgcn_s_memrealtime();
+            o[2] = __builtin_amdgcn_s_getreg(0x1804);  // HW_REG_HW_ID
+            o[3] = static_cast<unsigned long long>((r1 - r0 + kTileRows - 1) / kTileRows) | (static_cast<unsigned long long>(cnt) << 32);
+        }
     }
 }
 
