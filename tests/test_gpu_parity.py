@@ -604,6 +604,20 @@ def test_full_size_ivf_1m_properties(eng):
         assert_topk_parity(ai, ad, ei[:2], ed[:2], "ivf(all lists) vs exact at 1M")
 
 
+def test_c_abi_from_plain_c(native_lib, tmp_path):
+    """examples/abi_demo.c: the library used the way a JNI / Panama binding uses it -- from C, without Python or
+    torch in the process."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_demo")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "abi_demo.c"),
+                           "-L" + native_lib.PKG, "-lhnswgpu", "-Wl,-rpath," + native_lib.PKG, "-lm", "-o", exe])
+    out = subprocess.run([exe, str(tmp_path / "demo.bin")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi_demo ok" in out.stdout
+
+
 def test_merge_topk_dev(eng):
     import torch
 
