@@ -14,28 +14,38 @@ namespace hg {
 // probes[q][p] = p-th nearest centroid; pairs[q*nprobe+p] = that list's row range + the offset of
 // its rows in the query's concatenated candidate stream (ties are broken in that order, which is
 // the order search-ivf-flat concatenates partitions in, ivf_flat.clj:281-294)
-__global__ void probe_pairs_kernel(const uint32_t *ord, int nq, int nprobe, const int64_t *listoff, Pair *pairs,
-                                   int32_t *probes, int32_t *qcnt) {
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(kWG) void probe_pairs_kernel(const uint32_t *ord, int nq, int nprobe, const int64_t *listoff,
+                                                          Pair *pairs, int32_t *probes, int32_t *qcnt) {
+    // one wave per query: lane p owns probe p (+64, +128, ...); the offsets of the probes in the query's
+    // concatenated candidate stream are an exclusive prefix sum over the list lengths (wave scan)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int q = blockIdx.x * kNWave + (threadIdx.x >> 6);
     if (q >= nq) return;
-    uint32_t base = 0;
-    for (int p = 0; p < nprobe; p++) {
-        uint32_t l = ord[static_cast<int64_t>(q) * nprobe + p];
+    uint32_t carry = 0;
+    for (int p0 = 0; p0 < nprobe; p0 += kWave) {
+        const int p = p0 + lane;
+        uint32_t l = p < nprobe ? ord[static_cast<int64_t>(q) * nprobe + p] : 0xffffffffu;
         Pair pr;
         pr.q = q;
-        pr.ord_base = base;
-        if (l == 0xffffffffu) {
-            pr.row_begin = pr.row_end = 0;
-            if (probes) probes[static_cast<int64_t>(q) * nprobe + p] = -1;
-        } else {
+        pr.row_begin = pr.row_end = 0;
+        if (l != 0xffffffffu) {
             pr.row_begin = listoff[l];
             pr.row_end = listoff[l + 1];
-            if (probes) probes[static_cast<int64_t>(q) * nprobe + p] = static_cast<int32_t>(l);
         }
-        base += static_cast<uint32_t>(pr.row_end - pr.row_begin);
-        pairs[static_cast<int64_t>(q) * nprobe + p] = pr;
+        const uint32_t len = static_cast<uint32_t>(pr.row_end - pr.row_begin);
+        uint32_t incl = len;  // inclusive scan across the wave
+        for (int off = 1; off < kWave; off <<= 1) {
+            uint32_t o = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += o;
+        }
+        pr.ord_base = carry + incl - len;
+        if (p < nprobe) {
+            pairs[static_cast<int64_t>(q) * nprobe + p] = pr;
+            if (probes) probes[static_cast<int64_t>(q) * nprobe + p] = l == 0xffffffffu ? -1 : static_cast<int32_t>(l);
+        }
+        carry += __shfl(incl, kWave - 1, kWave);
     }
-    if (qcnt) qcnt[q] = static_cast<int32_t>(base);
+    if (qcnt && lane == 0) qcnt[q] = static_cast<int32_t>(carry);
 }
 
 // ---- grouping of (query, probed list) pairs by list, for the tiled scan --------------------------------
@@ -459,7 +469,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
     }
     if (d_given_probes) {  // caller-chosen lists (the :turbo mode's random partitions, :271-272); -1 = none
-        hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + 127) / 128), dim3(128), 0, st,
+        hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st,
                            reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff,
                            idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf);
         HG_HIP(hipGetLastError());
@@ -479,7 +489,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
                              nprobe, st, -1));
     else
         HG_TRY(scan_topk(idx, a, nq, 1, idx->nlist, st, -1));
-    hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + 127) / 128), dim3(128), 0, st, idx->s_ord.as<uint32_t>(), nq,
+    hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st, idx->s_ord.as<uint32_t>(), nq,
                        nprobe, idx->d_listoff, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf);
     HG_HIP(hipGetLastError());
     }
