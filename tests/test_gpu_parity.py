@@ -663,6 +663,18 @@ def test_reference_api_mirror(eng, oracle):
     assert len(ivf_flat.search_knn(ivf, vecs[5], 3, "turbo")) == 3
     assert ivf_flat.index_info(ivf)["partitions"] == 8
     ivf.close()
+    from hnsw_clj_amd import pure_hnsw, ultra_optimized
+
+    uo = ultra_optimized.build_index(data, show_progress=False)          # README `hnsw.ultra-optimized`
+    assert ultra_optimized.search(uo, vecs[4], 5)[0]["id"] == "vec_4"
+    uo.close()
+    ph = pure_hnsw.build_index(data, show_progress=False)                 # README `hnsw.hnsw-search`
+    r1 = pure_hnsw.search_knn(ph, vecs[6], 5, "turbo")
+    r2 = pure_hnsw.search_knn(ph, vecs[6], 5, "precise")
+    assert r1[0]["id"] == r2[0]["id"] == "vec_6" and len(r2) == 5
+    info = pure_hnsw.index_info(ph)
+    assert info["vectors"] == 100 and info["params"]["M"] == 16 and info["avg-edges-per-node"] > 1
+    ph.close()
     assert simd_optimized.cosine_distance([1, 0], [-1, 0]) == 2.0
     assert simd_optimized.dot_product([1, 2, 3], [4, 5, 6]) == 32.0
     bd = simd_optimized.batch_cosine_distances(vecs[0], vecs[:10])
