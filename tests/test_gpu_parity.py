@@ -298,6 +298,36 @@ def test_randomised_differential(eng, oracle):
             assert_exact(ids, d, oi, od, tag + " ivf nlist=%d nprobe=%d" % (nlist, nprobe))
 
 
+def test_documented_limits(eng, oracle):
+    """The maxima include/hnswgpu.h documents work (ef 4096, k 1024, M0 64, dim 3072) and one past them is an
+    error code, not a fault."""
+    O = oracle
+    base = _data(O, 6000, 24)
+    Q = _data(O, 3, 24, seed=43)
+    g = O.hnsw_build(base, O.COSINE, M=32, ef_construction=80, mode=O.MODE_FAST)      # M0 = 64
+    with eng.Index(base) as idx:
+        idx.set_graph(g)
+        ids, d, st = idx.hnsw_search(Q, 1024, 4096, want_stats=True)
+        oi, od, ost, _ = O.hnsw_search(base, g, Q, 1024, ef=4096, mode=O.MODE_DEV)
+        assert_exact(ids, d, oi, od, "ef=4096 k=1024")
+        np.testing.assert_array_equal(st, ost)
+        with pytest.raises(Exception, match="4096"):
+            idx.hnsw_search(Q, 10, 4097)
+        ei, ed = idx.exact_knn(Q, 1024)
+        oi, od, _ = O.exact_knn(base, Q, 1024, mode=O.MODE_DEV)
+        assert_exact(ei, ed, oi, od, "exact k=1024")
+        with pytest.raises(Exception, match="1024"):
+            idx.exact_knn(Q, 1025)
+        idx.ivf_build(4, 2, 42)
+        cen, off, lids = idx.get_ivf()
+        ii, dd = idx.ivf_search(Q, 1024, 4)
+        oi, od, _ = O.ivf_search(base, cen, off, lids, Q, 1024, 4, mode=_ivf_mode(O, O.COSINE, 24, 3, 4, 4))
+        assert_exact(ii, dd, oi, od, "ivf k=1024")
+        with pytest.raises(Exception, match="M"):
+            bad = O.Graph(g.levels, np.full((6000, 65), -1, np.int32), g.up_off, g.up_adj, g.M, g.entry, g.max_level)
+            idx.set_graph(bad)
+
+
 def test_hnsw_large_index_hbm_visited(eng, oracle):
     """n > 262,144 rows: the visited set moves from the LDS bitset to generation stamps in HBM and the
     grid becomes persistent.  Same traversal, checked bit for bit against the oracle on the same graph."""
