@@ -64,6 +64,11 @@ _SIGS = {
     "hnswgpu_ivf_search_dev": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
     "hnswgpu_ivf_search_lists": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
     "hnswgpu_merge_topk_dev": ["i32", "p", "p", "i32", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_merge_lists_dev": ["i32", "p", "p", "i32", "i32", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_rerank": ["p", "p", "i32", "p", "i32", "i32", "p", "p"],
+    "hnswgpu_rerank_dev": ["p", "p", "i32", "p", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_dense_distances": ["p", "p", "i32", "p"],
+    "hnswgpu_dense_distances_dev": ["p", "p", "i32", "p", "p"],
     "hnswgpu_save": ["p", "p"],
     "hnswgpu_load": ["p", "i32", "p"],
     "hnswgpu_set_profiling": ["p", "i32"],

@@ -218,12 +218,16 @@ int launch_merge(const MergeArgs &a, hipStream_t st) {
     return 0;
 }
 
-int launch_gather(int nch, const GatherArgs &a, hipStream_t st) {
-    if (a.m <= 0) return 0;
+int launch_gather(int nch, GatherArgs a, int32_t nq, hipStream_t st) {
+    if (a.m <= 0 || nq <= 0) return 0;
     bool l2 = a.metric == METRIC_L2;
-#define CALL(N, R, L)                                                                                      \
-    hipLaunchKernelGGL((gather_dist_kernel<N, R, L>), dim3((a.m + kNWave * R - 1) / (kNWave * R)), dim3(kWG), 0, \
-                       st, a)
+#define CALL(N, R, L)                                                                                         \
+    do {                                                                                                      \
+        a.blocks_per_query = (a.m + kNWave * R - 1) / (kNWave * R);                                           \
+        int64_t blocks = static_cast<int64_t>(a.blocks_per_query) * nq;                                       \
+        HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "gather grid too large");                           \
+        hipLaunchKernelGGL((gather_dist_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), 0, st, a); \
+    } while (0)
     HG_DISPATCH(nch, l2, CALL);
 #undef CALL
     HG_HIP(hipGetLastError());
@@ -425,19 +429,20 @@ __global__ void ord_to_ids_kernel(const uint32_t *ord, int64_t cnt, int32_t *ids
 
 // [nshard][nq][k] (id, dist) -> [nq][k]; ties keep the lower shard (then the lower rank) first
 __global__ __launch_bounds__(kWave) void merge_shards_kernel(const int32_t *ids, const float *dist, int nshard,
-                                                             int nq, int k, int32_t *out_ids, float *out_dist) {
+                                                             int nq, int kin, int k, int32_t *out_ids,
+                                                             float *out_dist) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *list = reinterpret_cast<uint64_t *>(smem);
     const int lane = threadIdx.x, q = blockIdx.x;
     int cnt = 0;
     uint64_t thr = ~0ull;
-    const int tot = nshard * k;
+    const int tot = nshard * kin;
     for (int base = 0; base < tot; base += kWave) {
         int i = base + lane;
         uint64_t key = ~0ull;
         if (i < tot) {
-            int s = i / k, r = i % k;
-            int64_t src = (static_cast<int64_t>(s) * nq + q) * k + r;
+            int s = i / kin, r = i % kin;
+            int64_t src = (static_cast<int64_t>(s) * nq + q) * kin + r;
             if (ids[src] >= 0) key = make_key(dist[src], static_cast<uint32_t>(i));
         }
         uint64_t mask = __ballot(key < thr);
@@ -457,8 +462,8 @@ __global__ __launch_bounds__(kWave) void merge_shards_kernel(const int32_t *ids,
         float d = __uint_as_float(0x7f800000u);
         if (ok) {
             uint32_t o = static_cast<uint32_t>(list[i]);
-            int s = o / k, r = o % k;
-            int64_t src = (static_cast<int64_t>(s) * nq + q) * k + r;
+            int s = o / kin, r = o % kin;
+            int64_t src = (static_cast<int64_t>(s) * nq + q) * kin + r;
             id = ids[src];
             d = dist[src];
         }
@@ -631,6 +636,7 @@ int hnswgpu_batch_distances(hnswgpu_index *idx, const float *q, const int32_t *i
     HG_TRY(upload_queries(idx, q, 1, st));
     HG_TRY(idx->s_outd.ensure(sizeof(float) * m));
     GatherArgs g;
+    memset(&g, 0, sizeof(g));
     g.rows = idx->d_base;
     g.row_norms = idx->d_norms;
     g.ld = idx->ld;
@@ -646,7 +652,7 @@ int hnswgpu_batch_distances(hnswgpu_index *idx, const float *q, const int32_t *i
     }
     g.m = m;
     g.out = idx->s_outd.as<float>();
-    HG_TRY(launch_gather(idx->nch, g, st));
+    HG_TRY(launch_gather(idx->nch, g, 1, st));
     HG_HIP(hipMemcpyAsync(out, g.out, sizeof(float) * m, hipMemcpyDeviceToHost, st));
     HG_TRY(end_call(idx, st));
     HG_HIP(hipStreamSynchronize(st));
@@ -754,16 +760,199 @@ int hnswgpu_exact_knn(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k,
     return 0;
 }
 
-int hnswgpu_merge_topk_dev(int32_t device, const int32_t *d_ids, const float *d_dist, int32_t nshard, int32_t nq,
-                           int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream) {
-    HG_REQUIRE(nshard >= 1 && nq >= 0 && k >= 1, HNSWGPU_EINVAL, "bad sizes");
-    HG_REQUIRE(k <= 1024, HNSWGPU_ELIMIT, "k > 1024 is not supported");
+int hnswgpu_merge_lists_dev(int32_t device, const int32_t *d_ids, const float *d_dist, int32_t nshard, int32_t nq,
+                            int32_t k_in, int32_t k_out, int32_t *d_out_ids, float *d_out_dist, void *stream) {
+    HG_REQUIRE(nshard >= 1 && nq >= 0 && k_in >= 1 && k_out >= 1, HNSWGPU_EINVAL, "bad sizes");
+    HG_REQUIRE(k_out <= 1024, HNSWGPU_ELIMIT, "k > 1024 is not supported");
+    HG_REQUIRE(static_cast<int64_t>(nshard) * k_in < 2147483647LL, HNSWGPU_ELIMIT, "nshard * k_in too large");
     if (nq == 0) return 0;
     HG_REQUIRE(d_ids && d_dist && d_out_ids && d_out_dist, HNSWGPU_EINVAL, "null argument");
     HG_HIP(hipSetDevice(device));
-    hipLaunchKernelGGL(merge_shards_kernel, dim3(nq), dim3(kWave), sizeof(uint64_t) * k,
-                       static_cast<hipStream_t>(stream), d_ids, d_dist, nshard, nq, k, d_out_ids, d_out_dist);
+    hipLaunchKernelGGL(merge_shards_kernel, dim3(nq), dim3(kWave), sizeof(uint64_t) * k_out,
+                       static_cast<hipStream_t>(stream), d_ids, d_dist, nshard, nq, k_in, k_out, d_out_ids,
+                       d_out_dist);
     HG_HIP(hipGetLastError());
+    return 0;
+}
+
+int hnswgpu_merge_topk_dev(int32_t device, const int32_t *d_ids, const float *d_dist, int32_t nshard, int32_t nq,
+                           int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream) {
+    return hnswgpu_merge_lists_dev(device, d_ids, d_dist, nshard, nq, k, k, d_out_ids, d_out_dist, stream);
+}
+
+// ---- re-rank: per query, exact distances to a candidate list, stable ascending sort, take k ----
+__global__ void rerank_decode_kernel(const uint32_t *ord, int64_t cnt, int k, const int32_t *cand, int m,
+                                     int32_t *out_ids) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    uint32_t o = ord[i];
+    out_ids[i] = o == 0xffffffffu ? -1 : cand[(i / k) * m + o];
+}
+
+static int rerank_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, const int32_t *d_cand, int32_t m,
+                          int32_t k, int32_t *d_ids, float *d_dist, hipStream_t st) {
+    const int64_t nkeys = static_cast<int64_t>(nq) * m, cnt = static_cast<int64_t>(nq) * k;
+    HG_TRY(idx->s_partial.ensure(sizeof(uint64_t) * nkeys));
+    HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * cnt));
+    HG_TRY(idx->s_dist.ensure(sizeof(float) * cnt));
+    GatherArgs g;
+    memset(&g, 0, sizeof(g));
+    g.rows = idx->d_base;
+    g.row_norms = idx->d_norms;
+    g.ld = idx->ld;
+    g.n = idx->n;
+    g.q = d_Q;
+    g.qld = idx->dim;
+    g.dim = idx->dim;
+    g.metric = idx->metric;
+    g.ids = d_cand;
+    g.m = m;
+    g.out_keys = idx->s_partial.as<uint64_t>();
+    HG_TRY(launch_gather(idx->nch, g, nq, st));
+    MergeArgs mg;
+    mg.partial = g.out_keys;
+    mg.keys_per_query = m;
+    mg.nq = nq;
+    mg.k = k;
+    mg.out_ord = idx->s_ord.as<uint32_t>();
+    mg.out_dist = idx->s_dist.as<float>();
+    HG_TRY(launch_merge(mg, st));
+    hipLaunchKernelGGL(rerank_decode_kernel, dim3(static_cast<unsigned>((cnt + 255) / 256)), dim3(256), 0, st,
+                       mg.out_ord, cnt, k, d_cand, m, d_ids);
+    HG_HIP(hipGetLastError());
+    HG_HIP(hipMemcpyAsync(d_dist, idx->s_dist.p, sizeof(float) * cnt, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+static int check_rerank_args(const hnswgpu_index *idx, const void *Q, int32_t nq, const void *cand, int32_t m,
+                             int32_t k, const void *ids, const void *dist) {
+    HG_TRY(check_search_args(idx, Q, nq, k, ids, dist));
+    HG_REQUIRE(m >= 1, HNSWGPU_EINVAL, "m must be >= 1");
+    HG_REQUIRE(nq == 0 || cand, HNSWGPU_EINVAL, "null argument");
+    HG_REQUIRE(static_cast<int64_t>(nq) * m < (1LL << 31), HNSWGPU_ELIMIT, "nq * m too large");
+    return 0;
+}
+
+int hnswgpu_rerank_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, const int32_t *d_cand, int32_t m,
+                       int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream) {
+    HG_TRY(check_rerank_args(idx, d_Q, nq, d_cand, m, k, d_out_ids, d_out_dist));
+    if (nq == 0) return 0;
+    HG_REQUIRE(idx->n > 0, HNSWGPU_ESTATE, "empty index: use the host entry point");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(rerank_enqueue(idx, d_Q, nq, d_cand, m, k, d_out_ids, d_out_dist, st));
+    return end_call(idx, st);
+}
+
+int hnswgpu_rerank(hnswgpu_index *idx, const float *Q, int32_t nq, const int32_t *cand, int32_t m, int32_t k,
+                   int32_t *out_ids, float *out_dist) {
+    HG_TRY(check_rerank_args(idx, Q, nq, cand, m, k, out_ids, out_dist));
+    if (nq == 0) return 0;
+    const int64_t cnt = static_cast<int64_t>(nq) * k;
+    if (idx->n == 0) {
+        fill_empty(out_ids, out_dist, cnt);
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(upload_queries(idx, Q, nq, st));
+    const size_t cbytes = sizeof(int32_t) * static_cast<size_t>(nq) * m;
+    HG_TRY(idx->s_misc.ensure(cbytes));
+    HG_HIP(hipMemcpyAsync(idx->s_misc.p, cand, cbytes, hipMemcpyHostToDevice, st));
+    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
+    HG_TRY(rerank_enqueue(idx, idx->s_q.as<float>(), nq, idx->s_misc.as<int32_t>(), m, k, idx->s_ids.as<int32_t>(),
+                          idx->s_outd.as<float>(), st));
+    HG_HIP(hipMemcpyAsync(out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipMemcpyAsync(out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
+    HG_TRY(end_call(idx, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ---- dense distances: every query against every row (batch-cosine-distances over a query batch) ----
+static int dense_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, float *d_out, hipStream_t st) {
+    const int tm = tile_mode();
+    if (tile_path_ok(idx) && tm != 0 && (tm == 1 || nq >= 16)) {
+        HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
+        const int tq = tile_tq(idx->dim);
+        TileArgs t;
+        memset(&t, 0, sizeof(t));
+        t.rows = idx->d_base;
+        t.row_norms = idx->d_norms;
+        t.ld = idx->ld;
+        t.dim = idx->dim;
+        t.metric = idx->metric;
+        t.Qp = idx->s_qp.as<float>();
+        t.q_norms = idx->s_qn.as<float>();
+        t.nrows_all = idx->n;
+        t.nq = nq;
+        t.out_stride = idx->n;
+        int64_t groups = (nq + tq - 1) / tq;
+        int64_t tiles = (idx->n + kTileRows - 1) / kTileRows;
+        int64_t want = std::max<int64_t>(1, std::min<int64_t>(tiles, (2048 + groups - 1) / groups));
+        int64_t cr = ((tiles + want - 1) / want) * kTileRows;
+        t.chunk_rows = static_cast<int32_t>(cr);
+        t.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (tiles + cr / kTileRows / 2) / (cr / kTileRows)));
+        t.out = d_out;
+        return launch_tile(t, groups, idx->dim, st);
+    }
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = idx->d_base;
+    a.row_norms = idx->d_norms;
+    a.ld = idx->ld;
+    a.nrows_all = idx->n;
+    a.Q = d_Q;
+    a.qld = idx->dim;
+    a.dim = idx->dim;
+    a.metric = idx->metric;
+    a.mode = MODE_STORE;
+    a.role = ROLE_EXACT;
+    a.k = 1;
+    a.npairs = nq;
+    a.nchunks = plan_chunks(idx->nch, idx->n, idx->n, nq, &a.chunk_rows);
+    a.out = d_out;
+    a.out_stride = idx->n;
+    return launch_scan(idx->nch, a, st);
+}
+
+static int check_dense_args(const hnswgpu_index *idx, const void *Q, int32_t nq, const void *out) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(nq >= 0, HNSWGPU_EINVAL, "nq < 0");
+    HG_REQUIRE(nq == 0 || idx->n == 0 || (Q && out), HNSWGPU_EINVAL, "null argument");
+    return 0;
+}
+
+int hnswgpu_dense_distances_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, float *d_out, void *stream) {
+    HG_TRY(check_dense_args(idx, d_Q, nq, d_out));
+    if (nq == 0 || idx->n == 0) return 0;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(dense_enqueue(idx, d_Q, nq, d_out, st));
+    return end_call(idx, st);
+}
+
+int hnswgpu_dense_distances(hnswgpu_index *idx, const float *Q, int32_t nq, float *out) {
+    HG_TRY(check_dense_args(idx, Q, nq, out));
+    if (nq == 0 || idx->n == 0) return 0;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(upload_queries(idx, Q, nq, st));
+    const size_t bytes = sizeof(float) * static_cast<size_t>(nq) * idx->n;
+    HG_TRY(idx->s_tile.ensure(bytes));
+    HG_TRY(dense_enqueue(idx, idx->s_q.as<float>(), nq, idx->s_tile.as<float>(), st));
+    HG_HIP(hipMemcpyAsync(out, idx->s_tile.p, bytes, hipMemcpyDeviceToHost, st));
+    HG_TRY(end_call(idx, st));
+    HG_HIP(hipStreamSynchronize(st));
     return 0;
 }
 

@@ -318,31 +318,37 @@ struct GatherArgs {
     const float *row_norms;
     int64_t ld;
     int64_t n;
-    const float *q;
+    const float *q;      // query y at q + y * qld
+    int64_t qld;
     int32_t dim;
     int32_t metric;
-    const int32_t *ids;  // nullptr = 0..m-1
+    const int32_t *ids;  // nullptr = 0..m-1; otherwise query y's candidates are ids[y * m .. y * m + m)
     int32_t m;
-    float *out;
+    int32_t blocks_per_query;  // grid = nq * blocks_per_query
+    float *out;          // optional: out[y * m + j]
+    uint64_t *out_keys;  // optional: make_key(dist, j) (all-ones for an id outside [0, n)) -- the re-rank path
 };
 
 template <int NCH, int RB, bool L2>
 __global__ __launch_bounds__(kWG) void gather_dist_kernel(GatherArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
+    const int64_t y = blockIdx.x / a.blocks_per_query;
+    const int bx = static_cast<int>(blockIdx.x % a.blocks_per_query);
+    int j0 = (bx * kNWave + wave) * RB;
+    if (j0 >= a.m) return;
     float4 q[NCH];
-    load_query<NCH>(q, a.q, a.dim, lane);
+    load_query<NCH>(q, a.q + y * a.qld, a.dim, lane);
     float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
     const int nvec = static_cast<int>(a.ld / 4);
-    int j0 = (blockIdx.x * kNWave + wave) * RB;
-    if (j0 >= a.m) return;
+    const int32_t *ids = a.ids ? a.ids + y * a.m : nullptr;
     float4 r[RB][NCH];
     int64_t rid[RB];
 #pragma unroll
     for (int b = 0; b < RB; b++) {
         int j = j0 + b;
         int64_t id = -1;
-        if (j < a.m) id = a.ids ? a.ids[j] : j;
+        if (j < a.m) id = ids ? ids[j] : j;
         bool ok = id >= 0 && id < a.n;
         rid[b] = ok ? id : -1;
         load_row<NCH>(r[b], a.rows + (ok ? id : 0) * a.ld, nvec, lane, ok);
@@ -353,7 +359,9 @@ __global__ __launch_bounds__(kWG) void gather_dist_kernel(GatherArgs a) {
         if (j0 + b < a.m && lane == 0) {
             float d = __uint_as_float(0x7fc00000u);  // NaN for an out-of-range id
             if (rid[b] >= 0) d = finish_dist(a.metric, s, qn, a.metric == METRIC_COS ? a.row_norms[rid[b]] : 0.0f);
-            a.out[j0 + b] = d;
+            if (a.out) a.out[y * a.m + j0 + b] = d;
+            if (a.out_keys)
+                a.out_keys[y * a.m + j0 + b] = rid[b] >= 0 ? make_key(d, static_cast<uint32_t>(j0 + b)) : ~0ull;
         }
     }
 }

@@ -138,6 +138,24 @@ class Index:
         check(lib().hnswgpu_exact_knn(self._h, _p(Q), len(Q), k, _p(ids), _p(d)))
         return ids, d
 
+    def rerank(self, Q, cand, k):
+        """Per query: exact distances to its candidate rows cand[q] (-1 = skip), stable sort, first k."""
+        Q = _queries(Q, self.dim)
+        cand = np.ascontiguousarray(cand, dtype=np.int32)
+        if cand.ndim != 2 or cand.shape[0] != len(Q):
+            raise ValueError("cand must be [nq, m]")
+        ids = np.empty((len(Q), k), np.int32)
+        d = np.empty((len(Q), k), np.float32)
+        check(lib().hnswgpu_rerank(self._h, _p(Q), len(Q), _p(cand), cand.shape[1], k, _p(ids), _p(d)))
+        return ids, d
+
+    def dense_distances(self, Q):
+        """[nq, n] distances from every query to every row."""
+        Q = _queries(Q, self.dim)
+        out = np.empty((len(Q), self.n), np.float32)
+        check(lib().hnswgpu_dense_distances(self._h, _p(Q), len(Q), _p(out)))
+        return out
+
     # -- HNSW
     def set_graph(self, g):
         check(lib().hnswgpu_set_graph(self._h, _p(g.levels), _p(g.l0_adj), g.M0, _p(g.up_off), _p(g.up_adj), g.M,
@@ -259,6 +277,27 @@ class Index:
         check(lib().hnswgpu_exact_knn_dev(self._h, Q.data_ptr(), Q.shape[0], k, ids.data_ptr(), d.data_ptr(), st))
         return ids, d
 
+    def rerank_dev(self, Q, cand, k, out=None):
+        import torch
+
+        Q, ids, d, st = self._dev_args(Q, k)
+        assert cand.is_cuda and cand.dtype == torch.int32 and cand.dim() == 2 and cand.shape[0] == Q.shape[0]
+        cand = cand.contiguous()
+        if out is not None:
+            ids, d = out
+        check(lib().hnswgpu_rerank_dev(self._h, Q.data_ptr(), Q.shape[0], cand.data_ptr(), cand.shape[1], k,
+                                       ids.data_ptr(), d.data_ptr(), st))
+        return ids, d
+
+    def dense_distances_dev(self, Q, out=None):
+        import torch
+
+        Q, _, _, st = self._dev_args(Q, 1)
+        if out is None:
+            out = torch.empty((Q.shape[0], self.n), dtype=torch.float32, device=Q.device)
+        check(lib().hnswgpu_dense_distances_dev(self._h, Q.data_ptr(), Q.shape[0], out.data_ptr(), st))
+        return out
+
     # -- measurement
     def set_profiling(self, on=True):
         check(lib().hnswgpu_set_profiling(self._h, 1 if on else 0))
@@ -291,6 +330,22 @@ def merge_topk_dev(ids, dist, out=None):
     st = torch.cuda.current_stream(ids.device).cuda_stream
     check(lib().hnswgpu_merge_topk_dev(ids.device.index or 0, ids.data_ptr(), dist.data_ptr(), ns, nq, k,
                                        oi.data_ptr(), od.data_ptr(), st))
+    return oi, od
+
+
+def merge_lists_dev(ids, dist, k, out=None):
+    """[nlists][nq][k_in] torch CUDA tensors (ids -1 padded) -> the k best of every query, [nq][k];
+    ties keep the lower list, then the lower rank, first (a stable sort of the concatenation)."""
+    import torch
+
+    assert ids.is_cuda and ids.dtype == torch.int32 and dist.dtype == torch.float32 and ids.dim() == 3
+    ids, dist = ids.contiguous(), dist.contiguous()
+    ns, nq, kin = ids.shape
+    oi = torch.empty((nq, k), dtype=torch.int32, device=ids.device) if out is None else out[0]
+    od = torch.empty((nq, k), dtype=torch.float32, device=ids.device) if out is None else out[1]
+    st = torch.cuda.current_stream(ids.device).cuda_stream
+    check(lib().hnswgpu_merge_lists_dev(ids.device.index or 0, ids.data_ptr(), dist.data_ptr(), ns, nq, kin, k,
+                                        oi.data_ptr(), od.data_ptr(), st))
     return oi, od
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HNSWGPU_VERSION 100
+#define HNSWGPU_VERSION 101
 
 #define HNSWGPU_COSINE 0
 #define HNSWGPU_L2 1
@@ -152,6 +152,30 @@ int hnswgpu_ivf_search_lists(hnswgpu_index *idx, const float *Q, int32_t nq, int
  * arrays of GLOBAL ids (-1 padded) and distances; ties keep the lower shard first. */
 int hnswgpu_merge_topk_dev(int32_t device, const int32_t *d_ids, const float *d_dist, int32_t nshard, int32_t nq,
                            int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream);
+
+/* Same merge with different input and output widths: [nshard][nq][k_in] lists -> [nq][k_out].  This is
+ * partitioned-hnsw's "k-per-partition results from every partition, sort, take k"
+ * (partitioned_hnsw.clj:149-196, :201-231) and ivf-hnsw's "2k from every probed partition graph, sort,
+ * take k" (hybrid/ivf_hnsw.clj:312-325). */
+int hnswgpu_merge_lists_dev(int32_t device, const int32_t *d_ids, const float *d_dist, int32_t nshard, int32_t nq,
+                            int32_t k_in, int32_t k_out, int32_t *d_out_ids, float *d_out_dist, void *stream);
+
+/* ---- re-rank and dense distances --------------------------------------------------------------------
+ * hnswgpu_rerank: per query, exact distances to its own candidate rows cand[q][0..m) (-1 or out-of-range
+ * = skipped), STABLE ascending sort (ties keep the candidate order, like Collections/sort), first k.
+ * Replaces P-HNSW's refine phase (ann/dimreduct/pcaf.clj:239-253), search-knn's final re-rank of the
+ * layer-0 result (ultra_fast.clj:362-370) and top-k-distances (simd_optimized.clj:271-280).
+ * Arithmetic: the gather order (wave-strided f32 fma chain + butterfly), as hnswgpu_batch_distances. */
+int hnswgpu_rerank(hnswgpu_index *idx, const float *Q, int32_t nq, const int32_t *cand, int32_t m, int32_t k,
+                   int32_t *out_ids, float *out_dist);
+int hnswgpu_rerank_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, const int32_t *d_cand, int32_t m,
+                       int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream);
+/* out[q * n + row] = distance(query q, base row) for every row: batch-cosine-distances
+ * (simd_optimized.clj:176-184) over a whole query batch, and -- on an index whose rows are a projection
+ * matrix with metric DOT -- P-HNSW's project-vector-simd (pcaf.clj:47-80; out = -projection).
+ * Cosine / dot with nq >= 16 runs on the MFMA tile kernel (tile order), otherwise the GEMV kernel. */
+int hnswgpu_dense_distances(hnswgpu_index *idx, const float *Q, int32_t nq, float *out);
+int hnswgpu_dense_distances_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, float *d_out, void *stream);
 
 /* ---- persistence ------------------------------------------------------------------------------------------
  * One flat binary file (header + plain arrays; layout in hnsw-clj_amd/csrc/persist.hip) with the base

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(native_lib):
     for n in names:
         assert hasattr(L, n), "libhnswgpu.so does not export %s" % n
     L.hnswgpu_version.restype = ctypes.c_int
-    assert L.hnswgpu_version() == 100
+    assert L.hnswgpu_version() == 101
 
 
 def test_python_binding_covers_header(native_lib):

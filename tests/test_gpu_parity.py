@@ -668,6 +668,164 @@ def test_merge_topk_dev(eng):
 
 
 # ---- the Python mirror of the reference API (names / shapes / edge cases of core_test.clj) ---------------
+def _dense_oracle(O, base, Q, metric, mode):
+    """[nq, n] distance matrix from the oracle's exact kNN with k = n."""
+    ids, d, _ = O.exact_knn(base, Q, len(base), metric=metric, mode=mode)
+    out = np.empty((len(Q), len(base)), np.float32)
+    np.put_along_axis(out, ids.astype(np.int64), d.astype(np.float32), axis=1)
+    return out
+
+
+def _stable_topk(ids, d, k):
+    """Collections/sort semantics: stable ascending by distance over the valid entries, first k, -1 padded."""
+    oi = np.full((len(ids), k), -1, np.int32)
+    od = np.full((len(ids), k), np.inf, np.float32)
+    for q in range(len(ids)):
+        keep = np.flatnonzero(ids[q] >= 0)
+        order = keep[np.argsort(d[q][keep], kind="stable")][:k]
+        oi[q, :len(order)] = ids[q][order]
+        od[q, :len(order)] = d[q][order]
+    return oi, od
+
+
+@pytest.mark.parametrize("metric,nq", [("cosine", 20), ("cosine", 5), ("dot", 33), ("l2", 20)])
+def test_dense_distances_and_rerank(eng, oracle, metric, nq):
+    O = oracle
+    m = O.METRICS[metric]
+    base = _data(O, 1500, 48)
+    base[7] = base[3]                                                # duplicates: ties in the re-rank
+    base[9] = base[3]
+    Q = _data(O, nq, 48, seed=43)
+    tiled = m != O.L2 and nq >= 16
+    with eng.Index(base, metric) as idx:
+        got = idx.dense_distances(Q)
+        want = _dense_oracle(O, base, Q, m, O.MODE_MFMA if tiled else O.MODE_DEV)
+        np.testing.assert_array_equal(got, want)
+        # re-rank: own candidate list per query, with skips (-1), an out-of-range id and duplicated rows
+        rng = np.random.default_rng(5)
+        cand = rng.integers(0, len(base), size=(nq, 37)).astype(np.int32)
+        cand[:, 5] = -1
+        cand[:, 11] = len(base) + 3
+        cand[:, 20:23] = [9, 3, 7]
+        dev = _dense_oracle(O, base, Q, m, O.MODE_DEV)
+        valid = (cand >= 0) & (cand < len(base))
+        cd = np.where(valid, np.take_along_axis(dev, np.clip(cand, 0, len(base) - 1).astype(np.int64), axis=1), np.inf)
+        for k in (1, 10, 37, 50):
+            ids, d = idx.rerank(Q, cand, k)
+            wi, wd = _stable_topk(np.where(valid, cand, -1), cd.astype(np.float32), k)
+            np.testing.assert_array_equal(ids, wi)
+            np.testing.assert_array_equal(d, wd)
+        assert idx.dense_distances(Q[:0]).shape == (0, len(base))
+    with eng.Index(np.zeros((0, 48), np.float32), metric) as empty:
+        ids, d = empty.rerank(Q, cand, 3)
+        assert (ids == -1).all() and np.isinf(d).all()
+
+
+def test_partitioned_hnsw_mirror(eng, oracle):
+    """partitioned_hnsw.clj: every mode's k-per-partition rule, searched per partition and merged like
+    Collections/sort -- checked against the oracle searching the SAME partition graphs."""
+    from hnsw_clj_amd import datagen, partitioned_hnsw as ph
+
+    O = oracle
+    vecs = _data(O, 2500, 32, "clustered", num_clusters=12, noise_level=0.4)
+    Q = _data(O, 30, 32, seed=43)
+    index = ph.build_index(datagen.indexed(vecs), num_partitions=8, ef_construction=60)
+    assert len(index.partitions) == 8 and sorted(np.concatenate(index.rows).tolist()) == list(range(2500))
+    assert ph.index_info(index)["avg-partition-size"] == 2500 / 8
+    graphs = [p.get_graph() for p in index.partitions]
+    for mode, k in (("lightning", 10), ("ultra", 10), ("turbo", 3), ("bogus", 4)):
+        kpp = ph.k_per_partition(mode, 8, k)
+        assert kpp == {"lightning": 3, "ultra": 2, "turbo": 3, "bogus": 3}[mode]
+        allid, alld = [], []
+        for r, g in zip(index.rows, graphs):
+            oi, od, _, _ = O.hnsw_search(vecs[r], g, Q, kpp, mode=O.MODE_DEV)
+            allid.append(np.where(oi >= 0, r[np.clip(oi, 0, None)], -1))
+            alld.append(od)
+        wi, wd = _stable_topk(np.concatenate(allid, 1), np.concatenate(alld, 1).astype(np.float32), k)
+        got = ph.search_batch(index, Q, k, mode)
+        for q in range(len(Q)):
+            assert [r["id"] for r in got[q]] == ["vec_%d" % i for i in wi[q] if i >= 0]
+            np.testing.assert_array_equal(np.float32([r["distance"] for r in got[q]]), wd[q][wi[q] >= 0])
+        assert ph.search_knn(index, Q[4], k, mode) == got[4]
+    # self-match through the String-id table (core_test.clj:33-47 protocol)
+    assert ph.search_partitioned_lightning(index, vecs[17], 5)[0]["id"] == "vec_17"
+    unshuffled = ph.build_index(datagen.indexed(vecs[:100]), num_partitions=3, shuffle=False, ef_construction=30)
+    assert [len(r) for r in unshuffled.rows] == [34, 34, 32] and unshuffled.rows[1][0] == 34
+    index.close()
+    unshuffled.close()
+
+
+def test_ivf_hnsw_mirror(eng, oracle):
+    """ivf_hnsw.clj: centroid routing, 2k from each probed partition's graph, stable merge."""
+    from hnsw_clj_amd import datagen, ivf_hnsw
+
+    O = oracle
+    vecs = _data(O, 3000, 32, "clustered", num_clusters=6, noise_level=0.5)
+    index = ivf_hnsw.build_index(datagen.indexed(vecs), num_partitions=6, ef_construction=60, max_iterations=4)
+    info = ivf_hnsw.index_info(index)
+    assert info["vectors"] == 3000 and info["partitions"] == 6
+    assert sorted(np.concatenate(index.rows).tolist()) == list(range(3000))
+    graphs = [p.get_graph() if p is not None else None for p in index.partitions]
+    k = 5
+    for nq, mode, honour in ((40, "fast", False), (3, "balanced", False), (40, "accurate", True)):
+        Q = _data(O, nq, 32, seed=43)
+        cfg = ivf_hnsw.MODE_CONFIGS[mode]
+        route_mode = O.MODE_MFMA if nq >= 16 else O.MODE_DEV
+        probes, _, _ = O.exact_knn(index.centroids, Q, cfg["num-probes"], mode=route_mode)
+        ef = max(cfg["ef-search"], 2 * k) if honour else None
+        allid = np.full((nq, cfg["num-probes"] * 2 * k), -1, np.int64)
+        alld = np.full((nq, cfg["num-probes"] * 2 * k), np.inf, np.float32)
+        for q in range(nq):
+            for r, p in enumerate(probes[q]):
+                if graphs[p] is None:
+                    continue
+                oi, od, _, _ = O.hnsw_search(vecs[index.rows[p]], graphs[p], Q[q:q + 1], 2 * k, ef=ef, mode=O.MODE_DEV)
+                allid[q, r * 2 * k:(r + 1) * 2 * k] = np.where(oi[0] >= 0, index.rows[p][np.clip(oi[0], 0, None)], -1)
+                alld[q, r * 2 * k:(r + 1) * 2 * k] = od[0]
+        wi, wd = _stable_topk(allid, alld, k)
+        got = ivf_hnsw.search_batch(index, Q, k, mode, honour_modes=honour)
+        for q in range(nq):
+            assert [r["id"] for r in got[q]] == ["vec_%d" % i for i in wi[q] if i >= 0], (mode, q)
+            np.testing.assert_array_equal(np.float32([r["distance"] for r in got[q]]), wd[q][wi[q] >= 0])
+    assert ivf_hnsw.search_knn(index, vecs[11], 3)[0]["id"] == "vec_11"
+    assert len(ivf_hnsw.search_knn(index, vecs[11], 3, 0.1)) == 3      # legacy search-percent: int(24 * 0.1) = 2 probes
+    index.close()
+
+
+def test_pcaf_mirror(eng, oracle):
+    """pcaf.clj: Random(42) gaussian projection, brute-force phase 1 in the projected space, exact re-rank."""
+    from hnsw_clj_amd import datagen, pcaf
+
+    O = oracle
+    vecs = _data(O, 2000, 96, "clustered", num_clusters=20, noise_level=0.6)
+    T = 16
+    P = pcaf.create_random_projection(96, T)
+    jr = O.JavaRandom(42)
+    want_p = np.float32([np.float32(0.25) * np.float32(jr.next_gaussian()) for _ in range(40)])
+    np.testing.assert_array_equal(P.reshape(-1)[:40], want_p)         # pcaf.clj:36-45
+    index = pcaf.build_index(datagen.indexed(vecs), n_components=T, k_filter=32)
+    assert pcaf.index_info(index)["reduction-ratio"] == 6.0
+    low = -_dense_oracle(O, P, vecs, O.DOT, O.MODE_MFMA)               # [n, T] projection, tile order (n >= 16)
+    for nq, mode, k in ((25, None, 10), (25, "precise", 30), (2, "turbo", 4)):
+        Q = _data(O, nq, 96, seed=43)
+        qlow = -_dense_oracle(O, P, Q, O.DOT, O.MODE_MFMA if nq >= 16 else O.MODE_DEV)
+        kf = min(pcaf.MODE_K_FILTER.get(mode, 32), 3 * k)
+        cand, _, _ = O.exact_knn(low, qlow, kf, mode=O.MODE_MFMA if nq >= 16 else O.MODE_DEV)
+        dev = _dense_oracle(O, vecs, Q, O.COSINE, O.MODE_DEV)
+        cd = np.take_along_axis(dev, cand.astype(np.int64), axis=1)
+        wi, wd = _stable_topk(cand, cd, k)
+        got = pcaf.search_batch(index, Q, k, mode)
+        for q in range(nq):
+            assert [r["id"] for r in got[q]] == ["vec_%d" % i for i in wi[q] if i >= 0], (mode, q)
+            gd = np.float32([r["distance"] for r in got[q]])
+            np.testing.assert_array_equal(gd, wd[q][wi[q] >= 0])
+            # and against the reference's f64 cosine on the same ids (north-star tolerance)
+            f64 = np.array([O.cosine_distance_ultra(Q[q], vecs[i]) for i in wi[q] if i >= 0])
+            assert np.all(np.abs(gd - f64) <= 1e-4 * np.abs(f64) + 1e-6)
+    assert pcaf.search_knn(index, vecs[5], 3)[0]["id"] == "vec_5"
+    pcaf.cleanup(index)
+
+
 def test_reference_api_mirror(eng, oracle):
     from hnsw_clj_amd import datagen, ivf_flat, parallel_search, protocol, simd_optimized, ultra_fast
 
