@@ -9,7 +9,7 @@ import subprocess
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SO = os.path.join(PKG, "libhnswgpu.so")
+SO = os.environ.get("HNSWGPU_LIBRARY") or os.path.join(PKG, "libhnswgpu.so")  # override: diagnostic builds
 
 COSINE, L2, DOT = 0, 1, 2
 

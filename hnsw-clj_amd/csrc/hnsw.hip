@@ -34,6 +34,7 @@ static int g_force_vg = []() {
 }();
 
 int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
+    a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions; read only by -DHG_HNSW_STAMPS builds
     if (a.nq <= 0) return 0;
     const int nch = idx->nch;
     const bool vg = g_force_vg || a.n > kLdsVisitedMaxRows;

@@ -421,7 +421,19 @@ struct HnswArgs {
     uint32_t *vis;
     int64_t vis_stride;
     uint32_t gen_base;
+    unsigned long long *dbg;  // -DHG_HNSW_STAMPS diagnostic builds only: per-phase s_memrealtime totals
 };
+
+#ifdef HG_HNSW_STAMPS
+#define HG_STAMP(slot)                                                  \
+    do {                                                                \
+        const unsigned long long t_now = wall_clock64(); \
+        st_acc[slot] += t_now - st_prev;                                \
+        st_prev = t_now;                                                \
+    } while (0)
+#else
+#define HG_STAMP(slot) do { } while (0)
+#endif
 
 constexpr uint32_t kExpanded = 0x80000000u;
 
@@ -460,6 +472,11 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
 
         int64_t n_eval = 0, n_hop = 0;
         int len = 0;
+#ifdef HG_HNSW_STAMPS
+        unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long st_prev = wall_clock64();
+        const unsigned long long st_w0 = st_prev, st_c0 = clock64();
+#endif
         __syncthreads();  // the previous query's result readers are done with the lists
         // seed: the entry point (ultra_fast.clj:358-359)
         {
@@ -494,6 +511,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
             __syncthreads();
             int cur_start = 0;
             const int deg = level == 0 ? a.M0 : a.M;
+            HG_STAMP(0);  // seed / level set-up
             for (;;) {
                 // ---- wave 0: next candidate (first unexpanded entry), its neighbour ids, visited filter,
                 //      compaction.  One barrier for all of it.
@@ -533,6 +551,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                     }
                 }
                 __syncthreads();
+                HG_STAMP(1);  // select + adjacency + visited filter
                 const int c = sc[0];
                 if (c < 0) break;
                 const int nc = sc[1];
@@ -567,18 +586,32 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                     if (lane < RB && myj < nc) cand_d[myj] = finish_dist(a.metric, mine, qn, myrn) + 0.0f;
                 }
                 __syncthreads();
+                HG_STAMP(2);  // row gather + distances
+                // ---- pre-filter: with a full list a candidate at or beyond the current worst can never be admitted
+                //      (:195-198 is a strict <, and the worst only shrinks within a hop), and it changes no other
+                //      entry's rank.  Late in a search that is most candidates: the merge loops below run over the
+                //      survivors only, and a hop without survivors skips the merge and its three barriers.
+                const float cdist = lane < nc ? cand_d[lane] : 0.0f;
+                const int cbits = __float_as_int(cdist);
+                const bool list_full = len >= ef_l;
+                const float worst0 = list_full ? __uint_as_float(curA[ef_l - 1].x) : 0.0f;
+                const bool surv = lane < nc && (!list_full || cdist < worst0);
+                const uint64_t smask = __ballot(surv);  // identical in every wave
+                if (smask == 0) {
+                    cur_start = c + 1;
+                    continue;  // nobody touches sc[] between the barrier above and wave 0's next write
+                }
                 // ---- merge, step 1 (all waves): every list entry counts the candidates that go before it
                 //      (its shift), every candidate counts the list entries that stay before it.  The
                 //      candidate distances sit one per lane and are broadcast with v_readlane.
-                const float cdist = lane < nc ? cand_d[lane] : 0.0f;
-                const int cbits = __float_as_int(cdist);
                 int cntA = 0;  // lane j: # list entries (of this wave's share) with d <= d_j
                 for (int base = 0; base < len; base += kThreads) {
                     const int i = base + tid;
                     const bool valid = i < len;
                     const float de = valid ? __uint_as_float(curA[i].x) : 0.0f;
                     int sh = 0;
-                    for (int j = 0; j < nc; j++) {
+                    for (uint64_t mm = smask; mm; mm &= mm - 1) {
+                        const int j = __ffsll(static_cast<unsigned long long>(mm)) - 1;
                         const float dj = __int_as_float(__builtin_amdgcn_readlane(cbits, j));
                         sh += (dj < de) ? 1 : 0;
                         const int below = __popcll(__ballot(valid && de <= dj));
@@ -590,28 +623,30 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                         if (P == ef_l - 1) sc[4] = static_cast<int32_t>(curA[i].x);
                     }
                 }
-                if (lane < nc) part[wave * kWave + lane] = cntA;
+                if (surv) part[wave * kWave + lane] = cntA;
                 __syncthreads();
+                HG_STAMP(3);  // merge step 1
                 // ---- merge, step 2 (wave 0): rank, admission and final position of every candidate
                 if (wave == 0) {
                     bool admitted = false;
                     int P = 0x7fffffff;
                     int before = 0, after_less = 0;
-                    for (int j = 0; j < nc; j++) {
+                    for (uint64_t mm = smask; mm; mm &= mm - 1) {
+                        const int j = __ffsll(static_cast<unsigned long long>(mm)) - 1;
                         const float o = __int_as_float(__builtin_amdgcn_readlane(cbits, j));
                         before += (j < lane && o <= cdist) ? 1 : 0;
                         after_less += (j > lane && o < cdist) ? 1 : 0;
                     }
-                    if (lane < nc) {
+                    if (surv) {
                         int below = 0;
 #pragma unroll
                         for (int w = 0; w < NW; w++) below += part[w * kWave + lane];
                         const int r = below + before;
                         admitted = r < ef_l;
                         P = r + after_less;
-                        cand_P[lane] = admitted ? P : -1;
                         if (admitted && P == ef_l - 1) sc[4] = cbits;
                     }
+                    if (lane < nc) cand_P[lane] = admitted ? P : -1;
                     uint64_t am = __ballot(admitted);
                     int minP = admitted ? P : 0x7fffffff;
                     for (int off = 1; off < kWave; off <<= 1) {
@@ -625,6 +660,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                     }
                 }
                 __syncthreads();
+                HG_STAMP(4);  // merge step 2
                 const int nadm = sc[2];
                 if (nadm == 0) {
                     cur_start = c + 1;
@@ -660,6 +696,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                 }
                 if (lane == 0 && ghosts) atomicAdd(&sc[5], ghosts);
                 __syncthreads();
+                HG_STAMP(5);  // merge step 3
                 const int newlen = full ? ef_l + sc[5] : total;
                 {
                     uint2 *t = curA;
@@ -686,6 +723,13 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
             a.out_dist[static_cast<int64_t>(qi) * a.k + i] =
                 ok ? __uint_as_float(curA[i].x) : __uint_as_float(0x7f800000u);
         }
+#ifdef HG_HNSW_STAMPS
+        HG_STAMP(6);
+        st_acc[10] = clock64() - st_c0;
+        st_acc[11] = wall_clock64() - st_w0;
+        if (a.dbg && tid == 0 && qi == 0)
+            for (int i = 0; i < 12; i++) a.dbg[i] = i == 7 ? static_cast<unsigned long long>(n_hop) : st_acc[i];
+#endif
         if (a.stats && tid == 0) {
             a.stats[2 * static_cast<int64_t>(qi)] = n_eval;
             a.stats[2 * static_cast<int64_t>(qi) + 1] = n_hop;
