@@ -367,10 +367,56 @@ int pad_queries(hnswgpu_index *idx, const float *d_Q, int64_t qld, int32_t nq, h
     return launch_norms(idx->nch, idx->s_qp.as<float>(), idx->ld, nq, idx->s_qn.as<float>(), st);
 }
 
+__global__ void key_decode_kernel(const unsigned long long *keys, int64_t cnt, uint32_t *ord, float *dist) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const uint64_t key = keys[i];
+    const bool ok = key != ~0ull;
+    ord[i] = ok ? static_cast<uint32_t>(key) : 0xffffffffu;
+    dist[i] = ok ? key_dist(key) : __uint_as_float(0x7f800000u);
+}
+
+// k = 1: the nearest row of every query with the argmin fused into the tile kernel (assign-to-nearest-centroid,
+// ivf_flat.clj:79-90): no dense distance array, no selection pass, one launch for any number of queries.
+static int tile_argmin_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int32_t nq, const float *rows,
+                           const float *row_norms, int64_t nrows, hipStream_t st, int prof_slot) {
+    const int tq = tile_tq(idx->dim);
+    const size_t kbytes = sizeof(unsigned long long) * static_cast<size_t>(nq);
+    HG_TRY(idx->s_tile.ensure(kbytes));
+    HG_HIP(hipMemsetAsync(idx->s_tile.p, 0xff, kbytes, st));
+    TileArgs t;
+    memset(&t, 0, sizeof(t));
+    t.rows = rows;
+    t.row_norms = row_norms;
+    t.ld = idx->ld;
+    t.dim = idx->dim;
+    t.metric = idx->metric;
+    t.Qp = Qp;
+    t.q_norms = q_norms;
+    t.nrows_all = nrows;
+    t.nq = nq;
+    t.out_key = idx->s_tile.as<unsigned long long>();
+    const int64_t groups = (nq + tq - 1) / tq;
+    const int64_t tiles = (nrows + kTileRows - 1) / kTileRows;
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(tiles, (2048 + groups - 1) / groups));
+    const int64_t cr = ((tiles + want - 1) / want) * kTileRows;
+    t.chunk_rows = static_cast<int32_t>(cr);
+    t.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (tiles + cr / kTileRows / 2) / (cr / kTileRows)));
+    hipEvent_t e0;
+    prof_begin(idx, prof_slot, st, &e0);
+    HG_TRY(launch_tile(t, groups, idx->dim, st));
+    prof_end(idx, prof_slot, st, e0);
+    hipLaunchKernelGGL(key_decode_kernel, dim3(static_cast<unsigned>((nq + 255) / 256)), dim3(256), 0, st, t.out_key,
+                       static_cast<int64_t>(nq), idx->s_ord.as<uint32_t>(), idx->s_dist.as<float>());
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
 int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int32_t nq, const float *rows,
                   const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot) {
     HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * k));
     HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * k));
+    if (k == 1) return tile_argmin_all(idx, Qp, q_norms, nq, rows, row_norms, nrows, st, prof_slot);
     // distance scratch [qb][nrows]; bound it to ~2 GiB by batching the queries
     const int tq = tile_tq(idx->dim);
     int64_t qb = std::max<int64_t>(tq, ((2LL << 30) / (4 * std::max<int64_t>(nrows, 1))) / tq * tq);

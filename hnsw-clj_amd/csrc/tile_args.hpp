@@ -79,6 +79,10 @@ struct TileArgs {
     int32_t chunk_rows;  // multiple of kTileRows
     int32_t nchunks;
     float *out;
+    // k = 1 (k-means assignment, nearest-row queries): when set, nothing dense is written; every query's
+    // best make_key(distance, row) is folded in registers and merged with one 64-bit atomicMin per wave
+    // (implicit groups only; the caller presets out_key[q] = ~0)
+    unsigned long long *out_key;
     int32_t dbg;  // developer ablation switches (HNSWGPU_TILE_DBG); 0 in production
     unsigned long long *dbg_buf;  // diagnostic builds only: per-workgroup {start, end, hw id, tiles} stamps
 };

@@ -95,81 +95,131 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     float *rnw = rn_s + wave * 32;
     const int64_t ob = li < tq ? ob_s[li] : -1;
     const float qn = li < tq ? qn_s[li] : 0.0f;
+    uint64_t best = ~0ull;  // argmin mode: best (distance, row) of query column li over this wave's rows
     for (int64_t t0 = r0 + wave * 32; t0 < r1; t0 += kTileRows) {  // this wave's 32 rows of every 256-row tile
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-        float4 stA[4], stB[4];
-        // unconditional loads from clamped addresses (rows past the segment end feed outputs that are never
-        // stored; columns past the row end are zeroed by a select): no branches, counted vmcnt possible
-        auto stage_load = [&](float4 (&st)[4], int ks) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                int f = lane + kWave * u;
-                int row = f >> 3, c4 = ks * (kTileK / 4) + (f & 7);
-                int64_t gr = t0 + row;
-                gr = gr < r1 ? gr : r1 - 1;
-                int c4c = c4 < nvec ? c4 : nvec - 1;
-                float4 v = reinterpret_cast<const float4 *>(a.rows + gr * a.ld)[c4c];
-                st[u] = c4 < nvec ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        // staging registers as named members (an array passed by reference to the helpers ended up in scratch)
+        struct Stage {
+            float4 v0, v1, v2, v3;
         };
-        auto stage_store = [&](const float4 (&st)[4]) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                int f = lane + kWave * u;
-                *reinterpret_cast<float4 *>(Aw + (f >> 3) * kTileLdA + (f & 7) * 4) = st[u];
-            }
+        Stage stA, stB;
+        // Unconditional loads from clamped addresses: rows past the segment end feed outputs that are never stored;
+        // columns past the row end re-read the row's last float4 and meet the ZERO padding of the query group in
+        // LDS (finite x 0 adds exactly nothing to the f32 chain); K-steps past the end re-read the last one into
+        // registers nobody uses.  No branch and no select around a load, so the compiler can count vmcnt instead
+        // of draining it -- with branches in the loop every stage_store waited for the loads issued just before it.
+        auto load1 = [&](int ks, int u) -> float4 {
+            int f = lane + kWave * u;
+            int row = f >> 3, c4 = ks * (kTileK / 4) + (f & 7);
+            int64_t gr = t0 + row;
+            gr = gr < r1 ? gr : r1 - 1;
+            c4 = c4 < nvec ? c4 : nvec - 1;
+            return reinterpret_cast<const float4 *>(a.rows + gr * a.ld)[c4];
         };
-        auto compute = [&](int ks) {
+        auto stage_load = [&](Stage &st, int ks) {
+            ks = ks < nk ? ks : nk - 1;
+            st.v0 = load1(ks, 0);
+            st.v1 = load1(ks, 1);
+            st.v2 = load1(ks, 2);
+            st.v3 = load1(ks, 3);
+        };
+        auto store1 = [&](const float4 &v, int u) {
+            int f = lane + kWave * u;
+            *reinterpret_cast<float4 *>(Aw + (f >> 3) * kTileLdA + (f & 7) * 4) = v;
+        };
+        auto stage_store = [&](const Stage &st) {
+            store1(st.v0, 0);
+            store1(st.v1, 1);
+            store1(st.v2, 2);
+            store1(st.v3, 3);
+        };
+        // LDS -> registers for one K-step: A from this wave's slab, B from the resident query group
+        auto lds_read = [&](float4 (&av)[kTileK / 8], float4 (&bv)[kTileK / 8], int ks) {
+            ks = ks < nk ? ks : nk - 1;
             const float *Ab = Aw + li * kTileLdA + 4 * half;
             const float *Bb = Bs + (li & (tq - 1)) * ldq + ks * kTileK + 4 * half;  // columns >= tq repeat, unused
-            float4 av[kTileK / 8], bv[kTileK / 8];
 #pragma unroll
             for (int t = 0; t < kTileK / 8; t++) {
                 av[t] = *reinterpret_cast<const float4 *>(Ab + 8 * t);
                 bv[t] = *reinterpret_cast<const float4 *>(Bb + 8 * t);
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the 8 LDS reads ahead of the MFMA chain
-            if (a.dbg & 1) {
-                asm volatile("" ::"v"(av[0].x), "v"(bv[0].x), "v"(av[3].w), "v"(bv[3].w));
-                return;
-            }
-#pragma unroll
-            for (int t = 0; t < kTileK / 8; t++) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bv[t].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv[t].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, bv[t].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bv[t].w, acc, 0, 0, 0);
-            }
         };
+        auto mfma4 = [&](const float4 &x, const float4 &y) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, y.w, acc, 0, 0, 0);
+        };
+        // One K-step (a macro, so that every register set is a named variable: the lambda form of this step put
+        // the staging registers in scratch memory), software-pipelined inside the wave: registers `cur` hold K-step ks (read from LDS during the
+        // previous step), `st` holds the global rows of K-step ks+1.  After the first 4 MFMAs the slab is
+        // overwritten with ks+1 and read back into `nxt` (LDS ops of one wave execute in issue order, and the reads
+        // of ks completed before this step began), `st` is refilled with K-step ks+3, and the remaining 12 MFMAs
+        // cover all three latencies.  Reading and multiplying the same step back to back instead left the two
+        // waves of a SIMD in lockstep (both waiting on LDS, then both queueing for the matrix core).
+#ifndef HG_TILE_ABLATE  // diagnostic builds (tools/tile_ablate.sh) drop parts of the step; 0 in the product
+#define HG_TILE_ABLATE 0
+#endif
+#define HG_TILE_STEP(cav, cbv, nav, nbv, st, ks_)                  \
+    do {                                                          \
+        if (!(HG_TILE_ABLATE & 1)) mfma4(cav[0], cbv[0]);         \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        if (!(HG_TILE_ABLATE & 4)) stage_store(st);               \
+        if (!(HG_TILE_ABLATE & 2)) lds_read(nav, nbv, (ks_) + 1); \
+        if (!(HG_TILE_ABLATE & 8)) stage_load(st, (ks_) + 3);     \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        if (!(HG_TILE_ABLATE & 1)) {                              \
+            mfma4(cav[1], cbv[1]);                                \
+            mfma4(cav[2], cbv[2]);                                \
+            mfma4(cav[3], cbv[3]);                                \
+        }                                                         \
+        __builtin_amdgcn_sched_barrier(0);                        \
+    } while (0)
         // this wave's row norms -> its LDS slot now; they are needed only after the K loop
         if (lane < 32) rnw[lane] = (a.metric == METRIC_COS && t0 + lane < r1) ? a.row_norms[t0 + lane] : 0.0f;
+        float4 av0[kTileK / 8], bv0[kTileK / 8], av1[kTileK / 8], bv1[kTileK / 8];
         stage_load(stA, 0);
+        stage_load(stB, 1);
         stage_store(stA);
-        if (nk > 1) stage_load(stA, 1);
-        if (nk > 2) stage_load(stB, 2);
-        // wave-private slab: LDS operations of one wave execute in issue order, so the reads of a K-step see the
-        // stores before them and the stores of the next K-step land after these reads
-        for (int ks = 0; ks < nk; ks += 2) {
-            compute(ks);  // stA holds K-step ks+1
-            if (ks + 1 < nk) stage_store(stA);
-            if (ks + 3 < nk && !(a.dbg & 2)) stage_load(stA, ks + 3);
-            if (ks + 1 >= nk) break;
-            compute(ks + 1);  // stB holds K-step ks+2
-            if (ks + 2 < nk) stage_store(stB);
-            if (ks + 4 < nk && !(a.dbg & 2)) stage_load(stB, ks + 4);
+        stage_load(stA, 2);
+        lds_read(av0, bv0, 0);
+        // entering step ks: cur regs = ks, the `st` passed in = ks+1, the other st = ks+2
+        int ks = 0;
+        for (; ks + 1 < nk; ks += 2) {
+            HG_TILE_STEP(av0, bv0, av1, bv1, stB, ks);
+            HG_TILE_STEP(av1, bv1, av0, bv0, stA, ks + 1);
         }
+        if (ks < nk) HG_TILE_STEP(av0, bv0, av1, bv1, stB, ks);
+#undef HG_TILE_STEP
         // ---- epilogue: D[row i][query col]: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-        if (ob >= 0 && !(a.dbg & 4)) {
+        if (HG_TILE_ABLATE & 16) asm volatile("" ::"v"(acc[0]), "v"(acc[15]));  // keep the chain alive
+        if (ob >= 0 && !(HG_TILE_ABLATE & 16)) {
+            if (a.out_key) {  // fused argmin: first minimum wins (strict <, ivf_flat.clj:86-89) = smallest (distance, row)
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                int i = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                int64_t gr = t0 + i;
-                float dv = finish_dist(a.metric, acc[reg], qn, rnw[i]) + 0.0f;
-                if (gr < r1) a.out[ob + (gr - rb0)] = dv;
+                for (int reg = 0; reg < 16; reg++) {
+                    int i = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    int64_t gr = t0 + i;
+                    float dv = finish_dist(a.metric, acc[reg], qn, rnw[i]);
+                    uint64_t key = gr < r1 ? make_key(dv, static_cast<uint32_t>(gr - rb0)) : ~0ull;
+                    best = key < best ? key : best;
+                }
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    int i = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    int64_t gr = t0 + i;
+                    float dv = finish_dist(a.metric, acc[reg], qn, rnw[i]) + 0.0f;
+                    if (gr < r1) a.out[ob + (gr - rb0)] = dv;
+                }
             }
         }
+    }
+    if (a.out_key && ob >= 0) {  // lanes li and li + 32 hold the two row-halves of query column li
+        const uint64_t other = __shfl_xor(best, 32, kWave);
+        best = other < best ? other : best;
+        if (half == 0 && best != ~0ull) atomicMin(a.out_key + (static_cast<int64_t>(g) * tq + li), best);
     }
     if (a.dbg_buf) {  // diagnostics only: when and where this workgroup ran
         __syncthreads();
