@@ -36,14 +36,19 @@ if sys.argv[1] == "hnsw":
     Q = x[:4096] + 0.02 * torch.randn(4096, dim, generator=g, device=dev)
     Q = (Q / Q.norm(dim=1, keepdim=True)).contiguous()
     ti, _ = idx.exact_knn_dev(Q[:512], 10)
+    stats = torch.zeros((len(Q), 2), dtype=torch.int64, device=dev)
     for ef in (64, 128, 256):
-        ids, _ = idx.hnsw_search_dev(Q, 10, ef)
+        ids, _ = idx.hnsw_search_dev(Q, 10, ef, stats=stats)
         torch.cuda.synchronize()
+        ev, hp = float(stats[:, 0].double().mean()), float(stats[:, 1].double().mean())
         t = time.time()
-        ids, _ = idx.hnsw_search_dev(Q, 10, ef)
+        for _ in range(3):
+            ids, _ = idx.hnsw_search_dev(Q, 10, ef)
         torch.cuda.synchronize()
-        dt = time.time() - t
-        print("  ef %3d  recall@10 %.4f  %d queries in %.2f ms = %.0f QPS" % (ef, bench.recall_at_k(ids[:512], ti), len(Q), dt * 1e3, len(Q) / dt), flush=True)
+        dt = (time.time() - t) / 3
+        gb = (ev * 4 * dim + hp * 4 * 32) * len(Q) / 1e9
+        print("  ef %3d  recall@10 %.4f  %d queries in %.2f ms = %.0f QPS; E %.0f H %.0f -> %.2f GB gathered = %.0f GB/s (%.2f of 8 TB/s)"
+              % (ef, bench.recall_at_k(ids[:512], ti), len(Q), dt * 1e3, len(Q) / dt, ev, hp, gb, gb / dt, gb / dt / 8000), flush=True)
 else:
     n, dim, nlist = 10_000_000, 768, 1024
     cen = torch.randn(nlist, dim, generator=g, device=dev)
