@@ -84,11 +84,21 @@ def main():
     ap.add_argument("--ivf-n", type=int, default=1_000_000)
     ap.add_argument("--sharded", action="store_true", help="also run the row-sharded IVF search (always on for N > 1)")
     ap.add_argument("--shard-rows", type=int, default=1_250_000, help="rows per GPU of the sharded IVF index")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.pmc_child:
+        return pmc_child(args)
+    traffic = None
+    # PMC passes are child processes and start BEFORE this process touches the GPU.  Not under a profiler: its
+    # preloaded library has already initialised the GPU here, and a profiler inside a profiler measures neither.
+    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if world == 1 and not args.no_ivf and not args.no_pmc and not profiled:
+        traffic = pmc_traffic(args)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.sharded:
@@ -219,6 +229,8 @@ def main():
     # ------------------------------------------------------------------ IVF-FLAT scan roofline (configs[2])
     if not args.no_ivf and rank == 0:
         result["roofline"] = ivf_roofline(engine, dev, args)
+        if traffic:
+            result["roofline"].update(traffic)
     elif rank == 0:
         result["roofline"] = result["roofline_hnsw"]
 
@@ -247,17 +259,7 @@ def ivf_roofline(engine, dev, args):
     list scan (scan_kernel over the probed lists); algorithmic bytes = sum over (query, probed list)
     pairs of len * (4*D + 4)  [rows + precomputed norms], SURVEY 8(d)."""
     n, nlist, nprobe = args.ivf_n, 1024, 32
-    g = torch.Generator(device=dev)
-    g.manual_seed(42)
-    centers = torch.randn(nlist, DIM, generator=g, device=dev)
-    which = torch.randint(0, nlist, (n,), generator=g, device=dev)
-    x = centers[which] + 0.3 * torch.randn(n, DIM, generator=g, device=dev)
-    x /= x.norm(dim=1, keepdim=True)
-    g.manual_seed(43)
-    nq_all = 1024
-    qw = torch.randint(0, nlist, (nq_all,), generator=g, device=dev)
-    Qa = centers[qw] + 0.3 * torch.randn(nq_all, DIM, generator=g, device=dev)
-    Qa /= Qa.norm(dim=1, keepdim=True)
+    x, Qa = ivf_dataset(dev, n, nlist, 1024)
     idx = engine.Index(x, "cosine", dev.index)
     del x
     t0 = time.time()
@@ -314,7 +316,7 @@ def ivf_roofline(engine, dev, args):
             "kernel": "scan_kernel<3,8,false,ROLE_LIST_SCAN>",
             "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch "
                         "(one GEMV per (query, probed list) pair)" % n,
-            "traffic_note": "PMC in profiles/: HBM read per launch ~= the algorithmic bytes",
+            "traffic_note": "null: no PMC pass in this run (--no-pmc, N > 1 or rocprofv3 unavailable); profiles/ holds one",
             "avg_launch_ms": r["avg_scan_ms"], "algorithmic_bytes_per_launch": int(r["algorithmic_GB"] * 1e9),
             "unique_bytes_GBs": r["unique_GBs"], "batch_32": r,
             "batched_mfma": {"bound": "mfma", "kernel": "tile_scan_kernel (v_mfma_f32_32x32x2_f32)",
@@ -324,6 +326,91 @@ def ivf_roofline(engine, dev, args):
                              "algorithmic_GBs": b["achieved_GBs"], "unique_GB": b["unique_GB"]},
             "ivf_recall_at_10": round(rec, 4), "ivf_build_s": round(build_s, 1),
             "mean_list_len": float(lens.mean()), "max_list_len": int(lens.max())}
+
+
+def ivf_dataset(dev, n, nlist, nq_all):
+    """S2 of BASELINE.md on the device: `nlist` gaussian centres, noise 0.3, L2-normalised rows; queries drawn the
+    same way with their own seed."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    centers = torch.randn(nlist, DIM, generator=g, device=dev)
+    which = torch.randint(0, nlist, (n,), generator=g, device=dev)
+    x = centers[which] + 0.3 * torch.randn(n, DIM, generator=g, device=dev)
+    x /= x.norm(dim=1, keepdim=True)
+    g.manual_seed(43)
+    qw = torch.randint(0, nlist, (nq_all,), generator=g, device=dev)
+    Qa = centers[qw] + 0.3 * torch.randn(nq_all, DIM, generator=g, device=dev)
+    Qa /= Qa.norm(dim=1, keepdim=True)
+    return x, Qa
+
+
+PMC_SCAN_KERNEL = "scan_kernel<3, 8, false, 0>"      # ROLE_LIST_SCAN instantiation for dim 768
+
+
+def pmc_child(args):
+    """Run under `rocprofv3 --pmc <one counter>`: the same 1M x 768 index and the same batch-32 searches as
+    ivf_roofline(), nothing else, so that every dispatch of the list-scan kernel in the counter file is one of
+    the launches `roofline.achieved` is quoted on."""
+    from hnsw_clj_amd import engine
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    x, Qa = ivf_dataset(dev, args.ivf_n, 1024, 1024)
+    idx = engine.Index(x, "cosine", 0)
+    del x
+    idx.ivf_build(1024, 10, 42)
+    Q = Qa[:32].contiguous()
+    for _ in range(6):
+        idx.ivf_search_dev(Q, K, 32)
+    torch.cuda.synchronize()
+    idx.close()
+
+
+def pmc_traffic(args):
+    """roofline.traffic: HBM bytes per launch of the list-scan kernel from the PMC counters, collected as
+    MI355X_MICROARCH.md (HBM section) prescribes -- FETCH_SIZE and WRITE_SIZE each in a rocprofv3 pass of its own
+    (kernel trace only beside them), units KB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read
+    (16 B per lane, this kernel's only global read of any size), so it is doubled; WRITE_SIZE is exact.
+    Returns None (traffic stays null) if rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        log("pmc: rocprofv3 not found, roofline.traffic stays null")
+        return None
+    got = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="hnswgpu_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--ivf-n", str(args.ivf_n)]
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            vals = []
+            for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if PMC_SCAN_KERNEL in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                log("pmc: %s pass failed (rc %d, %d rows): %s" % (ctr, r.returncode, len(vals), r.stderr.decode()[-300:]))
+                return None
+            got[ctr] = (sum(vals) / len(vals) * 1024.0, len(vals))
+            log("pmc: %s pass %.0fs, %d launches of %s" % (ctr, time.time() - t0, len(vals), PMC_SCAN_KERNEL))
+        except Exception as e:  # noqa: BLE001 -- a missing profiler must not take the bench down
+            log("pmc: %s pass: %s: %s" % (ctr, type(e).__name__, e))
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, wr = 2.0 * got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
+    return {"traffic": int(rd + wr),
+            "traffic_note": "HBM bytes per launch of the list-scan kernel at batch 32: 2 x FETCH_SIZE (gfx950 wide-read "
+                            "correction) + WRITE_SIZE, each from its own rocprofv3 --pmc pass over %d launches of the same "
+                            "index and batch in a child process (read %d B, written %d B)" % (got["FETCH_SIZE"][1], rd, wr)}
 
 
 def sharded_ivf(engine, dev, rank, world, args):

@@ -41,7 +41,7 @@ __host__ __device__ inline int64_t tile_nchunks(int64_t rows, int64_t chunk_rows
 }
 __host__ inline size_t tile_lds_bytes(int dim) {
     return sizeof(float) * (static_cast<size_t>(tile_tq(dim)) * tile_ldq(dim) + kTileRows * kTileLdA) +
-           sizeof(float) * kTileQ + sizeof(int64_t) * kTileQ + sizeof(float) * kTileRows;
+           sizeof(float) * kTileQ + sizeof(int64_t) * kTileQ + sizeof(float) * kTileRows + sizeof(int32_t) * kTileQ;
 }
 
 struct GroupMember {

@@ -19,6 +19,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     float *qn_s = As + kTileRows * kTileLdA;                     // [32]
     int64_t *ob_s = reinterpret_cast<int64_t *>(qn_s + kTileQ);  // [32] output bases (-1 = empty slot)
     float *rn_s = reinterpret_cast<float *>(ob_s + kTileQ);      // [256] row norms of the current tile
+    int32_t *qi_s = reinterpret_cast<int32_t *>(rn_s + kTileRows);  // [32] query index of every slot (-1 = empty)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
@@ -54,14 +55,21 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     const int64_t r0 = rb0 + static_cast<int64_t>(chunk) * per;
     const int64_t r1 = r0 + per < rb1 ? r0 + per : rb1;
     if (r0 >= r1 || cnt <= 0) return;
-    unsigned long long t_start = 0;
-    if (a.dbg_buf) t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_start = 0, c_start = 0;
+    if (a.dbg_buf) {
+        t_start = __builtin_amdgcn_s_memrealtime();
+        c_start = __builtin_amdgcn_s_memtime();
+    }
 
-    // ---- resident query group -> LDS (zero rows for empty slots)
+    // ---- resident query group -> LDS (zero rows for empty slots).  Two steps, so that no load in the copy loop
+    //      depends on another load: (1) 32 threads resolve their slot's query index / output base / norm into LDS;
+    //      (2) every thread copies its float4s with all of its loads in flight together.  (A loop of
+    //      load -> wait -> store, with the member lookup inside it, cost 12-24 dependent memory round trips per
+    //      workgroup before the first MFMA.)
     if (tid < kTileQ) {
+        int qi = -1;
+        int64_t ob = -1;
         if (tid < cnt) {
-            int qi;
-            int64_t ob;
             if (a.members) {
                 GroupMember m = a.members[a.grp_mem_begin[g] + tid];
                 qi = m.q;
@@ -70,23 +78,37 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
                 qi = g * tq + tid;
                 ob = static_cast<int64_t>(qi) * a.out_stride;
             }
-            ob_s[tid] = ob;
-            qn_s[tid] = a.q_norms ? a.q_norms[qi] : 0.0f;
-        } else {
-            ob_s[tid] = -1;
-            qn_s[tid] = 0.0f;
         }
+        qi_s[tid] = qi;
+        ob_s[tid] = ob;
+        qn_s[tid] = (qi >= 0 && a.q_norms) ? a.q_norms[qi] : 0.0f;
     }
+    __syncthreads();
     const int nvec = static_cast<int>(a.ld / 4);
     const int nk = (a.dim + kTileK - 1) / kTileK;
-    for (int f = tid; f < tq * (nk * kTileK / 4); f += kTileThreads) {
-        int slot = f / (nk * kTileK / 4), c4 = f % (nk * kTileK / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (slot < cnt && c4 < nvec) {
-            int qi = a.members ? a.members[a.grp_mem_begin[g] + slot].q : g * tq + slot;
-            v = reinterpret_cast<const float4 *>(a.Qp + static_cast<int64_t>(qi) * a.ld)[c4];
+    {
+        constexpr int kQU = 14;  // tq x ldq stays under 100 KiB -> at most 14 float4 per thread: one batch
+        const int per_row = nk * kTileK / 4, total = tq * per_row;
+        for (int f0 = tid; f0 < total; f0 += kTileThreads * kQU) {
+            float4 v[kQU];
+            int off[kQU];    // LDS offset of the float4 (-1 = past the end of the group)
+            bool live[kQU];  // false = zero fill (empty slot, or a column past the row end)
+#pragma unroll
+            for (int u = 0; u < kQU; u++) {  // unconditional loads from clamped addresses; masked at the store
+                int f = f0 + u * kTileThreads;
+                const bool in = f < total;
+                f = in ? f : total - 1;
+                const int slot = f / per_row, c4 = f - slot * per_row;
+                const int qi = qi_s[slot];
+                const int qc = qi >= 0 ? qi : 0, cc = c4 < nvec ? c4 : nvec - 1;
+                v[u] = reinterpret_cast<const float4 *>(a.Qp + static_cast<int64_t>(qc) * a.ld)[cc];
+                off[u] = in ? slot * ldq + 4 * c4 : -1;
+                live[u] = qi >= 0 && c4 < nvec;
+            }
+#pragma unroll
+            for (int u = 0; u < kQU; u++)
+                if (off[u] >= 0) *reinterpret_cast<float4 *>(Bs + off[u]) = live[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        *reinterpret_cast<float4 *>(Bs + slot * ldq + 4 * c4) = v;
     }
     __syncthreads();  // the only workgroup barrier: the query group is complete
 
@@ -159,7 +181,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
         // of ks completed before this step began), `st` is refilled with K-step ks+3, and the remaining 12 MFMAs
         // cover all three latencies.  Reading and multiplying the same step back to back instead left the two
         // waves of a SIMD in lockstep (both waiting on LDS, then both queueing for the matrix core).
-#ifndef HG_TILE_ABLATE  // diagnostic builds (tools/tile_ablate.sh) drop parts of the step; 0 in the product
+#ifndef HG_TILE_ABLATE  // diagnostic builds (tools/tile_variant.sh) drop parts of the step; 0 in the product
 #define HG_TILE_ABLATE 0
 #endif
 #define HG_TILE_STEP(cav, cbv, nav, nbv, st, ks_)                  \
@@ -227,7 +249,11 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
             unsigned long long *o = a.dbg_buf + 4ull * blockIdx.x;
             o[0] = t_start;
             o[1] = __builtin_amdgcn_s_memrealtime();
-            o[2] = __builtin_amdgcn_s_getreg(0x1804);  // HW_REG_HW_ID
+            // HW_REG_HW_ID (id 4, all 32 bits: cu_id 11:8, sh_id 12, se_id 15:13) | HW_REG_XCC_ID (id 20) << 32
+            //   | shader-clock cycles of this workgroup / 16 << 36 (against the 100 MHz stamps: the clock it ran at)
+            o[2] = static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(0xF804)) |
+                   ((static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(0xF814)) & 0xf) << 32) |
+                   (((__builtin_amdgcn_s_memtime() - c_start) >> 4) << 36);
             o[3] = static_cast<unsigned long long>((r1 - r0 + kTileRows - 1) / kTileRows) | (static_cast<unsigned long long>(cnt) << 32);
         }
     }

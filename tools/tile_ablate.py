@@ -1,7 +1,7 @@
 """Developer tool: time the MFMA tile kernel on the k-means assignment shape (n x dim rows against nlist centroids).
-Ablations are compile-time variants of the library (tools/tile_ablate.sh <mask> builds
-build_dbg/libhnswgpu_abl<mask>.so with parts of the K-step removed); select one with HNSWGPU_LIBRARY.
-usage: [HNSWGPU_LIBRARY=build_dbg/libhnswgpu_abl30.so] python tools/tile_ablate.py [n] [dim] [nlist]"""
+Ablations are compile-time variants of the library (tools/tile_variant.sh name=-DHG_TILE_ABLATE=<mask> builds
+build_dbg/libhnswgpu_<name>.so with parts of the K-step removed); select one with HNSWGPU_LIBRARY.
+usage: [HNSWGPU_LIBRARY=build_dbg/libhnswgpu_<name>.so] python tools/tile_ablate.py [n] [dim] [nlist]"""
 import os
 import sys
 
