@@ -99,7 +99,7 @@ int launch_scan(int nch, const ScanArgs &a, hipStream_t st) {
 // (A single wave scanning ~45k keys made the merge the longest kernel of a one-query IVF search.)
 __device__ __forceinline__ void fold_keys(const uint64_t *in, int64_t n, int k, bool regk, uint64_t *list, int lane,
                                           uint64_t &mine, int &cnt) {
-    uint64_t thr = ~0ull;
+    uint64_t thr = ~0ull, cap = ~0ull;
     constexpr int U = 4;
     for (int64_t base = 0; base < n; base += U * kWave) {
         uint64_t key[U];
@@ -107,6 +107,13 @@ __device__ __forceinline__ void fold_keys(const uint64_t *in, int64_t n, int k, 
         for (int u = 0; u < U; u++) {
             int64_t i = base + u * kWave + lane;
             key[u] = i < n ? in[i] : ~0ull;
+        }
+        if (regk && base == 0) {  // start from a bound on the k-th smallest key instead of ~0 (kth_bound)
+            uint64_t m = key[0];
+#pragma unroll
+            for (int u = 1; u < U; u++) m = key[u] < m ? key[u] : m;
+            cap = kth_bound(m, k, lane);
+            thr = cap;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -118,7 +125,8 @@ __device__ __forceinline__ void fold_keys(const uint64_t *in, int64_t n, int k, 
                 if (kb < thr) {
                     if (regk) {
                         wave_insert_reg(mine, cnt, k, kb, lane);
-                        thr = wave_kth_reg(mine, k);
+                        const uint64_t kth = wave_kth_reg(mine, k);
+                        thr = kth < cap ? kth : cap;
                     } else {
                         wave_insert(list, cnt, k, kb, lane);
                         thr = cnt == k ? list[k - 1] : ~0ull;
@@ -350,10 +358,32 @@ int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t s
     return 0;
 }
 
-int launch_select(const SelectArgs &a, hipStream_t st) {
-    if (a.nq <= 0) return 0;
-    size_t lds = sizeof(uint64_t) * kNWave * a.k;
-    hipLaunchKernelGGL(select_topk_kernel, dim3((a.nq + kNWave - 1) / kNWave), dim3(kWG), lds, st, a);
+int launch_select(const SelectArgs &a0, hipStream_t st) {
+    if (a0.nq <= 0) return 0;
+    SelectArgs a = a0;
+    // waves per query: measured at 1024 queries x 31k candidates (k = 10): 232 / 135 / 84 / 90 / 106 us with
+    // 1 / 2 / 4 / 8 / 16 waves (past 4 the second-level merge and the larger workgroups cost more than the shorter
+    // streams save); the per-query count is only known on the device, the row stride bounds it
+    const int64_t cand = a.q_cnt ? a.stride : a.cnt_all;
+    int w = 1;
+    while (w < 16 && cand >= 16384LL * w && static_cast<int64_t>(a.nq) * w * 2 <= 16384) w *= 2;
+    if (const char *e = getenv("HNSWGPU_SELECT_W")) w = std::max(1, std::min(16, atoi(e)));  // tuning override
+    while (w & (w - 1)) w &= w - 1;
+    a.wpq = w;
+    const size_t lds = sizeof(uint64_t) * (w == 1 ? kNWave : w + 1) * a.k;
+    HG_REQUIRE(lds <= 150 * 1024, HNSWGPU_ELIMIT, "k too large for the select kernel");
+    if (lds > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
+    }
+    if (w == 1)
+        hipLaunchKernelGGL(select_topk_kernel, dim3((a.nq + kNWave - 1) / kNWave), dim3(kWG), lds, st, a);
+    else
+        hipLaunchKernelGGL(select_topk_kernel, dim3(a.nq), dim3(w * kWave), lds, st, a);
     HG_HIP(hipGetLastError());
     return 0;
 }

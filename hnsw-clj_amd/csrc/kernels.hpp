@@ -155,6 +155,23 @@ __device__ __forceinline__ uint64_t wave_kth_reg(uint64_t mine, int k) {
     return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
+// An exclusive upper bound for the k-th smallest key of a set, from 64 per-lane minima of (parts of) that set
+// (k <= 64): the k-th smallest of the lane minima has at least k keys at or below it.  Used to start a top-k
+// fold with a tight threshold: with the threshold at ~0 every key of the first block of a stream went through
+// the one-at-a-time insertion path (512 cross-lane broadcasts before the first rejection).
+__device__ __forceinline__ uint64_t kth_bound(uint64_t lane_min, int k, int lane) {
+    const uint32_t hi = static_cast<uint32_t>(lane_min >> 32);  // the distance part decides; ties are let through
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < kWave; j++) {
+        const uint32_t o = __builtin_amdgcn_readlane(hi, j);
+        rank += (o < hi || (o == hi && j < lane)) ? 1 : 0;
+    }
+    const uint64_t sel = __ballot(rank == k - 1);  // ranks are a permutation of 0..63: exactly one lane
+    const uint32_t b = __builtin_amdgcn_readlane(hi, __ffsll(static_cast<unsigned long long>(sel)) - 1);
+    return b == 0xffffffffu ? ~0ull : (static_cast<uint64_t>(b) + 1) << 32;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Row norms (ivf_flat.clj:171-177): one wave per row.
 // ------------------------------------------------------------------------------------------------

@@ -95,6 +95,7 @@ struct SelectArgs {
     int64_t stride;
     int64_t cnt_all;
     int32_t nq, k;
+    int32_t wpq;  // waves per query (set by launch_select)
     uint32_t *out_ord;
     float *out_dist;
 };

@@ -259,13 +259,20 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     }
 }
 
-__global__ __launch_bounds__(kWG) void select_topk_kernel(SelectArgs a) {
+// W = a.wpq waves per query.  W = 1: four queries per 256-thread workgroup, one wave each.  W > 1: one query per
+// workgroup of W waves; wave w folds the 512-candidate blocks w, w + W, ... and wave 0 merges the W partial lists.
+// (One wave per query left a batch of 1024 queries with four waves per CU, each walking 31k candidates through
+// ~60 dependent load round trips: 143 us per launch, twice per batched IVF search.)  Keys are a total order on
+// (distance, position), so the result does not depend on W.
+__global__ __launch_bounds__(1024) void select_topk_kernel(SelectArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    const int q = blockIdx.x * kNWave + wave;
-    if (q >= a.nq) return;
-    uint64_t *list = reinterpret_cast<uint64_t *>(smem) + static_cast<size_t>(wave) * a.k;
+    const int W = a.wpq;
+    const int q = W == 1 ? blockIdx.x * kNWave + wave : blockIdx.x;
+    if (q >= a.nq) return;  // W > 1: uniform over the workgroup
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *list = lists + static_cast<size_t>(wave) * a.k;
     const float *in = a.dist + static_cast<int64_t>(q) * a.stride;
     const int64_t n = a.q_cnt ? a.q_cnt[q] : a.cnt_all;
     int cnt = 0;
@@ -273,26 +280,40 @@ __global__ __launch_bounds__(kWG) void select_topk_kernel(SelectArgs a) {
     const bool regk = a.k <= kWave;
     uint64_t mine = ~0ull;
     constexpr int U = 8;  // 8 independent 64-wide loads in flight per iteration (one latency per 512 candidates)
-    for (int64_t base = 0; base < n; base += U * kWave) {
+    const int64_t first = W == 1 ? 0 : static_cast<int64_t>(wave) * U * kWave;
+    uint64_t cap = ~0ull;  // bound on the k-th smallest key, known before anything is inserted (kth_bound)
+    for (int64_t base = first; base < n; base += static_cast<int64_t>(W) * U * kWave) {
         float v[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             int64_t i = base + u * kWave + lane;
             v[u] = i < n ? in[i] : __uint_as_float(0x7fc00000u);
         }
+        uint64_t key[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             int64_t i = base + u * kWave + lane;
-            uint64_t key = i < n ? make_key(v[u], static_cast<uint32_t>(i)) : ~0ull;
-            uint64_t mask = __ballot(key < thr);
+            key[u] = i < n ? make_key(v[u], static_cast<uint32_t>(i)) : ~0ull;
+        }
+        if (regk && base == first) {
+            uint64_t m = key[0];
+#pragma unroll
+            for (int u = 1; u < U; u++) m = key[u] < m ? key[u] : m;
+            cap = kth_bound(m, a.k, lane);
+            thr = cap;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint64_t mask = __ballot(key[u] < thr);
             while (mask) {
                 int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
                 mask &= mask - 1;
-                uint64_t kb = __shfl(key, b, kWave);
+                uint64_t kb = __shfl(key[u], b, kWave);
                 if (kb < thr) {
                     if (regk) {
                         wave_insert_reg(mine, cnt, a.k, kb, lane);
-                        thr = wave_kth_reg(mine, a.k);
+                        const uint64_t kth = wave_kth_reg(mine, a.k);
+                        thr = kth < cap ? kth : cap;
                     } else {
                         wave_insert(list, cnt, a.k, kb, lane);
                         thr = cnt == a.k ? list[a.k - 1] : ~0ull;
@@ -303,12 +324,49 @@ __global__ __launch_bounds__(kWG) void select_topk_kernel(SelectArgs a) {
     }
     if (regk) {
         if (lane < a.k) list[lane] = mine;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    } else {
+        for (int i = cnt + lane; i < a.k; i += kWave) list[i] = ~0ull;
     }
+    if (W > 1) {
+        __syncthreads();
+        if (wave != 0) return;
+        // second level: W * k keys (sentinels included) -> final list behind the W slots
+        uint64_t *fin = lists + static_cast<size_t>(W) * a.k;
+        const int tot = W * a.k;
+        thr = ~0ull;
+        mine = ~0ull;
+        cnt = 0;
+        for (int base = 0; base < tot; base += kWave) {
+            const int i = base + lane;
+            const uint64_t key = i < tot ? lists[i] : ~0ull;
+            uint64_t mask = __ballot(key < thr);
+            while (mask) {
+                int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+                mask &= mask - 1;
+                uint64_t kb = __shfl(key, b, kWave);
+                if (kb < thr) {
+                    if (regk) {
+                        wave_insert_reg(mine, cnt, a.k, kb, lane);
+                        thr = wave_kth_reg(mine, a.k);
+                    } else {
+                        wave_insert(fin, cnt, a.k, kb, lane);
+                        thr = cnt == a.k ? fin[a.k - 1] : ~0ull;
+                    }
+                }
+            }
+        }
+        if (regk) {
+            if (lane < a.k) fin[lane] = mine;
+        } else {
+            for (int i = cnt + lane; i < a.k; i += kWave) fin[i] = ~0ull;
+        }
+        list = fin;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < a.k; i += kWave) {
-        bool ok = i < cnt;
-        uint64_t key = ok ? list[i] : ~0ull;
+        const uint64_t key = list[i];
+        const bool ok = key != ~0ull;
         a.out_ord[static_cast<int64_t>(q) * a.k + i] = ok ? static_cast<uint32_t>(key) : 0xffffffffu;
         a.out_dist[static_cast<int64_t>(q) * a.k + i] = ok ? key_dist(key) : __uint_as_float(0x7f800000u);
     }
