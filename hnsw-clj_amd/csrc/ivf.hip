@@ -94,11 +94,13 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *cnt, int 
                 grp_seg[g] = l;
                 grp_mem_begin[g] = mem + b;
                 grp_mem_cnt[g] = c - b < tq ? c - b : tq;
-                for (int ch = 0; ch < nch; ch++, w++) {
+            }
+            // work items chunk-major: the groups of one chunk (same rows) are neighbours -- see tile_scan_kernel
+            for (int ch = 0; ch < nch; ch++)
+                for (int g = g0; g < g0 + ng; g++, w++) {
                     wi_group[w] = g;
                     wi_chunk[w] = ch;
                 }
-            }
         }
         __syncthreads();
         if (tid == 1023) {

@@ -25,9 +25,22 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     const int wave = tid >> 6;
     int g, chunk;
     if (a.members) {
-        if (static_cast<int>(blockIdx.x) >= *a.nitems) return;
-        g = a.wi_group[blockIdx.x];
-        chunk = a.wi_chunk[blockIdx.x];
+        // The work list is ordered (list, chunk, group): the groups that scan the SAME rows are neighbours.
+        // Workgroups are dealt to the 8 XCDs round-robin, so neighbours in blockIdx would land on eight different
+        // L2s and every group would pull its rows over the fabric again.  Give each XCD one contiguous eighth of
+        // the work list instead (workgroup b -> XCD b % 8, slot b / 8): the second and third group of a chunk then
+        // run beside the first on the same L2 and find its lines there.  Idle workgroups still sit at the end.
+        const int nitems = *a.nitems;
+        int item = blockIdx.x;
+        if (!(a.dbg & 1)) {
+            const int per_xcd = (nitems + 7) >> 3;
+            const int slot = blockIdx.x >> 3;
+            if (slot >= per_xcd) return;
+            item = (blockIdx.x & 7) * per_xcd + slot;
+        }
+        if (item >= nitems) return;
+        g = a.wi_group[item];
+        chunk = a.wi_chunk[item];
     } else {
         g = blockIdx.x / a.nchunks;
         chunk = blockIdx.x % a.nchunks;

@@ -1,0 +1,34 @@
+"""Developer tool: list-scan kernel time and end-to-end time of batched IVF searches on the bench index
+(1M x 768, k-means lists, nprobe 32).  usage: [HNSWGPU_TILE_DBG=1] python tools/ivf_batch_time.py [nq ...]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from hnsw_clj_amd import engine
+
+dev = torch.device("cuda", 0)
+x, Qa = bench.ivf_dataset(dev, 1_000_000, 1024, 4096)
+idx = engine.Index(x, "cosine", 0)
+del x
+idx.ivf_build(1024, 10, 42)
+for nq in [int(a) for a in sys.argv[1:]] or [256, 1024, 4096]:
+    Q = Qa[:nq].contiguous()
+    for _ in range(3):
+        idx.ivf_search_dev(Q, 10, 32)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        idx.ivf_search_dev(Q, 10, 32)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 10
+    idx.set_profiling(True)
+    idx.get_profile(engine.PROF_IVF_SCAN, reset=True)
+    for _ in range(10):
+        idx.ivf_search_dev(Q, 10, 32)
+    ms, cnt = idx.get_profile(engine.PROF_IVF_SCAN, reset=True)
+    idx.set_profiling(False)
+    print("batch %5d: scan kernel %.3f ms, search %.3f ms = %.0f QPS" % (nq, ms / cnt, wall * 1e3, nq / wall), flush=True)
