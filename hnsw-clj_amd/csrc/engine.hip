@@ -338,6 +338,9 @@ unsigned long long *g_tile_dbg_buf = nullptr;  // set through hnswgpu_debug_set_
 int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t st) {
     int64_t blocks = ngroups_bound * a.nchunks;
     if (blocks <= 0) return 0;
+    // explicit work list: workgroup b serves item (b % 8) * ceil(nitems / 8) + b / 8 (one contiguous eighth of the
+    // list per XCD), so the grid must cover 8 * ceil(nitems / 8) workgroups, not just nitems
+    if (a.members) blocks = (blocks + 7) & ~7LL;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "tile grid too large");
     size_t lds = tile_lds_bytes(dim);
     static bool attr_set = false;

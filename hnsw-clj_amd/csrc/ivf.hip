@@ -459,9 +459,12 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     memset(&a, 0, sizeof(a));
     HG_TRY(idx->s_pairs.ensure(sizeof(Pair) * static_cast<size_t>(nq) * nprobe));
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
-    // tiled (MFMA) list scan when the batch is large enough for queries to share lists
+    // tiled (MFMA) list scan once the batch holds more (query, list) pairs than there are lists: the GEMV scan
+    // streams a list once per pair, the tile scan once per group of <= 32 pairs.  Measured on 1M x 768 / 1024 lists /
+    // nprobe 32 (tools/ivf_batch_time.py): batch 32 = 1024 pairs: 0.58 ms as GEMVs, 0.56 tiled; batch 48: 0.74 vs
+    // 0.66; batch 96: 1.44 vs 0.77; batch 127: 1.85 vs 0.79 (the rule used to be 4 pairs per list: batch 128).
     const int tm = tile_mode();
-    const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs >= 4LL * idx->nlist);
+    const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs > static_cast<int64_t>(idx->nlist));
     int32_t *probes_buf = d_out_probes;
     int32_t *qcnt_buf = nullptr;
     if (use_tile) {

@@ -31,8 +31,8 @@ def eng(native_lib):
 
 def _ivf_mode(O, metric, dim, nq, nprobe, nlist):
     """Which kernel serves an IVF search (ivf.hip: ivf_search_enqueue): the MFMA tile path once the batch has
-    >= 4 (query, list) pairs per list (cosine / dot), else the GEMV scan."""
-    tiled = metric != O.L2 and dim <= 3072 and nq * min(nprobe, nlist) >= 4 * nlist
+    more (query, list) pairs than there are lists (cosine / dot), else the GEMV scan."""
+    tiled = metric != O.L2 and dim <= 3072 and nq * min(nprobe, nlist) > nlist
     return O.MODE_MFMA if tiled else O.MODE_DEV
 
 
@@ -455,6 +455,25 @@ def test_ivf_single_query_many_partials(eng, oracle, k):
         ei, ed = idx.exact_knn(Q[:1], k)           # probing every list == brute force (GEMV order on both sides)
         ids, d = idx.ivf_search(Q[:1], k, 16)
         assert_exact(ids, d, ei, ed, "ivf(all lists) == exact")
+
+
+@pytest.mark.parametrize("nlist,n", [(3, 900), (5, 2600), (7, 5000), (13, 1300)])
+def test_ivf_tile_path_small_work_lists(eng, oracle, nlist, n):
+    """Few lists and few queries on the MFMA tile path: work lists of 1 .. ~40 items, i.e. not a multiple of the 8
+    XCD slices the kernel deals them into (a grid that covered only `nitems` workgroups left candidates unwritten),
+    several chunks per list, groups of 1 .. 9 queries, k beyond the candidate count."""
+    O = oracle
+    base = _data(O, n, 40)
+    Q = _data(O, 9, 40, seed=43)
+    with eng.Index(base) as idx:
+        idx.ivf_build(nlist, 2, 42)
+        cen, off, lids = idx.get_ivf()
+        for nq in (2, 5, 9):
+            for nprobe, k in [(nlist, 10), (max(1, nlist // 2), 64), (nlist, 1000)]:
+                mode = _ivf_mode(O, O.COSINE, 40, nq, nprobe, nlist)
+                ids, d = idx.ivf_search(Q[:nq], k, nprobe)
+                oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, mode=mode)
+                assert_exact(ids, d, oi, od, "nlist=%d nq=%d nprobe=%d k=%d mode=%d" % (nlist, nq, nprobe, k, mode))
 
 
 def test_ivf_ragged_lists_and_full_probe(eng, oracle):
