@@ -121,7 +121,7 @@ __device__ __forceinline__ void fold_keys(const uint64_t *in, int64_t n, int k, 
             while (mask) {
                 int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
                 mask &= mask - 1;
-                uint64_t kb = __shfl(key[u], b, kWave);
+                uint64_t kb = lane_bcast(key[u], b);
                 if (kb < thr) {
                     if (regk) {
                         wave_insert_reg(mine, cnt, k, kb, lane);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(MergeArgs a) {
             while (mask) {
                 int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
                 mask &= mask - 1;
-                uint64_t kb = __shfl(key, b, kWave);
+                uint64_t kb = lane_bcast(key, b);
                 if (kb < thr) {
                     if (regk) {
                         wave_insert_reg(mine, cnt, a.k, kb, lane);
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(kWave) void merge_shards_kernel(const int32_t *ids,
         while (mask) {
             int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
             mask &= mask - 1;
-            uint64_t kb = __shfl(key, b, kWave);
+            uint64_t kb = lane_bcast(key, b);
             if (kb < thr) {
                 wave_insert(list, cnt, k, kb, lane);
                 thr = cnt == k ? list[k - 1] : ~0ull;

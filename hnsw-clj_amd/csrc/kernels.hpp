@@ -137,13 +137,24 @@ __device__ __forceinline__ void wave_insert(uint64_t *list, int &cnt, int k, uin
     cnt = newcnt;
 }
 
+// Broadcast lane `src`'s 64-bit value (src wave-uniform): two v_readlane instead of two LDS-crossbar permutes.
+__device__ __forceinline__ uint64_t lane_bcast(uint64_t v, int src) {
+    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), src);
+    const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(v >> 32), src);
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+// Lane i takes lane i - 1's value across the whole wave (lane 0 keeps its own): one DPP move (wave_shr:1, a GFX9
+// control gfx950 still has) instead of an LDS-crossbar permute.
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x138, 0xF, 0xF, false));
+}
+
 // The same list kept in registers when k <= 64: lane i holds the i-th smallest key (lanes >= cnt hold
 // ~0).  One ballot + one lane shift per insertion instead of an LDS round trip.
 __device__ __forceinline__ void wave_insert_reg(uint64_t &mine, int &cnt, int k, uint64_t key, int lane) {
     int pos = __popcll(__ballot(mine < key));  // ascending: the smaller keys form a prefix of the lanes
     if (pos >= k) return;
-    uint32_t lo = static_cast<uint32_t>(mine), hi = static_cast<uint32_t>(mine >> 32);
-    uint32_t ulo = __shfl_up(lo, 1, kWave), uhi = __shfl_up(hi, 1, kWave);
+    const uint32_t ulo = wave_shr1(static_cast<uint32_t>(mine)), uhi = wave_shr1(static_cast<uint32_t>(mine >> 32));
     uint64_t up = (static_cast<uint64_t>(uhi) << 32) | ulo;
     mine = lane < pos ? mine : (lane == pos ? key : up);
     if (lane >= k) mine = ~0ull;

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(SelectArgs a) {
             while (mask) {
                 int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
                 mask &= mask - 1;
-                uint64_t kb = __shfl(key[u], b, kWave);
+                uint64_t kb = lane_bcast(key[u], b);
                 if (kb < thr) {
                     if (regk) {
                         wave_insert_reg(mine, cnt, a.k, kb, lane);
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(SelectArgs a) {
             while (mask) {
                 int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
                 mask &= mask - 1;
-                uint64_t kb = __shfl(key, b, kWave);
+                uint64_t kb = lane_bcast(key, b);
                 if (kb < thr) {
                     if (regk) {
                         wave_insert_reg(mine, cnt, a.k, kb, lane);
