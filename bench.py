@@ -29,7 +29,10 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 N31K, DIM, K = 31173, 768, 10
 M, EFC = 16, 200
-EF_SWEEP = [50, 64, 80, 96, 112, 128, 160, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096]
+# the reference's own ef (max(k, 50), ultra_fast.clj:355) first, then steps of ~4 % so that the operating point is the
+# smallest ef that meets the recall bar, not the next power-of-two-ish value above it
+EF_SWEEP = [50, 56, 64, 72, 80, 88, 96, 100, 104, 108, 112, 116, 120, 128, 136, 144, 152, 160, 176, 192, 224, 256, 320, 384,
+            512, 768, 1024, 1536, 2048, 3072, 4096]
 
 
 def log(*a):

@@ -244,36 +244,33 @@ class Index:
         return ids, d
 
     # -- zero-copy device entry points (torch tensors, torch's current stream)
-    def _dev_args(self, Q, k):
+    def _dev_args(self, Q, k, out=None):
         import torch
 
         assert Q.is_cuda and Q.dtype == torch.float32 and Q.dim() == 2 and Q.shape[1] == self.dim
         Q = Q.contiguous()
-        ids = torch.empty((Q.shape[0], k), dtype=torch.int32, device=Q.device)
-        d = torch.empty((Q.shape[0], k), dtype=torch.float32, device=Q.device)
+        if out is not None:      # caller-owned result tensors: nothing is allocated on the call path
+            ids, d = out
+        else:
+            ids = torch.empty((Q.shape[0], k), dtype=torch.int32, device=Q.device)
+            d = torch.empty((Q.shape[0], k), dtype=torch.float32, device=Q.device)
         st = torch.cuda.current_stream(Q.device).cuda_stream
         return Q, ids, d, st
 
     def hnsw_search_dev(self, Q, k, ef=0, out=None, stats=None):
-        Q, ids, d, st = self._dev_args(Q, k)
-        if out is not None:
-            ids, d = out
+        Q, ids, d, st = self._dev_args(Q, k, out)
         check(lib().hnswgpu_hnsw_search_dev(self._h, Q.data_ptr(), Q.shape[0], k, int(ef or 0), ids.data_ptr(),
                                             d.data_ptr(), stats.data_ptr() if stats is not None else None, st))
         return ids, d
 
     def ivf_search_dev(self, Q, k, nprobe, out=None):
-        Q, ids, d, st = self._dev_args(Q, k)
-        if out is not None:
-            ids, d = out
+        Q, ids, d, st = self._dev_args(Q, k, out)
         check(lib().hnswgpu_ivf_search_dev(self._h, Q.data_ptr(), Q.shape[0], k, nprobe, ids.data_ptr(),
                                            d.data_ptr(), st))
         return ids, d
 
     def exact_knn_dev(self, Q, k, out=None):
-        Q, ids, d, st = self._dev_args(Q, k)
-        if out is not None:
-            ids, d = out
+        Q, ids, d, st = self._dev_args(Q, k, out)
         check(lib().hnswgpu_exact_knn_dev(self._h, Q.data_ptr(), Q.shape[0], k, ids.data_ptr(), d.data_ptr(), st))
         return ids, d
 

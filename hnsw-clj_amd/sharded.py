@@ -4,7 +4,7 @@ The reference shards with threads: split the rows into P partitions, search each
 sort, take k (src/hnsw/ann/partition/partitioned_hnsw.clj:149-196).  Here rank r owns a contiguous
 row range; every rank searches its shard for the full k (k' = k, so recall is not traded away like
 the reference's k-per-partition heuristic :158-162), then ONE all-gather of nq*k*(4+4) bytes per
-rank and a merge kernel produce the global top-k on every rank.  The payload (80 KB per rank at
+rank (ids and distance bits packed in one int32 tensor) and a merge kernel produce the global top-k on every rank.  The payload (80 KB per rank at
 nq=1024, k=10) is latency-bound, so a single all-gather beats anything ring-pipelined.
 
 ``replicated`` mode (the 31k x 768 config, which fits every GPU): the index is replicated, the
@@ -34,11 +34,13 @@ class ShardedSearcher:
         world = dist.get_world_size(self.group)
         ids, d = self.local_search(Q, k)
         gids = torch.where(ids >= 0, ids + self.row_offset, ids)  # local row -> global row id
-        all_ids = torch.empty((world,) + tuple(gids.shape), dtype=gids.dtype, device=gids.device)
-        all_d = torch.empty((world,) + tuple(d.shape), dtype=d.dtype, device=d.device)
-        # views of one [world, nq, k] buffer: the merge kernel reads the gathered lists in place
-        dist.all_gather(list(all_ids.unbind(0)), gids.contiguous(), group=self.group)
-        dist.all_gather(list(all_d.unbind(0)), d.contiguous(), group=self.group)
+        # ONE collective per batch: (id, distance bits) packed as int32 pairs, nq * k * 8 bytes per rank
+        mine = torch.stack((gids, d.contiguous().view(torch.int32)), dim=0).contiguous()      # [2, nq, k]
+        flat = torch.empty((world * 2,) + tuple(gids.shape), dtype=torch.int32, device=mine.device)
+        dist.all_gather_into_tensor(flat, mine, group=self.group)     # rank r's pair lands at rows [2r, 2r + 2)
+        both = flat.view((world, 2) + tuple(gids.shape))
+        all_ids = both[:, 0].contiguous()                   # [world, nq, k]: the merge kernel's layout
+        all_d = both[:, 1].contiguous().view(torch.float32)
         merge = self.merge_fn
         if merge is None:
             if not all_ids.is_cuda:
