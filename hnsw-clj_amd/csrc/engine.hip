@@ -100,13 +100,22 @@ int launch_scan(int nch, const ScanArgs &a, hipStream_t st) {
 __device__ __forceinline__ void fold_keys(const uint64_t *in, int64_t n, int k, bool regk, uint64_t *list, int lane,
                                           uint64_t &mine, int &cnt) {
     uint64_t thr = ~0ull, cap = ~0ull;
-    constexpr int U = 4;
+    constexpr int U = 8;
+    // the next block's loads are issued before this block is folded (one memory round trip per block otherwise)
+    uint64_t nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        int64_t i = u * kWave + lane;
+        nxt[u] = i < n ? in[i] : ~0ull;
+    }
     for (int64_t base = 0; base < n; base += U * kWave) {
         uint64_t key[U];
 #pragma unroll
+        for (int u = 0; u < U; u++) key[u] = nxt[u];
+#pragma unroll
         for (int u = 0; u < U; u++) {
-            int64_t i = base + u * kWave + lane;
-            key[u] = i < n ? in[i] : ~0ull;
+            int64_t i = base + (U + u) * kWave + lane;
+            nxt[u] = i < n ? in[i] : ~0ull;
         }
         if (regk && base == 0) {  // start from a bound on the k-th smallest key instead of ~0 (kth_bound)
             uint64_t m = key[0];
@@ -309,6 +318,33 @@ int scan_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_quer
     m.out_dist = idx->s_dist.as<float>();
     HG_TRY(launch_merge(m, st));
     return 0;
+}
+
+// Every query against ALL `nrows` rows of the scan's table, top-k by a dense pass: the scan stores the distances
+// ([nq][nrows] floats) and select_topk_kernel picks the k smallest (key = (distance, row), the same keys the
+// partial-list path builds).  For a short table and a large k -- centroid routing: 1024 centroids, k = nprobe = 32 --
+// the partial-list path emitted a k-slot list per wave for ~8 rows each and spent 31-38 us merging them.
+int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st) {
+    a.mode = MODE_STORE;
+    a.npairs = nq;
+    a.nchunks = plan_chunks(idx->nch, nrows, nrows, nq, &a.chunk_rows);
+    HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(nq) * nrows));
+    HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * a.k));
+    HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * a.k));
+    a.out = idx->s_tile.as<float>();
+    a.out_stride = nrows;
+    const int k = a.k;
+    HG_TRY(launch_scan(idx->nch, a, st));
+    SelectArgs s;
+    memset(&s, 0, sizeof(s));
+    s.dist = a.out;
+    s.stride = nrows;
+    s.cnt_all = nrows;
+    s.nq = nq;
+    s.k = k;
+    s.out_ord = idx->s_ord.as<uint32_t>();
+    s.out_dist = idx->s_dist.as<float>();
+    return launch_select(s, st);
 }
 
 int begin_call(hnswgpu_index *idx, hipStream_t st) {

@@ -123,6 +123,7 @@ int pick_nch(int64_t ld);  // 0 if unsupported
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);
 int launch_scan(int nch, const ScanArgs &a, hipStream_t st);
 int launch_merge(const MergeArgs &a, hipStream_t st);
+int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st);
 extern unsigned long long *g_tile_dbg_buf;
 int launch_gather(int nch, GatherArgs a, int32_t nq, hipStream_t st);
 int scan_rows_per_iter(int nch);  // kNWave * RB

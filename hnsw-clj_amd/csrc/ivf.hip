@@ -492,6 +492,8 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     if (use_tile)  // every query against the centroid table on the tile kernel as well
         HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
                              nprobe, st, -1));
+    else if (static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20))  // dense [nq][nlist] distances + select
+        HG_TRY(scan_dense_topk(idx, a, nq, idx->nlist, st));
     else
         HG_TRY(scan_topk(idx, a, nq, 1, idx->nlist, st, -1));
     hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st, idx->s_ord.as<uint32_t>(), nq,

@@ -295,12 +295,23 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(SelectArgs a) {
     constexpr int U = 8;  // 8 independent 64-wide loads in flight per iteration (one latency per 512 candidates)
     const int64_t first = W == 1 ? 0 : static_cast<int64_t>(wave) * U * kWave;
     uint64_t cap = ~0ull;  // bound on the k-th smallest key, known before anything is inserted (kth_bound)
-    for (int64_t base = first; base < n; base += static_cast<int64_t>(W) * U * kWave) {
+    // the next block's loads are issued before this block is folded: one memory round trip per block would
+    // otherwise sit between every two folds (15 blocks per wave at 31k candidates and 4 waves)
+    const int64_t step = static_cast<int64_t>(W) * U * kWave;
+    float vn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int64_t i = first + u * kWave + lane;
+        vn[u] = i < n ? in[i] : __uint_as_float(0x7fc00000u);
+    }
+    for (int64_t base = first; base < n; base += step) {
         float v[U];
 #pragma unroll
+        for (int u = 0; u < U; u++) v[u] = vn[u];
+#pragma unroll
         for (int u = 0; u < U; u++) {
-            int64_t i = base + u * kWave + lane;
-            v[u] = i < n ? in[i] : __uint_as_float(0x7fc00000u);
+            const int64_t i = base + step + u * kWave + lane;
+            vn[u] = i < n ? in[i] : __uint_as_float(0x7fc00000u);
         }
         uint64_t key[U];
 #pragma unroll
