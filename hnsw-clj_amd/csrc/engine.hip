@@ -146,6 +146,16 @@ __device__ __forceinline__ void fold_keys(const uint64_t *in, int64_t n, int k, 
     }
 }
 
+// hipFuncSetAttribute is per device: remember it per (call site, device), not once per process (one process may
+// hold handles on several GPUs -- the partitioned and IVF-HNSW mirrors do)
+static bool attr_needed(bool (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+}
+
 __global__ __launch_bounds__(1024) void merge_topk_kernel(MergeArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem);  // [W][k]
@@ -223,11 +233,10 @@ int launch_merge(const MergeArgs &a, hipStream_t st) {
     size_t lds = sizeof(uint64_t) * (w + 1) * a.k;
     HG_REQUIRE(lds <= 150 * 1024, HNSWGPU_ELIMIT, "k too large for the merge kernel");
     if (lds > 48 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_done[64] = {};
+        if (attr_needed(attr_done)) {
             HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_set = true;
         }
     }
     hipLaunchKernelGGL(merge_topk_kernel, dim3(a.nq), dim3(static_cast<unsigned>(w * kWave)), lds, st, a);
@@ -379,11 +388,10 @@ int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t s
     if (a.members) blocks = (blocks + 7) & ~7LL;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "tile grid too large");
     size_t lds = tile_lds_bytes(dim);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_done[64] = {};
+    if (attr_needed(attr_done)) {
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_scan_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     static const int dbg = []() {
         const char *e = getenv("HNSWGPU_TILE_DBG");
@@ -412,11 +420,10 @@ int launch_select(const SelectArgs &a0, hipStream_t st) {
     const size_t lds = sizeof(uint64_t) * (w == 1 ? kNWave : w + 1) * a.k;
     HG_REQUIRE(lds <= 150 * 1024, HNSWGPU_ELIMIT, "k too large for the select kernel");
     if (lds > 48 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_done[64] = {};
+        if (attr_needed(attr_done)) {
             HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_set = true;
         }
     }
     if (w == 1)

@@ -476,6 +476,34 @@ def test_ivf_tile_path_small_work_lists(eng, oracle, nlist, n):
                 assert_exact(ids, d, oi, od, "nlist=%d nq=%d nprobe=%d k=%d mode=%d" % (nlist, nq, nprobe, k, mode))
 
 
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+def test_ivf_many_equal_distances(eng, oracle, metric):
+    """Hundreds of candidates tie on the distance bits (duplicated rows, the query among them): every top-k fold
+    (register lists, LDS lists, the k-th-key bound that seeds them, the several-waves-per-query select and its
+    second-level merge) must fall back on the order key exactly like the reference's stable sort
+    (ivf_flat.clj:229-233,291-294).  Small and large batches: GEMV scan + partial-list merge, and tile scan + select."""
+    O = oracle
+    m = {"cosine": O.COSINE, "dot": O.DOT, "l2": O.L2}[metric]
+    rs = np.random.RandomState(5)
+    base = _data(O, 3000, 40)
+    dup = rs.choice(3000, 700, replace=False)
+    base[dup[:400]] = base[dup[0]]            # 400 copies of one row
+    base[dup[400:]] = base[dup[400]] * 2.0    # 300 copies of another (same cosine distance as its original)
+    Q = np.concatenate([base[dup[:1]], base[dup[400:401]], _data(O, 10, 40, seed=43)]).astype(np.float32)
+    with eng.Index(base, metric) as idx:
+        idx.ivf_build(6, 2, 42)
+        cen, off, lids = idx.get_ivf()
+        for nq in (1, 2, 12):
+            for k in (10, 64, 500):
+                mode = _ivf_mode(O, m, 40, nq, 6, 6)
+                ids, d = idx.ivf_search(Q[:nq], k, 6)
+                oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, 6, metric=m, mode=mode)
+                assert_exact(ids, d, oi, od, "ties %s nq=%d k=%d" % (metric, nq, k))
+        ei, ed = idx.exact_knn(Q, 450)
+        oi, od, _ = O.exact_knn(base, Q, 450, metric=m, mode=O.MODE_DEV if (m == O.L2 or len(Q) < 16) else O.MODE_MFMA)
+        assert_exact(ei, ed, oi, od, "ties exact %s" % metric)
+
+
 def test_ivf_ragged_lists_and_full_probe(eng, oracle):
     """Empty lists, a list holding almost everything, nprobe > nlist, k > candidates."""
     O = oracle
