@@ -5,6 +5,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 #include "engine.hpp"
 #include "javarandom.hpp"
@@ -190,37 +196,63 @@ struct HostGraph {
     std::vector<int32_t> dirty0;
     std::vector<int64_t> dirtyu;
     std::vector<uint8_t> flag0, flagu;
+    // 1 once a list has been pruned: it is then sorted by (distance, insertion order) and stays so
+    std::vector<uint8_t> sorted0, sortedu;
 
-    void mark(int32_t node, int lc) {
+    // the dirty lists a linking thread appends to (its own: a node's flags are only touched by the thread that owns
+    // the node, the lists are concatenated after the batch)
+    struct Dirty {
+        std::vector<int32_t> d0;
+        std::vector<int64_t> du;
+    };
+
+    void mark(int32_t node, int lc, Dirty &out) {
         if (lc == 0) {
             if (!flag0[node]) {
                 flag0[node] = 1;
-                dirty0.push_back(node);
+                out.d0.push_back(node);
             }
         } else {
             int64_t blk = up_off[node] + (lc - 1);
             if (!flagu[blk]) {
                 flagu[blk] = 1;
-                dirtyu.push_back(blk);
+                out.du.push_back(blk);
             }
         }
     }
 
     // one direction of "Connect bidirectionally" (ultra_fast.clj:255-266) + prune-connections-ultra
-    // (:279-299): an over-full list keeps its m closest by (distance, insertion order).  Edge
-    // distances are stored with the edges, so pruning needs no distance evaluation.
-    void add_edge(int32_t from, int32_t to, int lc, float dist) {
+    // (:279-299): an over-full list keeps its m closest by (distance, insertion order) -- (take max-conns
+    // (sort-by dist connections)), a stable sort.  Edge distances are stored with the edges, so pruning needs no
+    // distance evaluation.  After its first pruning a list IS that sorted order, and appending one edge and
+    // stable-sorting again equals inserting it behind the last edge with distance <= its own and dropping the
+    // last: a shift instead of a sort (the sort was most of the 0.25 s of host time in a 0.33 s 31k x 768 build).
+    void add_edge(int32_t from, int32_t to, int lc, float dist, Dirty &out) {
         float *d;
         int32_t *cnt;
         int m;
         int32_t *a = adj(from, lc, &d, &cnt, &m);
         for (int i = 0; i < *cnt; i++)
             if (a[i] == to) return;
+        uint8_t &srt = lc == 0 ? sorted0[from] : sortedu[up_off[from] + (lc - 1)];
+        if (*cnt == m && srt) {
+            if (!(dist < d[m - 1])) return;  // sorts last (ties go behind the older edges) and is dropped again
+            int pos = m - 1;
+            while (pos > 0 && dist < d[pos - 1]) pos--;
+            for (int i = m - 1; i > pos; i--) {
+                a[i] = a[i - 1];
+                d[i] = d[i - 1];
+            }
+            a[pos] = to;
+            d[pos] = dist;
+            mark(from, lc, out);
+            return;
+        }
         a[*cnt] = to;
         d[*cnt] = dist;
         (*cnt)++;
-        mark(from, lc);
-        if (*cnt > m) {  // (take max-conns (sort-by dist connections)): stable sort, drop the last
+        mark(from, lc, out);
+        if (*cnt > m) {  // first overflow of this list: the stable sort itself
             int ord[kMaxDeg + 1];
             const int c = *cnt;
             for (int i = 0; i < c; i++) ord[i] = i;
@@ -237,8 +269,67 @@ struct HostGraph {
             }
             a[m] = -1;
             *cnt = m;
+            srt = 1;
         }
     }
+};
+
+// Host threads of the linker.  A batch's edges are applied in two sweeps that give every adjacency list exactly the
+// sequence of updates the sequential loop gives it: (A) every new node's OWN lists (disjoint between nodes),
+// (B) the reverse edges, each thread walking the whole batch in order and applying the edges whose TARGET node it
+// owns (node mod T).  No locks, and the graph does not depend on the thread count.
+class LinkPool {
+public:
+    explicit LinkPool(int n) {
+        for (int i = 1; i < n; i++) th_.emplace_back([this, i] { worker(i); });
+    }
+    ~LinkPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int size() const { return static_cast<int>(th_.size()) + 1; }
+    void run(const std::function<void(int)> &f) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &f;
+            pending_ = static_cast<int>(th_.size());
+            gen_++;
+        }
+        cv_.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+    }
+
+private:
+    void worker(int id) {
+        int seen = 0;
+        for (;;) {
+            const std::function<void(int)> *f;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                f = job_;
+            }
+            (*f)(id);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *job_ = nullptr;
+    int gen_ = 0, pending_ = 0;
+    bool stop_ = false;
 };
 
 // dst[ids[i] * width + j] = packed[i * width + j]
@@ -519,6 +610,13 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
 
     g.flag0.assign(n, 0);
     g.flagu.assign(std::max<int64_t>(blocks, 1), 0);
+    g.sorted0.assign(n, 0);
+    g.sortedu.assign(std::max<int64_t>(blocks, 1), 0);
+    // linker threads: at most 16 (a GPU box's CPU share per GPU), HNSWGPU_BUILD_THREADS overrides (1 = sequential)
+    int nthreads = static_cast<int>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
+    if (const char *e = getenv("HNSWGPU_BUILD_THREADS")) nthreads = std::max(1, std::min(64, atoi(e)));
+    LinkPool pool(nthreads);
+    std::vector<HostGraph::Dirty> dirties(pool.size());
     std::vector<int32_t> pack;
     std::vector<int64_t> pack_ids;
     HG_HIP(hipMemsetAsync(idx->d_l0, 0xff, sizeof(int32_t) * n * M0, st));
@@ -526,7 +624,12 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
     g.entry = 0;  // first element becomes the entry point (:229-231)
     g.top = g.levels[0];
     int64_t done = 1;
+    const bool timing = getenv("HNSWGPU_BUILD_TIMING") != nullptr;  // developer switch: where a build spends its time
+    double t_gpu = 0.0, t_link = 0.0;
+    int64_t nbatch = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (done < n) {
+        const double tb0 = timing ? now() : 0.0;
         // a batch never exceeds 1/8 of the graph it is searched against; beyond 2048 it grows slowly (1/64)
         // so that big indexes amortise the per-batch round trip without starving early quality
         int64_t B = std::min<int64_t>({maxB, std::max<int64_t>(1, done / 8), 2048 + done / 64, n - done});
@@ -561,32 +664,76 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
         HG_HIP(hipMemcpyAsync(h_up.data(), a.up_out_ids, sizeof(int32_t) * B * maxlv, hipMemcpyDeviceToHost, st));
         HG_HIP(hipMemcpyAsync(h_upd.data(), a.up_out_dist, sizeof(float) * B * maxlv, hipMemcpyDeviceToHost, st));
         HG_HIP(hipStreamSynchronize(st));
+        const double tb1 = timing ? now() : 0.0;
         const int top_at_start = g.top;
-        for (int64_t b = 0; b < B; b++) {
+        const int take = std::min(M0, ef);
+        // (A) own lists of node done + b; (B) reverse edges into the lists of nodes owned by thread `me` (of `nt`)
+        auto link_own = [&](int64_t b, HostGraph::Dirty &dirty) {
             const int32_t id = static_cast<int32_t>(done + b);
             const int L = g.levels[id];
             for (int lc = std::min(L, top_at_start); lc >= 1; lc--) {
-                int32_t nb = h_up[b * maxlv + (lc - 1)];
+                const int32_t nb = h_up[b * maxlv + (lc - 1)];
                 if (nb < 0 || nb == id) continue;
-                float d = h_upd[b * maxlv + (lc - 1)];
-                g.add_edge(id, nb, lc, d);
-                g.add_edge(nb, id, lc, d);
+                g.add_edge(id, nb, lc, h_upd[b * maxlv + (lc - 1)], dirty);
             }
-            const int take = std::min(M0, ef);
             for (int t = 0; t < take; t++) {
-                int32_t nb = h_ids[b * M0 + t];
+                const int32_t nb = h_ids[b * M0 + t];
                 if (nb < 0) break;
                 if (nb == id) continue;
-                g.add_edge(id, nb, 0, h_d[b * M0 + t]);
-                g.add_edge(nb, id, 0, h_d[b * M0 + t]);
+                g.add_edge(id, nb, 0, h_d[b * M0 + t], dirty);
             }
-            if (L > g.top) {  // :271-273
+        };
+        auto link_reverse = [&](int64_t b, int me, int nt, HostGraph::Dirty &dirty) {
+            const int32_t id = static_cast<int32_t>(done + b);
+            const int L = g.levels[id];
+            for (int lc = std::min(L, top_at_start); lc >= 1; lc--) {
+                const int32_t nb = h_up[b * maxlv + (lc - 1)];
+                if (nb < 0 || nb == id || nb % nt != me) continue;
+                g.add_edge(nb, id, lc, h_upd[b * maxlv + (lc - 1)], dirty);
+            }
+            for (int t = 0; t < take; t++) {
+                const int32_t nb = h_ids[b * M0 + t];
+                if (nb < 0) break;
+                if (nb == id || nb % nt != me) continue;
+                g.add_edge(nb, id, 0, h_d[b * M0 + t], dirty);
+            }
+        };
+        const int nt = B >= 256 ? pool.size() : 1;  // small batches: the hand-over costs more than it saves
+        if (nt == 1) {
+            for (int64_t b = 0; b < B; b++) link_own(b, dirties[0]);
+            for (int64_t b = 0; b < B; b++) link_reverse(b, 0, 1, dirties[0]);
+        } else {
+            pool.run([&](int me) {
+                const int64_t lo = B * me / nt, hi = B * (me + 1) / nt;
+                for (int64_t b = lo; b < hi; b++) link_own(b, dirties[me]);
+            });
+            pool.run([&](int me) {
+                for (int64_t b = 0; b < B; b++) link_reverse(b, me, nt, dirties[me]);
+            });
+        }
+        for (auto &dd : dirties) {
+            g.dirty0.insert(g.dirty0.end(), dd.d0.begin(), dd.d0.end());
+            g.dirtyu.insert(g.dirtyu.end(), dd.du.begin(), dd.du.end());
+            dd.d0.clear();
+            dd.du.clear();
+        }
+        for (int64_t b = 0; b < B; b++) {  // :271-273
+            const int32_t id = static_cast<int32_t>(done + b);
+            if (g.levels[id] > g.top) {
                 g.entry = id;
-                g.top = L;
+                g.top = g.levels[id];
             }
         }
         done += B;
+        if (timing) {
+            t_gpu += tb1 - tb0;
+            t_link += now() - tb1;
+            nbatch++;
+        }
     }
+    if (timing)
+        fprintf(stderr, "hnsw build: %lld batches, %.2f s upload + search + download, %.2f s host linking\n",
+                static_cast<long long>(nbatch), t_gpu, t_link);
     HG_TRY(upload_graph(idx, g, st, tmp0, tmpu));
     idx->h_levels = g.levels;
     idx->h_upoff = g.up_off;

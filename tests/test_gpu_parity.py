@@ -251,6 +251,26 @@ def test_hnsw_build_on_device(eng, oracle):
     assert rec_gpu_graph >= 0.9 and rec_gpu_graph >= rec_ref - 0.03, (rec_gpu_graph, rec_ref)
 
 
+def test_hnsw_build_linker_threads_do_not_change_the_graph(eng, oracle, monkeypatch):
+    """The host linker applies a batch's edges with several threads (own lists by node range, reverse edges by
+    target node mod T): every adjacency list must see the sequential loop's update sequence, so the graph is
+    identical for 1, 3 and 16 threads -- levels, both adjacency arrays, entry point."""
+    O = oracle
+    base = _data(O, 9000, 24, "clustered", num_clusters=32, noise_level=0.6)
+    base[100:140] = base[100]                                # equal edge distances: pruning ties
+    graphs = []
+    with eng.Index(base) as idx:
+        for nt in ("1", "3", "16"):
+            monkeypatch.setenv("HNSWGPU_BUILD_THREADS", nt)
+            idx.hnsw_build(8, 64, 7)
+            graphs.append(idx.get_graph())
+    for g in graphs[1:]:
+        for f in ("levels", "l0_adj", "up_off", "up_adj"):
+            np.testing.assert_array_equal(getattr(g, f), getattr(graphs[0], f), err_msg=f)
+        assert (g.entry, g.max_level, g.M) == (graphs[0].entry, graphs[0].max_level, graphs[0].M)
+    assert ((graphs[0].l0_adj >= 0).sum(1) >= 1).all()
+
+
 def test_randomised_differential(eng, oracle):
     """40 random configurations (size, dim, metric, M, ef, k, nlist, nprobe, batch): every search entry point of
     the C ABI against the oracle's matching device-order mode, bit for bit."""
