@@ -23,16 +23,27 @@ namespace hg {
 constexpr int kTileWaves = 8;    // waves per workgroup (two per SIMD), each owns 32 rows of a tile
 constexpr int kTileThreads = kTileWaves * 64;
 constexpr int kTileRows = 32 * kTileWaves;  // rows per tile
-constexpr int kTileQ = 32;      // MFMA N: queries per group for dim <= 896 (16 up to 1792, 8 up to 3072: LDS)
+constexpr int kTileQ = 32;      // MFMA N: queries per group
 constexpr int kTileK = 32;      // K per staging step
 constexpr int kTileLdA = kTileK + 4;  // padded LDS row of the A (rows) tile: conflict-free ds_read_b128
-constexpr int kTileMaxDim = 3072;     // group size shrinks with dim so that tq x (dim+pad) floats stay < 100 KiB
+constexpr int kTileMaxDim = 3072;     // rows up to this length are supported by the callers' row loaders
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__host__ __device__ inline int tile_ldq(int dim) { return ((dim + 63) / 64) * 64 + 4; }
-// queries resident per workgroup: the 32-column MFMA tile is filled fully, half or a quarter
-__host__ __device__ inline int tile_tq(int dim) { return dim <= 896 ? 32 : (dim <= 1792 ? 16 : 8); }
+// The query group is resident in LDS one K-PHASE at a time: all of K when a row has at most 28 K-steps (dim <= 896),
+// otherwise phases of 24 K-steps (768 columns, the 96 KiB a 32-query group may take).  A tile's accumulators
+// live across its phases, so the f32 chain over k is the same one whatever the phase length.  (Before, dims
+// above 896 / 1792 kept only 16 / 8 queries resident and left half / three quarters of every 32-column MFMA empty.)
+__host__ __device__ inline int tile_phase_steps(int dim) {
+    const int nk = (dim + kTileK - 1) / kTileK;
+    return nk <= 28 ? nk : 24;
+}
+__host__ __device__ inline int tile_ldq(int dim) {  // LDS row of one query: the phase's columns (+4: bank spread)
+    const int cols = tile_phase_steps(dim) * kTileK;
+    return ((cols + 63) / 64) * 64 + 4;
+}
+// queries resident per workgroup = the MFMA tile's 32 columns, for every supported dim
+__host__ __device__ inline int tile_tq(int dim) { return kTileQ; }
 // chunks a segment of `rows` rows is cut into: round(tiles / tiles_per_chunk), at least 1, at most max_chunks
 __host__ __device__ inline int64_t tile_nchunks(int64_t rows, int64_t chunk_rows, int64_t max_chunks) {
     const int64_t tiles = (rows + kTileRows - 1) / kTileRows, tpc = chunk_rows / kTileRows;

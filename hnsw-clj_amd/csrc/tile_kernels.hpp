@@ -13,7 +13,7 @@ namespace hg {
 __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ldq = tile_ldq(a.dim);
-    const int tq = tile_tq(a.dim);                               // queries resident in LDS (32 / 16 / 8)
+    const int tq = tile_tq(a.dim);                               // queries resident in LDS
     float *Bs = reinterpret_cast<float *>(smem);                 // [tq][ldq]     resident query group
     float *As = Bs + tq * ldq;                                   // [8][32][36]   wave-private row slabs
     float *qn_s = As + kTileRows * kTileLdA;                     // [32]
@@ -99,9 +99,12 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     __syncthreads();
     const int nvec = static_cast<int>(a.ld / 4);
     const int nk = (a.dim + kTileK - 1) / kTileK;
-    {
+    const int kps = tile_phase_steps(a.dim);   // K-steps of one residency phase
+    const int nphase = (nk + kps - 1) / kps;   // 1 for dim <= 896
+    // columns [phase * kps * 32, + kps * 32) of every resident query -> Bs (zero beyond the row end)
+    auto fill_queries = [&](int phase) {
         constexpr int kQU = 14;  // tq x ldq stays under 100 KiB -> at most 14 float4 per thread: one batch
-        const int per_row = nk * kTileK / 4, total = tq * per_row;
+        const int per_row = kps * kTileK / 4, total = tq * per_row, c0 = phase * per_row;
         for (int f0 = tid; f0 < total; f0 += kTileThreads * kQU) {
             float4 v[kQU];
             int off[kQU];    // LDS offset of the float4 (-1 = past the end of the group)
@@ -113,17 +116,20 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
                 f = in ? f : total - 1;
                 const int slot = f / per_row, c4 = f - slot * per_row;
                 const int qi = qi_s[slot];
-                const int qc = qi >= 0 ? qi : 0, cc = c4 < nvec ? c4 : nvec - 1;
+                const int qc = qi >= 0 ? qi : 0, cg = c0 + c4, cc = cg < nvec ? cg : nvec - 1;
                 v[u] = reinterpret_cast<const float4 *>(a.Qp + static_cast<int64_t>(qc) * a.ld)[cc];
                 off[u] = in ? slot * ldq + 4 * c4 : -1;
-                live[u] = qi >= 0 && c4 < nvec;
+                live[u] = qi >= 0 && cg < nvec;
             }
 #pragma unroll
             for (int u = 0; u < kQU; u++)
                 if (off[u] >= 0) *reinterpret_cast<float4 *>(Bs + off[u]) = live[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    if (nphase == 1) {
+        fill_queries(0);
+        __syncthreads();  // single phase: the only workgroup barrier after the slot table -- the query group is complete
     }
-    __syncthreads();  // the only workgroup barrier: the query group is complete
 
     const int half = lane >> 5, li = lane & 31;
     float *Aw = As + wave * 32 * kTileLdA;  // this wave's slab: 32 rows x 32 floats (+4 pad)
@@ -131,7 +137,11 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     const int64_t ob = li < tq ? ob_s[li] : -1;
     const float qn = li < tq ? qn_s[li] : 0.0f;
     uint64_t best = ~0ull;  // argmin mode: best (distance, row) of query column li over this wave's rows
-    for (int64_t t0 = r0 + wave * 32; t0 < r1; t0 += kTileRows) {  // this wave's 32 rows of every 256-row tile
+    for (int64_t tb = r0; tb < r1; tb += kTileRows) {
+        const int64_t t0 = tb + wave * 32;  // this wave's 32 rows of the 256-row tile
+        // single phase: no barrier below, a wave without rows in this tile (ragged chunk end) is done; several
+        // phases: every wave takes part in the refills' barriers and multiplies clamped rows it never stores
+        if (nphase == 1 && t0 >= r1) break;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[i] = 0.0f;
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
             c4 = c4 < nvec ? c4 : nvec - 1;
             return reinterpret_cast<const float4 *>(a.rows + gr * a.ld)[c4];
         };
-        auto stage_load = [&](Stage &st, int ks) {
+        auto stage_load = [&](Stage &st, int ks) {  // ks: K-step of the whole row
             ks = ks < nk ? ks : nk - 1;
             st.v0 = load1(ks, 0);
             st.v1 = load1(ks, 1);
@@ -171,8 +181,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
             store1(st.v3, 3);
         };
         // LDS -> registers for one K-step: A from this wave's slab, B from the resident query group
-        auto lds_read = [&](float4 (&av)[kTileK / 8], float4 (&bv)[kTileK / 8], int ks) {
-            ks = ks < nk ? ks : nk - 1;
+        auto lds_read = [&](float4 (&av)[kTileK / 8], float4 (&bv)[kTileK / 8], int ks) {  // ks: step within the phase
+            ks = ks < kps ? ks : kps - 1;
             const float *Ab = Aw + li * kTileLdA + 4 * half;
             const float *Bb = Bs + (li & (tq - 1)) * ldq + ks * kTileK + 4 * half;  // columns >= tq repeat, unused
 #pragma unroll
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
         __builtin_amdgcn_sched_barrier(0);                        \
         if (!(HG_TILE_ABLATE & 4)) stage_store(st);               \
         if (!(HG_TILE_ABLATE & 2)) lds_read(nav, nbv, (ks_) + 1); \
-        if (!(HG_TILE_ABLATE & 8)) stage_load(st, (ks_) + 3);     \
+        if (!(HG_TILE_ABLATE & 8)) stage_load(st, kb + (ks_) + 3); \
         __builtin_amdgcn_sched_barrier(0);                        \
         if (!(HG_TILE_ABLATE & 1)) {                              \
             mfma4(cav[1], cbv[1]);                                \
@@ -215,18 +225,27 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
         // this wave's row norms -> its LDS slot now; they are needed only after the K loop
         if (lane < 32) rnw[lane] = (a.metric == METRIC_COS && t0 + lane < r1) ? a.row_norms[t0 + lane] : 0.0f;
         float4 av0[kTileK / 8], bv0[kTileK / 8], av1[kTileK / 8], bv1[kTileK / 8];
-        stage_load(stA, 0);
-        stage_load(stB, 1);
-        stage_store(stA);
-        stage_load(stA, 2);
-        lds_read(av0, bv0, 0);
-        // entering step ks: cur regs = ks, the `st` passed in = ks+1, the other st = ks+2
-        int ks = 0;
-        for (; ks + 1 < nk; ks += 2) {
-            HG_TILE_STEP(av0, bv0, av1, bv1, stB, ks);
-            HG_TILE_STEP(av1, bv1, av0, bv0, stA, ks + 1);
+        for (int phase = 0; phase < nphase; phase++) {
+            const int kb = phase * kps;                          // first K-step of the phase
+            const int kn = nk - kb < kps ? nk - kb : kps;        // its K-steps
+            if (nphase > 1) {
+                __syncthreads();  // every wave has multiplied the previous phase (or tile): Bs may change
+                fill_queries(phase);
+                __syncthreads();
+            }
+            stage_load(stA, kb);
+            stage_load(stB, kb + 1);
+            stage_store(stA);
+            stage_load(stA, kb + 2);
+            lds_read(av0, bv0, 0);
+            // entering step ks: cur regs = ks, the `st` passed in = ks+1, the other st = ks+2
+            int ks = 0;
+            for (; ks + 1 < kn; ks += 2) {
+                HG_TILE_STEP(av0, bv0, av1, bv1, stB, ks);
+                HG_TILE_STEP(av1, bv1, av0, bv0, stA, ks + 1);
+            }
+            if (ks < kn) HG_TILE_STEP(av0, bv0, av1, bv1, stB, ks);
         }
-        if (ks < nk) HG_TILE_STEP(av0, bv0, av1, bv1, stB, ks);
 #undef HG_TILE_STEP
         // ---- epilogue: D[row i][query col]: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         if (HG_TILE_ABLATE & 16) asm volatile("" ::"v"(acc[0]), "v"(acc[15]));  // keep the chain alive

@@ -524,6 +524,25 @@ def test_ivf_many_equal_distances(eng, oracle, metric):
         assert_exact(ei, ed, oi, od, "ties exact %s" % metric)
 
 
+@pytest.mark.parametrize("dim", [900, 1536, 2500])
+def test_ivf_tile_path_several_k_phases(eng, oracle, dim):
+    """Rows longer than 896 floats: the query group is resident in LDS one 768-column phase at a time and is refilled
+    per tile and phase (2 / 2 / 4 phases here, the last one short and odd), with the tile's accumulators carried
+    across the phases.  Lists of several tiles with ragged ends, groups of 1 .. 32 queries, all on the MFMA tile path."""
+    O = oracle
+    base = _data(O, 2300, dim)
+    Q = _data(O, 70, dim, seed=43)
+    with eng.Index(base) as idx:
+        idx.ivf_build(5, 2, 42)
+        cen, off, lids = idx.get_ivf()
+        for nq, nprobe, k in [(70, 5, 10), (33, 2, 40), (7, 5, 3)]:
+            mode = _ivf_mode(O, O.COSINE, dim, nq, nprobe, 5)
+            assert mode == O.MODE_MFMA
+            ids, d = idx.ivf_search(Q[:nq], k, nprobe)
+            oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, mode=mode)
+            assert_exact(ids, d, oi, od, "dim=%d nq=%d nprobe=%d k=%d" % (dim, nq, nprobe, k))
+
+
 def test_ivf_ragged_lists_and_full_probe(eng, oracle):
     """Empty lists, a list holding almost everything, nprobe > nlist, k > candidates."""
     O = oracle
