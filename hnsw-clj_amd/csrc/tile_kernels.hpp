@@ -259,14 +259,31 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
                     uint64_t key = gr < r1 ? make_key(dv, static_cast<uint32_t>(gr - rb0)) : ~0ull;
                     best = key < best ? key : best;
                 }
-            } else {
+            }
+        }
+        if (!a.out_key && !(HG_TILE_ABLATE & 16)) {
+            // Dense output: query column c's distances to this wave's 32 rows are 32 CONSECUTIVE floats of c's
+            // candidate array.  In the MFMA layout a lane holds one column, so a store instruction would touch 64
+            // different arrays (64 four-byte segments); transposed through the wave's LDS slab (its K loop is
+            // over), lanes 0..31 / 32..63 write two 128-byte runs per instruction.
+            float *T = Aw;  // [32 columns][kTileLdA]: T[c][i] = distance of column c to row i
 #pragma unroll
-                for (int reg = 0; reg < 16; reg++) {
-                    int i = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                    int64_t gr = t0 + i;
-                    float dv = finish_dist(a.metric, acc[reg], qn, rnw[i]) + 0.0f;
-                    if (gr < r1) a.out[ob + (gr - rb0)] = dv;
-                }
+            for (int g4 = 0; g4 < 4; g4++) {
+                const int i = 8 * g4 + 4 * half;
+                float4 v;
+                v.x = finish_dist(a.metric, acc[4 * g4 + 0], qn, rnw[i + 0]) + 0.0f;
+                v.y = finish_dist(a.metric, acc[4 * g4 + 1], qn, rnw[i + 1]) + 0.0f;
+                v.z = finish_dist(a.metric, acc[4 * g4 + 2], qn, rnw[i + 2]) + 0.0f;
+                v.w = finish_dist(a.metric, acc[4 * g4 + 3], qn, rnw[i + 3]) + 0.0f;
+                *reinterpret_cast<float4 *>(T + li * kTileLdA + i) = v;
+            }
+            const int64_t gr = t0 + li;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int c = 2 * j + half;
+                const float dv = T[c * kTileLdA + li];
+                const int64_t obc = ob_s[c];
+                if (obc >= 0 && gr < r1) a.out[obc + (gr - rb0)] = dv;
             }
         }
     }
