@@ -48,6 +48,45 @@ __global__ __launch_bounds__(kWG) void probe_pairs_kernel(const uint32_t *ord, i
     if (qcnt && lane == 0) qcnt[q] = static_cast<int32_t>(carry);
 }
 
+// ---- execution order of the GEMV list scan: pairs sorted by the list they probe (counting sort in one workgroup;
+// the order inside a list is whatever the atomics give -- it only decides WHEN a pair runs, not what it computes)
+constexpr int kOrderMaxLists = 16384;  // LDS histogram: 64 KiB
+__global__ __launch_bounds__(1024) void pair_order_kernel(const int32_t *probes, int npairs, int nlist, int32_t *order) {
+    extern __shared__ int32_t ocnt[];  // [nlist + 1] (bucket nlist: pairs without a list), then [1024] scan scratch
+    int32_t *part = ocnt + nlist + 1;
+    const int tid = threadIdx.x, nb = nlist + 1;
+    for (int i = tid; i < nb; i += 1024) ocnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < npairs; i += 1024) {
+        const int l = probes[i];
+        atomicAdd(&ocnt[l >= 0 && l < nlist ? l : nlist], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the buckets: every thread a contiguous range, then the 1024 range sums
+    const int per = (nb + 1023) / 1024, lo = tid * per, hi = lo + per < nb ? lo + per : nb;
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += ocnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int add = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int i = lo; i < hi; i++) {
+        const int c = ocnt[i];
+        ocnt[i] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (int i = tid; i < npairs; i += 1024) {
+        const int l = probes[i];
+        order[atomicAdd(&ocnt[l >= 0 && l < nlist ? l : nlist], 1)] = i;
+    }
+}
+
 // ---- grouping of (query, probed list) pairs by list, for the tiled scan --------------------------------
 __global__ void ivf_hist_kernel(const int32_t *probes, int64_t npairs, int32_t *cnt) {
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -467,12 +506,22 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs > static_cast<int64_t>(idx->nlist));
     int32_t *probes_buf = d_out_probes;
     int32_t *qcnt_buf = nullptr;
-    if (use_tile) {
-        HG_TRY(idx->s_grp.ensure(sizeof(int32_t) * (npairs + nq + 16)));
+    // GEMV scan with enough pairs for lists to be probed twice: run the pairs in list order (see ScanArgs::order).
+    // Below half a pair per list there is next to nothing to share and the sort's ~10 us would be all cost.
+    static const int order_mode = []() {
+        const char *e = getenv("HNSWGPU_SCAN_ORDER");  // 0 = never (A/B)
+        return e ? atoi(e) : 1;
+    }();
+    const bool use_order = !use_tile && order_mode && idx->nlist <= kOrderMaxLists && npairs * 2 >= idx->nlist &&
+                           npairs <= (1 << 22);
+    int32_t *order_buf = nullptr;
+    if (use_tile || use_order) {
+        HG_TRY(idx->s_grp.ensure(sizeof(int32_t) * (2 * npairs + nq + 16)));
         if (!probes_buf) probes_buf = idx->s_grp.as<int32_t>();
-        qcnt_buf = idx->s_grp.as<int32_t>() + npairs;
-        HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
+        qcnt_buf = use_tile ? idx->s_grp.as<int32_t>() + npairs : nullptr;
+        order_buf = idx->s_grp.as<int32_t>() + npairs + nq + 16;
     }
+    if (use_tile) HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
     if (d_given_probes) {  // caller-chosen lists (the :turbo mode's random partitions, :271-272); -1 = none
         hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st,
                            reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff,
@@ -515,6 +564,16 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     if (use_tile) {
         HG_TRY(ivf_tile_scan(idx, d_Q, nq, k, nprobe, probes_buf, qcnt_buf, st));
     } else {
+        if (use_order) {
+            const size_t olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);
+            if (olds > 48 * 1024)
+                HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_order_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(olds)));
+            hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), olds, st, probes_buf, static_cast<int>(npairs),
+                               idx->nlist, order_buf);
+            HG_HIP(hipGetLastError());
+            a.order = order_buf;
+        }
         HG_TRY(scan_topk(idx, a, nq, nprobe, idx->max_list_len, st, PROF_IVF_SCAN,
                          std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1))));
     }

@@ -222,6 +222,10 @@ struct ScanArgs {
     int32_t metric;
     int32_t mode;
     const Pair *pairs;  // nullptr = implicit pairs
+    // optional execution order of the pairs (a permutation that puts the pairs probing the same list next to each
+    // other): with it, workgroups are dealt to the XCDs in runs of kScanRun neighbouring work items, so pairs that
+    // stream the same rows run side by side on ONE L2 and the second reader finds the first one's lines there
+    const int32_t *order;
     int32_t npairs;
     int32_t chunk_rows;
     int32_t nchunks;
@@ -235,6 +239,7 @@ struct ScanArgs {
 // ROLE only names the caller in profiler output (rocprofv3 groups dispatches by kernel name); the
 // code is identical for every role.
 constexpr int ROLE_LIST_SCAN = 0, ROLE_ROUTE = 1, ROLE_ASSIGN = 2, ROLE_SEED = 3, ROLE_EXACT = 4;
+constexpr int kScanRun = 8;  // neighbouring work items that share an XCD when ScanArgs::order is set
 
 template <int NCH, int RB, bool L2, int ROLE>
 __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
@@ -246,8 +251,19 @@ __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
     // chunk-major: every pair's chunk 0 first, then chunk 1, ...  Chunks past a short list's end are empty
     // workgroups; this order keeps them at the END of the dispatch instead of interleaved with working ones
     // (interleaved idle workgroups cost the tile kernel half its CU occupancy on k-means lists).
-    const int32_t pair = static_cast<int32_t>(bid % a.npairs);
-    const int32_t chunk = static_cast<int32_t>(bid / a.npairs);
+    int32_t pair, chunk;
+    if (a.order) {
+        // workgroup b runs on XCD b % 8: XCD x takes the runs x, x + 8, x + 16, ... of kScanRun work items each
+        // (work items stay chunk-major: [chunk][pair in list order])
+        const int64_t j = bid >> 3;
+        const int64_t item = ((j / kScanRun) * 8 + (bid & 7)) * kScanRun + j % kScanRun;
+        if (item >= static_cast<int64_t>(a.npairs) * a.nchunks) return;
+        pair = a.order[item % a.npairs];
+        chunk = static_cast<int32_t>(item / a.npairs);
+    } else {
+        pair = static_cast<int32_t>(bid % a.npairs);
+        chunk = static_cast<int32_t>(bid / a.npairs);
+    }
     int64_t rb0, rb1;
     int32_t qi;
     uint32_t ord_base;
