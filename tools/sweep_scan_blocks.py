@@ -31,11 +31,11 @@ if os.environ.get("BALANCED"):
 else:
     idx.ivf_build(nlist, 10, 42)
 idx.set_profiling(True)
-for nq in (8, 32, 96):
+for nq in (8, 16, 24, 32):
     Q = Qa[:nq].contiguous()
     res = {}
     for rep in range(4):
-        for blocks in (4096, 8192, 16384, 32768, 65536, 131072):
+        for blocks in (1024, 2048, 3072, 4096, 6144, 8192, 16384, 32768, 65536):
             os.environ["HNSWGPU_SCAN_BLOCKS"] = str(blocks)
             idx.ivf_search_dev(Q, K, nprobe)
             idx.get_profile(engine.PROF_IVF_SCAN, reset=True)
