@@ -295,7 +295,7 @@ int plan_chunks(int nch, int64_t max_rows, int64_t mean_rows, int64_t npairs, in
     // 4096-6144 workgroups is best for every small batch (batch 32: 0.348 ms against 0.43 at 32768 and 0.45 at 1024;
     // batch 16: 0.215 against 0.237; batch 8: 0.135 against 0.144) -- ~250 rows per workgroup, a query loaded once
     // per 8 loop trips, and 8x fewer partial lists for the merge
-    int64_t target_blocks = env_blocks > 0 ? env_blocks : (npairs <= 1536 ? 4096 : 16384);
+    int64_t target_blocks = env_blocks > 0 ? env_blocks : (npairs <= 4096 ? 4096 : 16384);
     int64_t want = (target_blocks + npairs - 1) / (npairs > 0 ? npairs : 1);
     if (want < 1) want = 1;
     if (want == 1) mean_rows = max_rows;  // already enough pairs: one workgroup per pair, no empty chunks
