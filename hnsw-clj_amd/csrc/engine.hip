@@ -281,7 +281,7 @@ void prof_end(hnswgpu_index *idx, int slot, hipStream_t st, hipEvent_t e0) {
     idx->prof_ev[slot].push_back({e0, e1});
 }
 
-int plan_chunks(int nch, int64_t max_rows, int64_t mean_rows, int64_t npairs, int32_t *chunk_rows) {
+int plan_chunks(int nch, int64_t max_rows, int64_t mean_rows, int64_t npairs, int32_t *chunk_rows, bool list_pairs) {
     // Enough NON-EMPTY workgroups to fill 256 CUs several times over, but no chunk below one loop trip
     // of every wave.  The chunk size comes from the MEAN segment length (short lists then simply leave
     // their trailing chunks empty -- those workgroups exit at once); the chunk count from the longest.
@@ -291,11 +291,13 @@ int plan_chunks(int nch, int64_t max_rows, int64_t mean_rows, int64_t npairs, in
     if (mean_rows > max_rows) mean_rows = max_rows;
     const char *env_e = getenv("HNSWGPU_SCAN_BLOCKS");  // tuning override (re-read per call: in-process sweeps)
     const int64_t env_blocks = env_e ? atoll(env_e) : 0LL;
-    // measured on 1M x 768 / 1024 k-means lists (tools/sweep_scan_blocks.py), pairs run in list order: a target of
-    // 4096-6144 workgroups is best for every small batch (batch 32: 0.348 ms against 0.43 at 32768 and 0.45 at 1024;
-    // batch 16: 0.215 against 0.237; batch 8: 0.135 against 0.144) -- ~250 rows per workgroup, a query loaded once
-    // per 8 loop trips, and 8x fewer partial lists for the merge
-    int64_t target_blocks = env_blocks > 0 ? env_blocks : (npairs <= 4096 ? 4096 : 16384);
+    // measured on 1M x 768 / 1024 k-means lists (tools/sweep_scan_blocks.py).  (query, list) pairs run in list
+    // order: a target of 4096-6144 workgroups is best for every small batch (batch 32: 0.348 ms against 0.43 at 32768
+    // and 0.45 at 1024; batch 16: 0.215 against 0.237; batch 8: 0.135 against 0.144) -- ~250 rows per workgroup, a
+    // query loaded once per 8 loop trips, 8x fewer partial lists for the merge.  One query streaming a whole table
+    // (k-means++ rounds, single-query exact kNN) wants the finest chunks instead: 473 us against 511 per 1M x 768 pass.
+    int64_t target_blocks = env_blocks > 0 ? env_blocks
+                                           : (list_pairs ? (npairs <= 4096 ? 4096 : 16384) : (npairs <= 1536 ? 32768 : 16384));
     int64_t want = (target_blocks + npairs - 1) / (npairs > 0 ? npairs : 1);
     if (want < 1) want = 1;
     if (want == 1) mean_rows = max_rows;  // already enough pairs: one workgroup per pair, no empty chunks
@@ -311,7 +313,8 @@ int scan_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_quer
               hipStream_t st, int prof_slot, int64_t mean_rows) {
     a.mode = MODE_TOPK;
     a.npairs = nq * pairs_per_query;
-    a.nchunks = plan_chunks(idx->nch, max_rows, mean_rows > 0 ? mean_rows : max_rows, a.npairs, &a.chunk_rows);
+    a.nchunks = plan_chunks(idx->nch, max_rows, mean_rows > 0 ? mean_rows : max_rows, a.npairs, &a.chunk_rows,
+                            a.pairs != nullptr);
     int64_t keys_per_query = static_cast<int64_t>(pairs_per_query) * a.nchunks * kNWave * a.k;
     HG_TRY(idx->s_partial.ensure(sizeof(uint64_t) * keys_per_query * nq));
     HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * a.k));

@@ -129,7 +129,8 @@ int launch_gather(int nch, GatherArgs a, int32_t nq, hipStream_t st);
 int scan_rows_per_iter(int nch);  // kNWave * RB
 
 // pick chunking for a scan: returns nchunks, sets chunk_rows
-int plan_chunks(int nch, int64_t max_rows, int64_t mean_rows, int64_t npairs, int32_t *chunk_rows);
+int plan_chunks(int nch, int64_t max_rows, int64_t mean_rows, int64_t npairs, int32_t *chunk_rows,
+                bool list_pairs = false);
 
 // scan + merge: per-query ascending top-k of (ord, dist) into s_ord / s_dist ([nq][k])
 int scan_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_query, int64_t max_rows,
