@@ -320,6 +320,9 @@ def ivf_roofline(engine, dev, args):
             "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch "
                         "(one GEMV per (query, probed list) pair)" % n,
             "traffic_note": "null: no PMC pass in this run (--no-pmc, N > 1 or rocprofv3 unavailable); profiles/ holds one",
+            "frac_note": "algorithmic bytes count a list once per (query, list) pair (SURVEY 8d); pairs of one batch that "
+                         "probe the same list run side by side on one XCD and share its L2, so frac can exceed 1 while the "
+                         "PMC traffic (and unique_bytes_GBs: every list counted once per batch) stays under the HBM rate",
             "avg_launch_ms": r["avg_scan_ms"], "algorithmic_bytes_per_launch": int(r["algorithmic_GB"] * 1e9),
             "unique_bytes_GBs": r["unique_GBs"], "batch_32": r,
             "batched_mfma": {"bound": "mfma", "kernel": "tile_scan_kernel (v_mfma_f32_32x32x2_f32)",
