@@ -70,10 +70,14 @@ int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, 
     return 0;
 }
 
-int launch_scan(int nch, const ScanArgs &a, hipStream_t st) {
+int launch_scan(int nch, const ScanArgs &a0, hipStream_t st) {
+    ScanArgs a = a0;
     int64_t blocks = static_cast<int64_t>(a.npairs) * a.nchunks;
     if (blocks <= 0) return 0;
-    if (a.order) blocks = (blocks + 8 * kScanRun - 1) / (8 * kScanRun) * (8 * kScanRun);  // whole runs on every XCD
+    if (a.order) {
+        if (a.run < 8) a.run = 8;
+        blocks = (blocks + 8 * a.run - 1) / (8 * a.run) * (8 * a.run);  // whole runs on every XCD
+    }
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "scan grid too large (%lld blocks)", (long long)blocks);
     size_t lds = a.mode == MODE_TOPK ? sizeof(uint64_t) * kNWave * a.k : 0;
     HG_REQUIRE(lds <= 64 * 1024, HNSWGPU_ELIMIT, "k too large for the scan kernel (k=%d)", a.k);

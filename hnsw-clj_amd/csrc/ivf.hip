@@ -574,6 +574,9 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
                                idx->nlist, order_buf);
             HG_HIP(hipGetLastError());
             a.order = order_buf;
+            // all the pairs of a list in one run (one XCD) while a run stays a small part of an XCD's share
+            a.run = 8;
+            while (a.run < 64 && static_cast<int64_t>(a.run) * idx->nlist < npairs) a.run *= 2;
         }
         HG_TRY(scan_topk(idx, a, nq, nprobe, idx->max_list_len, st, PROF_IVF_SCAN,
                          std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1))));

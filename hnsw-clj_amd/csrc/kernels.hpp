@@ -223,9 +223,10 @@ struct ScanArgs {
     int32_t mode;
     const Pair *pairs;  // nullptr = implicit pairs
     // optional execution order of the pairs (a permutation that puts the pairs probing the same list next to each
-    // other): with it, workgroups are dealt to the XCDs in runs of kScanRun neighbouring work items, so pairs that
+    // other): with it, workgroups are dealt to the XCDs in runs of `run` neighbouring work items, so pairs that
     // stream the same rows run side by side on ONE L2 and the second reader finds the first one's lines there
     const int32_t *order;
+    int32_t run;  // work items per run (a power of two, >= the mean number of pairs per list; set by the launcher)
     int32_t npairs;
     int32_t chunk_rows;
     int32_t nchunks;
@@ -239,7 +240,6 @@ struct ScanArgs {
 // ROLE only names the caller in profiler output (rocprofv3 groups dispatches by kernel name); the
 // code is identical for every role.
 constexpr int ROLE_LIST_SCAN = 0, ROLE_ROUTE = 1, ROLE_ASSIGN = 2, ROLE_SEED = 3, ROLE_EXACT = 4;
-constexpr int kScanRun = 8;  // neighbouring work items that share an XCD when ScanArgs::order is set
 
 template <int NCH, int RB, bool L2, int ROLE>
 __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
@@ -253,10 +253,10 @@ __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
     // (interleaved idle workgroups cost the tile kernel half its CU occupancy on k-means lists).
     int32_t pair, chunk;
     if (a.order) {
-        // workgroup b runs on XCD b % 8: XCD x takes the runs x, x + 8, x + 16, ... of kScanRun work items each
+        // workgroup b runs on XCD b % 8: XCD x takes the runs x, x + 8, x + 16, ... of a.run work items each
         // (work items stay chunk-major: [chunk][pair in list order])
         const int64_t j = bid >> 3;
-        const int64_t item = ((j / kScanRun) * 8 + (bid & 7)) * kScanRun + j % kScanRun;
+        const int64_t item = ((j / a.run) * 8 + (bid & 7)) * a.run + j % a.run;
         if (item >= static_cast<int64_t>(a.npairs) * a.nchunks) return;
         pair = a.order[item % a.npairs];
         chunk = static_cast<int32_t>(item / a.npairs);

@@ -1,5 +1,5 @@
 """Developer tool: list-scan kernel time and end-to-end time of batched IVF searches on the bench index
-(1M x 768, k-means lists, nprobe 32).  usage: [HNSWGPU_TILE_DBG=1] python tools/ivf_batch_time.py [nq ...]"""
+(1M x 768, k-means lists, nprobe 32).  usage: [METRIC=l2] [HNSWGPU_TILE_DBG=1] python tools/ivf_batch_time.py [nq ...]"""
 import os
 import sys
 import time
@@ -12,7 +12,8 @@ from hnsw_clj_amd import engine
 
 dev = torch.device("cuda", 0)
 x, Qa = bench.ivf_dataset(dev, 1_000_000, 1024, 4096)
-idx = engine.Index(x, "cosine", 0)
+metric = os.environ.get("METRIC", "cosine")   # METRIC=l2: no tile path, every batch size on the GEMV scan
+idx = engine.Index(x, metric, 0)
 del x
 idx.ivf_build(1024, 10, 42)
 for nq in [int(a) for a in sys.argv[1:]] or [256, 1024, 4096]:
