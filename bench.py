@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--ivf-n", type=int, default=1_000_000)
     ap.add_argument("--sharded", action="store_true", help="also run the row-sharded IVF search (always on for N > 1)")
     ap.add_argument("--shard-rows", type=int, default=1_250_000, help="rows per GPU of the sharded IVF index")
+    ap.add_argument("--hnsw-shard-rows", type=int, default=1_250_000,
+                    help="rows per GPU of the sharded 1536-d HNSW index (0 = skip that leg)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -245,6 +247,13 @@ def main():
             sh = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
             result["sharded_ivf"] = sh
+        if args.hnsw_shard_rows > 0:
+            try:
+                sh = sharded_hnsw(engine, dev, rank, world, args)
+            except Exception as e:  # same guard: a secondary leg never takes the headline number down
+                sh = {"error": "%s: %s" % (type(e).__name__, e)}
+            if rank == 0:
+                result["sharded_hnsw"] = sh
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if not args.no_cpu and rank == 0 and world == 1:
@@ -467,6 +476,65 @@ def sharded_ivf(engine, dev, rank, world, args):
                         "nprobe 32, all-gather of per-shard top-10 + merge" % (world * n, world, n),
             "qps": round(nq * steps / el, 1), "ms_per_batch": round(el / steps * 1e3, 3), "valid": ok,
             "ivf_build_s_per_shard": round(build_s, 1), "collective": "all_gather of %d B per rank" % (nq * K * 8)}
+
+
+def sharded_hnsw(engine, dev, rank, world, args):
+    """BASELINE.json configs[4]: 1536-d cosine HNSW, row-sharded (1.25M rows per GPU = 10M x 1536 on 8), one
+    independent sub-graph per GPU (= PartitionedHNSWIndex, partitioned_hnsw.clj:23-27, searched with the full k),
+    ef_search = 256, batch = 1024 queries replicated on every rank, ONE all-gather of the per-shard top-k and a merge
+    kernel.  Weak scaling in rows.  Data: the latent-manifold generator of the 31k leg (r = 32; torch, on the device);
+    queries are held-out draws from the same manifold.  Recall against exact kNN over ALL shards (same gather/merge)."""
+    from hnsw_clj_amd.sharded import ShardedSearcher
+
+    n, dim, r, ef, nq = args.hnsw_shard_rows, 1536, 32, 256, 1024
+
+    def manifold(gen, m, w):
+        out = torch.empty(m, dim, device=dev)
+        for i in range(0, m, 250_000):
+            c = min(250_000, m - i)
+            x = torch.randn(c, r, generator=gen, device=dev) @ w / r ** 0.5 + 0.1 * torch.randn(c, dim, generator=gen, device=dev)
+            out[i:i + c] = x / x.norm(dim=1, keepdim=True)
+        return out
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)                                  # the latent basis is global
+    w = torch.randn(r, dim, generator=g, device=dev)
+    g.manual_seed(2000 + rank)                         # every shard draws its own rows
+    x = manifold(g, n, w)
+    g.manual_seed(43)                                  # the same query batch on every rank
+    Q = manifold(g, nq, w)
+    idx = engine.Index(x, "cosine", dev.index)
+    del x
+    t0 = time.time()
+    idx.hnsw_build(M, EFC, 42)
+    build_s = time.time() - t0
+    s = ShardedSearcher(lambda q, k: idx.hnsw_search_dev(q, k, ef), rank * n)
+    truth = ShardedSearcher(lambda q, k: idx.exact_knn_dev(q, k), rank * n)
+    ti, _ = truth.search(Q[:256].contiguous(), K)
+    for _ in range(2):
+        ids, d = s.search(Q, K)
+    rec = recall_at_k(ids[:256], ti)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    steps = 10
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ids, d = s.search(Q, K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ok = bool((ids >= 0).all() and (ids < world * n).all() and (d[:, 1:] >= d[:, :-1]).all())
+    idx.close()
+    return {"workload": "hnsw (M=16, ef_construction=200) %d x 1536 cosine row-sharded over %d GPU(s) (%d rows, one sub-graph "
+                        "each), ef_search 256, batch 1024, all-gather of per-shard top-10 + merge" % (world * n, world, n),
+            "qps": round(nq * steps / el, 1), "ms_per_batch": round(el / steps * 1e3, 3), "recall_at_10": round(rec, 4),
+            "valid": ok, "hnsw_build_s_per_shard": round(build_s, 1), "collective": "all_gather of %d B per rank" % (nq * K * 8)}
 
 
 def cpu_baseline(idx, base, queries, ef):
