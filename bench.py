@@ -104,12 +104,17 @@ def main():
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if world == 1 and not args.no_ivf and not args.no_pmc and not profiled:
         traffic = pmc_traffic(args)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(torch.cuda.device_count(), 1)     # rehearsals may put several ranks on one GPU (local_rank >= ndev)
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1 or args.sharded:
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29517"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("HNSWGPU_BENCH_BACKEND", "nccl")   # "gloo": rehearse N ranks on fewer GPUs (RCCL refuses)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from hnsw_clj_amd import engine
@@ -119,7 +124,7 @@ def main():
     base = make_31k(args.dist, 42, N31K)
     queries = make_31k(args.dist, 43 + rank, args.nq)            # held-out, per-rank batch
     log("[rank %d] data %.1fs" % (rank, time.time() - t0))
-    idx = engine.Index(base, "cosine", local_rank)
+    idx = engine.Index(base, "cosine", dev.index)
     t0 = time.time()
     idx.hnsw_build(M, EFC, 42)
     build_s = time.time() - t0
