@@ -9,6 +9,7 @@
 
 #include "engine.hpp"
 #include "tile_kernels.hpp"
+#include "l2_kernels.hpp"
 
 namespace hg {
 
@@ -378,7 +379,10 @@ int end_call(hnswgpu_index *idx, hipStream_t st) {
     return 0;
 }
 
-bool tile_path_ok(const hnswgpu_index *idx) { return idx->metric != METRIC_L2 && idx->dim <= kTileMaxDim; }
+// the batched (query group resident in LDS) path: MFMA tiles for cosine / dot, the register-row VALU kernel for L2
+bool tile_path_ok(const hnswgpu_index *idx) {
+    return idx->metric == METRIC_L2 ? idx->dim <= kL2MaxDim : idx->dim <= kTileMaxDim;
+}
 
 int tile_mode() {
     static const int m = []() {
@@ -397,6 +401,29 @@ int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t s
     // list per XCD), so the grid must cover 8 * ceil(nitems / 8) workgroups, not just nitems
     if (a.members) blocks = (blocks + 7) & ~7LL;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "tile grid too large");
+    if (a.metric == METRIC_L2) {  // same groups, work list and outputs; rows in registers instead of MFMA tiles
+        const size_t l2lds = l2_group_lds_bytes(a.ld);
+        const int nch = static_cast<int>((a.ld / 4 + kWave - 1) / kWave);
+        HG_REQUIRE(nch >= 1 && nch <= 4, HNSWGPU_ELIMIT, "L2 group scan supports dim <= %d", kL2MaxDim);
+        TileArgs b2 = a;
+        b2.dbg = 0;
+        b2.dbg_buf = nullptr;
+#define CALL_L2(N, R)                                                                                            \
+    do {                                                                                                         \
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_group_kernel<N, R>),                       \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                     \
+        hipLaunchKernelGGL((l2_group_kernel<N, R>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), l2lds, st, b2); \
+    } while (0)
+        switch (nch) {
+            case 1: CALL_L2(1, 8); break;
+            case 2: CALL_L2(2, 8); break;
+            case 3: CALL_L2(3, 8); break;
+            default: CALL_L2(4, 4); break;
+        }
+#undef CALL_L2
+        HG_HIP(hipGetLastError());
+        return 0;
+    }
     size_t lds = tile_lds_bytes(dim);
     static bool attr_done[64] = {};
     if (attr_needed(attr_done)) {
