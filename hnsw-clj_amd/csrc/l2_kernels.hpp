@@ -7,7 +7,8 @@
 // outputs as tile_scan_kernel (TileArgs) -- and every wave holds RB rows in registers and walks the group's queries
 // over them: a row is fetched once per GROUP, the work per (row, query) pair is the GEMV kernel's own
 // lane_partial + wave_sum + sqrt, so the distances are bit-identical to scan_kernel's (oracle mode DEV).
-// VALU-bound: ~36 instructions per (row, query) pair and wave.
+// VALU-bound (63 % of the VALU issue rate by SQ_INSTS_VALU at batch 1024); pairing rows for v_pk_add_f32 /
+// v_pk_fma_f32 changed neither the counted instructions nor the time and was dropped.
 #pragma once
 #include "kernels.hpp"
 #include "tile_args.hpp"
@@ -90,18 +91,18 @@ __global__ __launch_bounds__(kTileThreads) void l2_group_kernel(TileArgs a) {
         const int total = cnt * nvec;
         for (int f0 = tid; f0 < total; f0 += kTileThreads * kQU) {
             float4 v[kQU];
+            int fc[kQU];
 #pragma unroll
-            for (int u = 0; u < kQU; u++) {
-                int f = f0 + u * kTileThreads;
-                f = f < total ? f : total - 1;
-                const int slot = f / nvec, c4 = f - slot * nvec;
+            for (int u = 0; u < kQU; u++) {  // clamped, unconditional: all loads of a thread in flight together
+                const int f = f0 + u * kTileThreads;
+                fc[u] = f < total ? f : total - 1;
+                const int slot = fc[u] / nvec, c4 = fc[u] - slot * nvec;
                 v[u] = reinterpret_cast<const float4 *>(a.Qp + static_cast<int64_t>(qi_s[slot]) * a.ld)[c4];
             }
+            // ... and unconditional stores: an index past the end re-writes element total - 1 with its own value
+            // (a store under `f < total` let the compiler sink each load into its branch: load, wait, store, 16 times)
 #pragma unroll
-            for (int u = 0; u < kQU; u++) {
-                const int f = f0 + u * kTileThreads;
-                if (f < total) Bs[f] = v[u];  // slot * nvec + c4 == f
-            }
+            for (int u = 0; u < kQU; u++) Bs[fc[u]] = v[u];  // slot * nvec + c4 == f
         }
     }
     __syncthreads();

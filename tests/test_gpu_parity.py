@@ -543,6 +543,37 @@ def test_ivf_tile_path_several_k_phases(eng, oracle, dim):
             assert_exact(ids, d, oi, od, "dim=%d nq=%d nprobe=%d k=%d" % (dim, nq, nprobe, k))
 
 
+@pytest.mark.parametrize("dim", [7, 100, 300, 768, 1000, 1100])
+def test_l2_batched_group_scan(eng, oracle, dim):
+    """Euclidean metric, batches large enough for the group path: the query group resident in LDS, rows in registers
+    (l2_group_kernel, dim <= 1024; dim 1100 stays on the GEMV scan).  Same arithmetic as the GEMV kernel, so every
+    result equals the oracle's device-order mode bit for bit: exact kNN, k-means assignment (fused argmin), dense
+    distances and IVF search over ragged multi-chunk lists."""
+    O = oracle
+    base = _data(O, 2100, dim)
+    base[40:60] = base[40]                                     # exact zeros and ties
+    Q = np.vstack([_data(O, 38, dim, seed=43), base[40:42]]).astype(np.float32)
+    with eng.Index(base, "l2") as idx:
+        ei, ed = idx.exact_knn(Q, 12)
+        oi, od, _ = O.exact_knn(base, Q, 12, metric=O.L2, mode=O.MODE_DEV)
+        assert_exact(ei, ed, oi, od, "l2 exact dim=%d" % dim)
+        assert ed[38, 0] == 0.0 and ed[39, 0] == 0.0             # d(x, x) = 0 exactly (core_test.clj:9-31)
+        cen = _data(O, 45, dim, seed=5)
+        a, ad = idx.kmeans_assign(cen)
+        oa, oad = O.kmeans_assign_f32(base, cen, O.L2, O.MODE_DEV)
+        np.testing.assert_array_equal(a, oa)
+        np.testing.assert_array_equal(ad.view(np.uint32), oad.view(np.uint32))
+        dd = idx.dense_distances(Q[:20])
+        want = _dense_oracle(O, base, Q[:20], O.L2, O.MODE_DEV)
+        np.testing.assert_array_equal(dd.view(np.uint32), want.astype(np.float32).view(np.uint32))
+        idx.ivf_build(6, 2, 42)
+        cen, off, lids = idx.get_ivf()
+        for nq, nprobe, k in [(40, 6, 10), (17, 3, 64), (5, 6, 200)]:
+            ids, d = idx.ivf_search(Q[:nq], k, nprobe)
+            oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=O.L2, mode=O.MODE_DEV)
+            assert_exact(ids, d, oi, od, "l2 ivf dim=%d nq=%d nprobe=%d k=%d" % (dim, nq, nprobe, k))
+
+
 def test_ivf_ragged_lists_and_full_probe(eng, oracle):
     """Empty lists, a list holding almost everything, nprobe > nlist, k > candidates."""
     O = oracle
