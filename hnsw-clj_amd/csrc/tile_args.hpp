@@ -13,7 +13,7 @@
 // MFMA carries k = 8t+j, half 1 carries k = 8t+4+j, and the instruction adds half 0's product first.
 // Norms are the same sqrt(reduce(v.v)) values as everywhere else (row_norms_kernel).
 // Cosine and dot only: rooted L2 from |q|^2+|v|^2-2q.v would lose the exact zeros the reference's
-// tests pin, so L2 stays on scan_kernel.
+// tests pin, so L2 batches run l2_group_kernel (l2_kernels.hpp: same groups and outputs, GEMV arithmetic).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
