@@ -29,6 +29,7 @@ constexpr int kTileLdA = kTileK + 4;  // padded LDS row of the A (rows) tile: co
 constexpr int kTileMaxDim = 3072;     // rows up to this length are supported by the callers' row loaders
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // The query group is resident in LDS one K-PHASE at a time: all of K when a row has at most 28 K-steps (dim <= 896),
 // otherwise phases of 24 K-steps (768 columns, the 96 KiB a 32-query group may take).  A tile's accumulators

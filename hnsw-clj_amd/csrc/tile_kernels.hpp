@@ -137,6 +137,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     const int64_t ob = li < tq ? ob_s[li] : -1;
     const float qn = li < tq ? qn_s[li] : 0.0f;
     uint64_t best = ~0ull;  // argmin mode: best (distance, row) of query column li over this wave's rows
+    uint64_t best16 = ~0ull;  // ... of column lane & 15 in the narrow (<= 16 queries) layout
     for (int64_t tb = r0; tb < r1; tb += kTileRows) {
         const int64_t t0 = tb + wave * 32;  // this wave's 32 rows of the 256-row tile
         // single phase: no barrier below, a wave without rows in this tile (ragged chunk end) is done; several
@@ -224,6 +225,116 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     } while (0)
         // this wave's row norms -> its LDS slot now; they are needed only after the K loop
         if (lane < 32) rnw[lane] = (a.metric == METRIC_COS && t0 + lane < r1) ? a.row_norms[t0 + lane] : 0.0f;
+        if (cnt <= 16) {
+            // ---- narrow groups (<= 16 queries): v_mfma_f32_16x16x4_f32, two 16-row blocks x 16 columns per wave, half
+            //      the matrix-core time of the 32-column tile whose other columns would be empty.  Lane l = (i = l & 15,
+            //      s = l >> 4) carries k-slot s of A[i][.] / B[.][i]; the slots are fed k = 8t + {0, 4, 1, 5} and then
+            //      8t + {2, 6, 3, 7}: the same f32 chain over k as the wide tile (hardware-checked bit for bit,
+            //      tools/micro/mfma16_order.hip), so the oracle's MFMA-order mode covers both.
+            const int i16 = lane & 15, ksl = lane >> 4, kq = 4 * (ksl & 1);
+            const bool khi = (ksl >> 1) != 0;
+            f32x4v accA, accB;  // rows 0..15 and 16..31 of this wave's 32
+#pragma unroll
+            for (int i = 0; i < 4; i++) accA[i] = accB[i] = 0.0f;
+            // one K-step's operands after the k-slot selection: [t][u] = element for MFMA u of block t
+            float na0[4][2], na1[4][2], nb[4][2], ca0[4][2], ca1[4][2], cb[4][2];
+            auto lds_read16 = [&](float (&a0)[4][2], float (&a1)[4][2], float (&b)[4][2], int ks) {
+                ks = ks < kps ? ks : kps - 1;
+                const float *A0 = Aw + i16 * kTileLdA + kq, *A1 = Aw + (16 + i16) * kTileLdA + kq;
+                const float *B0 = Bs + i16 * ldq + ks * kTileK + kq;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float4 x = *reinterpret_cast<const float4 *>(A0 + 8 * t);
+                    const float4 y = *reinterpret_cast<const float4 *>(A1 + 8 * t);
+                    const float4 z = *reinterpret_cast<const float4 *>(B0 + 8 * t);
+                    a0[t][0] = khi ? x.y : x.x;
+                    a0[t][1] = khi ? x.w : x.z;
+                    a1[t][0] = khi ? y.y : y.x;
+                    a1[t][1] = khi ? y.w : y.z;
+                    b[t][0] = khi ? z.y : z.x;
+                    b[t][1] = khi ? z.w : z.z;
+                }
+            };
+            auto mfma16 = [&](const float (&a0)[4][2], const float (&a1)[4][2], const float (&b)[4][2], int t) {
+                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t][0], b[t][0], accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][0], b[t][0], accB, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t][1], b[t][1], accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][1], b[t][1], accB, 0, 0, 0);
+            };
+#define HG_TILE_STEP16(ca0_, ca1_, cb_, na0_, na1_, nb_, st, ks_)       \
+    do {                                                               \
+        mfma16(ca0_, ca1_, cb_, 0);                                    \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        stage_store(st);                                               \
+        lds_read16(na0_, na1_, nb_, (ks_) + 1);                        \
+        stage_load(st, kb + (ks_) + 3);                                \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        mfma16(ca0_, ca1_, cb_, 1);                                    \
+        mfma16(ca0_, ca1_, cb_, 2);                                    \
+        mfma16(ca0_, ca1_, cb_, 3);                                    \
+        __builtin_amdgcn_sched_barrier(0);                             \
+    } while (0)
+            for (int phase = 0; phase < nphase; phase++) {
+                const int kb = phase * kps;
+                const int kn = nk - kb < kps ? nk - kb : kps;
+                if (nphase > 1) {
+                    __syncthreads();
+                    fill_queries(phase);
+                    __syncthreads();
+                }
+                stage_load(stA, kb);
+                stage_load(stB, kb + 1);
+                stage_store(stA);
+                stage_load(stA, kb + 2);
+                lds_read16(ca0, ca1, cb, 0);
+                int ks = 0;
+                for (; ks + 1 < kn; ks += 2) {
+                    HG_TILE_STEP16(ca0, ca1, cb, na0, na1, nb, stB, ks);
+                    HG_TILE_STEP16(na0, na1, nb, ca0, ca1, cb, stA, ks + 1);
+                }
+                if (ks < kn) HG_TILE_STEP16(ca0, ca1, cb, na0, na1, nb, stB, ks);
+            }
+#undef HG_TILE_STEP16
+            // epilogue: lane (i16, ksl) holds D[4 ksl + r][i16] in accA[r] and D[16 + 4 ksl + r][i16] in accB[r]
+            const int64_t ob16 = ob_s[i16];
+            const float qn16 = qn_s[i16];
+            if (a.out_key) {
+                if (ob16 >= 0) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const int i = (r < 4 ? 0 : 16) + 4 * ksl + (r & 3);
+                        const int64_t gr = t0 + i;
+                        const float dv = finish_dist(a.metric, r < 4 ? accA[r & 3] : accB[r & 3], qn16, rnw[i]);
+                        const uint64_t key = gr < r1 ? make_key(dv, static_cast<uint32_t>(gr - rb0)) : ~0ull;
+                        best16 = key < best16 ? key : best16;
+                    }
+                }
+            } else {
+                float *T = Aw;  // [16 columns][kTileLdA]: T[c][i] = distance of column c to row i
+                float4 v;
+                int i = 4 * ksl;
+                v.x = finish_dist(a.metric, accA[0], qn16, rnw[i + 0]) + 0.0f;
+                v.y = finish_dist(a.metric, accA[1], qn16, rnw[i + 1]) + 0.0f;
+                v.z = finish_dist(a.metric, accA[2], qn16, rnw[i + 2]) + 0.0f;
+                v.w = finish_dist(a.metric, accA[3], qn16, rnw[i + 3]) + 0.0f;
+                *reinterpret_cast<float4 *>(T + i16 * kTileLdA + i) = v;
+                i = 16 + 4 * ksl;
+                v.x = finish_dist(a.metric, accB[0], qn16, rnw[i + 0]) + 0.0f;
+                v.y = finish_dist(a.metric, accB[1], qn16, rnw[i + 1]) + 0.0f;
+                v.z = finish_dist(a.metric, accB[2], qn16, rnw[i + 2]) + 0.0f;
+                v.w = finish_dist(a.metric, accB[3], qn16, rnw[i + 3]) + 0.0f;
+                *reinterpret_cast<float4 *>(T + i16 * kTileLdA + i) = v;
+                const int64_t gr = t0 + li;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int c = 2 * j + half;
+                    const float dv = T[c * kTileLdA + li];
+                    const int64_t obc = ob_s[c];
+                    if (obc >= 0 && gr < r1) a.out[obc + (gr - rb0)] = dv;
+                }
+            }
+            continue;
+        }
         float4 av0[kTileK / 8], bv0[kTileK / 8], av1[kTileK / 8], bv1[kTileK / 8];
         for (int phase = 0; phase < nphase; phase++) {
             const int kb = phase * kps;                          // first K-step of the phase
@@ -287,7 +398,14 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
             }
         }
     }
-    if (a.out_key && ob >= 0) {  // lanes li and li + 32 hold the two row-halves of query column li
+    if (a.out_key && cnt <= 16) {  // narrow layout: lanes i16 + 16 s, s = 0..3, hold four row quarters of column i16
+        uint64_t other = __shfl_xor(best16, 16, kWave);
+        best16 = other < best16 ? other : best16;
+        other = __shfl_xor(best16, 32, kWave);
+        best16 = other < best16 ? other : best16;
+        if (lane < 16 && ob_s[lane] >= 0 && best16 != ~0ull)
+            atomicMin(a.out_key + (static_cast<int64_t>(g) * tq + lane), best16);
+    } else if (a.out_key && ob >= 0) {  // lanes li and li + 32 hold the two row-halves of query column li
         const uint64_t other = __shfl_xor(best, 32, kWave);
         best = other < best ? other : best;
         if (half == 0 && best != ~0ull) atomicMin(a.out_key + (static_cast<int64_t>(g) * tq + li), best);
