@@ -498,13 +498,13 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     memset(&a, 0, sizeof(a));
     HG_TRY(idx->s_pairs.ensure(sizeof(Pair) * static_cast<size_t>(nq) * nprobe));
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
-    // tiled (MFMA) list scan once the batch holds more than 2.75 (query, list) pairs per list: the GEMV scan streams a
+    // tiled (MFMA) list scan once the batch holds more than 2 (query, list) pairs per list: the GEMV scan streams a
     // list once per pair (pairs of one list side by side on one L2, see ScanArgs::order), the tile scan once per
-    // group of <= 32 pairs but at ~4.7 TB/s.  Measured on 1M x 768 / 1024 lists / nprobe 32 (tools/ivf_batch_time.py,
-    // GEMV vs tiled, end to end): batch 32: 0.42 vs 0.56 ms; 48: 0.52 vs 0.64; 64: 0.67 vs 0.72; 80: 0.73 vs 0.77;
-    // 96: 0.82 vs 0.76; 128: 1.03 vs 0.77.
+    // group of <= 32 pairs but at ~5 TB/s.  Measured on 1M x 768 / 1024 lists / nprobe 32 (tools/ivf_batch_time.py,
+    // GEMV vs tiled, end to end): batch 32: 0.42 vs 0.56 ms; 48: 0.54 vs 0.61; 64: 0.64 vs 0.64; 80: 0.72 vs 0.65;
+    // 96: 0.82 vs 0.71; 128: 1.03 vs 0.71.
     const int tm = tile_mode();
-    const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs * 4 > 11LL * idx->nlist);
+    const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs > 2LL * idx->nlist);
     int32_t *probes_buf = d_out_probes;
     int32_t *qcnt_buf = nullptr;
     // GEMV scan with enough pairs for lists to be probed twice: run the pairs in list order (see ScanArgs::order).

@@ -31,8 +31,8 @@ def eng(native_lib):
 
 def _ivf_mode(O, metric, dim, nq, nprobe, nlist):
     """Which kernel serves an IVF search (ivf.hip: ivf_search_enqueue): the MFMA tile path once the batch has
-    more than 2.75 (query, list) pairs per list (cosine / dot), else the GEMV scan."""
-    tiled = metric != O.L2 and dim <= 3072 and nq * min(nprobe, nlist) * 4 > 11 * nlist
+    more than 2 (query, list) pairs per list (cosine / dot), else the GEMV scan."""
+    tiled = metric != O.L2 and dim <= 3072 and nq * min(nprobe, nlist) > 2 * nlist
     return O.MODE_MFMA if tiled else O.MODE_DEV
 
 
