@@ -410,8 +410,10 @@ int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t s
         b2.dbg_buf = nullptr;
 #define CALL_L2(N, R)                                                                                            \
     do {                                                                                                         \
-        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_group_kernel<N, R>),                       \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                     \
+        static bool l2_attr_done[64] = {};                                                                       \
+        if (attr_needed(l2_attr_done))                                                                           \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_group_kernel<N, R>),                   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
         hipLaunchKernelGGL((l2_group_kernel<N, R>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), l2lds, st, b2); \
     } while (0)
         switch (nch) {
