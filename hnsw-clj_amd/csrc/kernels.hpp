@@ -465,6 +465,10 @@ struct HnswArgs {
     uint32_t *vis;
     int64_t vis_stride;
     uint32_t gen_base;
+    // optional [nq]: set to 1 when the list ran out of ghost slots for query q -- more than cap - ef unexpanded
+    // candidates tied with the ef-th distance at once; the surplus ties are not expanded (the reference would expand
+    // them), so the host entry point repeats such queries with a larger list
+    int32_t *overflow;
     unsigned long long *dbg;  // -DHG_HNSW_STAMPS diagnostic builds only: per-phase s_memrealtime totals
 };
 
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
     int32_t *posA = part + NW * kWave;  // [cap] merged position of every list entry
     uint32_t *bits = reinterpret_cast<uint32_t *>(posA + a.cap);
     uint32_t *stamps = VG ? a.vis + static_cast<int64_t>(blockIdx.x) * a.vis_stride : nullptr;
-    // sc[0]=cursor sc[1]=ncand sc[2]=nadmit sc[3]=minP sc[4]=worst bits sc[5]=nghost
+    // sc[0]=cursor sc[1]=ncand sc[2]=nadmit sc[3]=minP sc[4]=worst bits sc[5]=nghost sc[6]=ghost overflow (per query)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
@@ -522,6 +526,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
         const unsigned long long st_w0 = st_prev, st_c0 = clock64();
 #endif
         __syncthreads();  // the previous query's result readers are done with the lists
+        if (tid == 0) sc[6] = 0;
         // seed: the entry point (ultra_fast.clj:358-359)
         {
             float4 r[NCH];
@@ -724,6 +729,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                         const int P = posA[i];
                         if (P < a.cap) curB[P] = e;
                         gh = full && P >= ef_l && P < a.cap && e.x == wbits;
+                        if (full && P >= a.cap && e.x == wbits && !(e.y & kExpanded)) sc[6] = 1;  // a tie with no slot left
                     }
                     ghosts += __popcll(__ballot(gh));
                 }
@@ -734,6 +740,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                         if (P >= 0) {
                             if (P < a.cap) curB[P] = make_uint2(static_cast<uint32_t>(cbits), static_cast<uint32_t>(cand_id[tid]));
                             gh = full && P >= ef_l && P < a.cap && static_cast<uint32_t>(cbits) == wbits;
+                            if (full && P >= a.cap && static_cast<uint32_t>(cbits) == wbits) sc[6] = 1;
                         }
                     }
                     if (wave == 0) ghosts += __popcll(__ballot(gh));
@@ -774,6 +781,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
         if (a.dbg && tid == 0 && qi == 0)
             for (int i = 0; i < 12; i++) a.dbg[i] = i == 7 ? static_cast<unsigned long long>(n_hop) : st_acc[i];
 #endif
+        if (a.overflow && tid == 0) a.overflow[qi] = sc[6];  // ordered after the last merge by its closing barrier
         if (a.stats && tid == 0) {
             a.stats[2 * static_cast<int64_t>(qi)] = n_eval;
             a.stats[2 * static_cast<int64_t>(qi) + 1] = n_hop;

@@ -101,7 +101,12 @@ int hnswgpu_exact_knn_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int3
  * seam of BatchSearchIndex/search-batch* (api/protocol.clj:58-67) and parallel-search-futures
  * (helper/parallel_search.clj:15-49).  ef is explicit; the reference's value is max(k, 50)
  * (ultra_fast.clj:355): pass ef <= 0 to get it.  stats (optional, nq x 2 int64): distance
- * evaluations and expansions per query. */
+ * evaluations and expansions per query.
+ * Ties: the reference still expands a candidate whose distance EQUALS the current ef-th distance
+ * (ultra_fast.clj:175-178, `<=`).  The traversal kernel keeps up to 32 such evicted-but-tied candidates per
+ * query; hnswgpu_hnsw_search repeats a query that had more (hundreds of duplicated rows) with the largest
+ * candidate list the LDS holds, so its results and counters are the reference's; the asynchronous
+ * hnswgpu_hnsw_search_dev does not, and leaves the surplus ties unexpanded. */
 int hnswgpu_set_graph(hnswgpu_index *idx, const int32_t *levels, const int32_t *l0_adj, int32_t M0,
                       const int64_t *up_off, const int32_t *up_adj, int32_t M, int32_t entry, int32_t max_level);
 int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, int64_t seed);

@@ -271,24 +271,54 @@ def test_hnsw_build_linker_threads_do_not_change_the_graph(eng, oracle, monkeypa
     assert ((graphs[0].l0_adj >= 0).sum(1) >= 1).all()
 
 
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+def test_hnsw_hundreds_of_tied_candidates(eng, oracle, metric):
+    """500 copies of one row: far more unexpanded candidates tie with the ef-th distance than the traversal
+    kernel's 32 ghost slots hold.  The reference still expands every one of them (ultra_fast.clj:175-178 uses <=), so
+    the synchronous entry point repeats such queries with the largest list the LDS holds: ids, distances AND the
+    traversal counters (distance evaluations, expansions) equal the oracle's."""
+    O = oracle
+    m = {"cosine": O.COSINE, "dot": O.DOT, "l2": O.L2}[metric]
+    rs = np.random.RandomState(9)
+    base = _data(O, 3000, 48, "clustered", num_clusters=6, noise_level=0.4)
+    dup = rs.choice(3000, 500, replace=False)
+    base[dup] = base[dup[0]]
+    Q = np.vstack([base[dup[:2]], _data(O, 6, 48, seed=43)]).astype(np.float32)
+    g = O.hnsw_build(base, m, M=5, ef_construction=40, seed=3, mode=O.MODE_DEV)
+    with eng.Index(base, metric) as idx:
+        idx.set_graph(g)
+        for ef, k in [(50, 10), (7, 3), (300, 70)]:
+            ids, d, st = idx.hnsw_search(Q, k, ef, want_stats=True)
+            oi, od, ost, _ = O.hnsw_search(base, g, Q, k, ef=max(ef, k), metric=m, mode=O.MODE_DEV)
+            assert_exact(ids, d, oi, od, "ties %s ef=%d" % (metric, ef))
+            np.testing.assert_array_equal(st, ost, err_msg="ties %s ef=%d" % (metric, ef))
+
+
 def test_randomised_differential(eng, oracle):
     """40 random configurations (size, dim, metric, M, ef, k, nlist, nprobe, batch): every search entry point of
     the C ABI against the oracle's matching device-order mode, bit for bit."""
     O = oracle
-    rs = np.random.RandomState(2026)
+    # HNSWGPU_SOAK=<n>: n more seeds with larger batches / dims (a soak run before a release, not part of the suite)
+    soak = int(os.environ.get("HNSWGPU_SOAK", "0"))
+    for seed in [2026] + [3000 + i for i in range(soak)]:
+        _differential_cases(eng, O, seed, big=seed != 2026)
+
+
+def _differential_cases(eng, O, seed, big):
+    rs = np.random.RandomState(seed)
     for case in range(40):
-        n = int(rs.choice([3, 17, 64, 200, 777, 1500]))
-        dim = int(rs.choice([1, 2, 7, 16, 33, 96, 130, 260, 400]))
+        n = int(rs.choice([3, 17, 64, 200, 777, 1500] + ([4000] if big else [])))
+        dim = int(rs.choice([1, 2, 7, 16, 33, 96, 130, 260, 400] + ([768, 1000, 1300] if big else [])))
         metric = int(rs.choice([O.COSINE, O.L2, O.DOT]))
         dist = str(rs.choice(["gaussian", "uniform", "clustered"]))
         base = _data(O, n, dim, dist, seed=100 + case, num_clusters=4, noise_level=0.3)
         if rs.rand() < 0.3:
             base[rs.randint(0, n, max(1, n // 10))] = base[0]            # duplicates -> exact ties
-        nq = int(rs.choice([1, 2, 5, 19, 40]))
+        nq = int(rs.choice([1, 2, 5, 19, 40] + ([33, 70, 150] if big else [])))
         Q = np.vstack([_data(O, nq, dim, dist, seed=500 + case, num_clusters=4, noise_level=0.3)])
         Q[0] = base[min(1, n - 1)]
         k = int(rs.choice([1, 3, 10, 70]))
-        tag = "case %d n=%d dim=%d metric=%d nq=%d k=%d" % (case, n, dim, metric, nq, k)
+        tag = "seed %d case %d n=%d dim=%d metric=%d nq=%d k=%d" % (seed, case, n, dim, metric, nq, k)
         with eng.Index(base, metric) as idx:
             # HNSW on an oracle-built graph
             M = int(rs.choice([2, 5, 16]))
