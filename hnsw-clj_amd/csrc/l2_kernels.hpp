@@ -6,7 +6,7 @@
 // for cosine).  Here a workgroup keeps a group of up to 32 queries resident in LDS -- the same groups, work list and
 // outputs as tile_scan_kernel (TileArgs) -- and every wave holds RB rows in registers and walks the group's queries
 // over them: a row is fetched once per GROUP, the work per (row, query) pair is the GEMV kernel's own
-// lane_partial + wave_sum + sqrt, so the distances are bit-identical to scan_kernel's (oracle mode DEV).
+// lane_partial + wave_sum + sqrt, so the distances are bit-identical to scan_kernel's (oracle/oracle.c "device order").
 // VALU-bound (63 % of the VALU issue rate by SQ_INSTS_VALU at batch 1024); pairing rows for v_pk_add_f32 /
 // v_pk_fma_f32 changed neither the counted instructions nor the time and was dropped.
 #pragma once
