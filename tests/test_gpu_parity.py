@@ -463,6 +463,30 @@ def test_ivf_build_exact_in_engine_arithmetic(eng, oracle, n, dim, nlist, metric
         np.testing.assert_array_equal(gc.view(np.uint32), cen.view(np.uint32))
 
 
+@pytest.mark.skipif(not os.environ.get("HNSWGPU_SOAK"), reason="soak run: HNSWGPU_SOAK=<configs>")
+def test_ivf_build_soak(eng, oracle):
+    """Random (n, dim, nlist, metric): the device k-means build against the restatement of its arithmetic, as above."""
+    O = oracle
+    rs = np.random.RandomState(77)
+    for case in range(int(os.environ["HNSWGPU_SOAK"])):
+        n = int(rs.choice([150, 900, 2600, 5000]))
+        dim = int(rs.choice([3, 33, 100, 260, 768, 1000]))
+        nlist = int(rs.choice([2, 9, 33, 70]))
+        metric = int(rs.choice([O.COSINE, O.L2, O.DOT]))
+        base = _data(O, n, dim, "clustered", num_clusters=7, noise_level=0.5, seed=600 + case)
+        tag = "case %d n=%d dim=%d nlist=%d metric=%d" % (case, n, dim, nlist, metric)
+        chosen, cen, assign = O.ivf_build_dev(base, nlist, 2, metric, 42)
+        with eng.Index(base, metric) as idx:
+            np.testing.assert_array_equal(idx.kmeanspp(nlist, 42), chosen, err_msg=tag)
+            idx.ivf_build(nlist, 2, 42)
+            gc, off, lids = idx.get_ivf()
+            got = np.empty(n, np.int32)
+            for l in range(nlist):
+                got[lids[off[l]:off[l + 1]]] = l
+            np.testing.assert_array_equal(got, assign, err_msg=tag)
+            np.testing.assert_array_equal(gc.view(np.uint32), cen.view(np.uint32), err_msg=tag)
+
+
 def test_ivf_large_batch_tiled_scan(eng, oracle):
     """nq * nprobe >= 4 * nlist: the (query, list) pairs are grouped by list and scanned by the MFMA tile
     kernel (routing included).  Bit-exact against the oracle's MFMA-order mode; groups of 32 overflow
