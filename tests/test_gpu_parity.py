@@ -859,6 +859,44 @@ def _stable_topk(ids, d, k):
     return oi, od
 
 
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+def test_ivf_search_given_lists_exact(eng, oracle, metric):
+    """hnswgpu_ivf_search_lists (caller-chosen partitions: the reference's :turbo / lightning paths) with ragged probe
+    rows (-1 = none), small and large batches (GEMV scan in list order with list-less pairs, tile / group scan):
+    the expected top-k is the stable sort of the probed lists' rows, concatenated in probe order, by the distances of
+    the kernel that serves the batch."""
+    O = oracle
+    m = {"cosine": O.COSINE, "dot": O.DOT, "l2": O.L2}[metric]
+    rs = np.random.RandomState(21)
+    n, dim, nlist = 1800, 40, 11
+    base = _data(O, n, dim, "clustered", num_clusters=5, noise_level=0.5)
+    assign = rs.randint(0, nlist, n)
+    assign[assign == 4] = 5                                   # an empty list
+    off, lids = O.lists_from_assign(assign, nlist)
+    cen = _data(O, nlist, dim, seed=77)
+    Qall = _data(O, 40, dim, seed=43)
+    with eng.Index(base, metric) as idx:
+        idx.set_ivf(cen, off, lids)
+        for nq, nprobe, k in [(3, 4, 5), (12, 3, 50), (40, 4, 10), (40, 2, 300)]:
+            Q = Qall[:nq]
+            probes = np.full((nq, nprobe), -1, np.int32)
+            for q in range(nq):
+                pick = rs.permutation(nlist)[:nprobe]
+                keep = rs.rand(nprobe) < 0.8
+                probes[q, keep] = pick[keep]
+            tiled = m != O.L2 and nq * nprobe > 2 * nlist
+            dense = _dense_oracle(O, base, Q, m, O.MODE_MFMA if tiled else O.MODE_DEV)
+            cand_ids = np.full((nq, n), -1, np.int32)
+            cand_d = np.full((nq, n), np.inf, np.float32)
+            for q in range(nq):
+                rows = np.concatenate([lids[off[l]:off[l + 1]] for l in probes[q] if l >= 0] + [np.empty(0, np.int32)])
+                cand_ids[q, :len(rows)] = rows
+                cand_d[q, :len(rows)] = dense[q, rows.astype(np.int64)]
+            want_i, want_d = _stable_topk(cand_ids, cand_d, k)
+            ids, d = idx.ivf_search_lists(Q, k, probes)
+            assert_exact(ids, d, want_i, want_d, "given lists %s nq=%d nprobe=%d k=%d" % (metric, nq, nprobe, k))
+
+
 @pytest.mark.parametrize("metric,nq", [("cosine", 20), ("cosine", 5), ("dot", 33), ("l2", 20)])
 def test_dense_distances_and_rerank(eng, oracle, metric, nq):
     O = oracle
