@@ -251,6 +251,35 @@ def test_hnsw_build_on_device(eng, oracle):
     assert rec_gpu_graph >= 0.9 and rec_gpu_graph >= rec_ref - 0.03, (rec_gpu_graph, rec_ref)
 
 
+def test_hnsw_build_small_and_degenerate(eng, oracle):
+    """Device build on tiny and degenerate inputs (1 .. 3 rows, all rows equal, M = 1 and M = 32, every metric; more
+    shapes with HNSWGPU_SOAK): the graph passes the import validator, and searching it on the device equals the
+    oracle's search of the same graph -- ids, distances, counters."""
+    O = oracle
+    rs = np.random.RandomState(31)
+    cases = [(1, 8, 4, O.COSINE), (2, 8, 1, O.L2), (3, 5, 2, O.DOT), (40, 16, 32, O.COSINE), (300, 24, 1, O.L2)]
+    for _ in range(int(os.environ.get("HNSWGPU_SOAK", "0"))):
+        cases.append((int(rs.choice([5, 33, 400, 2500])), int(rs.choice([1, 7, 64, 300])), int(rs.choice([1, 2, 8, 16, 32])),
+                      int(rs.choice([O.COSINE, O.L2, O.DOT]))))
+    for ci, (n, dim, M, metric) in enumerate(cases):
+        base = _data(O, n, dim, "clustered", num_clusters=3, noise_level=0.4, seed=200 + ci)
+        if ci % 2 == 1:
+            base[: max(1, n // 3)] = base[0]                    # a third of the rows identical
+        Q = np.vstack([base[:1], _data(O, 4, dim, seed=43)]).astype(np.float32)
+        tag = "case %d n=%d dim=%d M=%d metric=%d" % (ci, n, dim, M, metric)
+        with eng.Index(base, metric) as idx:
+            idx.hnsw_build(M, 30, 5)
+            g = idx.get_graph()
+            assert g.levels[g.entry] == g.max_level, tag
+            assert ((g.l0_adj >= -1) & (g.l0_adj < n)).all(), tag
+            idx.set_graph(g)                                    # the validator accepts what the build produced
+            for ef, k in [(1, 1), (20, 5)]:
+                ids, d, st = idx.hnsw_search(Q, k, ef, want_stats=True)
+                oi, od, ost, _ = O.hnsw_search(base, g, Q, k, ef=max(ef, k), metric=metric, mode=O.MODE_DEV)
+                assert_exact(ids, d, oi, od, tag + " ef=%d" % ef)
+                np.testing.assert_array_equal(st, ost, err_msg=tag)
+
+
 def test_hnsw_build_linker_threads_do_not_change_the_graph(eng, oracle, monkeypatch):
     """The host linker applies a batch's edges with several threads (own lists by node range, reverse edges by
     target node mod T): every adjacency list must see the sequential loop's update sequence, so the graph is
