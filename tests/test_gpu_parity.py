@@ -657,6 +657,24 @@ def test_l2_batched_group_scan(eng, oracle, dim):
             assert_exact(ids, d, oi, od, "l2 ivf dim=%d nq=%d nprobe=%d k=%d" % (dim, nq, nprobe, k))
 
 
+def test_ivf_many_lists_many_probes(eng, oracle):
+    """300 lists, 70 .. 300 probes per query: centroid routing selects more than 64 centroids (top-k lists in LDS
+    instead of registers, dense routing + select for small batches, tile routing for large ones), hundreds of
+    (query, list) pairs per query run in list order."""
+    O = oracle
+    base = _data(O, 6000, 16, "clustered", num_clusters=12, noise_level=0.5)
+    Q = _data(O, 33, 16, seed=43)
+    with eng.Index(base) as idx:
+        idx.ivf_build(300, 2, 42)
+        cen, off, lids = idx.get_ivf()
+        for nq, nprobe, k in [(2, 70, 10), (2, 300, 100), (33, 128, 10), (33, 300, 5)]:
+            mode = _ivf_mode(O, O.COSINE, 16, nq, nprobe, 300)
+            ids, d, pr = idx.ivf_search(Q[:nq], k, nprobe, want_probes=True)
+            oi, od, opr = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, mode=mode)
+            np.testing.assert_array_equal(pr, opr, err_msg="probes nq=%d nprobe=%d" % (nq, nprobe))
+            assert_exact(ids, d, oi, od, "many lists nq=%d nprobe=%d k=%d mode=%d" % (nq, nprobe, k, mode))
+
+
 def test_ivf_ragged_lists_and_full_probe(eng, oracle):
     """Empty lists, a list holding almost everything, nprobe > nlist, k > candidates."""
     O = oracle
