@@ -49,6 +49,10 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     // exceeds one residency round fewer waves per query win: 10,000 queries run at 601k / 776k / 802k QPS.
     int nw = g_hnsw_nw > 0 ? g_hnsw_nw : (a.nq > 1536 ? 1 : (a.nq > 768 ? 2 : 4));
     int grid = a.nq;
+    if (a.q_index) {  // repeat pass: few (usually no) work items, one large-list workgroup per CU at most
+        nw = 4;
+        grid = std::min(a.nq, 256);
+    }
     if (vg) {
         a.nwords = 0;
         // one slab of n stamps per workgroup; a persistent grid bounds the slab count
@@ -151,8 +155,7 @@ static void fill_args(const hnswgpu_index *idx, HnswArgs &a) {
 }
 
 static int search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t ef,
-                          int32_t *d_ids, float *d_dist, int64_t *d_stats, hipStream_t st, int32_t ghosts = kGhost,
-                          int32_t *d_overflow = nullptr) {
+                          int32_t *d_ids, float *d_dist, int64_t *d_stats, hipStream_t st) {
     HnswArgs a;
     fill_args(idx, a);
     a.Q = d_Q;
@@ -160,15 +163,36 @@ static int search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int3
     a.nq = nq;
     a.ef = ef;
     a.k = k;
-    a.cap = ef + ghosts;
+    a.cap = ef + kGhost;
     a.out_ids = d_ids;
     a.out_dist = d_dist;
     a.stats = d_stats;
-    a.overflow = d_overflow;
+    // queries that run out of ghost slots (hundreds of duplicated rows) list themselves in s_probes[1 ..]
+    HG_TRY(idx->s_probes.ensure(sizeof(int32_t) * (static_cast<size_t>(nq) + 1)));
+    int32_t *again_cnt = idx->s_probes.as<int32_t>(), *again = again_cnt + 1;
+    HG_HIP(hipMemsetAsync(again_cnt, 0, sizeof(int32_t), st));
+    a.again = again;
+    a.again_cnt = again_cnt;
     hipEvent_t e0;
     prof_begin(idx, PROF_HNSW, st, &e0);
     int rc = launch_hnsw_idx(idx, a, st);
     prof_end(idx, PROF_HNSW, st, e0);
+    if (rc) return rc;
+    // ... and are repeated, on the device and without a host round trip, with the largest candidate list the LDS
+    // holds, so that every tie the reference would still expand (ultra_fast.clj:175-178, `<=`) is kept.  The pass
+    // finds no work item on ordinary data (a few microseconds).
+    const int vgw = (g_force_vg || idx->n > kLdsVisitedMaxRows) ? 0 : static_cast<int>((idx->n + 31) / 32);
+    const size_t fixed = hnsw_lds_bytes(0, vgw, 4);
+    const int64_t cap_max = static_cast<int64_t>((kMaxLds - fixed) / (2 * sizeof(uint2) + sizeof(int32_t)));
+    const int32_t big = static_cast<int32_t>(std::min<int64_t>(cap_max - ef, idx->n));
+    if (big > kGhost) {
+        a.cap = ef + big;
+        a.again = nullptr;
+        a.again_cnt = nullptr;
+        a.q_index = again;
+        a.nq_dev = again_cnt;
+        rc = launch_hnsw_idx(idx, a, st);
+    }
     return rc;
 }
 
@@ -553,50 +577,11 @@ int hnswgpu_hnsw_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t 
     HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
     HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
     HG_TRY(idx->s_stats.ensure(sizeof(int64_t) * 2 * nq));
-    HG_TRY(idx->s_probes.ensure(sizeof(int32_t) * static_cast<size_t>(nq)));
-    int32_t *d_ovf = idx->s_probes.as<int32_t>();
     HG_TRY(search_enqueue(idx, idx->s_q.as<float>(), nq, k, ef, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(),
-                          idx->s_stats.as<int64_t>(), st, kGhost, d_ovf));
+                          idx->s_stats.as<int64_t>(), st));
     HG_HIP(hipMemcpyAsync(out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
     HG_HIP(hipMemcpyAsync(out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
     if (stats) HG_HIP(hipMemcpyAsync(stats, idx->s_stats.p, sizeof(int64_t) * 2 * nq, hipMemcpyDeviceToHost, st));
-    std::vector<int32_t> ovf(nq);
-    HG_HIP(hipMemcpyAsync(ovf.data(), d_ovf, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, st));
-    HG_HIP(hipStreamSynchronize(st));
-    // Queries whose candidate list ran out of ghost slots (more than kGhost unexpanded candidates tied with the
-    // ef-th distance: heavily duplicated rows) are repeated with the largest list the LDS holds, so
-    // that every tie the reference would still expand (ultra_fast.clj:175-178, `<=`) is kept.  Rare, and only this
-    // synchronous entry point can afford it; hnswgpu_hnsw_search_dev keeps the fixed list.
-    std::vector<int32_t> again;
-    for (int32_t q = 0; q < nq; q++)
-        if (ovf[q]) again.push_back(q);
-    if (!again.empty()) {
-        const int vgw = (g_force_vg || idx->n > kLdsVisitedMaxRows) ? 0 : static_cast<int>((idx->n + 31) / 32);
-        const size_t fixed = hnsw_lds_bytes(0, vgw, 4);
-        const int64_t cap_max = static_cast<int64_t>((kMaxLds - fixed) / (2 * sizeof(uint2) + sizeof(int32_t)));
-        const int32_t big = static_cast<int32_t>(std::min<int64_t>(cap_max - ef, idx->n));
-        if (big > kGhost) {
-            const int32_t m = static_cast<int32_t>(again.size());
-            std::vector<float> Qa(static_cast<size_t>(m) * idx->dim);
-            for (int32_t i = 0; i < m; i++)
-                memcpy(&Qa[static_cast<size_t>(i) * idx->dim], Q + static_cast<size_t>(again[i]) * idx->dim, sizeof(float) * idx->dim);
-            HG_TRY(upload_queries(idx, Qa.data(), m, st));
-            HG_TRY(search_enqueue(idx, idx->s_q.as<float>(), m, k, ef, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(),
-                                  idx->s_stats.as<int64_t>(), st, big, nullptr));
-            std::vector<int32_t> ri(static_cast<size_t>(m) * k);
-            std::vector<float> rd(static_cast<size_t>(m) * k);
-            std::vector<int64_t> rs(static_cast<size_t>(m) * 2);
-            HG_HIP(hipMemcpyAsync(ri.data(), idx->s_ids.p, sizeof(int32_t) * ri.size(), hipMemcpyDeviceToHost, st));
-            HG_HIP(hipMemcpyAsync(rd.data(), idx->s_outd.p, sizeof(float) * rd.size(), hipMemcpyDeviceToHost, st));
-            HG_HIP(hipMemcpyAsync(rs.data(), idx->s_stats.p, sizeof(int64_t) * rs.size(), hipMemcpyDeviceToHost, st));
-            HG_HIP(hipStreamSynchronize(st));
-            for (int32_t i = 0; i < m; i++) {
-                memcpy(out_ids + static_cast<size_t>(again[i]) * k, &ri[static_cast<size_t>(i) * k], sizeof(int32_t) * k);
-                memcpy(out_dist + static_cast<size_t>(again[i]) * k, &rd[static_cast<size_t>(i) * k], sizeof(float) * k);
-                if (stats) memcpy(stats + 2 * static_cast<size_t>(again[i]), &rs[2 * static_cast<size_t>(i)], sizeof(int64_t) * 2);
-            }
-        }
-    }
     HG_TRY(end_call(idx, st));
     HG_HIP(hipStreamSynchronize(st));
     return 0;

@@ -465,10 +465,14 @@ struct HnswArgs {
     uint32_t *vis;
     int64_t vis_stride;
     uint32_t gen_base;
-    // optional [nq]: set to 1 when the list ran out of ghost slots for query q -- more than cap - ef unexpanded
-    // candidates tied with the ef-th distance at once; the surplus ties are not expanded (the reference would expand
-    // them), so the host entry point repeats such queries with a larger list
-    int32_t *overflow;
+    // Ghost overflow (more than cap - ef unexpanded candidates tied with the ef-th distance at once: the surplus ties
+    // are not expanded, the reference would expand them).  First pass: such a query appends its index to again[]
+    // (again_cnt = their number).  Second pass, same kernel with the largest list the LDS holds: q_index = again,
+    // nq_dev = again_cnt -- work item i is query q_index[i], and only *nq_dev items exist.
+    int32_t *again;
+    int32_t *again_cnt;
+    const int32_t *q_index;
+    const int32_t *nq_dev;
     unsigned long long *dbg;  // -DHG_HNSW_STAMPS diagnostic builds only: per-phase s_memrealtime totals
 };
 
@@ -510,7 +514,9 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
     const int nvec = static_cast<int>(a.ld / 4);
     uint32_t gen = a.gen_base;
 
-    for (int qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
+    const int nq_eff = a.nq_dev ? (*a.nq_dev < a.nq ? *a.nq_dev : a.nq) : a.nq;
+    for (int wi = blockIdx.x; wi < nq_eff; wi += gridDim.x) {
+        const int qi = a.q_index ? a.q_index[wi] : wi;  // the query this work item serves
         uint2 *curA = listA, *curB = listB;
         const float *qptr = a.q_rows ? a.rows + static_cast<int64_t>(a.q_rows[qi]) * a.ld : a.Q + qi * a.qld;
         float4 q[NCH];
@@ -781,7 +787,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
         if (a.dbg && tid == 0 && qi == 0)
             for (int i = 0; i < 12; i++) a.dbg[i] = i == 7 ? static_cast<unsigned long long>(n_hop) : st_acc[i];
 #endif
-        if (a.overflow && tid == 0) a.overflow[qi] = sc[6];  // ordered after the last merge by its closing barrier
+        if (a.again && tid == 0 && sc[6]) a.again[atomicAdd(a.again_cnt, 1)] = qi;  // sc[6]: ordered by the last merge's barrier
         if (a.stats && tid == 0) {
             a.stats[2 * static_cast<int64_t>(qi)] = n_eval;
             a.stats[2 * static_cast<int64_t>(qi) + 1] = n_hop;

@@ -104,9 +104,8 @@ int hnswgpu_exact_knn_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int3
  * evaluations and expansions per query.
  * Ties: the reference still expands a candidate whose distance EQUALS the current ef-th distance
  * (ultra_fast.clj:175-178, `<=`).  The traversal kernel keeps up to 32 such evicted-but-tied candidates per
- * query; hnswgpu_hnsw_search repeats a query that had more (hundreds of duplicated rows) with the largest
- * candidate list the LDS holds, so its results and counters are the reference's; the asynchronous
- * hnswgpu_hnsw_search_dev does not, and leaves the surplus ties unexpanded. */
+ * query; a query that had more (hundreds of duplicated rows) is repeated on the device, in the same call, with the
+ * largest candidate list the LDS holds, so results and counters are the reference's on such data too. */
 int hnswgpu_set_graph(hnswgpu_index *idx, const int32_t *levels, const int32_t *l0_adj, int32_t M0,
                       const int64_t *up_off, const int32_t *up_adj, int32_t M, int32_t entry, int32_t max_level);
 int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, int64_t seed);

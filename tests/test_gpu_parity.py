@@ -329,8 +329,9 @@ def test_hnsw_build_linker_threads_do_not_change_the_graph(eng, oracle, monkeypa
 def test_hnsw_hundreds_of_tied_candidates(eng, oracle, metric):
     """500 copies of one row: far more unexpanded candidates tie with the ef-th distance than the traversal
     kernel's 32 ghost slots hold.  The reference still expands every one of them (ultra_fast.clj:175-178 uses <=), so
-    the synchronous entry point repeats such queries with the largest list the LDS holds: ids, distances AND the
-    traversal counters (distance evaluations, expansions) equal the oracle's."""
+    search repeats such queries on the device (a second pass of the kernel over the flagged queries) with the largest
+    list the LDS holds: ids, distances AND the traversal counters (distance evaluations, expansions) equal the oracle's,
+    through the synchronous and the asynchronous entry point."""
     O = oracle
     m = {"cosine": O.COSINE, "dot": O.DOT, "l2": O.L2}[metric]
     rs = np.random.RandomState(9)
@@ -346,6 +347,14 @@ def test_hnsw_hundreds_of_tied_candidates(eng, oracle, metric):
             oi, od, ost, _ = O.hnsw_search(base, g, Q, k, ef=max(ef, k), metric=m, mode=O.MODE_DEV)
             assert_exact(ids, d, oi, od, "ties %s ef=%d" % (metric, ef))
             np.testing.assert_array_equal(st, ost, err_msg="ties %s ef=%d" % (metric, ef))
+        import torch                                         # the asynchronous entry point repeats them as well
+        Qt = torch.from_numpy(Q).cuda()
+        stt = torch.zeros((len(Q), 2), dtype=torch.int64, device="cuda")
+        ti, td = idx.hnsw_search_dev(Qt, 10, 50, stats=stt)
+        torch.cuda.synchronize()
+        oi, od, ost, _ = O.hnsw_search(base, g, Q, 10, ef=50, metric=m, mode=O.MODE_DEV)
+        assert_exact(ti.cpu().numpy(), td.cpu().numpy(), oi, od, "ties dev %s" % metric)
+        np.testing.assert_array_equal(stt.cpu().numpy(), ost)
 
 
 def test_randomised_differential(eng, oracle):
