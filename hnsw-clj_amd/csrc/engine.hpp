@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <condition_variable>
 #include <mutex>
+#include <string>
 #include <string>
 #include <utility>
 #include <vector>
@@ -80,6 +82,24 @@ struct hnswgpu_index {
     float *d_norms = nullptr;
     hipStream_t stream = nullptr;
     std::mutex mu;
+    // Combining of concurrent synchronous searches (hnswgpu_hnsw_search from many host threads, the reference's
+    // parallel-search-futures pattern): callers queue their request; one of them -- the leader -- launches everything
+    // that is queued with the same (k, ef) as ONE batch and hands the results back.  Twenty threads issuing single
+    // queries then share a launch instead of queueing twenty of them one after the other.
+    struct SearchReq {
+        const float *Q;
+        int32_t nq, k, ef;
+        int32_t *out_ids;
+        float *out_dist;
+        int64_t *stats;
+        int rc = 0;
+        bool done = false;
+        std::string err;
+    };
+    std::mutex cmb_mu;
+    std::condition_variable cmb_cv;
+    std::vector<SearchReq *> cmb_pending;
+    bool cmb_leader = false;
     // cross-stream ordering of the shared scratch buffers: the last call's completion event
     hipEvent_t ev_last = nullptr;
     hipStream_t ev_stream = nullptr;

@@ -543,6 +543,47 @@ static int check_hnsw_args(const hnswgpu_index *idx, const void *Q, int32_t nq, 
     return 0;
 }
 
+// One launch for a set of queued synchronous requests with the same (k, ef): queries concatenated on the host,
+// results scattered back (see hnswgpu_index::SearchReq).
+static int hnsw_search_batch(hnswgpu_index *idx, const std::vector<hnswgpu_index::SearchReq *> &batch, int32_t total) {
+    const int32_t k = batch[0]->k, ef = batch[0]->ef;
+    const int64_t cnt = static_cast<int64_t>(total) * k;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
+    const float *Qall = batch[0]->Q;
+    std::vector<float> cat;
+    if (batch.size() > 1) {
+        cat.resize(static_cast<size_t>(total) * idx->dim);
+        size_t o = 0;
+        for (auto *r : batch) {
+            memcpy(&cat[o], r->Q, sizeof(float) * static_cast<size_t>(r->nq) * idx->dim);
+            o += static_cast<size_t>(r->nq) * idx->dim;
+        }
+        Qall = cat.data();
+    }
+    HG_TRY(upload_queries(idx, Qall, total, st));
+    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
+    HG_TRY(idx->s_stats.ensure(sizeof(int64_t) * 2 * total));
+    HG_TRY(search_enqueue(idx, idx->s_q.as<float>(), total, k, ef, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(),
+                          idx->s_stats.as<int64_t>(), st));
+    int64_t q0 = 0;
+    for (auto *r : batch) {  // straight into every caller's buffers
+        const int64_t c = static_cast<int64_t>(r->nq) * k;
+        HG_HIP(hipMemcpyAsync(r->out_ids, idx->s_ids.as<int32_t>() + q0 * k, sizeof(int32_t) * c, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipMemcpyAsync(r->out_dist, idx->s_outd.as<float>() + q0 * k, sizeof(float) * c, hipMemcpyDeviceToHost, st));
+        if (r->stats)
+            HG_HIP(hipMemcpyAsync(r->stats, idx->s_stats.as<int64_t>() + 2 * q0, sizeof(int64_t) * 2 * r->nq,
+                                  hipMemcpyDeviceToHost, st));
+        q0 += r->nq;
+    }
+    HG_TRY(end_call(idx, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 int hnswgpu_hnsw_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t ef,
                             int32_t *d_out_ids, float *d_out_dist, int64_t *d_stats, void *stream) {
     HG_TRY(check_hnsw_args(idx, d_Q, nq, k, &ef, d_out_ids, d_out_dist));
@@ -569,22 +610,51 @@ int hnswgpu_hnsw_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t 
         if (stats) memset(stats, 0, sizeof(int64_t) * 2 * nq);
         return 0;
     }
-    std::lock_guard<std::mutex> lk(idx->mu);
-    HG_HIP(hipSetDevice(idx->device));
-    hipStream_t st = idx->stream;
-    HG_TRY(begin_call(idx, st));
-    HG_TRY(upload_queries(idx, Q, nq, st));
-    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
-    HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
-    HG_TRY(idx->s_stats.ensure(sizeof(int64_t) * 2 * nq));
-    HG_TRY(search_enqueue(idx, idx->s_q.as<float>(), nq, k, ef, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(),
-                          idx->s_stats.as<int64_t>(), st));
-    HG_HIP(hipMemcpyAsync(out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
-    HG_HIP(hipMemcpyAsync(out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
-    if (stats) HG_HIP(hipMemcpyAsync(stats, idx->s_stats.p, sizeof(int64_t) * 2 * nq, hipMemcpyDeviceToHost, st));
-    HG_TRY(end_call(idx, st));
-    HG_HIP(hipStreamSynchronize(st));
-    return 0;
+    // queue the request; whoever finds no leader becomes one and serves the queue, batch by batch
+    hnswgpu_index::SearchReq me;
+    me.Q = Q;
+    me.nq = nq;
+    me.k = k;
+    me.ef = ef;
+    me.out_ids = out_ids;
+    me.out_dist = out_dist;
+    me.stats = stats;
+    std::unique_lock<std::mutex> cl(idx->cmb_mu);
+    idx->cmb_pending.push_back(&me);
+    while (!me.done) {
+        if (idx->cmb_leader) {  // somebody is launching: wait for my result, or for the leadership to be free
+            idx->cmb_cv.wait(cl, [&] { return me.done || !idx->cmb_leader; });
+            continue;
+        }
+        // lead ONE batch: everything queued with the first request's (k, ef), in arrival order, up to 16384 queries
+        idx->cmb_leader = true;
+        std::vector<hnswgpu_index::SearchReq *> batch, rest;
+        int64_t total = 0;
+        for (auto *r : idx->cmb_pending) {
+            if (r->k == idx->cmb_pending[0]->k && r->ef == idx->cmb_pending[0]->ef &&
+                (batch.empty() || total + r->nq <= 16384)) {
+                batch.push_back(r);
+                total += r->nq;
+            } else {
+                rest.push_back(r);
+            }
+        }
+        idx->cmb_pending.swap(rest);
+        cl.unlock();
+        const int rc = hnsw_search_batch(idx, batch, static_cast<int32_t>(total));
+        const char *msg = rc ? hnswgpu_last_error() : "";
+        cl.lock();
+        for (auto *r : batch) {
+            r->rc = rc;
+            if (rc) r->err = msg;
+            r->done = true;
+        }
+        idx->cmb_leader = false;
+        idx->cmb_cv.notify_all();
+    }
+    cl.unlock();
+    if (me.rc) set_error("%s", me.err.c_str());
+    return me.rc;
 }
 
 // build-index / insert-batch (ultra_fast.clj:303-344) as batched insertion: every node of a batch
