@@ -754,6 +754,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
         }
     if (idx->ev_last) (void)hipEventDestroy(idx->ev_last);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    if (idx->h_pin) (void)hipHostFree(idx->h_pin);
     delete idx;
     return 0;
 }

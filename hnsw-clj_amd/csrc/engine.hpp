@@ -100,6 +100,10 @@ struct hnswgpu_index {
     std::condition_variable cmb_cv;
     std::vector<SearchReq *> cmb_pending;
     bool cmb_leader = false;
+    bool cmb_linger = false;  // a leader is waiting a moment for the callers the previous batch released
+    int cmb_last = 0;         // requests in the previous batch
+    void *h_pin = nullptr;    // pinned host staging of the combined batch (queries in, results out)
+    size_t h_pin_cap = 0;
     // cross-stream ordering of the shared scratch buffers: the last call's completion event
     hipEvent_t ev_last = nullptr;
     hipStream_t ev_stream = nullptr;

@@ -552,35 +552,58 @@ static int hnsw_search_batch(hnswgpu_index *idx, const std::vector<hnswgpu_index
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
     HG_TRY(begin_call(idx, st));
-    const float *Qall = batch[0]->Q;
-    std::vector<float> cat;
-    if (batch.size() > 1) {
-        cat.resize(static_cast<size_t>(total) * idx->dim);
-        size_t o = 0;
-        for (auto *r : batch) {
-            memcpy(&cat[o], r->Q, sizeof(float) * static_cast<size_t>(r->nq) * idx->dim);
-            o += static_cast<size_t>(r->nq) * idx->dim;
-        }
-        Qall = cat.data();
-    }
-    HG_TRY(upload_queries(idx, Qall, total, st));
     HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
     HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
     HG_TRY(idx->s_stats.ensure(sizeof(int64_t) * 2 * total));
+    if (batch.size() == 1) {  // a lone caller: its own buffers, no staging
+        auto *r = batch[0];
+        HG_TRY(upload_queries(idx, r->Q, total, st));
+        HG_TRY(search_enqueue(idx, idx->s_q.as<float>(), total, k, ef, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(),
+                              idx->s_stats.as<int64_t>(), st));
+        HG_HIP(hipMemcpyAsync(r->out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipMemcpyAsync(r->out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
+        if (r->stats) HG_HIP(hipMemcpyAsync(r->stats, idx->s_stats.p, sizeof(int64_t) * 2 * total, hipMemcpyDeviceToHost, st));
+        HG_TRY(end_call(idx, st));
+        HG_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+    // several callers: one pinned staging block [queries | ids | distances | stats], three transfers per batch
+    const size_t qb = sizeof(float) * static_cast<size_t>(total) * idx->dim, ib = sizeof(int32_t) * cnt,
+                 db = sizeof(float) * cnt, sb = sizeof(int64_t) * 2 * total;
+    const size_t need = qb + ib + db + sb + 64;
+    if (need > idx->h_pin_cap) {
+        if (idx->h_pin) (void)hipHostFree(idx->h_pin);
+        idx->h_pin = nullptr;
+        idx->h_pin_cap = 0;
+        HG_HIP(hipHostMalloc(&idx->h_pin, need + need / 2, hipHostMallocDefault));
+        idx->h_pin_cap = need + need / 2;
+    }
+    char *hp = static_cast<char *>(idx->h_pin);
+    float *hq = reinterpret_cast<float *>(hp);
+    int64_t *hs = reinterpret_cast<int64_t *>(hp + ((qb + 7) & ~size_t(7)));
+    int32_t *hi = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(hs) + sb);
+    float *hd = reinterpret_cast<float *>(reinterpret_cast<char *>(hi) + ib);
+    size_t o = 0;
+    for (auto *r : batch) {
+        memcpy(hq + o, r->Q, sizeof(float) * static_cast<size_t>(r->nq) * idx->dim);
+        o += static_cast<size_t>(r->nq) * idx->dim;
+    }
+    HG_TRY(upload_queries(idx, hq, total, st));
     HG_TRY(search_enqueue(idx, idx->s_q.as<float>(), total, k, ef, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(),
                           idx->s_stats.as<int64_t>(), st));
-    int64_t q0 = 0;
-    for (auto *r : batch) {  // straight into every caller's buffers
-        const int64_t c = static_cast<int64_t>(r->nq) * k;
-        HG_HIP(hipMemcpyAsync(r->out_ids, idx->s_ids.as<int32_t>() + q0 * k, sizeof(int32_t) * c, hipMemcpyDeviceToHost, st));
-        HG_HIP(hipMemcpyAsync(r->out_dist, idx->s_outd.as<float>() + q0 * k, sizeof(float) * c, hipMemcpyDeviceToHost, st));
-        if (r->stats)
-            HG_HIP(hipMemcpyAsync(r->stats, idx->s_stats.as<int64_t>() + 2 * q0, sizeof(int64_t) * 2 * r->nq,
-                                  hipMemcpyDeviceToHost, st));
-        q0 += r->nq;
-    }
+    HG_HIP(hipMemcpyAsync(hi, idx->s_ids.p, ib, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipMemcpyAsync(hd, idx->s_outd.p, db, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipMemcpyAsync(hs, idx->s_stats.p, sb, hipMemcpyDeviceToHost, st));
     HG_TRY(end_call(idx, st));
     HG_HIP(hipStreamSynchronize(st));
+    int64_t q0 = 0;
+    for (auto *r : batch) {
+        const size_t c = static_cast<size_t>(r->nq) * k;
+        memcpy(r->out_ids, hi + q0 * k, sizeof(int32_t) * c);
+        memcpy(r->out_dist, hd + q0 * k, sizeof(float) * c);
+        if (r->stats) memcpy(r->stats, hs + 2 * q0, sizeof(int64_t) * 2 * r->nq);
+        q0 += r->nq;
+    }
     return 0;
 }
 
@@ -621,13 +644,25 @@ int hnswgpu_hnsw_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t 
     me.stats = stats;
     std::unique_lock<std::mutex> cl(idx->cmb_mu);
     idx->cmb_pending.push_back(&me);
+    if (idx->cmb_linger) idx->cmb_cv.notify_all();  // a leader is counting arrivals
     while (!me.done) {
         if (idx->cmb_leader) {  // somebody is launching: wait for my result, or for the leadership to be free
             idx->cmb_cv.wait(cl, [&] { return me.done || !idx->cmb_leader; });
             continue;
         }
-        // lead ONE batch: everything queued with the first request's (k, ef), in arrival order, up to 16384 queries
+        // lead ONE batch: everything queued with the first request's (k, ef), in arrival order, up to 16384 queries.
+        // The callers the previous batch released are on their way back: give them up to 60 us to queue up, or every
+        // other batch would hold a single request (first one back) and the next one everybody else.
         idx->cmb_leader = true;
+        // (measured with examples/parallel_callers.c: a small crowd is worth waiting for in full -- 20 threads 26k QPS
+        // against 12k without the wait --, of a large one three quarters are enough: 100 threads 73k QPS against 14k)
+        const int target = idx->cmb_last <= 24 ? idx->cmb_last : idx->cmb_last - idx->cmb_last / 4;
+        if (idx->cmb_last > 1 && static_cast<int>(idx->cmb_pending.size()) < target) {
+            idx->cmb_linger = true;
+            idx->cmb_cv.wait_for(cl, std::chrono::microseconds(idx->cmb_last <= 24 ? 100 : 60),
+                                 [&] { return static_cast<int>(idx->cmb_pending.size()) >= target; });
+            idx->cmb_linger = false;
+        }
         std::vector<hnswgpu_index::SearchReq *> batch, rest;
         int64_t total = 0;
         for (auto *r : idx->cmb_pending) {
@@ -640,6 +675,7 @@ int hnswgpu_hnsw_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t 
             }
         }
         idx->cmb_pending.swap(rest);
+        idx->cmb_last = static_cast<int>(batch.size());
         cl.unlock();
         const int rc = hnsw_search_batch(idx, batch, static_cast<int32_t>(total));
         const char *msg = rc ? hnswgpu_last_error() : "";

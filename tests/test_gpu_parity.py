@@ -902,6 +902,22 @@ def test_c_abi_from_plain_c(native_lib, tmp_path):
     assert "abi_demo ok" in out.stdout
 
 
+def test_parallel_callers_from_plain_c(native_lib, tmp_path):
+    """examples/parallel_callers.c: the reference's throughput protocol (helper/parallel_search.clj:15-49) -- 1 .. 200
+    threads of single-query hnswgpu_hnsw_search calls on one handle.  The library combines concurrent callers into one
+    launch; the program fails unless every thread count returns exactly the ids of one big batch."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "parallel_callers")
+    subprocess.check_call(["gcc", "-O2", "-pthread", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "parallel_callers.c"), "-L" + native_lib.PKG, "-lhnswgpu",
+                           "-Wl,-rpath," + native_lib.PKG, "-lm", "-o", exe])
+    out = subprocess.run([exe, "6000", "64", "60"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "parallel_callers ok" in out.stdout and "DIFFER" not in out.stdout
+
+
 def test_merge_topk_dev(eng):
     import torch
 
