@@ -260,6 +260,10 @@ def main():
             if rank == 0:
                 result["sharded_hnsw"] = sh
 
+    # ------------------------------------------------------------------ the reference's own protocol (rank 0, N = 1)
+    if rank == 0 and world == 1:
+        result["config"]["reference_protocol"] = reference_protocol(ef)
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if not args.no_cpu and rank == 0 and world == 1:
         result["cpu_baseline"] = cpu_baseline(idx, base, queries, ef)
@@ -540,6 +544,35 @@ def sharded_hnsw(engine, dev, rank, world, args):
                         "each), ef_search 256, batch 1024, all-gather of per-shard top-10 + merge" % (world * n, world, n),
             "qps": round(nq * steps / el, 1), "ms_per_batch": round(el / steps * 1e3, 3), "recall_at_10": round(rec, 4),
             "valid": ok, "hnsw_build_s_per_shard": round(build_s, 1), "collective": "all_gather of %d B per rank" % (nq * K * 8)}
+
+
+def reference_protocol(ef):
+    """The protocol of the reference's published number (wip/reproduce_02ms.clj:37-92, helper/parallel_search.clj:15-49):
+    T threads, each issuing single-query search-knn calls on one index -- here from plain C with pthreads
+    (examples/parallel_callers.c; the synchronous C entry point combines concurrent callers into one launch).
+    Returns {threads: QPS} or a note when the example cannot be built / run."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("gcc") is None:
+        return {"note": "gcc not found"}
+    try:
+        exe = os.path.join(tempfile.mkdtemp(prefix="hnswgpu_pc_", dir="/tmp"), "parallel_callers")
+        pkg = os.path.join(ROOT, "hnsw-clj_amd")
+        subprocess.check_call(["gcc", "-O2", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "examples", "parallel_callers.c"), "-L" + pkg, "-lhnswgpu",
+                               "-Wl,-rpath," + pkg, "-lm", "-o", exe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out = subprocess.run([exe, str(N31K), str(DIM), str(ef)], capture_output=True, text=True, timeout=240)
+        qps = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"(\d+) threads x .*? = +(\d+) QPS", out.stdout)}
+        if out.returncode != 0 or not qps:
+            return {"note": "parallel_callers failed: " + (out.stdout + out.stderr)[-200:]}
+        return {"workload": "T threads of single-query hnswgpu_hnsw_search calls (plain C, pthreads), %d x %d, ef %d, k 10; "
+                            "ids checked against one batch" % (N31K, DIM, ef),
+                "qps_by_threads": qps, "published_reference": "4,719-5,376 QPS at 20 JVM threads, Apple M4 -- other hardware"}
+    except Exception as e:  # noqa: BLE001 -- a side measurement never takes the bench down
+        return {"note": "%s: %s" % (type(e).__name__, e)}
 
 
 def cpu_baseline(idx, base, queries, ef):
