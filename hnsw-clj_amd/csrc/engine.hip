@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "engine.hpp"
 #include "tile_kernels.hpp"
@@ -377,6 +378,69 @@ int end_call(hnswgpu_index *idx, hipStream_t st) {
     idx->ev_stream = st;
     idx->ev_valid = true;
     return 0;
+}
+
+int ensure_pinned(hnswgpu_index *idx, size_t bytes) {
+    if (bytes <= idx->h_pin_cap) return 0;
+    if (idx->h_pin) (void)hipHostFree(idx->h_pin);
+    idx->h_pin = nullptr;
+    idx->h_pin_cap = 0;
+    HG_HIP(hipHostMalloc(&idx->h_pin, bytes + bytes / 2, hipHostMallocDefault));
+    idx->h_pin_cap = bytes + bytes / 2;
+    return 0;
+}
+
+int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
+                   const std::function<bool(const hnswgpu_index::SearchReq *, const hnswgpu_index::SearchReq *, int64_t)> &take,
+                   const std::function<int(const std::vector<hnswgpu_index::SearchReq *> &, int32_t)> &run) {
+    std::unique_lock<std::mutex> cl(c.mu);
+    c.pending.push_back(&me);
+    if (c.linger) c.cv.notify_all();  // a leader is counting arrivals
+    while (!me.done) {
+        if (c.leader) {  // somebody is launching: wait for my result, or for the leadership to be free
+            c.cv.wait(cl, [&] { return me.done || !c.leader; });
+            continue;
+        }
+        // Lead ONE batch: the first queued request and everything behind it that may join it, in arrival order.
+        // The callers the previous batch released are on their way back: give them a moment to queue up, or every
+        // other batch would hold a single request (first one back) and the next one everybody else.  (Measured with
+        // examples/parallel_callers.c: a small crowd is worth waiting for in full -- 20 threads 29k QPS against 12k
+        // without the wait --, of a large one three quarters are enough: 100 threads 76k QPS against 14k.)
+        c.leader = true;
+        const int target = c.last <= 24 ? c.last : c.last - c.last / 4;
+        if (c.last > 1 && static_cast<int>(c.pending.size()) < target) {
+            c.linger = true;
+            c.cv.wait_for(cl, std::chrono::microseconds(c.last <= 24 ? 100 : 60),
+                          [&] { return static_cast<int>(c.pending.size()) >= target; });
+            c.linger = false;
+        }
+        std::vector<hnswgpu_index::SearchReq *> batch, rest;
+        int64_t total = 0;
+        for (auto *r : c.pending) {
+            if (batch.empty() || take(batch[0], r, total)) {
+                batch.push_back(r);
+                total += r->nq;
+            } else {
+                rest.push_back(r);
+            }
+        }
+        c.pending.swap(rest);
+        c.last = static_cast<int>(batch.size());
+        cl.unlock();
+        const int rc = run(batch, static_cast<int32_t>(total));
+        const char *msg = rc ? hnswgpu_last_error() : "";
+        cl.lock();
+        for (auto *r : batch) {
+            r->rc = rc;
+            if (rc) r->err = msg;
+            r->done = true;
+        }
+        c.leader = false;
+        c.cv.notify_all();
+    }
+    cl.unlock();
+    if (me.rc) set_error("%s", me.err.c_str());
+    return me.rc;
 }
 
 // the batched (query group resident in LDS) path: MFMA tiles for cosine / dot, the register-row VALU kernel for L2

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <string>
@@ -88,7 +89,7 @@ struct hnswgpu_index {
     // queries then share a launch instead of queueing twenty of them one after the other.
     struct SearchReq {
         const float *Q;
-        int32_t nq, k, ef;
+        int32_t nq, k, ef;  // ef: layer-0 breadth of an HNSW request, nprobe of an IVF request
         int32_t *out_ids;
         float *out_dist;
         int64_t *stats;
@@ -96,12 +97,15 @@ struct hnswgpu_index {
         bool done = false;
         std::string err;
     };
-    std::mutex cmb_mu;
-    std::condition_variable cmb_cv;
-    std::vector<SearchReq *> cmb_pending;
-    bool cmb_leader = false;
-    bool cmb_linger = false;  // a leader is waiting a moment for the callers the previous batch released
-    int cmb_last = 0;         // requests in the previous batch
+    struct Combiner {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<SearchReq *> pending;
+        bool leader = false;
+        bool linger = false;  // a leader is waiting a moment for the callers the previous batch released
+        int last = 0;         // requests in the previous batch
+    };
+    Combiner cmb_hnsw, cmb_ivf;
     void *h_pin = nullptr;    // pinned host staging of the combined batch (queries in, results out)
     size_t h_pin_cap = 0;
     // cross-stream ordering of the shared scratch buffers: the last call's completion event
@@ -147,6 +151,14 @@ int pick_nch(int64_t ld);  // 0 if unsupported
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);
 int launch_scan(int nch, const ScanArgs &a, hipStream_t st);
 int launch_merge(const MergeArgs &a, hipStream_t st);
+// Serve `me` through combiner `c`: queue it, lead one batch at a time while it is not done.  `take(first, r, total)`
+// says whether request r may join a batch that starts with `first` and already holds `total` queries; `run` launches
+// a batch and returns its error code.
+int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
+                   const std::function<bool(const hnswgpu_index::SearchReq *, const hnswgpu_index::SearchReq *, int64_t)> &take,
+                   const std::function<int(const std::vector<hnswgpu_index::SearchReq *> &, int32_t)> &run);
+// pinned staging block of a combined batch (grown on demand)
+int ensure_pinned(hnswgpu_index *idx, size_t bytes);
 int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st);
 extern unsigned long long *g_tile_dbg_buf;
 int launch_gather(int nch, GatherArgs a, int32_t nq, hipStream_t st);

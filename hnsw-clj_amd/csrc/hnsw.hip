@@ -570,14 +570,7 @@ static int hnsw_search_batch(hnswgpu_index *idx, const std::vector<hnswgpu_index
     // several callers: one pinned staging block [queries | ids | distances | stats], three transfers per batch
     const size_t qb = sizeof(float) * static_cast<size_t>(total) * idx->dim, ib = sizeof(int32_t) * cnt,
                  db = sizeof(float) * cnt, sb = sizeof(int64_t) * 2 * total;
-    const size_t need = qb + ib + db + sb + 64;
-    if (need > idx->h_pin_cap) {
-        if (idx->h_pin) (void)hipHostFree(idx->h_pin);
-        idx->h_pin = nullptr;
-        idx->h_pin_cap = 0;
-        HG_HIP(hipHostMalloc(&idx->h_pin, need + need / 2, hipHostMallocDefault));
-        idx->h_pin_cap = need + need / 2;
-    }
+    HG_TRY(ensure_pinned(idx, qb + ib + db + sb + 64));
     char *hp = static_cast<char *>(idx->h_pin);
     float *hq = reinterpret_cast<float *>(hp);
     int64_t *hs = reinterpret_cast<int64_t *>(hp + ((qb + 7) & ~size_t(7)));
@@ -642,55 +635,14 @@ int hnswgpu_hnsw_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t 
     me.out_ids = out_ids;
     me.out_dist = out_dist;
     me.stats = stats;
-    std::unique_lock<std::mutex> cl(idx->cmb_mu);
-    idx->cmb_pending.push_back(&me);
-    if (idx->cmb_linger) idx->cmb_cv.notify_all();  // a leader is counting arrivals
-    while (!me.done) {
-        if (idx->cmb_leader) {  // somebody is launching: wait for my result, or for the leadership to be free
-            idx->cmb_cv.wait(cl, [&] { return me.done || !idx->cmb_leader; });
-            continue;
-        }
-        // lead ONE batch: everything queued with the first request's (k, ef), in arrival order, up to 16384 queries.
-        // The callers the previous batch released are on their way back: give them up to 60 us to queue up, or every
-        // other batch would hold a single request (first one back) and the next one everybody else.
-        idx->cmb_leader = true;
-        // (measured with examples/parallel_callers.c: a small crowd is worth waiting for in full -- 20 threads 26k QPS
-        // against 12k without the wait --, of a large one three quarters are enough: 100 threads 73k QPS against 14k)
-        const int target = idx->cmb_last <= 24 ? idx->cmb_last : idx->cmb_last - idx->cmb_last / 4;
-        if (idx->cmb_last > 1 && static_cast<int>(idx->cmb_pending.size()) < target) {
-            idx->cmb_linger = true;
-            idx->cmb_cv.wait_for(cl, std::chrono::microseconds(idx->cmb_last <= 24 ? 100 : 60),
-                                 [&] { return static_cast<int>(idx->cmb_pending.size()) >= target; });
-            idx->cmb_linger = false;
-        }
-        std::vector<hnswgpu_index::SearchReq *> batch, rest;
-        int64_t total = 0;
-        for (auto *r : idx->cmb_pending) {
-            if (r->k == idx->cmb_pending[0]->k && r->ef == idx->cmb_pending[0]->ef &&
-                (batch.empty() || total + r->nq <= 16384)) {
-                batch.push_back(r);
-                total += r->nq;
-            } else {
-                rest.push_back(r);
-            }
-        }
-        idx->cmb_pending.swap(rest);
-        idx->cmb_last = static_cast<int>(batch.size());
-        cl.unlock();
-        const int rc = hnsw_search_batch(idx, batch, static_cast<int32_t>(total));
-        const char *msg = rc ? hnswgpu_last_error() : "";
-        cl.lock();
-        for (auto *r : batch) {
-            r->rc = rc;
-            if (rc) r->err = msg;
-            r->done = true;
-        }
-        idx->cmb_leader = false;
-        idx->cmb_cv.notify_all();
-    }
-    cl.unlock();
-    if (me.rc) set_error("%s", me.err.c_str());
-    return me.rc;
+    return combine_search(
+        idx->cmb_hnsw, me,
+        [](const hnswgpu_index::SearchReq *first, const hnswgpu_index::SearchReq *r, int64_t total) {
+            return r->k == first->k && r->ef == first->ef && total + r->nq <= 16384;  // one traversal arithmetic: any mix
+        },
+        [idx](const std::vector<hnswgpu_index::SearchReq *> &batch, int32_t total) {
+            return hnsw_search_batch(idx, batch, total);
+        });
 }
 
 // build-index / insert-batch (ultra_fast.clj:303-344) as batched insertion: every node of a batch

@@ -777,10 +777,72 @@ int hnswgpu_ivf_search_lists(hnswgpu_index *idx, const float *Q, int32_t nq, int
     return 0;
 }
 
+// One launch for a set of queued synchronous IVF requests with the same (k, nprobe); see combine_search.
+static int ivf_search_batch(hnswgpu_index *idx, const std::vector<hnswgpu_index::SearchReq *> &batch, int32_t total) {
+    const int32_t k = batch[0]->k, np = std::min(batch[0]->ef, idx->nlist);
+    const int64_t cnt = static_cast<int64_t>(total) * k;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
+    const size_t qb = sizeof(float) * static_cast<size_t>(total) * idx->dim, ib = sizeof(int32_t) * cnt, db = sizeof(float) * cnt;
+    HG_TRY(ensure_pinned(idx, qb + ib + db + 64));
+    char *hp = static_cast<char *>(idx->h_pin);
+    float *hq = reinterpret_cast<float *>(hp);
+    int32_t *hi = reinterpret_cast<int32_t *>(hp + qb);
+    float *hd = reinterpret_cast<float *>(hp + qb + ib);
+    size_t o = 0;
+    for (auto *r : batch) {
+        memcpy(hq + o, r->Q, sizeof(float) * static_cast<size_t>(r->nq) * idx->dim);
+        o += static_cast<size_t>(r->nq) * idx->dim;
+    }
+    HG_TRY(upload_queries(idx, hq, total, st));
+    HG_TRY(ivf_search_enqueue(idx, idx->s_q.as<float>(), total, k, np, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(),
+                              nullptr, st));
+    HG_HIP(hipMemcpyAsync(hi, idx->s_ids.p, ib, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipMemcpyAsync(hd, idx->s_outd.p, db, hipMemcpyDeviceToHost, st));
+    HG_HIP(hipStreamSynchronize(st));
+    int64_t q0 = 0;
+    for (auto *r : batch) {
+        const size_t c = static_cast<size_t>(r->nq) * k;
+        memcpy(r->out_ids, hi + q0 * k, sizeof(int32_t) * c);
+        memcpy(r->out_dist, hd + q0 * k, sizeof(float) * c);
+        q0 += r->nq;
+    }
+    return 0;
+}
+
 int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t nprobe,
                        int32_t *out_ids, float *out_dist, int32_t *out_probes) {
     HG_TRY(check_ivf_args(idx, Q, nq, k, nprobe, out_ids, out_dist));
     if (nq == 0) return 0;
+    if (!out_probes) {
+        // Concurrent callers are combined into one launch (see hnswgpu_index::SearchReq) -- but only while the
+        // combined batch is served by the SAME kernel each request would get alone: the GEMV scan and the MFMA tile
+        // scan sum in different orders, and a call's distance bits must not depend on what other threads are doing.
+        // (Euclidean: one arithmetic on both paths, so any mix.)
+        hnswgpu_index::SearchReq me;
+        me.Q = Q;
+        me.nq = nq;
+        me.k = k;
+        me.ef = nprobe;
+        me.out_ids = out_ids;
+        me.out_dist = out_dist;
+        me.stats = nullptr;
+        const int64_t np = std::min(nprobe, idx->nlist), gemv_pairs = 2LL * idx->nlist;
+        const bool one_arith = idx->metric == METRIC_L2 || !tile_path_ok(idx) || tile_mode() == 0;
+        return combine_search(
+            idx->cmb_ivf, me,
+            [=](const hnswgpu_index::SearchReq *first, const hnswgpu_index::SearchReq *r, int64_t total) {
+                if (r->k != first->k || r->ef != first->ef || total + r->nq > 16384) return false;
+                return one_arith || (total + r->nq) * np <= gemv_pairs;  // everybody on the GEMV scan, as when alone
+            },
+            [idx](const std::vector<hnswgpu_index::SearchReq *> &batch, int32_t total) {
+                return ivf_search_batch(idx, batch, total);
+            });
+    }
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
@@ -795,12 +857,10 @@ int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k
                               idx->s_probes.as<int32_t>(), st));
     HG_HIP(hipMemcpyAsync(out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
     HG_HIP(hipMemcpyAsync(out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
-    if (out_probes) {
-        if (np < nprobe)
-            for (int64_t i = 0; i < static_cast<int64_t>(nq) * nprobe; i++) out_probes[i] = -1;
-        HG_HIP(hipMemcpy2DAsync(out_probes, sizeof(int32_t) * nprobe, idx->s_probes.p, sizeof(int32_t) * np,
-                                sizeof(int32_t) * np, nq, hipMemcpyDeviceToHost, st));
-    }
+    if (np < nprobe)
+        for (int64_t i = 0; i < static_cast<int64_t>(nq) * nprobe; i++) out_probes[i] = -1;
+    HG_HIP(hipMemcpy2DAsync(out_probes, sizeof(int32_t) * nprobe, idx->s_probes.p, sizeof(int32_t) * np,
+                            sizeof(int32_t) * np, nq, hipMemcpyDeviceToHost, st));
     HG_HIP(hipStreamSynchronize(st));
     return 0;
 }
