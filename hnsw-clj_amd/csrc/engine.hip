@@ -302,8 +302,11 @@ int plan_chunks(int nch, int64_t max_rows, int64_t mean_rows, int64_t npairs, in
     // and 0.45 at 1024; batch 16: 0.215 against 0.237; batch 8: 0.135 against 0.144) -- ~250 rows per workgroup, a
     // query loaded once per 8 loop trips, 8x fewer partial lists for the merge.  One query streaming a whole table
     // (k-means++ rounds, single-query exact kNN) wants the finest chunks instead: 473 us against 511 per 1M x 768 pass.
+    // A handful of queries: fewer, longer chunks still -- the merge of the per-wave partial lists is then the larger
+    // part of the search (one query, 32 lists: 69 us end to end at 512 workgroups, 78 at 4096).
+    const int64_t small_target = std::min<int64_t>(4096, std::max<int64_t>(512, 8 * npairs));
     int64_t target_blocks = env_blocks > 0 ? env_blocks
-                                           : (list_pairs ? (npairs <= 4096 ? 4096 : 16384) : (npairs <= 1536 ? 32768 : 16384));
+                                           : (list_pairs ? (npairs <= 4096 ? small_target : 16384) : (npairs <= 1536 ? 32768 : 16384));
     int64_t want = (target_blocks + npairs - 1) / (npairs > 0 ? npairs : 1);
     if (want < 1) want = 1;
     if (want == 1) mean_rows = max_rows;  // already enough pairs: one workgroup per pair, no empty chunks
