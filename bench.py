@@ -8,7 +8,13 @@ achieved HBM GB/s against the roofline (1M x 768, nlist=1024, nprobe=32).
 A "step" is one pass of the hot path over one batch of `--nq` queries already resident in HBM:
 one hnswgpu_hnsw_search_dev launch.  With N > 1 every rank holds a replica of the 31k index and its
 own query batch (the 31k x 768 index fits one GPU, so the queries are what shard: "replicas", no
-collective on the data path); value = all ranks' queries / max-over-ranks time.
+collective on the data path); value = all ranks' queries / max-over-ranks time.  The row-sharded
+configurations (configs[3]: ONE IVF index whose lists are dealt to the GPUs; configs[4]: one HNSW
+sub-graph per GPU) run beside it for N > 1 and are reported in `sharded_ivf` / `sharded_hnsw`.
+
+`python bench.py --gpus N` starts its N ranks itself (child processes with RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set; the parent never touches the GPU and relays rank 0's line); under
+torch.distributed.run the ranks are already there and it just runs as one of them.
 
 Prints ONE JSON line on rank 0.
 """
@@ -27,6 +33,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+# MI355X_MICROARCH.md "Indexed rows": uniformly random ~1 KB rows of a table that fits the 256 MiB Infinity Cache are
+# gathered at 8.6 TB/s (38 MB table) to 7.4-7.9 TB/s (151 MB); random whole rows of a table far beyond it, gathered
+# into registers, at 5.5-5.8 TB/s.  These, not the HBM spec, bound the traversal's row gather.
+IC_GATHER_GBS = (7400.0, 8600.0)
+HBM_GATHER_GBS = (5500.0, 5800.0)
 N31K, DIM, K = 31173, 768, 10
 M, EFC = 16, 200
 # the reference's own ef (max(k, 50), ultra_fast.clj:355) first, then steps of ~4 % so that the operating point is the
@@ -70,11 +81,39 @@ def recall_at_k(ids, truth):
     return float((hit / truth.shape[1]).mean())
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N child processes, one rank per GPU.  This process has not
+    touched the GPU (importing torch does not) and never will: it waits, relays rank 0's JSON line and returns the
+    worst exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    line, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:      # rank 0 is gone and a peer still waits in a collective
+            p.kill()
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    return rc
+
+
 def main():
-    # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL's version banner
-    # does) are sent to stderr for the duration of the run
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -90,8 +129,20 @@ def main():
     ap.add_argument("--hnsw-shard-rows", type=int, default=1_250_000,
                     help="rows per GPU of the sharded 1536-d HNSW index (0 = skip that leg)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--no-dists", action="store_true", help="skip the gaussian / uniform / clustered operating points")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)   # tests/: ranks report and exit
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        sys.exit(launch_ranks(args.gpus))
+    if args.launch_selftest:     # no GPU needed: what a rank sees of the launcher's environment
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR")}))
+        sys.exit(3 if os.environ.get("HNSWGPU_SELFTEST_FAIL_RANK") == os.environ.get("RANK", "0") else 0)
+    # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL's version banner
+    # does) are sent to stderr for the duration of the run
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,7 +166,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        log("[rank %d] --gpus %d but WORLD_SIZE %d: running with the %d ranks the launcher started" % (rank, args.gpus, world, world))
 
     from hnsw_clj_amd import engine
 
@@ -230,17 +282,22 @@ def main():
             "single_query_latency_ms": {"p50": round(lat[len(lat) // 2], 4), "min": round(lat[0], 4),
                                         "p95": round(lat[int(len(lat) * 0.95)], 4)},
         },
-        "roofline_hnsw": {"bound": "hbm", "achieved": round(hnsw_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(hnsw_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+        "roofline_hnsw": {"bound": "infinity-cache gather", "achieved": round(hnsw_gbs, 1), "peak": IC_GATHER_GBS[1],
+                          "unit": "GB/s", "frac": round(hnsw_gbs / IC_GATHER_GBS[1], 4), "traffic": None,
+                          "peak_range": list(IC_GATHER_GBS), "frac_of_hbm_spec": round(hnsw_gbs / HBM_PEAK_GBS, 4),
                           "kernel": "hnsw_search_kernel", "avg_launch_ms": round(hnsw_avg_ms, 4),
-                          "note": "31k x 768 = 95.8 MB is Infinity-Cache resident: latency/occupancy bound, not HBM"},
+                          "algorithmic_bytes_per_query": int(hnsw_bytes_q),
+                          "note": "31,173 x 768 f32 = 95.8 MB is Infinity-Cache resident, so the bound is the guide's measured "
+                                  "ceiling for random ~1 KB rows of a 38-151 MB table (7.4-8.6 TB/s), not HBM; the HBM-resident "
+                                  "traversal (1.25M x 1536, configs[4]) is the sharded_hnsw leg / tests, against 5.5-5.8 TB/s"},
     }
+    result["config"]["qps_host_buffers"] = host_buffer_qps(idx, queries, ef, args.steps)
+    if rank == 0 and world == 1 and not args.no_dists:
+        result["config"]["by_distribution"] = by_distribution(engine, dev, args)
 
     # ------------------------------------------------------------------ IVF-FLAT scan roofline (configs[2])
     if not args.no_ivf and rank == 0:
-        result["roofline"] = ivf_roofline(engine, dev, args)
-        if traffic:
-            result["roofline"].update(traffic)
+        result["roofline"] = ivf_roofline(engine, dev, args, traffic)
     elif rank == 0:
         result["roofline"] = result["roofline_hnsw"]
 
@@ -275,10 +332,65 @@ def main():
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
 
 
-def ivf_roofline(engine, dev, args):
+def host_buffer_qps(idx, queries, ef, steps):
+    """The reference's own seam -- search-batch* takes and returns HOST arrays (api/protocol.clj:58-67): the same batch
+    through hnswgpu_hnsw_search (PCIe upload of nq x 768 floats, launch, download of ids + distances).  Never `value`."""
+    steps = max(3, min(steps, 10))
+    idx.hnsw_search(queries, K, ef)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        idx.hnsw_search(queries, K, ef)
+    return round(len(queries) * steps / (time.perf_counter() - t0), 1)
+
+
+def by_distribution(engine, dev, args):
+    """the generator's three distributions beside the headline's manifold set -- gaussian (primary in
+    the survey), uniform[0,1) (what the published run and benchmark_python_hnswlib.py:31 used), clustered-normalised.
+    Each: build on the device, ground truth by GPU brute force over the full base, then the FIRST ef of the sweep whose
+    recall@10 reaches 0.98 -- or the last point of the sweep if none does (ef <= 4096 is the kernel's limit)."""
+    out = {}
+    sweep = [50, 100, 200, 400, 800, 1600, 3200, 4096]
+    nq = min(args.nq, 4096)
+    for name in ("gaussian", "uniform", "clustered"):
+        t0 = time.time()
+        base = make_31k(name, 42, N31K)
+        Q = torch.from_numpy(make_31k(name, 43, nq)).to(dev)
+        with engine.Index(base, "cosine", dev.index) as idx:
+            idx.hnsw_build(M, EFC, 42)
+            truth, _ = idx.exact_knn_dev(Q, K)
+            pts, hit = [], None
+            for e in sweep:
+                ids, _ = idx.hnsw_search_dev(Q, K, e)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    idx.hnsw_search_dev(Q, K, e)
+                torch.cuda.synchronize()
+                qps = 3 * nq / (time.perf_counter() - t1)
+                r = recall_at_k(ids, truth)
+                pts.append([e, round(r, 4), round(qps, 1)])
+                if r >= 0.98:
+                    hit = pts[-1]
+                    break
+            first = hit or pts[-1]
+            out[name] = {"ef": first[0], "recall_at_10": first[1], "qps": first[2], "reached_0.98": hit is not None,
+                         "sweep_ef_recall_qps": pts, "queries": nq}
+        log("by_distribution %s: %s (%.1fs)" % (name, out[name], time.time() - t0))
+    out["note"] = ("i.i.d. gaussian / uniform 768-d have no neighbourhood structure (recall needs ef in the thousands: near "
+                   "brute force); clustered leaves the reference-style graph (closest-m pruning, no diversity heuristic, "
+                   "ultra_fast.clj:279-299) disconnected between clusters.  DESIGN.md section 6.")
+    return out
+
+
+def ivf_roofline(engine, dev, args, traffic):
     """1M x 768 clustered-normalised, nlist=1024, nprobe=32.  The timed kernel is the
-    list scan (scan_kernel over the probed lists); algorithmic bytes = sum over (query, probed list)
-    pairs of len * (4*D + 4)  [rows + precomputed norms], SURVEY 8(d)."""
+    list scan (scan_kernel over the probed lists).  Three byte counts per launch:
+      algorithmic = sum over (query, probed list) pairs of len * (4*D + 4)  [rows + precomputed norms], SURVEY 8(d);
+      unique      = the same with every list counted once per batch (pairs of one batch that probe the same list run
+                    side by side on one XCD and the second reader finds the first one's lines in that L2);
+      traffic     = what the fabric actually moved: PMC, 2 x FETCH_SIZE + WRITE_SIZE (pmc_traffic()).
+    roofline.achieved / frac are TRAFFIC / kernel time against the 8 TB/s HBM spec -- a fraction of the roofline, never
+    above 1; without a PMC pass (N > 1, --no-pmc) they fall back to the unique bytes, a lower bound of the traffic."""
     n, nlist, nprobe = args.ivf_n, 1024, 32
     x, Qa = ivf_dataset(dev, n, nlist, 1024)
     idx = engine.Index(x, "cosine", dev.index)
@@ -290,7 +402,7 @@ def ivf_roofline(engine, dev, args):
     _, off, _ = idx.get_ivf()
     lens = np.diff(off)
     out = {}
-    for nq in (32, 1024):
+    for nq in (1, 32, 1024):
         Q = Qa[:nq].contiguous()
         _, _, probes = idx.ivf_search(Q.cpu().numpy(), K, nprobe, want_probes=True)
         rows = int(lens[probes.ravel()].sum())
@@ -298,7 +410,7 @@ def ivf_roofline(engine, dev, args):
         alg_bytes = rows * (4 * DIM + 4)
         for _ in range(3):
             idx.ivf_search_dev(Q, K, nprobe)
-        steps = 20 if nq == 32 else 5
+        steps = 5 if nq == 1024 else 20
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -315,41 +427,67 @@ def ivf_roofline(engine, dev, args):
         out[nq] = {"nq": nq, "avg_scan_ms": round(avg_ms, 4), "search_wall_ms": round(wall * 1e3, 4),
                    "qps": round(nq / wall, 1), "algorithmic_GB": round(alg_bytes / 1e9, 4),
                    "unique_GB": round(uniq * (4 * DIM + 4) / 1e9, 4),
-                   "achieved_GBs": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
+                   "algorithmic_GBs": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
                    "unique_GBs": round(uniq * (4 * DIM + 4) / (avg_ms * 1e-3) / 1e9, 1)}
+    # single query, true latency: one call, one sync, host timer
+    lat = []
+    for i in range(60):
+        t1 = time.perf_counter()
+        idx.ivf_search_dev(Qa[i:i + 1], K, nprobe)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e6)
+    lat = sorted(lat[10:])
     # recall of the IVF configuration against exact kNN (GPU brute force)
     ti, _ = idx.exact_knn_dev(Qa[:256].contiguous(), K)
     ii, _ = idx.ivf_search_dev(Qa[:256].contiguous(), K, nprobe)
     torch.cuda.synchronize()
     rec = recall_at_k(ii, ti)
     idx.close()
-    # Two regimes, two kernels, each against its own bound:
-    #  * batch 32 -> scan_kernel (one GEMV per (query, list) pair, BASELINE.json configs[2] "fused GEMV"):
-    #    HBM-bound, achieved = algorithmic bytes / kernel time.  This is the `roofline` object.
+    # Three regimes, each against its own bound:
+    #  * batch 32 -> scan_kernel (one GEMV per (query, list) pair, BASELINE.json configs[2] "fused GEMV"): HBM-bound.
+    #    This is the `roofline` object.
+    #  * batch 1 (configs[2] names no batch): the same kernel with nothing to share -- every list is read once.
     #  * batch 1024 (configs[3]) -> the pairs are grouped by list and scanned by the f32-MFMA tile kernel:
     #    rows are fetched once per 32-query group, so the bound is the f32 matrix rate, not HBM.
     r = out[32]
     b = out[1024]
+    o = out[1]
     flops = 2.0 * b["algorithmic_GB"] * 1e9 / (4 * DIM + 4) * DIM      # 2 * rows scanned * D
     tf = flops / (b["avg_scan_ms"] * 1e-3) / 1e12
-    return {"bound": "hbm", "achieved": r["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(r["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "scan_kernel<3,8,false,ROLE_LIST_SCAN>",
-            "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch "
-                        "(one GEMV per (query, probed list) pair)" % n,
-            "traffic_note": "null: no PMC pass in this run (--no-pmc, N > 1 or rocprofv3 unavailable); profiles/ holds one",
-            "frac_note": "algorithmic bytes count a list once per (query, list) pair (SURVEY 8d); pairs of one batch that "
-                         "probe the same list run side by side on one XCD and share its L2, so frac can exceed 1 while the "
-                         "PMC traffic (and unique_bytes_GBs: every list counted once per batch) stays under the HBM rate",
-            "avg_launch_ms": r["avg_scan_ms"], "algorithmic_bytes_per_launch": int(r["algorithmic_GB"] * 1e9),
-            "unique_bytes_GBs": r["unique_GBs"], "batch_32": r,
-            "batched_mfma": {"bound": "mfma", "kernel": "tile_scan_kernel (v_mfma_f32_32x32x2_f32)",
-                             "workload": "same index, batch of 1024 queries per launch, pairs grouped by list",
-                             "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
-                             "avg_launch_ms": b["avg_scan_ms"], "qps_end_to_end": b["qps"],
-                             "algorithmic_GBs": b["achieved_GBs"], "unique_GB": b["unique_GB"]},
-            "ivf_recall_at_10": round(rec, 4), "ivf_build_s": round(build_s, 1),
-            "mean_list_len": float(lens.mean()), "max_list_len": int(lens.max())}
+    tr = traffic["traffic"] if traffic else None
+    achieved = (tr / 1e9 if tr else r["unique_GB"]) / (r["avg_scan_ms"] * 1e-3)
+    res = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr,
+           "achieved_from": "PMC traffic / kernel time" if tr else "unique bytes / kernel time (no PMC pass in this run: "
+                            "--no-pmc, N > 1 or rocprofv3 unavailable; a lower bound of the traffic; profiles/ holds a PMC run)",
+           "frac_of_copy_ceiling": round(achieved / 6290.0, 4),
+           "kernel": "scan_kernel<3,8,false,ROLE_LIST_SCAN>",
+           "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch "
+                       "(one GEMV per (query, probed list) pair)" % n,
+           "avg_launch_ms": r["avg_scan_ms"], "algorithmic_bytes_per_launch": int(r["algorithmic_GB"] * 1e9),
+           "algorithmic_GBs": r["algorithmic_GBs"], "frac_algorithmic": round(r["algorithmic_GBs"] / HBM_PEAK_GBS, 4),
+           "unique_bytes_GBs": r["unique_GBs"], "frac_unique": round(r["unique_GBs"] / HBM_PEAK_GBS, 4),
+           "reuse_note": "algorithmic bytes count a list once per (query, list) pair (SURVEY 8d); pairs of one batch that "
+                         "probe the same list run side by side on one XCD and share its L2, so algorithmic_GBs can exceed the "
+                         "HBM rate -- it is a throughput figure, not a roofline fraction",
+           "batch_32": r,
+           "batch_1": {"kernel_ms": o["avg_scan_ms"], "algorithmic_bytes": int(o["algorithmic_GB"] * 1e9),
+                       "achieved": o["algorithmic_GBs"], "unit": "GB/s", "frac": round(o["algorithmic_GBs"] / HBM_PEAK_GBS, 4),
+                       "end_to_end_us": {"p50": round(lat[len(lat) // 2], 1), "min": round(lat[0], 1),
+                                         "p95": round(lat[int(len(lat) * 0.95)], 1)},
+                       "end_to_end_frac": round(o["algorithmic_GB"] * 1e9 / (lat[len(lat) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                       "note": "one query, 32 lists, every byte read once (algorithmic = unique); end to end = route, "
+                               "probe table, scan, merge, decode in one call + sync"},
+           "batched_mfma": {"bound": "mfma", "kernel": "tile_scan_kernel (v_mfma_f32_32x32x2_f32)",
+                            "workload": "same index, batch of 1024 queries per launch, pairs grouped by list",
+                            "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                            "avg_launch_ms": b["avg_scan_ms"], "qps_end_to_end": b["qps"],
+                            "algorithmic_GBs": b["algorithmic_GBs"], "unique_GB": b["unique_GB"]},
+           "ivf_recall_at_10": round(rec, 4), "ivf_build_s": round(build_s, 1),
+           "mean_list_len": float(lens.mean()), "max_list_len": int(lens.max())}
+    if traffic:
+        res["traffic_note"] = traffic["traffic_note"]
+    return res
 
 
 def ivf_dataset(dev, n, nlist, nq_all):
@@ -438,38 +576,46 @@ def pmc_traffic(args):
 
 
 def sharded_ivf(engine, dev, rank, world, args):
-    """BASELINE.json configs[3]: 768-d index row-sharded over the GPUs (1.25M rows per GPU = 10M x 768 on 8),
-    batch = 1024 queries replicated on every rank, per-shard IVF search (nlist 1024, nprobe 32, k 10), ONE
-    all-gather of the per-shard top-k over RCCL/xGMI and a merge kernel on every rank.  Weak scaling in rows."""
-    from hnsw_clj_amd.sharded import ShardedSearcher
+    """BASELINE.json configs[3]: ONE 768-d IVF-FLAT index over all GPUs (1.25M rows per GPU = 10M x 768 on 8; nlist 1024,
+    nprobe 32, k 10, batch 1024).  SURVEY 8(e)'s split: centroids replicated, whole inverted lists dealt to the ranks
+    balanced by row count, every rank routes identically and scans the probed lists it holds, ONE all-gather of the
+    per-rank top-k over RCCL/xGMI, merge by (distance, position in the whole index's candidate stream) on every rank.
+    The build is distributed too (hnsw-clj_amd/sharded.py: seeds from rank 0, Lloyd over all rows with all-reduced list
+    sums, all-to-all of the rows).  Rank 0 then rebuilds the UNSHARDED index (same centroids and lists; the rows are
+    synthetic, so it regenerates every rank's) and the merged answer must equal its answer: ids and distance bits."""
+    from hnsw_clj_amd.sharded import Comm, ShardedIVF, lists_from_assign
 
     n, nlist, nprobe, nq = args.shard_rows, 1024, 32, 1024
     g = torch.Generator(device=dev)
     g.manual_seed(7)                                   # the cluster centres are global
     centers = torch.randn(nlist, DIM, generator=g, device=dev)
-    g.manual_seed(1000 + rank)                         # every shard draws its own rows
-    which = torch.randint(0, nlist, (n,), generator=g, device=dev)
-    x = centers[which] + 0.3 * torch.randn(n, DIM, generator=g, device=dev)
-    x /= x.norm(dim=1, keepdim=True)
+
+    def rows_of(r):                                    # rank r's rows, reproducible on any rank
+        g.manual_seed(1000 + r)
+        which = torch.randint(0, nlist, (n,), generator=g, device=dev)
+        x = centers[which] + 0.3 * torch.randn(n, DIM, generator=g, device=dev)
+        return x / x.norm(dim=1, keepdim=True)
+
     g.manual_seed(43)                                  # the same query batch on every rank
     qw = torch.randint(0, nlist, (nq,), generator=g, device=dev)
     Q = centers[qw] + 0.3 * torch.randn(nq, DIM, generator=g, device=dev)
     Q /= Q.norm(dim=1, keepdim=True)
-    idx = engine.Index(x, "cosine", dev.index)
-    del x
+    x = rows_of(rank)
+    comm = Comm(device=dev)
     t0 = time.time()
-    idx.ivf_build(nlist, 10, 42)
+    idx = ShardedIVF.build(x, "cosine", nlist, 10, 42, comm=comm)
+    torch.cuda.synchronize()
     build_s = time.time() - t0
-    s = ShardedSearcher(lambda q, k: idx.ivf_search_dev(q, k, nprobe), rank * n)
+    del x
     for _ in range(3):
-        ids, d = s.search(Q, K)
+        ids, d = idx.search(Q, K, nprobe)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     steps = 10
     t0 = time.perf_counter()
     for _ in range(steps):
-        ids, d = s.search(Q, K)
+        ids, d = idx.search(Q, K, nprobe)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -478,13 +624,34 @@ def sharded_ivf(engine, dev, rank, world, args):
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    # sanity: merged ids are global row ids of the right range, distances ascending
-    ok = bool((ids >= 0).all() and (ids < world * n).all() and (d[:, 1:] >= d[:, :-1]).all())
+    held = comm.all_gather(torch.tensor([int(idx.shard.n)], dtype=torch.int64)).view(-1).tolist()
+    assign_all = comm.all_gather(torch.from_numpy(idx.assign)).numpy().reshape(-1)     # every rank holds n rows
+    res = {"workload": "hnsw.ivf-flat, ONE index of %d x 768 over %d GPU(s): centroids replicated, %d whole lists dealt by "
+                       "row count, batch 1024, nprobe 32, all-gather of per-rank top-10 + keyed merge" % (world * n, world, nlist),
+           "qps": round(nq * steps / el, 1), "ms_per_batch": round(el / steps * 1e3, 3),
+           "rows_held_per_rank": held, "distributed_build_s": round(build_s, 1),
+           "collective": "all_gather of %d B per rank" % (nq * K * 12)}
+    if rank == 0:
+        torch.cuda.empty_cache()
+        xa = torch.cat([rows_of(r) for r in range(world)])
+        with engine.Index(xa, "cosine", dev.index) as full:
+            del xa
+            off, lids = lists_from_assign(assign_all, nlist)
+            full.set_ivf(idx.centroids, off, lids)
+            ui, ud = full.ivf_search_dev(Q, K, nprobe)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                full.ivf_search_dev(Q, K, nprobe)
+            torch.cuda.synchronize()
+            res["unsharded_one_gpu_ms_per_batch"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+            res["ids_equal_unsharded"] = bool(torch.equal(ids, ui))
+            res["distance_bits_equal_unsharded"] = bool(torch.equal(d.view(torch.int32), ud.view(torch.int32)))
+            ti, _ = full.exact_knn_dev(Q[:256].contiguous(), K)
+            res["recall_at_10"] = round(recall_at_k(ids[:256], ti), 4)
+        torch.cuda.empty_cache()
     idx.close()
-    return {"workload": "hnsw.ivf-flat %d x 768 row-sharded over %d GPU(s) (%d rows each), batch 1024, nlist 1024/shard, "
-                        "nprobe 32, all-gather of per-shard top-10 + merge" % (world * n, world, n),
-            "qps": round(nq * steps / el, 1), "ms_per_batch": round(el / steps * 1e3, 3), "valid": ok,
-            "ivf_build_s_per_shard": round(build_s, 1), "collective": "all_gather of %d B per rank" % (nq * K * 8)}
+    return res
 
 
 def sharded_hnsw(engine, dev, rank, world, args):
@@ -600,11 +767,19 @@ def cpu_baseline(idx, base, queries, ef):
     cores = best[1]
     nq = int(min(400000, max(256, 12000.0 * best[0])))                          # ~12 s of wall time
     qs = np.resize(queries, (nq, queries.shape[1]))                              # tile the timed queries
-    _, _, _, ms = O.hnsw_search(base, og, qs, K, ef=ef, nthreads=cores)
+    _, _, _, ms, lat = O.hnsw_search(base, og, qs, K, ef=ef, nthreads=cores, want_lat=True)
     n1 = max(16, min(nq, int(3000.0 / max(ms * cores / nq, 1e-3))))              # ~3 s single thread
-    _, _, _, ms1 = O.hnsw_search(base, og, qs[:n1], K, ef=ef, nthreads=1)
+    _, _, _, ms1, lat1 = O.hnsw_search(base, og, qs[:n1], K, ef=ef, nthreads=1, want_lat=True)
     _, _, _, msf = O.hnsw_search(base, og, qs, K, ef=ef, mode=O.MODE_FAST, nthreads=cores)
+
+    def pct(a):   # bench.clj:108-122: min / p50 / p95 / p99 / max / avg of the per-query times
+        a = np.sort(np.asarray(a, np.float64))
+        return {"min": round(float(a[0]), 4), "p50": round(float(a[len(a) // 2]), 4), "p95": round(float(a[int(len(a) * 0.95)]), 4),
+                "p99": round(float(a[int(len(a) * 0.99)]), 4), "max": round(float(a[-1]), 4), "avg": round(float(a.mean()), 4)}
+
     return {"value": round(nq / (ms * 1e-3), 1), "unit": "queries/s", "cores": cores, "kind": "port",
+            "latency_ms_per_query": pct(lat), "single_thread_latency_ms_per_query": pct(lat1),
+            "reference_protocol_latency_ms": round(ms / nq, 5),     # wall / queries, reproduce_02ms.clj:80-83 (a throughput figure)
             "sample": "%d queries (the timed batch, tiled), same graph/ef/k, f64 reference-order oracle, one task per "
                       "query on %d threads (parallel_search.clj:15-49); thread count = best of a pilot over %s on a box "
                       "reporting %d logical CPUs" % (nq, cores, cands, os.cpu_count() or 1),

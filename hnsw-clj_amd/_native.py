@@ -63,6 +63,10 @@ _SIGS = {
     "hnswgpu_ivf_search": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
     "hnswgpu_ivf_search_dev": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
     "hnswgpu_ivf_search_lists": ["p", "p", "i32", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_set_ivf_shard": ["p", "p", "i32", "p", "p", "p"],
+    "hnswgpu_ivf_search_shard_dev": ["p", "p", "i32", "i32", "i32", "p", "p", "p", "p"],
+    "hnswgpu_merge_keyed_dev": ["i32", "p", "p", "p", "i32", "i32", "i32", "p", "p", "p"],
+    "hnswgpu_list_sums": ["p", "i32", "p", "p", "p"],
     "hnswgpu_merge_topk_dev": ["i32", "p", "p", "i32", "i32", "i32", "p", "p", "p"],
     "hnswgpu_merge_lists_dev": ["i32", "p", "p", "i32", "i32", "i32", "i32", "p", "p", "p"],
     "hnswgpu_rerank": ["p", "p", "i32", "p", "i32", "i32", "p", "p"],

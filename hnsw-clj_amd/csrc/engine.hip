@@ -155,7 +155,7 @@ __device__ __forceinline__ void fold_keys(const uint64_t *in, int64_t n, int k, 
 
 // hipFuncSetAttribute is per device: remember it per (call site, device), not once per process (one process may
 // hold handles on several GPUs -- the partitioned and IVF-HNSW mirrors do)
-static bool attr_needed(bool (&done)[64]) {
+bool attr_needed(bool (&done)[64]) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
     if (done[dev]) return false;
@@ -700,6 +700,51 @@ __global__ __launch_bounds__(kWave) void merge_shards_kernel(const int32_t *ids,
     }
 }
 
+// [nshard][nq][k] (id, dist, order) -> [nq][k] by (distance, order): the shards of ONE inverted-file index number
+// their candidates by the position in the candidate stream of the whole index (Pair::gord_base), so this merge equals
+// the unsharded search's own stable sort (ivf_flat.clj:291-294) -- ties included.  One wave per query.
+__global__ __launch_bounds__(kWave) void merge_keyed_kernel(const int32_t *ids, const float *dist, const uint32_t *ord,
+                                                            int nshard, int nq, int k, int32_t *out_ids,
+                                                            float *out_dist) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *list = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *src = reinterpret_cast<uint32_t *>(list + k);
+    const int lane = threadIdx.x, q = blockIdx.x;
+    int cnt = 0;
+    uint64_t thr = ~0ull;
+    const int tot = nshard * k;
+    for (int base = 0; base < tot; base += kWave) {
+        const int i = base + lane;
+        uint64_t key = ~0ull;
+        if (i < tot) {
+            const int64_t at = (static_cast<int64_t>(i / k) * nq + q) * k + i % k;
+            if (ids[at] >= 0) key = make_key(dist[at], ord[at]);
+        }
+        uint64_t mask = __ballot(key < thr);
+        while (mask) {
+            const int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+            mask &= mask - 1;
+            const uint64_t kb = lane_bcast(key, b);
+            if (kb < thr) {
+                wave_insert_kv(list, src, cnt, k, kb, static_cast<uint32_t>(base + b), lane);
+                thr = cnt == k ? list[k - 1] : ~0ull;
+            }
+        }
+    }
+    for (int i = lane; i < k; i += kWave) {
+        int32_t id = -1;
+        float d = __uint_as_float(0x7f800000u);
+        if (i < cnt) {
+            const uint32_t o = src[i];
+            const int64_t at = (static_cast<int64_t>(o / k) * nq + q) * k + o % k;
+            id = ids[at];
+            d = dist[at];
+        }
+        out_ids[static_cast<int64_t>(q) * k + i] = id;
+        out_dist[static_cast<int64_t>(q) * k + i] = d;
+    }
+}
+
 }  // namespace hg
 
 using namespace hg;
@@ -807,7 +852,8 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     if (!idx) return 0;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,
+    if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows in place: freed once, below
+    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
                     idx->d_cent,  idx->d_cnorms, idx->d_lrows,  idx->d_lnorms,  idx->d_listoff, idx->d_listids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1007,6 +1053,19 @@ int hnswgpu_merge_lists_dev(int32_t device, const int32_t *d_ids, const float *d
 int hnswgpu_merge_topk_dev(int32_t device, const int32_t *d_ids, const float *d_dist, int32_t nshard, int32_t nq,
                            int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream) {
     return hnswgpu_merge_lists_dev(device, d_ids, d_dist, nshard, nq, k, k, d_out_ids, d_out_dist, stream);
+}
+
+int hnswgpu_merge_keyed_dev(int32_t device, const int32_t *d_ids, const float *d_dist, const uint32_t *d_order,
+                            int32_t nshard, int32_t nq, int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream) {
+    HG_REQUIRE(nshard >= 1 && nq >= 0 && k >= 1, HNSWGPU_EINVAL, "bad sizes");
+    HG_REQUIRE(k <= 1024, HNSWGPU_ELIMIT, "k > 1024 is not supported");
+    if (nq == 0) return 0;
+    HG_REQUIRE(d_ids && d_dist && d_order && d_out_ids && d_out_dist, HNSWGPU_EINVAL, "null argument");
+    HG_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(merge_keyed_kernel, dim3(nq), dim3(kWave), (sizeof(uint64_t) + sizeof(uint32_t)) * k,
+                       static_cast<hipStream_t>(stream), d_ids, d_dist, d_order, nshard, nq, k, d_out_ids, d_out_dist);
+    HG_HIP(hipGetLastError());
+    return 0;
 }
 
 // ---- re-rank: per query, exact distances to a candidate list, stable ascending sort, take k ----

@@ -128,8 +128,12 @@ struct hnswgpu_index {
     float *d_cent = nullptr, *d_cnorms = nullptr, *d_lrows = nullptr, *d_lnorms = nullptr;
     int64_t *d_listoff = nullptr;
     int32_t *d_listids = nullptr;
+    // a SHARD of a larger IVF index (hnswgpu_set_ivf_shard): prefix sums of the list lengths of the WHOLE index, so
+    // that every shard numbers its candidates as the unsharded search would; nullptr on an ordinary index
+    int64_t *d_glistoff = nullptr;
+    bool lrows_alias = false;  // lists are the base rows in place (list_ids = 0..n-1): d_lrows / d_lnorms alias d_base / d_norms
     std::vector<float> h_cent;
-    std::vector<int64_t> h_listoff;
+    std::vector<int64_t> h_listoff, h_glistlen;
     std::vector<int32_t> h_listids;
 
     // scratch (grown on demand, reused across calls; calls are serialised by `mu`)
@@ -146,6 +150,8 @@ struct hnswgpu_index {
 namespace hg {
 
 int pick_nch(int64_t ld);  // 0 if unsupported
+// hipFuncSetAttribute is per device: true the first time a call site asks on the current device
+bool attr_needed(bool (&done)[64]);
 
 // launch wrappers (engine.hip / hnsw.hip)
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);

@@ -481,8 +481,10 @@ int hnswgpu_set_graph(hnswgpu_index *idx, const int32_t *levels, const int32_t *
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
+    // every earlier call on this handle is ordered before `st` by begin_call: once `st` is idle nothing can still be
+    // traversing the graph that is about to be freed (and no other handle on this GPU is stalled)
     HG_TRY(begin_call(idx, st));
-    HG_HIP(hipDeviceSynchronize());  // nothing may still be traversing the graph that is about to be freed
+    HG_HIP(hipStreamSynchronize(st));
     free_graph(idx);
     HG_TRY(alloc_graph(idx, M, M0, blocks));
     if (n > 0) {
@@ -672,7 +674,7 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
     }
     const int64_t blocks = n > 0 ? g.up_off[n] : 0;
     HG_TRY(begin_call(idx, st));
-    HG_HIP(hipDeviceSynchronize());
+    HG_HIP(hipStreamSynchronize(st));  // as in hnswgpu_set_graph
     free_graph(idx);
     HG_TRY(alloc_graph(idx, M, M0, blocks));
     if (n == 0) {

@@ -15,35 +15,44 @@ namespace hg {
 // its rows in the query's concatenated candidate stream (ties are broken in that order, which is
 // the order search-ivf-flat concatenates partitions in, ivf_flat.clj:281-294)
 __global__ __launch_bounds__(kWG) void probe_pairs_kernel(const uint32_t *ord, int nq, int nprobe, const int64_t *listoff,
-                                                          Pair *pairs, int32_t *probes, int32_t *qcnt) {
+                                                          const int64_t *glistoff, Pair *pairs, int32_t *probes,
+                                                          int32_t *qcnt) {
     // one wave per query: lane p owns probe p (+64, +128, ...); the offsets of the probes in the query's
     // concatenated candidate stream are an exclusive prefix sum over the list lengths (wave scan)
     const int lane = threadIdx.x & (kWave - 1);
     const int q = blockIdx.x * kNWave + (threadIdx.x >> 6);
     if (q >= nq) return;
-    uint32_t carry = 0;
+    uint32_t carry = 0, gcarry = 0;
     for (int p0 = 0; p0 < nprobe; p0 += kWave) {
         const int p = p0 + lane;
         uint32_t l = p < nprobe ? ord[static_cast<int64_t>(q) * nprobe + p] : 0xffffffffu;
         Pair pr;
         pr.q = q;
+        pr.pad = 0;
         pr.row_begin = pr.row_end = 0;
+        uint32_t glen = 0;
         if (l != 0xffffffffu) {
             pr.row_begin = listoff[l];
             pr.row_end = listoff[l + 1];
+            glen = static_cast<uint32_t>(glistoff[l + 1] - glistoff[l]);
         }
         const uint32_t len = static_cast<uint32_t>(pr.row_end - pr.row_begin);
-        uint32_t incl = len;  // inclusive scan across the wave
+        uint32_t incl = len, gincl = glen;  // inclusive scans across the wave
         for (int off = 1; off < kWave; off <<= 1) {
-            uint32_t o = __shfl_up(incl, off, kWave);
-            if (lane >= off) incl += o;
+            uint32_t o = __shfl_up(incl, off, kWave), go = __shfl_up(gincl, off, kWave);
+            if (lane >= off) {
+                incl += o;
+                gincl += go;
+            }
         }
         pr.ord_base = carry + incl - len;
+        pr.gord_base = gcarry + gincl - glen;
         if (p < nprobe) {
             pairs[static_cast<int64_t>(q) * nprobe + p] = pr;
             if (probes) probes[static_cast<int64_t>(q) * nprobe + p] = l == 0xffffffffu ? -1 : static_cast<int32_t>(l);
         }
         carry += __shfl(incl, kWave - 1, kWave);
+        gcarry += __shfl(gincl, kWave - 1, kWave);
     }
     if (qcnt && lane == 0) qcnt[q] = static_cast<int32_t>(carry);
 }
@@ -170,11 +179,11 @@ __global__ void ivf_scatter_kernel(const Pair *pairs, const int32_t *probes, int
 }
 
 __global__ void ivf_decode_kernel(const uint32_t *ord, int nq, int k, const Pair *pairs, int nprobe,
-                                  const int32_t *listids, int32_t *out_ids) {
+                                  const int32_t *listids, int32_t *out_ids, uint32_t *out_gord) {
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= static_cast<int64_t>(nq) * k) return;
     int q = static_cast<int>(i / k);
-    uint32_t o = ord[i];
+    uint32_t o = ord[i], go = 0xffffffffu;
     int32_t id = -1;
     if (o != 0xffffffffu) {
         const Pair *pp = pairs + static_cast<int64_t>(q) * nprobe;
@@ -182,8 +191,10 @@ __global__ void ivf_decode_kernel(const uint32_t *ord, int nq, int k, const Pair
         while (p + 1 < nprobe && pp[p + 1].ord_base <= o) p++;
         // lists of length 0 share an ord_base with their successor: take the last one that fits
         id = listids[pp[p].row_begin + (o - pp[p].ord_base)];
+        go = pp[p].gord_base + (o - pp[p].ord_base);  // position in the candidate stream of the whole index
     }
     out_ids[i] = id;
+    if (out_gord) out_gord[i] = go;
 }
 
 // dst row pos <- src row listids[pos]; one wave per row, float4 lanes
@@ -213,6 +224,19 @@ __global__ __launch_bounds__(kWG) void centroid_mean_kernel(const float *rows, i
         double s = 0.0;
         for (int64_t i = b; i < e; i++) s = s + static_cast<double>(rows[static_cast<int64_t>(listids[i]) * ld + c0]);
         cent[static_cast<int64_t>(l) * ld + c0] = static_cast<float>(s / static_cast<double>(e - b));
+    }
+}
+
+// The f64 column sums of compute-centroid (ivf_flat.clj:70-75) without the division: what one shard of a row-sharded
+// index contributes to a Lloyd update (the sums of all shards are added, then divided by the global count).
+__global__ __launch_bounds__(kWG) void list_sum_kernel(const float *rows, int64_t ld, int dim, const int64_t *listoff,
+                                                       const int32_t *listids, double *sums) {
+    int l = blockIdx.x;
+    int64_t b = listoff[l], e = listoff[l + 1];
+    for (int c0 = threadIdx.x; c0 < dim; c0 += kWG) {
+        double s = 0.0;
+        for (int64_t i = b; i < e; i++) s = s + static_cast<double>(rows[static_cast<int64_t>(listids[i]) * ld + c0]);
+        sums[static_cast<int64_t>(l) * dim + c0] = s;
     }
 }
 
@@ -254,24 +278,38 @@ static int validate_lists(int64_t n, int32_t nlist, const int64_t *off, const in
 }
 
 static void free_ivf(hnswgpu_index *idx) {
-    void *ptrs[] = {idx->d_cent, idx->d_cnorms, idx->d_lrows, idx->d_lnorms, idx->d_listoff, idx->d_listids};
+    if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows themselves: not ours to free
+    void *ptrs[] = {idx->d_cent, idx->d_cnorms, idx->d_lrows, idx->d_lnorms, idx->d_listoff, idx->d_listids, idx->d_glistoff};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     idx->d_cent = idx->d_cnorms = idx->d_lrows = idx->d_lnorms = nullptr;
-    idx->d_listoff = nullptr;
+    idx->d_listoff = idx->d_glistoff = nullptr;
     idx->d_listids = nullptr;
+    idx->lrows_alias = false;
+    idx->h_glistlen.clear();
     idx->nlist = 0;
 }
 
 // device centroids (nlist x ld) + host lists -> the searchable layout
 static int install_lists(hnswgpu_index *idx, int32_t nlist, const int64_t *off, const int32_t *ids, hipStream_t st) {
     int64_t n = idx->n;
+    // rows that already arrive in list order (a shard filled list by list, hnsw-clj_amd/sharded.py) are scanned in
+    // place: no second copy of the base
+    bool identity = n > 0;
+    for (int64_t i = 0; i < n && identity; i++) identity = ids[i] == i;
     HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_listoff), sizeof(int64_t) * (nlist + 1)));
     HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_listids), sizeof(int32_t) * std::max<int64_t>(n, 1)));
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lrows), sizeof(float) * std::max<int64_t>(n, 1) * idx->ld));
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lnorms), sizeof(float) * std::max<int64_t>(n, 1)));
     HG_HIP(hipMemcpyAsync(idx->d_listoff, off, sizeof(int64_t) * (nlist + 1), hipMemcpyHostToDevice, st));
-    if (n > 0) {
+    if (identity) {
+        idx->lrows_alias = true;
+        idx->d_lrows = idx->d_base;
+        idx->d_lnorms = idx->d_norms;
+        HG_HIP(hipMemcpyAsync(idx->d_listids, ids, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    } else {
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lrows), sizeof(float) * std::max<int64_t>(n, 1) * idx->ld));
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lnorms), sizeof(float) * std::max<int64_t>(n, 1)));
+    }
+    if (n > 0 && !identity) {
         HG_HIP(hipMemcpyAsync(idx->d_listids, ids, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(permute_rows_kernel, dim3(static_cast<unsigned>((n + kNWave - 1) / kNWave)), dim3(kWG), 0,
                            st, idx->d_base, idx->d_norms, idx->ld, idx->d_listids, n, idx->d_lrows, idx->d_lnorms);
@@ -491,7 +529,8 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
 
 static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
                               int32_t *d_out_ids, float *d_out_dist, int32_t *d_out_probes, hipStream_t st,
-                              const int32_t *d_given_probes = nullptr) {
+                              const int32_t *d_given_probes = nullptr, uint32_t *d_out_gord = nullptr) {
+    const int64_t *glistoff = idx->d_glistoff ? idx->d_glistoff : idx->d_listoff;
     if (nprobe > idx->nlist && !d_given_probes) nprobe = idx->nlist;
     // 1. centroid routing (:261-269): top-nprobe of the centroid table, stable on the centroid index
     ScanArgs a;
@@ -525,7 +564,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     if (use_tile) HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
     if (d_given_probes) {  // caller-chosen lists (the :turbo mode's random partitions, :271-272); -1 = none
         hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st,
-                           reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff,
+                           reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff, glistoff,
                            idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf);
         HG_HIP(hipGetLastError());
     } else {
@@ -547,7 +586,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     else
         HG_TRY(scan_topk(idx, a, nq, 1, idx->nlist, st, -1));
     hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st, idx->s_ord.as<uint32_t>(), nq,
-                       nprobe, idx->d_listoff, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf);
+                       nprobe, idx->d_listoff, glistoff, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf);
     HG_HIP(hipGetLastError());
     }
     // 2. scan the probed lists (:217-234) and merge (:291-294)
@@ -567,9 +606,13 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     } else {
         if (use_order) {
             const size_t olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);
-            if (olds > 48 * 1024)
-                HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_order_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(olds)));
+            if (olds > 48 * 1024) {  // once per device, for the largest histogram the kernel supports
+                static bool attr_done[64] = {};
+                if (attr_needed(attr_done))
+                    HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_order_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(sizeof(int32_t) * (kOrderMaxLists + 1 + 1024))));
+            }
             hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), olds, st, probes_buf, static_cast<int>(npairs),
                                idx->nlist, order_buf);
             HG_HIP(hipGetLastError());
@@ -583,7 +626,8 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     }
     int64_t cnt = static_cast<int64_t>(nq) * k;
     hipLaunchKernelGGL(ivf_decode_kernel, dim3(static_cast<unsigned>((cnt + 255) / 256)), dim3(256), 0, st,
-                       idx->s_ord.as<uint32_t>(), nq, k, idx->s_pairs.as<Pair>(), nprobe, idx->d_listids, d_out_ids);
+                       idx->s_ord.as<uint32_t>(), nq, k, idx->s_pairs.as<Pair>(), nprobe, idx->d_listids, d_out_ids,
+                       d_out_gord);
     HG_HIP(hipGetLastError());
     HG_HIP(hipMemcpyAsync(d_out_dist, idx->s_dist.p, sizeof(float) * cnt, hipMemcpyDeviceToDevice, st));
     return 0;
@@ -595,25 +639,54 @@ using namespace hg;
 
 extern "C" {
 
-int hnswgpu_set_ivf(hnswgpu_index *idx, const float *centroids, int32_t nlist, const int64_t *list_off,
-                    const int32_t *list_ids) {
+static int set_ivf_impl(hnswgpu_index *idx, const float *centroids, int32_t nlist, const int64_t *list_off,
+                        const int32_t *list_ids, const int64_t *global_len) {
     HG_REQUIRE(idx && centroids && list_off && (list_ids || idx->n == 0), HNSWGPU_EINVAL, "null argument");
     HG_REQUIRE(nlist >= 1, HNSWGPU_EINVAL, "nlist must be >= 1");
     HG_TRY(validate_lists(idx->n, nlist, list_off, list_ids));
+    std::vector<int64_t> goff;
+    if (global_len) {
+        goff.assign(static_cast<size_t>(nlist) + 1, 0);
+        for (int l = 0; l < nlist; l++) {
+            HG_REQUIRE(global_len[l] >= list_off[l + 1] - list_off[l], HNSWGPU_EINVAL,
+                       "list %d: global length %lld < the %lld rows this shard holds", l, (long long)global_len[l],
+                       (long long)(list_off[l + 1] - list_off[l]));
+            goff[l + 1] = goff[l] + global_len[l];
+        }
+        HG_REQUIRE(goff[nlist] < 0xffffffffLL, HNSWGPU_ELIMIT, "the whole index must hold fewer than 2^32 rows");
+    }
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
+    // every earlier call on this handle is ordered before `st` by begin_call: waiting for `st` alone retires all work
+    // that may still read the lists about to be freed (no device-wide synchronisation: other handles keep running)
     HG_TRY(begin_call(idx, st));
-    HG_HIP(hipDeviceSynchronize());
+    HG_HIP(hipStreamSynchronize(st));
     free_ivf(idx);
     HG_TRY(alloc_centroids(idx, nlist));
     HG_HIP(hipMemsetAsync(idx->d_cent, 0, sizeof(float) * nlist * idx->ld, st));
     HG_HIP(hipMemcpy2DAsync(idx->d_cent, sizeof(float) * idx->ld, centroids, sizeof(float) * idx->dim,
                             sizeof(float) * idx->dim, nlist, hipMemcpyHostToDevice, st));
     HG_TRY(launch_norms(idx->nch, idx->d_cent, idx->ld, nlist, idx->d_cnorms, st));
-    HG_TRY(install_lists(idx, nlist, list_off, list_ids, st));
+    if (global_len) {
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_glistoff), sizeof(int64_t) * (nlist + 1)));
+        HG_HIP(hipMemcpyAsync(idx->d_glistoff, goff.data(), sizeof(int64_t) * (nlist + 1), hipMemcpyHostToDevice, st));
+    }
+    HG_TRY(install_lists(idx, nlist, list_off, list_ids, st));  // synchronises: goff may go out of scope
+    if (global_len) idx->h_glistlen.assign(global_len, global_len + nlist);
     idx->h_cent.assign(centroids, centroids + static_cast<size_t>(nlist) * idx->dim);
     return 0;
+}
+
+int hnswgpu_set_ivf(hnswgpu_index *idx, const float *centroids, int32_t nlist, const int64_t *list_off,
+                    const int32_t *list_ids) {
+    return set_ivf_impl(idx, centroids, nlist, list_off, list_ids, nullptr);
+}
+
+int hnswgpu_set_ivf_shard(hnswgpu_index *idx, const float *centroids, int32_t nlist, const int64_t *list_off,
+                          const int32_t *list_ids, const int64_t *global_list_len) {
+    HG_REQUIRE(global_list_len, HNSWGPU_EINVAL, "global_list_len is null");
+    return set_ivf_impl(idx, centroids, nlist, list_off, list_ids, global_list_len);
 }
 
 int hnswgpu_get_ivf(const hnswgpu_index *idx, float *centroids, int64_t *list_off, int32_t *list_ids) {
@@ -674,6 +747,31 @@ int hnswgpu_list_means(hnswgpu_index *idx, int32_t nlist, const int64_t *list_of
     return 0;
 }
 
+int hnswgpu_list_sums(hnswgpu_index *idx, int32_t nlist, const int64_t *list_off, const int32_t *list_ids,
+                      double *out_sums) {
+    HG_REQUIRE(idx && list_off && (list_ids || idx->n == 0) && out_sums, HNSWGPU_EINVAL, "null argument");
+    HG_REQUIRE(nlist >= 1, HNSWGPU_EINVAL, "nlist must be >= 1");
+    HG_TRY(validate_lists(idx->n, nlist, list_off, list_ids));
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
+    const size_t sbytes = sizeof(double) * static_cast<size_t>(nlist) * idx->dim;
+    HG_TRY(idx->s_misc.ensure(sizeof(int64_t) * (nlist + 1)));
+    HG_TRY(idx->s_misc2.ensure(sizeof(int32_t) * std::max<int64_t>(idx->n, 1)));
+    HG_TRY(idx->s_tile.ensure(sbytes));
+    HG_HIP(hipMemcpyAsync(idx->s_misc.p, list_off, sizeof(int64_t) * (nlist + 1), hipMemcpyHostToDevice, st));
+    if (idx->n > 0)
+        HG_HIP(hipMemcpyAsync(idx->s_misc2.p, list_ids, sizeof(int32_t) * idx->n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(list_sum_kernel, dim3(nlist), dim3(kWG), 0, st, idx->d_base, idx->ld, idx->dim,
+                       idx->s_misc.as<int64_t>(), idx->s_misc2.as<int32_t>(), idx->s_tile.as<double>());
+    HG_HIP(hipGetLastError());
+    HG_HIP(hipMemcpyAsync(out_sums, idx->s_tile.p, sbytes, hipMemcpyDeviceToHost, st));
+    HG_TRY(end_call(idx, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 int hnswgpu_kmeanspp(hnswgpu_index *idx, int32_t nlist, int64_t seed, int32_t *out_rows) {
     HG_REQUIRE(idx && out_rows, HNSWGPU_EINVAL, "null argument");
     HG_REQUIRE(nlist >= 1 && idx->n >= 1, HNSWGPU_EINVAL, "need nlist >= 1 and a non-empty index");
@@ -695,7 +793,7 @@ int hnswgpu_ivf_build(hnswgpu_index *idx, int32_t nlist, int32_t max_iter, int64
     hipStream_t st = idx->stream;
     const int64_t n = idx->n;
     HG_TRY(begin_call(idx, st));
-    HG_HIP(hipDeviceSynchronize());
+    HG_HIP(hipStreamSynchronize(st));  // see set_ivf_impl: retires every earlier call on this handle, and only those
     free_ivf(idx);
     std::vector<int32_t> chosen;
     HG_TRY(kmeanspp_device(idx, nlist, seed, chosen, st));
@@ -748,6 +846,19 @@ int hnswgpu_ivf_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     hipStream_t st = static_cast<hipStream_t>(stream);
     HG_TRY(begin_call(idx, st));
     HG_TRY(ivf_search_enqueue(idx, d_Q, nq, k, nprobe, d_out_ids, d_out_dist, nullptr, st));
+    return end_call(idx, st);
+}
+
+int hnswgpu_ivf_search_shard_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
+                                 int32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_order, void *stream) {
+    HG_TRY(check_ivf_args(idx, d_Q, nq, k, nprobe, d_out_ids, d_out_dist));
+    if (nq == 0) return 0;
+    HG_REQUIRE(d_out_order, HNSWGPU_EINVAL, "d_out_order is null");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(ivf_search_enqueue(idx, d_Q, nq, k, nprobe, d_out_ids, d_out_dist, nullptr, st, nullptr, d_out_order));
     return end_call(idx, st);
 }
 

@@ -137,6 +137,45 @@ __device__ __forceinline__ void wave_insert(uint64_t *list, int &cnt, int k, uin
     cnt = newcnt;
 }
 
+// wave_insert with a 32-bit payload carried beside every key (the merge over shards: key = (distance, global order),
+// payload = where the candidate sits in the gathered arrays).
+__device__ __forceinline__ void wave_insert_kv(uint64_t *list, uint32_t *val, int &cnt, int k, uint64_t key, uint32_t v,
+                                               int lane) {
+    int pos = 0;
+    for (int base = 0; base < cnt; base += kWave) {
+        int i = base + lane;
+        bool lt = (i < cnt) && (list[i] < key);
+        pos += __popcll(__ballot(lt));
+    }
+    if (pos >= k) return;
+    int newcnt = cnt + 1 < k ? cnt + 1 : k;
+    for (int top = newcnt - 1; top > pos; top -= kWave) {
+        int i = top - lane;
+        bool act = i > pos;
+        uint64_t kk = 0;
+        uint32_t vv = 0;
+        if (act) {
+            kk = list[i - 1];
+            vv = val[i - 1];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (act) {
+            list[i] = kk;
+            val[i] = vv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+        list[pos] = key;
+        val[pos] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    cnt = newcnt;
+}
+
 // Broadcast lane `src`'s 64-bit value (src wave-uniform): two v_readlane instead of two LDS-crossbar permutes.
 __device__ __forceinline__ uint64_t lane_bcast(uint64_t v, int src) {
     const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), src);
@@ -207,7 +246,12 @@ __global__ __launch_bounds__(kWG) void row_norms_kernel(const float *rows, int64
 struct Pair {
     int64_t row_begin, row_end;
     int32_t q;
-    uint32_t ord_base;
+    uint32_t ord_base;   // offset of this list's rows in the query's candidate stream over THIS handle's rows
+    // the same offset in the candidate stream of the WHOLE index when this handle holds only some of the inverted
+    // lists (hnswgpu_set_ivf_shard): shards order their results by it, so a merge over shards breaks ties exactly as
+    // one unsharded search would (ivf_flat.clj:281-294 concatenates the probed partitions in probe order)
+    uint32_t gord_base;
+    uint32_t pad;
 };
 
 struct ScanArgs {

@@ -194,6 +194,16 @@ class Index:
         ids = np.ascontiguousarray(list_ids, np.int32)
         check(lib().hnswgpu_set_ivf(self._h, _p(cen), cen.shape[0], _p(off), _p(ids)))
 
+    def set_ivf_shard(self, centroids, list_off, list_ids, global_list_len):
+        """This handle holds some of the inverted lists of a larger index (see include/hnswgpu.h)."""
+        cen = _f32(centroids)
+        off = np.ascontiguousarray(list_off, np.int64)
+        ids = np.ascontiguousarray(list_ids, np.int32)
+        gl = np.ascontiguousarray(global_list_len, np.int64)
+        if len(gl) != cen.shape[0] or len(off) != cen.shape[0] + 1:
+            raise ValueError("need nlist global lengths and nlist + 1 offsets")
+        check(lib().hnswgpu_set_ivf_shard(self._h, _p(cen), cen.shape[0], _p(off), _p(ids), _p(gl)))
+
     @property
     def nlist(self):
         nl = C.c_int32()
@@ -220,6 +230,14 @@ class Index:
         ids = np.ascontiguousarray(list_ids, np.int32)
         out = np.empty((len(off) - 1, self.dim), np.float32)
         check(lib().hnswgpu_list_means(self._h, len(off) - 1, _p(off), _p(ids), _p(out)))
+        return out
+
+    def list_sums(self, list_off, list_ids):
+        """f64 column sums of every list (compute-centroid without the division)."""
+        off = np.ascontiguousarray(list_off, np.int64)
+        ids = np.ascontiguousarray(list_ids, np.int32)
+        out = np.empty((len(off) - 1, self.dim), np.float64)
+        check(lib().hnswgpu_list_sums(self._h, len(off) - 1, _p(off), _p(ids), _p(out)))
         return out
 
     def kmeanspp(self, nlist, seed=42):
@@ -268,6 +286,16 @@ class Index:
         check(lib().hnswgpu_ivf_search_dev(self._h, Q.data_ptr(), Q.shape[0], k, nprobe, ids.data_ptr(),
                                            d.data_ptr(), st))
         return ids, d
+
+    def ivf_search_shard_dev(self, Q, k, nprobe):
+        """ivf_search_dev + every result's position in the candidate stream of the whole (sharded) index."""
+        import torch
+
+        Q, ids, d, st = self._dev_args(Q, k)
+        order = torch.empty((Q.shape[0], k), dtype=torch.int32, device=Q.device)   # uint32 bits
+        check(lib().hnswgpu_ivf_search_shard_dev(self._h, Q.data_ptr(), Q.shape[0], k, nprobe, ids.data_ptr(),
+                                                 d.data_ptr(), order.data_ptr(), st))
+        return ids, d, order
 
     def exact_knn_dev(self, Q, k, out=None):
         Q, ids, d, st = self._dev_args(Q, k, out)
@@ -327,6 +355,22 @@ def merge_topk_dev(ids, dist, out=None):
     st = torch.cuda.current_stream(ids.device).cuda_stream
     check(lib().hnswgpu_merge_topk_dev(ids.device.index or 0, ids.data_ptr(), dist.data_ptr(), ns, nq, k,
                                        oi.data_ptr(), od.data_ptr(), st))
+    return oi, od
+
+
+def merge_keyed_dev(ids, dist, order, out=None):
+    """[nshard][nq][k] (global id, distance, order) of the shards of ONE IVF index -> [nq][k] by (distance, order)."""
+    import torch
+
+    assert ids.is_cuda and ids.dtype == torch.int32 and dist.dtype == torch.float32 and order.dtype == torch.int32
+    assert ids.dim() == 3 and ids.shape == dist.shape == order.shape
+    ids, dist, order = ids.contiguous(), dist.contiguous(), order.contiguous()
+    ns, nq, k = ids.shape
+    oi = torch.empty((nq, k), dtype=torch.int32, device=ids.device) if out is None else out[0]
+    od = torch.empty((nq, k), dtype=torch.float32, device=ids.device) if out is None else out[1]
+    st = torch.cuda.current_stream(ids.device).cuda_stream
+    check(lib().hnswgpu_merge_keyed_dev(ids.device.index or 0, ids.data_ptr(), dist.data_ptr(), order.data_ptr(), ns, nq,
+                                        k, oi.data_ptr(), od.data_ptr(), st))
     return oi, od
 
 

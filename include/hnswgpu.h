@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HNSWGPU_VERSION 101
+#define HNSWGPU_VERSION 102
 
 #define HNSWGPU_COSINE 0
 #define HNSWGPU_L2 1
@@ -128,7 +128,13 @@ int hnswgpu_hnsw_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, in
  *   strict <, lowest index wins ties.
  * hnswgpu_ivf_search: search-ivf-flat (ivf_flat.clj:236-294) with explicit nprobe for a batch of
  *   queries: centroid routing (:261-269), brute-force scan of the probed lists with precomputed
- *   norms (:217-234), merge, take k.  out_probes optional (nq x nprobe list ids). */
+ *   norms (:217-234), merge, take k.  out_probes optional (nq x nprobe list ids).
+ *   Two summation orders serve this call (cosine / dot): up to 2 (query, list) pairs per list (nq * nprobe <=
+ *   2 * nlist) every pair is one GEMV (wave-strided f32 chain + butterfly); larger batches are grouped by list and
+ *   scanned by the f32-MFMA tile kernel (k-ordered f32 chain).  Both are within 1e-6 of the f64 reference, but a
+ *   query's distance BITS (and the order of candidates that tie within that) depend on which kernel its batch
+ *   selects: search-batch* over nq queries is not bit for bit nq single search-knn calls.  Calls combined from
+ *   concurrent host threads never change the kernel a call would get alone.  Euclidean: one arithmetic throughout. */
 int hnswgpu_ivf_build(hnswgpu_index *idx, int32_t nlist, int32_t max_iter, int64_t seed);
 int hnswgpu_set_ivf(hnswgpu_index *idx, const float *centroids, int32_t nlist, const int64_t *list_off,
                     const int32_t *list_ids);
@@ -149,6 +155,31 @@ int hnswgpu_ivf_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
  * partitions, ivf_flat.clj:243-251,271-272) and lightning's partition scan (lightning.clj:144-187). */
 int hnswgpu_ivf_search_lists(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t nprobe,
                              const int32_t *probes, int32_t *out_ids, float *out_dist);
+
+/* ---- one IVF index over several GPUs --------------------------------------------------------------------
+ * The reference shards an index with threads: split, search every part, concatenate, sort, take k
+ * (ann/partition/partitioned_hnsw.clj:149-196).  For IVF-FLAT the split that keeps ONE index is by inverted list:
+ * the centroid table is replicated (nlist x dim), every WHOLE list lives on exactly one GPU, every GPU routes a
+ * query to the same nprobe lists (ivf_flat.clj:261-269) and scans the probed lists it holds (:281-288); the
+ * per-GPU top-k lists are all-gathered and merged (:291-294).
+ * hnswgpu_set_ivf_shard: like hnswgpu_set_ivf on a handle whose base holds only this shard's rows; lists the
+ *   shard does not hold have list_off[l] == list_off[l+1].  global_list_len[l] = rows of list l in the WHOLE index:
+ *   a search then numbers its candidates by their position in the candidate stream of the whole index.
+ * hnswgpu_ivf_search_shard_dev: hnswgpu_ivf_search_dev plus d_out_order[nq][k] (uint32, 0xffffffff padded): that
+ *   position.  On an ordinary index (hnswgpu_set_ivf / hnswgpu_ivf_build) it is the position in the index's own stream.
+ * hnswgpu_merge_keyed_dev: [nshard][nq][k] (global id, distance, order) -> [nq][k] ascending by (distance, order):
+ *   bit for bit the result (ids, distances, tie order) of searching the unsharded index with the same batch.
+ * hnswgpu_list_sums: the f64 column sums of compute-centroid (ivf_flat.clj:66-77) for caller-given lists, without
+ *   the division -- one shard's contribution to a Lloyd update over a row-sharded base (sums of all shards are
+ *   added, e.g. by an RCCL all-reduce, then divided by the global member count).  out_sums: nlist x dim doubles. */
+int hnswgpu_set_ivf_shard(hnswgpu_index *idx, const float *centroids, int32_t nlist, const int64_t *list_off,
+                          const int32_t *list_ids, const int64_t *global_list_len);
+int hnswgpu_ivf_search_shard_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
+                                 int32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_order, void *stream);
+int hnswgpu_merge_keyed_dev(int32_t device, const int32_t *d_ids, const float *d_dist, const uint32_t *d_order,
+                            int32_t nshard, int32_t nq, int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream);
+int hnswgpu_list_sums(hnswgpu_index *idx, int32_t nlist, const int64_t *list_off, const int32_t *list_ids,
+                      double *out_sums);
 
 /* ---- multi-GPU merge --------------------------------------------------------------------------------
  * Merge `nshard` per-shard top-k lists (what RCCL all-gather delivers) into the global top-k:

@@ -3,6 +3,7 @@ include/hnswgpu.h declares; host-side logic of the Python mirror; the product ne
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -22,7 +23,7 @@ def test_library_exports_every_declared_symbol(native_lib):
     for n in names:
         assert hasattr(L, n), "libhnswgpu.so does not export %s" % n
     L.hnswgpu_version.restype = ctypes.c_int
-    assert L.hnswgpu_version() == 101
+    assert L.hnswgpu_version() == 102
 
 
 def test_python_binding_covers_header(native_lib):
@@ -86,3 +87,25 @@ def test_shard_ranges():
             assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in rs]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher spawns N child ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
+    relays rank 0's single JSON line and returns the worst exit code -- the driver's invocation (no GPU needed here)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-selftest"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "3", "MASTER_ADDR": "127.0.0.1"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest"],
+                       env=dict(env, HNSWGPU_SELFTEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3                               # a failing rank fails the run
+    # under torch.distributed.run (WORLD_SIZE set) it runs as the rank it is and spawns nothing
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest"],
+                       env=dict(env, RANK="1", WORLD_SIZE="2", LOCAL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == ""

@@ -1,0 +1,147 @@
+"""BASELINE.json configs[3] and configs[4] at the size ONE GPU holds of them (10M rows over 8 GPUs = 1.25M per GPU):
+size-independent properties at full per-GPU size, and bit-equality with the oracle on a 64-query subsample of the very
+same index / graph.
+
+configs[3]: hnsw.ivf-flat 10M x 768 sharded over 8 MI355X, nlist 1024, nprobe 32, batch 1024 (and the HBM-bound batch 32).
+configs[4]: 10M x 1536 cosine HNSW, ef_search 256, one sub-graph per GPU.
+Reference: src/hnsw/ann/partition/ivf_flat.clj:217-294, src/hnsw/ultra_fast.clj:151-212,346-374."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from util import assert_exact, assert_topk_parity, close  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+N_SHARD = 1_250_000
+
+
+@pytest.fixture(scope="module")
+def eng(native_lib):
+    from hnsw_clj_amd import engine
+
+    assert engine.device_count() >= 1, "no GPU visible"
+    return engine
+
+
+def _check_topk(ids, d, n, k):
+    assert (np.diff(d, axis=1) >= 0).all(), "distances not ascending"
+    assert (ids >= 0).all() and (ids < n).all()
+    assert all(len(set(r.tolist())) == k for r in ids), "duplicate ids in a result"
+
+
+def test_config3_ivf_per_gpu_shard(eng, oracle):
+    """1.25M x 768, nlist 1024 (k-means++ seed 42, 10 Lloyd passes on the device), nprobe 32, k 10, batch 1024 (MFMA
+    tile scan) and batch 32 (GEMV scan, the HBM-bound regime)."""
+    import torch
+
+    O = oracle
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    n, nlist, nprobe, k = N_SHARD, 1024, 32, 10
+    cen = torch.randn(nlist, 768, generator=g, device=dev)
+    x = cen[torch.randint(0, nlist, (n,), generator=g, device=dev)] + 0.3 * torch.randn(n, 768, generator=g, device=dev)
+    x /= x.norm(dim=1, keepdim=True)
+    g.manual_seed(43)
+    Q = cen[torch.randint(0, nlist, (1024,), generator=g, device=dev)] + 0.3 * torch.randn(1024, 768, generator=g, device=dev)
+    Q = (Q / Q.norm(dim=1, keepdim=True)).contiguous()
+    base = x.cpu().numpy()
+    qh = Q.cpu().numpy()
+    with eng.Index(x, "cosine") as idx:
+        del x
+        idx.ivf_build(nlist, 10, 42)
+        cent, off, lids = idx.get_ivf()
+        assert off[0] == 0 and off[-1] == n and np.array_equal(np.sort(lids), np.arange(n, dtype=np.int32))
+        res = {}
+        for nq in (1024, 32):
+            Qb = Q[:nq].contiguous()
+            i1, d1 = idx.ivf_search_dev(Qb, k, nprobe)
+            i2, d2 = idx.ivf_search_dev(Qb, k, nprobe)
+            torch.cuda.synchronize()
+            assert torch.equal(i1, i2) and torch.equal(d1.view(torch.int32), d2.view(torch.int32)), "not idempotent"
+            ids, d = i1.cpu().numpy(), d1.cpu().numpy()
+            _check_topk(ids, d, n, k)
+            res[nq] = (ids, d)
+            # every returned distance is the true distance of that id (gather order: bit-equal on the GEMV path,
+            # within the tolerance of the two summation orders on the MFMA path)
+            for r in (0, nq // 2, nq - 1):
+                true = idx.batch_distances(qh[r], ids[r])
+                if nq == 32:
+                    np.testing.assert_array_equal(true.view(np.uint32), d[r].view(np.uint32))
+                else:
+                    assert close(d[r], true).all()
+        # the two kernels agree within tolerance; recall against GPU brute force over all 1.25M rows
+        assert_topk_parity(res[32][0], res[32][1], res[1024][0][:32], res[1024][1][:32], "gemv vs tile at 1.25M")
+        ei, _ = idx.exact_knn_dev(Q[:128].contiguous(), k)
+        torch.cuda.synchronize()
+        ei = ei.cpu().numpy()
+        rec = np.mean([len(set(res[1024][0][r]) & set(ei[r])) / k for r in range(128)])
+        assert rec >= 0.9, rec
+        # oracle, same centroids and lists, 64-query subsample: the batch-1024 answers in MFMA order, a 64-query batch
+        # (64 * 32 pairs = 2 per list: still the GEMV scan) in the GEMV order -- ids and distance bits
+        oi, od, _ = O.ivf_search(base, cent, off, lids, qh[:64], k, nprobe, mode=O.MODE_MFMA)
+        assert_exact(res[1024][0][:64], res[1024][1][:64], oi, od, "config3 batch 1024 vs oracle (MFMA order)")
+        i64, d64 = idx.ivf_search(qh[:64], k, nprobe)
+        oi, od, _ = O.ivf_search(base, cent, off, lids, qh[:64], k, nprobe, mode=O.MODE_DEV)
+        assert_exact(i64, d64, oi, od, "config3 batch 64 vs oracle (GEMV order)")
+        fi, fd, _ = O.ivf_search(base, cent, off, lids, qh[:16], k, nprobe)           # f64 reference order
+        assert_topk_parity(res[1024][0][:16], res[1024][1][:16], fi, fd, "config3 vs f64 oracle")
+
+
+def test_config4_hnsw_per_gpu_shard(eng, oracle):
+    """1.25M x 1536 cosine (rows on a 32-dimensional manifold, as bench.py's sharded_hnsw leg), graph built on the device
+    (M 16, ef_construction 200), 1024 queries at ef_search 256: the traversal is HBM-resident (7.7 GB of rows) and
+    keeps its visited stamps in HBM."""
+    import torch
+
+    O = oracle
+    dev = torch.device("cuda", 0)
+    n, dim, r, ef, nq, k = N_SHARD, 1536, 32, 256, 1024, 10
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    w = torch.randn(r, dim, generator=g, device=dev)
+
+    def manifold(m):
+        out = torch.empty(m, dim, device=dev)
+        for i in range(0, m, 250_000):
+            c = min(250_000, m - i)
+            y = torch.randn(c, r, generator=g, device=dev) @ w / r ** 0.5 + 0.1 * torch.randn(c, dim, generator=g, device=dev)
+            out[i:i + c] = y / y.norm(dim=1, keepdim=True)
+        return out
+
+    g.manual_seed(2000)
+    x = manifold(n)
+    g.manual_seed(43)
+    Q = manifold(nq)
+    base = x.cpu().numpy()
+    qh = Q.cpu().numpy()
+    with eng.Index(x, "cosine") as idx:
+        del x
+        idx.hnsw_build(16, 200, 42)
+        stats = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+        i1, d1 = idx.hnsw_search_dev(Q, k, ef, stats=stats)
+        i2, d2 = idx.hnsw_search_dev(Q, k, ef)
+        torch.cuda.synchronize()
+        assert torch.equal(i1, i2) and torch.equal(d1.view(torch.int32), d2.view(torch.int32)), "not idempotent"
+        ids, d, st = i1.cpu().numpy(), d1.cpu().numpy(), stats.cpu().numpy()
+        _check_topk(ids, d, n, k)
+        assert st[:, 0].min() > ef and st[:, 1].min() >= ef // 2, "counters: evaluations / expansions per query"
+        for q in (0, 511, 1023):                     # returned distance == the row's true distance, bit for bit
+            np.testing.assert_array_equal(idx.batch_distances(qh[q], ids[q]).view(np.uint32), d[q].view(np.uint32))
+        ei, _ = idx.exact_knn_dev(Q[:256].contiguous(), k)
+        torch.cuda.synchronize()
+        ei = ei.cpu().numpy()
+        rec = np.mean([len(set(ids[q]) & set(ei[q])) / k for q in range(256)])
+        assert rec >= 0.9, rec
+        # the oracle on the SAME graph, 64-query subsample: ids, distance bits, both traversal counters
+        gr = idx.get_graph()
+        og = O.Graph(gr.levels, gr.l0_adj, gr.up_off, gr.up_adj, gr.M, gr.entry, gr.max_level)
+        oi, od, ost, _ = O.hnsw_search(base, og, qh[:64], k, ef=ef, mode=O.MODE_DEV, nthreads=8)
+        assert_exact(ids[:64], d[:64], oi, od, "config4 vs oracle (device order)")
+        np.testing.assert_array_equal(st[:64], ost)
+        fi, fd, _, _ = O.hnsw_search(base, og, qh[:16], k, ef=ef, nthreads=8)          # f64 reference order
+        assert_topk_parity(ids[:16], d[:16], fi, fd, "config4 vs f64 oracle")
