@@ -417,27 +417,65 @@ int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
                           [&] { return static_cast<int>(c.pending.size()) >= target; });
             c.linger = false;
         }
-        std::vector<hnswgpu_index::SearchReq *> batch, rest;
-        int64_t total = 0;
-        for (auto *r : c.pending) {
-            if (batch.empty() || take(batch[0], r, total)) {
-                batch.push_back(r);
-                total += r->nq;
-            } else {
-                rest.push_back(r);
+        // Nothing below may leave `leader` set or a batch unanswered: an exception (bad_alloc from the vectors, the
+        // message copies or anything `run` allocates) would otherwise park every current and future caller in cv.wait
+        // for good.  Whatever happens, the batch is marked done -- with an error if need be -- and the leadership freed.
+        std::vector<hnswgpu_index::SearchReq *> batch;
+        int rc = 0;
+        const char *msg = "";
+        try {
+            std::vector<hnswgpu_index::SearchReq *> rest;
+            int64_t total = 0;
+            batch.reserve(c.pending.size());
+            rest.reserve(c.pending.size());
+            for (auto *r : c.pending) {
+                if (batch.empty() || take(batch[0], r, total)) {
+                    batch.push_back(r);
+                    total += r->nq;
+                } else {
+                    rest.push_back(r);
+                }
+            }
+            c.pending.swap(rest);
+            c.last = static_cast<int>(batch.size());
+            cl.unlock();
+            try {
+                rc = run(batch, static_cast<int32_t>(total));
+                if (rc) msg = hnswgpu_last_error();
+            } catch (const std::bad_alloc &) {
+                rc = HNSWGPU_ENOMEM;
+                msg = "host allocation failed while serving a combined batch";
+            } catch (...) {
+                rc = HNSWGPU_EINVAL;
+                msg = "unexpected exception while serving a combined batch";
+            }
+            cl.lock();
+        } catch (...) {  // thrown while the queue was being split (lock still held): fail what was taken so far and me
+            rc = HNSWGPU_ENOMEM;
+            msg = "host allocation failed while forming a combined batch";
+            if (std::find(batch.begin(), batch.end(), &me) == batch.end()) {
+                c.pending.erase(std::remove(c.pending.begin(), c.pending.end(), &me), c.pending.end());
+                me.rc = rc;
+                me.done = true;
+                try {
+                    me.err = msg;
+                } catch (...) {
+                }
             }
         }
-        c.pending.swap(rest);
-        c.last = static_cast<int>(batch.size());
-        cl.unlock();
-        const int rc = run(batch, static_cast<int32_t>(total));
-        const char *msg = rc ? hnswgpu_last_error() : "";
-        cl.lock();
         for (auto *r : batch) {
             r->rc = rc;
-            if (rc) r->err = msg;
+            if (rc) {
+                try {
+                    r->err = msg;
+                } catch (...) {  // the code still says what happened
+                }
+            }
             r->done = true;
         }
+        // requests taken into `batch` before a failed split are answered above; they may still sit in c.pending
+        if (rc)
+            for (auto *r : batch) c.pending.erase(std::remove(c.pending.begin(), c.pending.end(), r), c.pending.end());
         c.leader = false;
         c.cv.notify_all();
     }

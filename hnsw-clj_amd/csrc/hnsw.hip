@@ -551,6 +551,8 @@ static int hnsw_search_batch(hnswgpu_index *idx, const std::vector<hnswgpu_index
     const int32_t k = batch[0]->k, ef = batch[0]->ef;
     const int64_t cnt = static_cast<int64_t>(total) * k;
     std::lock_guard<std::mutex> lk(idx->mu);
+    // under the lock: a concurrent set_graph / hnsw_build may have replaced the graph since the caller's argument check
+    HG_REQUIRE(idx->has_graph && idx->n > 0, HNSWGPU_ESTATE, "index has no graph (call hnswgpu_hnsw_build / hnswgpu_set_graph)");
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
     HG_TRY(begin_call(idx, st));

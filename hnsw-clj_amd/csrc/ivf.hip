@@ -890,9 +890,13 @@ int hnswgpu_ivf_search_lists(hnswgpu_index *idx, const float *Q, int32_t nq, int
 
 // One launch for a set of queued synchronous IVF requests with the same (k, nprobe); see combine_search.
 static int ivf_search_batch(hnswgpu_index *idx, const std::vector<hnswgpu_index::SearchReq *> &batch, int32_t total) {
-    const int32_t k = batch[0]->k, np = std::min(batch[0]->ef, idx->nlist);
+    const int32_t k = batch[0]->k;
     const int64_t cnt = static_cast<int64_t>(total) * k;
     std::lock_guard<std::mutex> lk(idx->mu);
+    // under the lock: a concurrent set_ivf / ivf_build may have replaced (or a failed one removed) the lists since the
+    // caller's argument check
+    HG_REQUIRE(idx->nlist > 0, HNSWGPU_ESTATE, "index has no IVF lists (call hnswgpu_ivf_build / hnswgpu_set_ivf)");
+    const int32_t np = std::min(batch[0]->ef, idx->nlist);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
     HG_TRY(begin_call(idx, st));
@@ -942,13 +946,21 @@ int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k
         me.out_ids = out_ids;
         me.out_dist = out_dist;
         me.stats = nullptr;
-        const int64_t np = std::min(nprobe, idx->nlist), gemv_pairs = 2LL * idx->nlist;
         const bool one_arith = idx->metric == METRIC_L2 || !tile_path_ok(idx) || tile_mode() == 0;
+        // the kernel a batch of `total` queries gets: ivf_search_enqueue's own predicate, on the BATCH's nprobe (the
+        // leader that evaluates this may have asked for another one)
+        auto tiled = [idx](int64_t total, int32_t nprobe_req) {
+            const int64_t nl = idx->nlist;
+            return total * std::min<int64_t>(nprobe_req, nl) > 2 * nl;
+        };
         return combine_search(
             idx->cmb_ivf, me,
             [=](const hnswgpu_index::SearchReq *first, const hnswgpu_index::SearchReq *r, int64_t total) {
                 if (r->k != first->k || r->ef != first->ef || total + r->nq > 16384) return false;
-                return one_arith || (total + r->nq) * np <= gemv_pairs;  // everybody on the GEMV scan, as when alone
+                if (one_arith) return true;
+                // every member must get the kernel it would get alone (the batch head included)
+                const bool batch_tiled = tiled(total + r->nq, first->ef);
+                return batch_tiled == tiled(r->nq, r->ef) && batch_tiled == tiled(first->nq, first->ef);
             },
             [idx](const std::vector<hnswgpu_index::SearchReq *> &batch, int32_t total) {
                 return ivf_search_batch(idx, batch, total);

@@ -3,9 +3,9 @@ API-compatible wrapper (``build-index`` / ``search-knn index q k [mode]`` / ``in
 
 Modes (:136-140): turbo 50 / fast 100 / balanced 200 / accurate 300 / precise 500.  In the reference these ef
 values are written into ``[:params :ef]`` but ``graph/search-knn`` never reads them (it uses (max k 50),
-graph.clj:304 -- SURVEY fact 9), so every mode searches with the same breadth.  ``honour_modes=True`` (default)
-makes the presets effective, which is what their doc-string promises; ``honour_modes=False`` reproduces the
-reference's actual behaviour."""
+graph.clj:304 -- SURVEY fact 9), so every mode searches with the same breadth.  The default reproduces what the
+reference DOES (``honour_modes=False``: ef = (max k 50) whatever the mode -- a drop-in must return the reference's
+results); ``honour_modes=True`` opts in to what the presets' doc-string promises."""
 from . import ultra_fast
 from .ultra_fast import cosine_distance_ultra
 
@@ -29,7 +29,7 @@ def build_pure_hnsw_index(data, M=16, ef_construction=200, ef=200, distance_fn=c
     return PureHNSWIndex(g, {"M": M, "ef-construction": ef_construction, "ef": ef})
 
 
-def search_pure_hnsw(index, query_vec, k, mode="balanced", ef=None, honour_modes=True):
+def search_pure_hnsw(index, query_vec, k, mode="balanced", ef=None, honour_modes=False):
     """pure_hnsw.clj:129-152"""
     want = MODE_EF.get(mode, ef or 200)
     return ultra_fast.search_knn(index.graph, query_vec, k, ef=max(want, k) if honour_modes else None)
@@ -39,9 +39,9 @@ def build_index(data, **opts):
     return build_pure_hnsw_index(data, **opts)
 
 
-def search_knn(index, query_vec, k, mode="balanced"):
+def search_knn(index, query_vec, k, mode="balanced", honour_modes=False):
     """pure_hnsw.clj:163-175"""
-    return search_pure_hnsw(index, query_vec, k, mode=mode)
+    return search_pure_hnsw(index, query_vec, k, mode=mode, honour_modes=honour_modes)
 
 
 def index_info(index):

@@ -178,21 +178,27 @@ float orc_dist_dev(int metric, const float *q, const float *v, int n, float qnor
     return 1.0f;
 }
 
-/* "fair-fight" f32: 8 partial sums so gcc can vectorise; norms precomputed. */
-static inline float fast_dot(const float *a, const float *b, int n) {
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+/* "fair-fight" f32: 16 independent partial sums (no re-association needed to vectorise them), norms precomputed.
+ * The file is built -O2, where gcc 11 does not run the vectoriser: these two functions ask for it themselves and are
+ * cloned per ISA (resolved once at load time), so the CPU baseline's f32 variant really is AVX2 / AVX-512 code on the
+ * GPU box's host cores (`gcc -fopt-info-vec` reports both loops vectorised; round 1's 8-sum form ran scalar). */
+#define ORC_VEC __attribute__((optimize("O3", "tree-vectorize"), target_clones("avx512f", "avx2", "default"), noinline))
+ORC_VEC static float fast_dot(const float *a, const float *b, int n) {
+    float s[16] = {0};
     int i = 0;
-    for (; i + 8 <= n; i += 8)
-        for (int j = 0; j < 8; j++) s[j] += a[i + j] * b[i + j];
+    for (; i + 16 <= n; i += 16)
+        for (int j = 0; j < 16; j++) s[j] += a[i + j] * b[i + j];
     float t = 0.0f;
     for (; i < n; i++) t += a[i] * b[i];
-    return ((s[0] + s[4]) + (s[1] + s[5])) + ((s[2] + s[6]) + (s[3] + s[7])) + t;
+    for (int w = 8; w >= 1; w >>= 1)
+        for (int j = 0; j < w; j++) s[j] += s[j + w];
+    return s[0] + t;
 }
-static inline float fast_l2sq(const float *a, const float *b, int n) {
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+ORC_VEC static float fast_l2sq(const float *a, const float *b, int n) {
+    float s[16] = {0};
     int i = 0;
-    for (; i + 8 <= n; i += 8)
-        for (int j = 0; j < 8; j++) {
+    for (; i + 16 <= n; i += 16)
+        for (int j = 0; j < 16; j++) {
             float d = a[i + j] - b[i + j];
             s[j] += d * d;
         }
@@ -201,7 +207,111 @@ static inline float fast_l2sq(const float *a, const float *b, int n) {
         float d = a[i] - b[i];
         t += d * d;
     }
-    return ((s[0] + s[4]) + (s[1] + s[5])) + ((s[2] + s[6]) + (s[3] + s[7])) + t;
+    for (int w = 8; w >= 1; w >>= 1)
+        for (int j = 0; j < w; j++) s[j] += s[j + w];
+    return s[0] + t;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* 2b. The reference's float32 Vector-API forms -- reached only from     */
+/*     P-HNSW/PCAF (ann/dimreduct/pcaf.clj:226,243); they document the reference's OWN f32        */
+/*     semantics: hardware-dependent summation order, hence the 1e-4 tolerance of north_star.     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* FloatVector.reduceLanes(ADD) over L f32 lanes.  The JDK leaves the association unspecified ("the order of
+ * operations may vary"): assoc 0 = lanes left to right, assoc 1 = pairwise tree (what a horizontal-add lowering does). */
+static float reduce_lanes(const float *v, int L, int assoc) {
+    if (assoc == 0) {
+        float s = v[0];
+        for (int j = 1; j < L; j++) s = s + v[j];
+        return s;
+    }
+    float t[16];
+    for (int j = 0; j < L; j++) t[j] = v[j];
+    for (int w = L / 2; w >= 1; w /= 2)
+        for (int j = 0; j < w; j++) t[j] = t[j] + t[j + w];
+    return t[0];
+}
+
+/* src/hnsw/simd.clj:26-43 (dot), :52-71 (euclidean), :81-115 (cosine): chunks of L = SPECIES_PREFERRED.length()
+ * (4 NEON, 8 AVX2, 16 AVX-512); per chunk f32 lane products, reduceLanes(ADD) in f32, the chunk sum widened to f64 and
+ * added to an f64 running sum; the tail (len mod L elements) multiplied and added in f64.  Cosine guard: (zero? magnitude). */
+double orc_f32_vector(int metric, const float *a, const float *b, int n, int L, int assoc) {
+    const int ub = n - n % L;
+    double dot = 0.0, na = 0.0, nb = 0.0;
+    float p[16], qa[16], qb[16];
+    for (int i = 0; i < ub; i += L) {
+        for (int j = 0; j < L; j++) {
+            if (metric == ORC_L2) {
+                const float d = a[i + j] - b[i + j];
+                p[j] = d * d;
+            } else {
+                p[j] = a[i + j] * b[i + j];
+                qa[j] = a[i + j] * a[i + j];
+                qb[j] = b[i + j] * b[i + j];
+            }
+        }
+        dot = dot + (double)reduce_lanes(p, L, assoc);
+        if (metric == ORC_COSINE) {
+            na = na + (double)reduce_lanes(qa, L, assoc);
+            nb = nb + (double)reduce_lanes(qb, L, assoc);
+        }
+    }
+    for (int j = ub; j < n; j++) {
+        const double aj = (double)a[j], bj = (double)b[j];
+        if (metric == ORC_L2) {
+            const double d = aj - bj;
+            dot = dot + d * d;
+        } else {
+            dot = dot + aj * bj;
+            na = na + aj * aj;
+            nb = nb + bj * bj;
+        }
+    }
+    if (metric == ORC_L2) return sqrt(dot);
+    if (metric == ORC_DOT) return dot;
+    const double mag = sqrt(na) * sqrt(nb);
+    return mag == 0.0 ? 1.0 : 1.0 - dot / mag;
+}
+
+/* src/hnsw/wip/vector.clj:21-45 (euclidean), :47-86 (cosine): the lane-accumulating twin -- L f32 lane accumulators
+ * (.add acc (.mul va vb): two roundings, no fma), ONE reduceLanes at the end, the tail in f64 (Clojure arithmetic on
+ * float widens), sqrt / divide in f64.  Cosine guard: (and (> n1 0) (> n2 0)).  (dot: the same accumulation.) */
+double orc_f32_lane_accumulate(int metric, const float *a, const float *b, int n, int L, int assoc) {
+    const int ub = n - n % L;
+    float sd[16] = {0}, sa[16] = {0}, sb[16] = {0};
+    for (int i = 0; i < ub; i += L)
+        for (int j = 0; j < L; j++) {
+            if (metric == ORC_L2) {
+                const float d = a[i + j] - b[i + j];
+                const float m = d * d;
+                sd[j] = sd[j] + m;
+            } else {
+                const float m = a[i + j] * b[i + j], ma = a[i + j] * a[i + j], mb = b[i + j] * b[i + j];
+                sd[j] = sd[j] + m;
+                sa[j] = sa[j] + ma;
+                sb[j] = sb[j] + mb;
+            }
+        }
+    double dot = (double)reduce_lanes(sd, L, assoc), n1 = 0.0, n2 = 0.0;
+    if (metric == ORC_COSINE) {
+        n1 = (double)reduce_lanes(sa, L, assoc);
+        n2 = (double)reduce_lanes(sb, L, assoc);
+    }
+    for (int j = ub; j < n; j++) {
+        const double aj = (double)a[j], bj = (double)b[j];
+        if (metric == ORC_L2) {
+            const double d = aj - bj;
+            dot = dot + d * d;
+        } else {
+            dot = dot + aj * bj;
+            n1 = n1 + aj * aj;
+            n2 = n2 + bj * bj;
+        }
+    }
+    if (metric == ORC_L2) return sqrt(dot);
+    if (metric == ORC_DOT) return dot;
+    return (n1 > 0.0 && n2 > 0.0) ? 1.0 - dot / (sqrt(n1) * sqrt(n2)) : 1.0;
 }
 
 /* One distance evaluator used by every driver below. */

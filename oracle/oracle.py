@@ -50,6 +50,10 @@ def lib():
         _lib.orc_dist_dev.argtypes = [i32, p, p, i32, C.c_float, C.c_float]
         _lib.orc_norm_dev.restype = C.c_float
         _lib.orc_norm_dev.argtypes = [p, i32]
+        _lib.orc_f32_vector.restype = d
+        _lib.orc_f32_vector.argtypes = [i32, p, p, i32, i32, i32]
+        _lib.orc_f32_lane_accumulate.restype = d
+        _lib.orc_f32_lane_accumulate.argtypes = [i32, p, p, i32, i32, i32]
         _lib.orc_fdlibm_log.restype = d
         _lib.orc_fdlibm_log.argtypes = [d]
         _lib.orc_norms.restype = None
@@ -131,6 +135,19 @@ def distance(metric, a, b):
     """f64 distance on float32-valued inputs (what the engine stores)."""
     a, b = _f32(a), _f32(b)
     return lib().orc_dist_f32in(int(metric), _p(a), _p(b), len(a))
+
+
+def f32_vector(metric, a, b, lanes=8, assoc=0):
+    """src/hnsw/simd.clj:26-43,52-71,81-115: the float32 Vector-API form (chunks of `lanes`, f32 lane reduce, f64
+    accumulate); assoc: 0 = lanes left to right, 1 = pairwise (reduceLanes leaves it unspecified).  dot returns +dot."""
+    a, b = _f32(a), _f32(b)
+    return lib().orc_f32_vector(int(metric), _p(a), _p(b), len(a), int(lanes), int(assoc))
+
+
+def f32_lane_accumulate(metric, a, b, lanes=8, assoc=0):
+    """src/hnsw/wip/vector.clj:21-86: f32 lane accumulators, one reduceLanes at the end."""
+    a, b = _f32(a), _f32(b)
+    return lib().orc_f32_lane_accumulate(int(metric), _p(a), _p(b), len(a), int(lanes), int(assoc))
 
 
 def norm_dev(v):

@@ -109,3 +109,41 @@ def test_bench_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest"],
                        env=dict(env, RANK="1", WORLD_SIZE="2", LOCAL_RANK="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == ""
+
+
+def test_load_rejects_damaged_headers_before_touching_anything(native_lib, tmp_path):
+    """hnswgpu_load validates the 64-byte header against the documented limits and against the file size BEFORE it
+    sizes a single read from it (no GPU involved up to that point): garbage row counts, dims, degrees and list counts
+    come back as HNSWGPU_EINVAL with a message -- never an overflowed size, a bad_alloc through the C boundary or an
+    over-read."""
+    import struct
+
+    L = native_lib.lib()
+
+    def header(n=10, dim=4, flags=0, M=0, M0=0, entry=0, max_level=0, up_blocks=0, nlist=0, metric=0, magic=b"HNSWGPU1", version=1):
+        return struct.pack("<8siiqiiiiiiqii", magic, version, metric, n, dim, flags, M, M0, entry, max_level, up_blocks, nlist, 0)
+
+    assert len(header()) == 64
+    body = b"\0" * (10 * 4 * 4)
+    cases = {
+        "not an index": header(magic=b"NOTANIDX") + body,
+        "rows": header(n=1 << 40) + body,
+        "negative rows": header(n=-5) + body,
+        "dim": header(dim=100000) + body,
+        "degree": header(flags=1, M=16, M0=1000) + body,
+        "up blocks": header(flags=1, M=16, M0=32, up_blocks=1 << 50) + body,
+        "lists": header(flags=2, nlist=-3) + body,
+        "metric": header(metric=9) + body,
+        "short": header() + body[:-8],
+        "long": header() + body + b"xx",
+        "version": header(version=7) + body,
+    }
+    for name, blob in cases.items():
+        path = str(tmp_path / (name.replace(" ", "_") + ".bin"))
+        open(path, "wb").write(blob)
+        h = ctypes.c_void_p(None)
+        rc = L.hnswgpu_load(path.encode(), 0, ctypes.byref(h))
+        assert rc == -1, "%s: rc %d (%s)" % (name, rc, L.hnswgpu_last_error())       # HNSWGPU_EINVAL
+        assert h.value is None and L.hnswgpu_last_error()
+    open(str(tmp_path / "tiny.bin"), "wb").write(b"HNSW")
+    assert L.hnswgpu_load(str(tmp_path / "tiny.bin").encode(), 0, ctypes.byref(ctypes.c_void_p(None))) == -1

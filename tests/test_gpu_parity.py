@@ -77,6 +77,31 @@ def test_batch_distances_and_norms(eng, oracle, dim):
                 assert np.allclose(idx.norms(), np.linalg.norm(base.astype(np.float64), axis=1), rtol=1e-6)
 
 
+@pytest.mark.parametrize("dim", [5, 100, 768, 1536, 3072])
+def test_device_f32_inside_the_spread_of_the_reference_f32_forms(eng, oracle, dim):
+    """SURVEY a4: the reference's own float32 kernels (simd.clj:18-115, chunked with SPECIES_PREFERRED = 4 / 8 / 16 lanes;
+    wip/vector.clj:21-86, lane accumulators) differ among themselves in the last bits.  The device's f32 result must lie
+    within north_star's 1e-4 of EVERY one of them (and they of the f64 form): the device is one more f32 summation order."""
+    O = oracle
+    rng = np.random.default_rng(dim)
+    base = rng.standard_normal((12, dim)).astype(np.float32)
+    base[3] = 0.75 * base[0] + 0.01 * base[3]                          # near-duplicate direction: small cosine distance
+    q = (base[0] + 0.05 * rng.standard_normal(dim)).astype(np.float32)
+    for metric in (O.COSINE, O.L2, O.DOT):
+        with eng.Index(base, metric) as idx:
+            d = idx.batch_distances(q)
+        scale = metric_scale(metric, q, base)
+        for r in range(len(base)):
+            forms = [f(metric, q, base[r], L, s) for f in (O.f32_vector, O.f32_lane_accumulate) for L in (4, 8, 16) for s in (0, 1)]
+            if metric == O.DOT:
+                forms = [-v for v in forms]                              # the engine's DOT is the ordering key -dot
+            f64 = O.distance(metric, q, base[r])
+            assert close(forms, f64, scale).all()
+            assert close(np.full(len(forms), d[r]), forms, scale).all(), (metric, r, d[r], forms)
+            spread = max(forms) - min(forms)
+            assert min(forms) - 4 * spread - 1e-6 * scale <= d[r] <= max(forms) + 4 * spread + 1e-6 * scale
+
+
 def test_dim_limit_and_bad_args(eng):
     with pytest.raises(Exception, match="3072"):
         eng.Index(np.zeros((2, 3073), np.float32))
@@ -793,6 +818,16 @@ def test_persistence_and_lightning(eng, oracle, tmp_path):
     with pytest.raises(Exception, match="truncated"):
         open(str(tmp_path / "short.bin"), "wb").write(raw[:5000])
         eng.Index.load(str(tmp_path / "short.bin"))
+    # the header's up_blocks and the body's up_off must describe the same array (set_graph indexes one with the other)
+    raw = bytearray(open(path, "rb").read())
+    upoff_end = 64 + 600 * 40 * 4 + 600 * 4 + 600 * 32 * 4 + 600 * 8
+    raw[upoff_end:upoff_end + 8] = (10 ** 9).to_bytes(8, "little")
+    open(str(tmp_path / "upoff.bin"), "wb").write(raw)
+    with pytest.raises(Exception, match="up_off"):
+        eng.Index.load(str(tmp_path / "upoff.bin"))
+    assert not os.path.exists(path + ".tmp")                                          # saved beside, renamed over
+    with pytest.raises(Exception, match="cannot open"):
+        g.index.save(str(tmp_path / "no_such_dir" / "x.bin"))
     g.close(), g2.close()
     ivf = ivf_flat.build_index(data, num_partitions=6, show_progress=False)
     index_io.save_index(ivf, path)
@@ -843,6 +878,37 @@ def test_concurrent_searches_from_host_threads(eng, oracle):
             assert (got_h[t][0] >= 0).sum() == 10
             assert np.array_equal(got_h[t][0], want_h[t][0]) and np.array_equal(got_h[t][1], want_h[t][1])
             assert np.array_equal(got_i[t][0], want_i[t][0]) and np.array_equal(got_i[t][1], want_i[t][1])
+
+
+def test_concurrent_ivf_callers_with_mixed_nprobe_keep_their_bits(eng, oracle):
+    """The combiner must serve every caller with the kernel it would get alone, whoever leads the batch: a thread asking
+    for nprobe 1 beside threads asking for nprobe 32 (which, combined without care, cross the GEMV -> MFMA boundary of
+    2 pairs per list) -- every result bit-equal to the same call made alone."""
+    import threading
+
+    O = oracle
+    base = _data(O, 6000, 48, "clustered", num_clusters=8, noise_level=0.5)
+    Q = _data(O, 48, 48, "clustered", num_clusters=8, noise_level=0.5, seed=43)
+    with eng.Index(base) as idx:
+        idx.ivf_build(64, 2, 42)
+        probes = [1 if t % 6 == 0 else 32 for t in range(48)]           # 40 x 32 pairs >> 2 x 64 lists when combined
+        want = [idx.ivf_search(Q[t], 10, probes[t]) for t in range(48)]
+        got, errs = [None] * 48, []
+
+        def work(t):
+            try:
+                for _ in range(8):
+                    got[t] = idx.ivf_search(Q[t], 10, probes[t])
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(48)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs
+        for t in range(48):
+            assert np.array_equal(got[t][0], want[t][0]), "thread %d (nprobe %d): ids" % (t, probes[t])
+            assert np.array_equal(got[t][1].view(np.uint32), want[t][1].view(np.uint32)), "thread %d: distance bits" % t
 
 
 def test_full_size_ivf_1m_properties(eng):
@@ -1168,6 +1234,21 @@ def test_reference_api_mirror(eng, oracle):
     r1 = pure_hnsw.search_knn(ph, vecs[6], 5, "turbo")
     r2 = pure_hnsw.search_knn(ph, vecs[6], 5, "precise")
     assert r1[0]["id"] == r2[0]["id"] == "vec_6" and len(r2) == 5
+    # the drop-in default is what the reference DOES: graph/search-knn ignores the mode presets and searches with
+    # ef = (max k 50) (graph.clj:304) -- checked against the oracle on the same graph; the presets are opt-in
+    gg = ph.graph.index.get_graph()
+    og = oracle.Graph(gg.levels, gg.l0_adj, gg.up_off, gg.up_adj, gg.M, gg.entry, gg.max_level)
+    for qi, (k_, mode) in enumerate([(5, "turbo"), (5, "precise"), (60, "balanced"), (3, "no-such-mode")]):
+        got = pure_hnsw.search_knn(ph, vecs[10 + qi] * 1.5, k_, mode)
+        oi, od, _, _ = oracle.hnsw_search(vecs, og, vecs[10 + qi] * 1.5, k_, ef=max(k_, 50), mode=oracle.MODE_DEV)
+        assert [r["id"] for r in got] == ["vec_%d" % i for i in oi[0] if i >= 0]
+        assert np.array_equal(np.float32([r["distance"] for r in got]).view(np.uint32),
+                              od[0][oi[0] >= 0].astype(np.float32).view(np.uint32))
+        uo_got = ultra_fast.search_knn(ph.graph, vecs[10 + qi] * 1.5, k_)       # hnsw.ultra-optimized/search == base/search-knn
+        assert uo_got == got
+    wide = pure_hnsw.search_knn(ph, vecs[12] * 1.5, 5, "precise", honour_modes=True)  # opt-in: ef 500
+    oi, od, _, _ = oracle.hnsw_search(vecs, og, vecs[12] * 1.5, 5, ef=500, mode=oracle.MODE_DEV)
+    assert [r["id"] for r in wide] == ["vec_%d" % i for i in oi[0]]
     info = pure_hnsw.index_info(ph)
     assert info["vectors"] == 100 and info["params"]["M"] == 16 and info["avg-edges-per-node"] > 1
     ph.close()

@@ -179,6 +179,40 @@ def test_kmeans_semantics(oracle):
     assert np.array_equal(np.sort(ii, 1), np.sort(ex, 1))
 
 
+# ---- the reference's float32 Vector-API forms ------------------------------------
+@pytest.mark.parametrize("lanes", [4, 8, 16])
+def test_f32_vector_forms(oracle, lanes):
+    """simd.clj:26-115 (chunked: f32 lane products, f32 lane reduce, f64 accumulate, f64 tail) and wip/vector.clj:21-86
+    (f32 lane accumulators, one reduce): the reference's own KATs (exact on small integers, whatever the lane count:
+    the 2- and 3-element vectors are all tail), and on random data every form within f32 round-off of the f64 form --
+    the spread that makes north_star's tolerance 1e-4 and not bitwise."""
+    O = oracle
+    for f in (O.f32_vector, O.f32_lane_accumulate):
+        assert f(O.L2, [1, 2, 3], [1, 2, 3], lanes) == 0.0                     # core_test.clj:9-31
+        assert f(O.L2, [0, 0], [3, 4], lanes) == 5.0
+        assert abs(f(O.L2, [1, 2, 3], [4, 5, 6], lanes) - 5.196152422706632) < 1e-12
+        assert abs(f(O.COSINE, [1, 2, 3], [4, 5, 6], lanes) - 0.025368153802923787) < 1e-12
+        assert f(O.COSINE, [1, 0], [-1, 0], lanes) == 2.0 and f(O.COSINE, [1, 0], [0, 1], lanes) == 1.0
+        assert f(O.COSINE, [0, 0, 0], [1, 2, 3], lanes) == 1.0                 # both zero guards give 1.0 here
+        assert f(O.DOT, [1, 2, 3], [4, 5, 6], lanes) == 32.0
+        # integers are exact in every association: 40 elements = full chunks + (for 16 lanes) a tail of 8
+        a, b = np.arange(40) % 7 - 3, np.arange(40) % 5 - 2
+        for assoc in (0, 1):
+            assert f(O.DOT, a, b, lanes, assoc) == float(np.dot(a, b))
+            assert f(O.L2, a, b, lanes, assoc) == float(np.sqrt(((a - b) ** 2).sum()))
+    rng = np.random.default_rng(lanes)
+    for dim in (5, 100, 768, 1536):
+        a = rng.standard_normal(dim).astype(np.float32)
+        b = (0.5 * a + rng.standard_normal(dim)).astype(np.float32)
+        scale = float(np.linalg.norm(a.astype(np.float64)) * np.linalg.norm(b.astype(np.float64)))
+        for m, ref, tol in ((O.COSINE, O.distance(O.COSINE, a, b), 4e-6), (O.L2, O.distance(O.L2, a, b), 4e-6),
+                            (O.DOT, O.dot_product(a.astype(np.float64), b.astype(np.float64)), 4e-6 * scale)):
+            vals = [f(m, a, b, lanes, s) for f in (O.f32_vector, O.f32_lane_accumulate) for s in (0, 1)]
+            assert all(abs(v - ref) <= tol * max(1.0, abs(ref)) for v in vals), (dim, m, ref, vals)
+            if dim >= 768 and m == O.COSINE:
+                assert len(set(vals)) > 1, "the forms are meant to differ in the last bits"
+
+
 # ---- committed golden fixtures -----------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["g256x64", "c1000x128"])
 def test_oracle_reproduces_golden(oracle, name):
