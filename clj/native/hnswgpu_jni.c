@@ -65,3 +65,63 @@ JNIEXPORT jint JNICALL Java_hnsw_gpu_Native_ivfSearch(JNIEnv *env, jclass c, jlo
     if (rc != 0) throw_last(env);
     return rc;
 }
+
+/* ---- INTEGRATION.md section 5 / the simd-optimized seams / persistence: the same mechanical shape ---- */
+
+JNIEXPORT jint JNICALL Java_hnsw_gpu_Native_setGraph(JNIEnv *env, jclass c, jlong h, jintArray levels, jintArray l0, jint M0,
+                                                     jlongArray upOff, jintArray upAdj, jint M, jint entry, jint maxLevel) {
+    jint *pl = (*env)->GetIntArrayElements(env, levels, NULL), *p0 = (*env)->GetIntArrayElements(env, l0, NULL);
+    jlong *po = (*env)->GetLongArrayElements(env, upOff, NULL);
+    jint *pu = (*env)->GetIntArrayElements(env, upAdj, NULL);
+    int rc = hnswgpu_set_graph((hnswgpu_index *)(intptr_t)h, (const int32_t *)pl, (const int32_t *)p0, M0, (const int64_t *)po,
+                               (const int32_t *)pu, M, entry, maxLevel); /* validates and copies before returning */
+    (*env)->ReleaseIntArrayElements(env, levels, pl, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, l0, p0, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, upOff, po, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, upAdj, pu, JNI_ABORT);
+    if (rc != 0) throw_last(env);
+    return rc;
+}
+
+JNIEXPORT jint JNICALL Java_hnsw_gpu_Native_setIvf(JNIEnv *env, jclass c, jlong h, jfloatArray centroids, jint nlist,
+                                                   jlongArray listOff, jintArray listIds) {
+    jfloat *pc = (*env)->GetFloatArrayElements(env, centroids, NULL);
+    jlong *po = (*env)->GetLongArrayElements(env, listOff, NULL);
+    jint *pi = (*env)->GetIntArrayElements(env, listIds, NULL);
+    int rc = hnswgpu_set_ivf((hnswgpu_index *)(intptr_t)h, pc, nlist, (const int64_t *)po, (const int32_t *)pi);
+    (*env)->ReleaseFloatArrayElements(env, centroids, pc, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, listOff, po, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, listIds, pi, JNI_ABORT);
+    if (rc != 0) throw_last(env);
+    return rc;
+}
+
+JNIEXPORT jint JNICALL Java_hnsw_gpu_Native_batchDistances(JNIEnv *env, jclass c, jlong h, jfloatArray q, jintArray ids,
+                                                           jint m, jfloatArray out) {
+    jfloat *pq = (*env)->GetFloatArrayElements(env, q, NULL);
+    jint *pi = ids ? (*env)->GetIntArrayElements(env, ids, NULL) : NULL;
+    jfloat *po = (*env)->GetFloatArrayElements(env, out, NULL);
+    int rc = hnswgpu_batch_distances((hnswgpu_index *)(intptr_t)h, pq, (const int32_t *)pi, m, po);
+    (*env)->ReleaseFloatArrayElements(env, q, pq, JNI_ABORT);
+    if (pi) (*env)->ReleaseIntArrayElements(env, ids, pi, JNI_ABORT);
+    (*env)->ReleaseFloatArrayElements(env, out, po, 0);
+    if (rc != 0) throw_last(env);
+    return rc;
+}
+
+JNIEXPORT jint JNICALL Java_hnsw_gpu_Native_save(JNIEnv *env, jclass c, jlong h, jstring path) {
+    const char *p = (*env)->GetStringUTFChars(env, path, NULL);
+    int rc = hnswgpu_save((hnswgpu_index *)(intptr_t)h, p);
+    (*env)->ReleaseStringUTFChars(env, path, p);
+    if (rc != 0) throw_last(env);
+    return rc;
+}
+
+JNIEXPORT jlong JNICALL Java_hnsw_gpu_Native_load(JNIEnv *env, jclass c, jstring path, jint device) {
+    hnswgpu_index *idx = NULL;
+    const char *p = (*env)->GetStringUTFChars(env, path, NULL);
+    int rc = hnswgpu_load(p, device, &idx);
+    (*env)->ReleaseStringUTFChars(env, path, p);
+    if (rc != 0) throw_last(env);
+    return (jlong)(intptr_t)idx;
+}

@@ -12,7 +12,16 @@
      (search-knn index query-vec k)                                  ; hnsw.ultra-fast/search-knn
      (search-batch index queries k)                                  ; BatchSearchIndex/search-batch*
      (build-ivf-index data & {:keys [num-partitions max-iterations]}) ; hnsw.ann.partition.ivf-flat/build-index
-     (search-ivf index query-vec k & {:keys [num-probes]})"
+     (search-ivf index query-vec k & {:keys [num-probes]})
+     (search-ivf-batch index queries k & {:keys [num-probes]})
+     (batch-distances index query-vec)                               ; simd-optimized/batch-cosine-distances
+     (top-k-distances index query-vec k)                             ; simd-optimized/top-k-distances
+     (from-ultra-graph graph)                                        ; a graph built by the reference's own insert-single
+     (from-ivf-flat-index ivf)                                       ; an IVFFlatIndex built by the reference's own k-means
+     (save idx path) / (load-index path ids)                         ; helper/index-io save-index / load-index
+   and, at the bottom, the extend-type that makes GpuIndex an ANNIndex / BatchSearchIndex / PersistableIndex next to the
+   records src/hnsw/api/unified.clj:30-95 extends."
+  (:require [hnsw.api.protocol :as proto])
   (:import [java.lang.foreign Arena FunctionDescriptor Linker MemorySegment SymbolLookup ValueLayout]
            [java.lang.invoke MethodHandle]))
 
@@ -33,6 +42,13 @@
 (def ^:private h-search   (delay (fn-handle "hnswgpu_hnsw_search" (FunctionDescriptor/of I (into-array [P P I I I P P P])))))
 (def ^:private h-ivfbuild (delay (fn-handle "hnswgpu_ivf_build" (FunctionDescriptor/of I (into-array [P I I L])))))
 (def ^:private h-ivfsearch (delay (fn-handle "hnswgpu_ivf_search" (FunctionDescriptor/of I (into-array [P P I I I P P P])))))
+(def ^:private h-setgraph (delay (fn-handle "hnswgpu_set_graph" (FunctionDescriptor/of I (into-array [P P P I P P I I I])))))
+(def ^:private h-setivf   (delay (fn-handle "hnswgpu_set_ivf" (FunctionDescriptor/of I (into-array [P P I P P])))))
+(def ^:private h-batchd   (delay (fn-handle "hnswgpu_batch_distances" (FunctionDescriptor/of I (into-array [P P P I P])))))
+(def ^:private h-exact    (delay (fn-handle "hnswgpu_exact_knn" (FunctionDescriptor/of I (into-array [P P I I P P])))))
+(def ^:private h-save     (delay (fn-handle "hnswgpu_save" (FunctionDescriptor/of I (into-array [P P])))))
+(def ^:private h-load     (delay (fn-handle "hnswgpu_load" (FunctionDescriptor/of I (into-array [P I P])))))
+(def ^:private h-info     (delay (fn-handle "hnswgpu_info" (FunctionDescriptor/of I (into-array [P P P P P P])))))
 (def ^:private h-error    (delay (fn-handle "hnswgpu_last_error" (FunctionDescriptor/of P (into-array ValueLayout [])))))
 
 (defn- check [rc]
@@ -114,5 +130,140 @@
                                    [(:handle idx) q (int 1) (int k) (int num-probes) ids ds MemorySegment/NULL]))
       (results idx ids ds 0 k))))
 
+(defn search-ivf-batch
+  "All queries against the inverted lists in one call (the batch seam of search-ivf-flat)."
+  [idx queries k & {:keys [num-probes] :or {num-probes 4}}]
+  (with-open [arena (Arena/ofConfined)]
+    (let [nq (count queries)
+          q (floats-of arena (vec queries) (:dim idx))
+          ids (.allocate arena (* 4 nq k) 4)
+          ds (.allocate arena (* 4 nq k) 4)]
+      (check (.invokeWithArguments ^MethodHandle @h-ivfsearch
+                                   [(:handle idx) q (int nq) (int k) (int num-probes) ids ds MemorySegment/NULL]))
+      (mapv #(results idx ids ds % k) (range nq)))))
+
+;; ===== the simd-optimized batch seams =====
+
+(defn batch-distances
+  "simd-optimized/batch-cosine-distances / batch-euclidean-distances [query vectors] (src/hnsw/simd_optimized.clj:164-184)
+   against the vectors the index already holds: distances from query-vec to every row, in row order (a double-array)."
+  ^doubles [idx ^doubles query-vec]
+  (with-open [arena (Arena/ofConfined)]
+    (let [n (count (:ids idx))
+          q (floats-of arena [query-vec] (:dim idx))
+          out (.allocate arena (* 4 (long n)) 4)]
+      (check (.invokeWithArguments ^MethodHandle @h-batchd [(:handle idx) q MemorySegment/NULL (int n) out]))
+      (let [res (double-array n)]
+        (dotimes [i n] (aset res i (double (.getAtIndex out ValueLayout/JAVA_FLOAT (long i)))))
+        res))))
+
+(defn top-k-distances
+  "simd-optimized/top-k-distances (src/hnsw/simd_optimized.clj:271-280): exact k nearest rows -> [[row-index distance] ...]."
+  [idx ^doubles query-vec k]
+  (with-open [arena (Arena/ofConfined)]
+    (let [q (floats-of arena [query-vec] (:dim idx))
+          ids (.allocate arena (* 4 k) 4)
+          ds (.allocate arena (* 4 k) 4)]
+      (check (.invokeWithArguments ^MethodHandle @h-exact [(:handle idx) q (int 1) (int k) ids ds]))
+      (vec (for [i (range k)
+                 :let [id (.getAtIndex ids I (long i))]
+                 :when (>= id 0)]
+             [id (double (.getAtIndex ds ValueLayout/JAVA_FLOAT (long i)))])))))
+
+;; ===== INTEGRATION.md section 5: serve an index the reference itself built =====
+
+(defn- ints-of ^MemorySegment [^Arena arena coll]
+  (let [seg (.allocate arena (* 4 (long (max 1 (count coll)))) 4)]
+    (doseq [[i v] (map-indexed vector coll)] (.setAtIndex seg I (long i) (int v)))
+    seg))
+
+(defn- longs-of ^MemorySegment [^Arena arena coll]
+  (let [seg (.allocate arena (* 8 (long (max 1 (count coll)))) 8)]
+    (doseq [[i v] (map-indexed vector coll)] (.setAtIndex seg L (long i) (long v)))
+    seg))
+
+(defn from-ultra-graph
+  "An UltraGraph built by the reference's own insert-single (src/hnsw/ultra_fast.clj:216-275) -> GpuIndex.
+   Flattens UltraNode{id vector level neighbors} (:99-102; neighbors = Object[level+1] of HashSet<String>) into the
+   arrays of include/hnswgpu.h: ids -> rows in iteration order of the node map; every neighbour set padded with -1
+   to M0 = max-M (level 0) / M (levels >= 1); up_off = prefix sum of the node levels."
+  [graph & {:keys [metric] :or {metric :cosine}}]
+  (let [nodes (vec (.values ^java.util.Map (.nodes graph)))
+        row-of (into {} (map-indexed (fn [i nd] [(.id nd) i]) nodes))
+        M (int (.M graph))
+        M0 (int (.max-M graph))
+        idx (create (mapv (fn [nd] [(.id nd) (.vector nd)]) nodes) metric :hnsw)
+        levels (mapv #(int (.level %)) nodes)
+        up-off (vec (reductions + 0 levels))
+        pad (fn [ids width] (take width (concat (map row-of ids) (repeat -1))))
+        nbrs (fn [nd lv] (seq ^java.util.Set (aget ^objects (.neighbors nd) (int lv))))
+        l0 (mapcat #(pad (nbrs % 0) M0) nodes)
+        up (mapcat (fn [nd] (mapcat #(pad (nbrs nd %) M) (range 1 (inc (.level nd))))) nodes)
+        entry (row-of (.get ^java.util.concurrent.atomic.AtomicReference (.entry-point graph)))]
+    (with-open [arena (Arena/ofConfined)]
+      (check (.invokeWithArguments ^MethodHandle @h-setgraph
+                                   [(:handle idx) (ints-of arena levels) (ints-of arena l0) M0
+                                    (longs-of arena up-off) (ints-of arena up) M (int entry) (int (nth levels entry))])))
+    idx))
+
+(defn from-ivf-flat-index
+  "An IVFFlatIndex built by the reference's own k-means (src/hnsw/ann/partition/ivf_flat.clj:137-211) -> GpuIndex:
+   centroids + list membership go to hnswgpu_set_ivf (rows = the partitions' vectors, partition by partition)."
+  [ivf & {:keys [metric] :or {metric :cosine}}]
+  (let [parts (:partitions ivf)
+        rows (vec (mapcat identity parts))                 ; [[id ^doubles vec] ...], list by list
+        idx (create rows metric :ivf)
+        off (vec (reductions + 0 (map count parts)))]
+    (with-open [arena (Arena/ofConfined)]
+      (check (.invokeWithArguments ^MethodHandle @h-setivf
+                                   [(:handle idx) (floats-of arena (vec (:centroids ivf)) (:dim idx)) (int (count parts))
+                                    (longs-of arena off) (ints-of arena (range (count rows)))])))
+    idx))
+
+;; ===== persistence (helper/index-io save-index / load-index, src/hnsw/helper/index_io.clj:10-80) =====
+
+(defn save
+  "One flat binary file (base + graph + lists); the String ids go beside it as EDN -- the engine knows rows only."
+  [idx ^String path]
+  (with-open [arena (Arena/ofConfined)]
+    (check (.invokeWithArguments ^MethodHandle @h-save [(:handle idx) (.allocateFrom arena path)])))
+  (spit (str path ".ids.edn") (pr-str {:ids (:ids idx) :kind (:kind idx)}))
+  true)
+
+(defn load-index
+  "Index instance from `save`'s files; nil if the file does not exist (index_io.clj:41-48 returns nil too)."
+  [^String path & {:keys [device] :or {device 0}}]
+  (when (.exists (java.io.File. path))
+    (with-open [arena (Arena/ofConfined)]
+      (let [out (.allocate arena 8 8)
+            dim (.allocate arena 4 4)]
+        (check (.invokeWithArguments ^MethodHandle @h-load [(.allocateFrom arena path) (int device) out]))
+        (let [h (.get out P 0)
+              {:keys [ids kind]} (read-string (slurp (str path ".ids.edn")))]
+          (check (.invokeWithArguments ^MethodHandle @h-info
+                                       [h MemorySegment/NULL dim MemorySegment/NULL MemorySegment/NULL MemorySegment/NULL]))
+          (->GpuIndex h ids (.get dim I 0) kind))))))
+
 (defn close! [idx]
   (check (.invokeWithArguments ^MethodHandle @h-destroy [(:handle idx)])))
+
+;; ===== first-class index next to the reference's own records (src/hnsw/api/unified.clj:30-95) =====
+
+(def ^:private mode->probes {:turbo 1 :fast 2 :balanced 4 :accurate 8 :precise 12})   ; ivf_flat.clj:243-247
+
+(extend-type GpuIndex
+  proto/ANNIndex
+  (search-knn* [this query k mode]
+    (if (= :ivf (:kind this))
+      (search-ivf this query k :num-probes (mode->probes mode 4))
+      (search-knn this query k)))                          ; ef = (max k 50) whatever the mode, as graph.clj:304
+  (index-info* [this] {:type (if (= :ivf (:kind this)) "GPU IVF-FLAT (MI355X)" "GPU HNSW (MI355X)")
+                       :vectors (count (:ids this)) :dim (:dim this)})
+  (index-type* [this] (if (= :ivf (:kind this)) :gpu-ivf-flat :gpu-hnsw))
+  proto/BatchSearchIndex
+  (search-batch* [this queries k mode]
+    (if (= :ivf (:kind this))
+      (search-ivf-batch this queries k :num-probes (mode->probes mode 4))
+      (search-batch this queries k)))
+  proto/PersistableIndex
+  (save-index* [this filepath] (save this filepath)))

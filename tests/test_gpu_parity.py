@@ -954,18 +954,48 @@ def test_full_size_ivf_1m_properties(eng):
         assert_topk_parity(ai, ad, ei[:2], ed[:2], "ivf(all lists) vs exact at 1M")
 
 
-def test_c_abi_from_plain_c(native_lib, tmp_path):
+def test_c_abi_from_plain_c(native_lib, oracle, tmp_path):
     """examples/abi_demo.c: the library used the way a JNI / Panama binding uses it -- from C, without Python or
-    torch in the process."""
+    torch in the process.  Its last part walks INTEGRATION.md section 5 (a graph held as per-node, per-level neighbour
+    SETS is flattened and served through hnswgpu_set_graph); the migrated index and its answers are written out, and
+    the CPU oracle must give the same answers on that very graph: ids, distance bits, traversal counters."""
     import subprocess
 
+    O = oracle
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "abi_demo")
     subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "abi_demo.c"),
                            "-L" + native_lib.PKG, "-lhnswgpu", "-Wl,-rpath," + native_lib.PKG, "-lm", "-o", exe])
-    out = subprocess.run([exe, str(tmp_path / "demo.bin")], capture_output=True, text=True, timeout=300)
+    mig, res = str(tmp_path / "migrated.bin"), str(tmp_path / "results.bin")
+    out = subprocess.run([exe, str(tmp_path / "demo.bin"), mig, res], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abi_demo ok" in out.stdout
+    # the flat index file (layout: hnsw-clj_amd/csrc/persist.hip): header, base, levels, l0_adj, up_off, up_adj
+    raw = open(mig, "rb").read()
+    hdr = np.frombuffer(raw[:64], np.int32)
+    n, dim = int(np.frombuffer(raw[16:24], np.int64)[0]), int(hdr[6])
+    flags, M, M0, entry, max_level = int(hdr[7]), int(hdr[8]), int(hdr[9]), int(hdr[10]), int(hdr[11])
+    up_blocks = int(np.frombuffer(raw[48:56], np.int64)[0])
+    assert raw[:8] == b"HNSWGPU1" and flags == 1 and (n, dim, M, M0) == (2000, 96, 16, 32)
+    o = 64
+    base = np.frombuffer(raw, np.float32, n * dim, o).reshape(n, dim)
+    o += 4 * n * dim
+    levels = np.frombuffer(raw, np.int32, n, o)
+    o += 4 * n
+    l0 = np.frombuffer(raw, np.int32, n * M0, o).reshape(n, M0)
+    o += 4 * n * M0
+    up_off = np.frombuffer(raw, np.int64, n + 1, o)
+    o += 8 * (n + 1)
+    up = np.frombuffer(raw, np.int32, up_blocks * M, o)
+    assert o + 4 * up_blocks * M == len(raw)
+    r = open(res, "rb").read()
+    ids = np.frombuffer(r, np.int32, 40, 0).reshape(8, 5)
+    d = np.frombuffer(r, np.float32, 40, 160).reshape(8, 5)
+    st = np.frombuffer(r, np.int64, 16, 320).reshape(8, 2)
+    og = O.Graph(levels, l0, up_off, up, M, entry, max_level)
+    oi, od, ost, _ = O.hnsw_search(base, og, base[100:108], 5, ef=64, mode=O.MODE_DEV)
+    assert_exact(ids, d, oi, od, "set_graph migration from C vs oracle")
+    np.testing.assert_array_equal(st, ost)
 
 
 def test_parallel_callers_from_plain_c(native_lib, tmp_path):
