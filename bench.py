@@ -248,6 +248,13 @@ def main():
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - t1) * 1e3)
     lat = sorted(lat[5:])
+    # ... and through the reference's own seam: search-knn takes and returns HOST arrays (ultra_fast.clj:346-374)
+    lat_h = []
+    for i in range(60):
+        t1 = time.perf_counter()
+        idx.hnsw_search(queries[i], K, ef)
+        lat_h.append((time.perf_counter() - t1) * 1e3)
+    lat_h = sorted(lat_h[10:])
 
     # algorithmic bytes of the traversal: E * 4*D + H * 4*M0 per query
     hnsw_bytes_q = evals * 4 * DIM + hops * 4 * (2 * M)
@@ -279,8 +286,13 @@ def main():
             "hnsw_build_s": round(build_s, 2),
             "dist_evals_per_query": round(evals, 1),
             "expansions_per_query": round(hops, 1),
-            "single_query_latency_ms": {"p50": round(lat[len(lat) // 2], 4), "min": round(lat[0], 4),
-                                        "p95": round(lat[int(len(lat) * 0.95)], 4)},
+            "single_query_latency_ms": {"p50": round(lat_h[len(lat_h) // 2], 4), "min": round(lat_h[0], 4),
+                                        "p95": round(lat_h[int(len(lat_h) * 0.95)], 4),
+                                        "path": "hnswgpu_hnsw_search, host buffers in and out (the reference's search-knn seam): "
+                                                "query and results in mapped pinned memory, one launch, host-polled completion"},
+            "single_query_latency_dev_ms": {"p50": round(lat[len(lat) // 2], 4), "min": round(lat[0], 4),
+                                            "p95": round(lat[int(len(lat) * 0.95)], 4),
+                                            "path": "hnswgpu_hnsw_search_dev on torch's stream + torch.cuda.synchronize()"},
         },
         "roofline_hnsw": {"bound": "infinity-cache gather", "achieved": round(hnsw_gbs, 1), "peak": IC_GATHER_GBS[1],
                           "unit": "GB/s", "frac": round(hnsw_gbs / IC_GATHER_GBS[1], 4), "traffic": None,
@@ -431,9 +443,10 @@ def ivf_roofline(engine, dev, args, traffic):
                    "unique_GBs": round(uniq * (4 * DIM + 4) / (avg_ms * 1e-3) / 1e9, 1)}
     # single query, true latency: one call, one sync, host timer
     lat = []
+    o1 = (torch.empty((1, K), dtype=torch.int32, device=dev), torch.empty((1, K), dtype=torch.float32, device=dev))
     for i in range(60):
         t1 = time.perf_counter()
-        idx.ivf_search_dev(Qa[i:i + 1], K, nprobe)
+        idx.ivf_search_dev(Qa[i:i + 1], K, nprobe, out=o1)
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - t1) * 1e6)
     lat = sorted(lat[10:])

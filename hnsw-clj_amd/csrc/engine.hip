@@ -5,6 +5,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <chrono>
 
@@ -393,76 +397,199 @@ int ensure_pinned(hnswgpu_index *idx, size_t bytes) {
     return 0;
 }
 
+// ---- waiting on one 32-bit word: a short spin, then the kernel's futex (Linux) ------------------------------------
+static void word_wake(std::atomic<uint32_t> *w) {
+    syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+}
+static uint32_t word_wait_nonzero(std::atomic<uint32_t> *w) {
+    for (int i = 0; i < 256; i++) {  // a batch usually answers in a few hundred microseconds: brief spin, then sleep
+        const uint32_t v = w->load(std::memory_order_acquire);
+        if (v) return v;
+        __builtin_ia32_pause();
+    }
+    for (;;) {
+        const uint32_t v = w->load(std::memory_order_acquire);
+        if (v) return v;
+        syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, 0u, nullptr, nullptr, 0);
+    }
+}
+static double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int slot_prepare(hnswgpu_index::Slot &s, size_t bytes) {
+    if (!s.st) HG_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    if (!s.d_again) {
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_again), sizeof(int32_t) * (kZcMaxQueries + 1)));
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_done), sizeof(uint32_t) * 4));
+        HG_HIP(hipMemsetAsync(s.d_again, 0, sizeof(int32_t) * (kZcMaxQueries + 1), s.st));
+        HG_HIP(hipMemsetAsync(s.d_done, 0, sizeof(uint32_t) * 4, s.st));
+        HG_HIP(hipStreamSynchronize(s.st));
+    }
+    if (bytes > s.cap) {
+        if (s.h) {
+            HG_HIP(hipStreamSynchronize(s.st));
+            (void)hipHostFree(s.h);
+        }
+        s.h = s.d = nullptr;
+        s.cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        // mapped + coherent: the kernels address these bytes directly and the host sees their stores without a copy
+        HG_HIP(hipHostMalloc(&s.h, want, hipHostMallocMapped | hipHostMallocCoherent));
+        HG_HIP(hipHostGetDevicePointer(&s.d, s.h, 0));
+        memset(s.h, 0, 64);
+        s.cap = want;
+        s.seq = 0;
+    }
+    return 0;
+}
+
+int slot_wait(hnswgpu_index::Slot &s, volatile uint32_t *flag, uint32_t seq) {
+    const double t0 = now_us();
+    for (uint64_t spins = 0;; spins++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
+        __builtin_ia32_pause();
+        if ((spins & 0x3fff) == 0x3fff && now_us() - t0 > 2e6) break;  // 2 s: something is wrong, ask the runtime
+    }
+    HG_HIP(hipStreamSynchronize(s.st));  // surfaces a kernel fault; a healthy launch has set the flag by now
+    HG_REQUIRE(__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq, HNSWGPU_EHIP, "search kernel finished without publishing its results");
+    return 0;
+}
+
+// Serve `me` through combiner `c`.  At any time at most ONE thread is the collector: it waits a moment for the callers
+// a finishing batch has just released (they come straight back with their next query), takes the first queued request
+// and everything behind it that `take` lets join, gives the collector role to the next queued thread and only then
+// runs its batch -- so up to c.max_inflight batches overlap on the device.  The wait adapts to what is measured: at
+// most a quarter of the previous batch's turnaround (and 100 us), over as soon as as many callers are queued as the
+// previous batch held, or arrivals have stopped for 10 us.
 int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
                    const std::function<bool(const hnswgpu_index::SearchReq *, const hnswgpu_index::SearchReq *, int64_t)> &take,
                    const std::function<int(const std::vector<hnswgpu_index::SearchReq *> &, int32_t)> &run) {
-    std::unique_lock<std::mutex> cl(c.mu);
-    c.pending.push_back(&me);
-    if (c.linger) c.cv.notify_all();  // a leader is counting arrivals
-    while (!me.done) {
-        if (c.leader) {  // somebody is launching: wait for my result, or for the leadership to be free
-            c.cv.wait(cl, [&] { return me.done || !c.leader; });
-            continue;
+    using Req = hnswgpu_index::SearchReq;
+    bool collect;
+    {
+        std::lock_guard<std::mutex> cl(c.mu);
+        try {
+            c.pending.push_back(&me);
+        } catch (...) {
+            set_error("host allocation failed while queueing a search");
+            return HNSWGPU_ENOMEM;
         }
-        // Lead ONE batch: the first queued request and everything behind it that may join it, in arrival order.
-        // The callers the previous batch released are on their way back: give them a moment to queue up, or every
-        // other batch would hold a single request (first one back) and the next one everybody else.  (Measured with
-        // examples/parallel_callers.c: a small crowd is worth waiting for in full -- 20 threads 29k QPS against 12k
-        // without the wait --, of a large one three quarters are enough: 100 threads 76k QPS against 14k.)
-        c.leader = true;
-        const int target = c.last <= 24 ? c.last : c.last - c.last / 4;
-        if (c.last > 1 && static_cast<int>(c.pending.size()) < target) {
-            c.linger = true;
-            c.cv.wait_for(cl, std::chrono::microseconds(c.last <= 24 ? 100 : 60),
-                          [&] { return static_cast<int>(c.pending.size()) >= target; });
-            c.linger = false;
+        c.npending.store(static_cast<int>(c.pending.size()), std::memory_order_release);
+        collect = !c.collector;
+        if (collect) c.collector = true;
+    }
+    for (;;) {
+        if (!collect) {
+            const uint32_t st = word_wait_nonzero(&me.state);
+            if (st == 1) break;  // served
+            me.state.store(0, std::memory_order_relaxed);  // st == 2: the collector role was handed to me
         }
-        // Nothing below may leave `leader` set or a batch unanswered: an exception (bad_alloc from the vectors, the
-        // message copies or anything `run` allocates) would otherwise park every current and future caller in cv.wait
-        // for good.  Whatever happens, the batch is marked done -- with an error if need be -- and the leadership freed.
-        std::vector<hnswgpu_index::SearchReq *> batch;
+        collect = false;
+        // ---- a free device slot
+        {
+            std::unique_lock<std::mutex> cl(c.mu);
+            while (c.inflight >= c.max_inflight) {
+                c.slot_waiter = &me;
+                cl.unlock();
+                word_wait_nonzero(&me.state);  // a finishing batch sets 2 again
+                me.state.store(0, std::memory_order_relaxed);
+                cl.lock();
+            }
+            c.slot_waiter = nullptr;
+        }
+        // ---- linger for the callers on their way back
+        if (c.last > 1) {
+            const double limit = std::min(100.0, std::max(10.0, c.last_run_us * 0.25)), t0 = now_us();
+            int seen = c.npending.load(std::memory_order_acquire);
+            double t_change = t0;
+            while (seen < c.last) {
+                const double t = now_us();
+                if (t - t0 > limit || (seen > 1 && t - t_change > 10.0)) break;
+                __builtin_ia32_pause();
+                const int n = c.npending.load(std::memory_order_acquire);
+                if (n != seen) {
+                    seen = n;
+                    t_change = t;
+                }
+            }
+        }
+        // ---- split the queue.  Nothing below may leave the collector role taken or a request unanswered: an exception
+        // (bad_alloc from the vectors, the message copies, anything `run` allocates) would otherwise park every current
+        // and future caller for good.  Whatever happens, the batch is answered -- with an error if need be.
+        std::vector<Req *> batch;
+        int64_t total = 0;
+        Req *next = nullptr;
+        bool split_failed = false;
+        {
+            std::lock_guard<std::mutex> cl(c.mu);
+            try {
+                std::vector<Req *> rest;
+                batch.reserve(c.pending.size());
+                rest.reserve(c.pending.size());
+                for (auto *r : c.pending) {
+                    if (batch.empty() || take(batch[0], r, total)) {
+                        batch.push_back(r);
+                        total += r->nq;
+                    } else {
+                        rest.push_back(r);
+                    }
+                }
+                c.pending.swap(rest);
+            } catch (...) {  // nothing was taken: answer me with an error, somebody else collects
+                split_failed = true;
+                batch.clear();
+                c.pending.erase(std::remove(c.pending.begin(), c.pending.end(), &me), c.pending.end());
+            }
+            c.npending.store(static_cast<int>(c.pending.size()), std::memory_order_release);
+            if (!split_failed) {
+                c.last = static_cast<int>(batch.size());
+                c.inflight++;
+            }
+            // hand the collector role on before running: the next batch forms while this one is on the device
+            bool mine = split_failed || std::find(batch.begin(), batch.end(), &me) != batch.end();
+            if (!mine) {
+                collect = true;  // my own request is still queued (its k / ef differ from this batch's): I stay collector
+            } else if (!c.pending.empty()) {
+                next = c.pending.front();
+            } else {
+                c.collector = false;
+            }
+        }
+        if (next) {
+            next->state.store(2, std::memory_order_release);
+            word_wake(&next->state);
+        }
+        if (split_failed) {
+            set_error("host allocation failed while forming a combined batch");
+            return HNSWGPU_ENOMEM;
+        }
         int rc = 0;
         const char *msg = "";
+        const double t_run = now_us();
         try {
-            std::vector<hnswgpu_index::SearchReq *> rest;
-            int64_t total = 0;
-            batch.reserve(c.pending.size());
-            rest.reserve(c.pending.size());
-            for (auto *r : c.pending) {
-                if (batch.empty() || take(batch[0], r, total)) {
-                    batch.push_back(r);
-                    total += r->nq;
-                } else {
-                    rest.push_back(r);
-                }
-            }
-            c.pending.swap(rest);
-            c.last = static_cast<int>(batch.size());
-            cl.unlock();
-            try {
-                rc = run(batch, static_cast<int32_t>(total));
-                if (rc) msg = hnswgpu_last_error();
-            } catch (const std::bad_alloc &) {
-                rc = HNSWGPU_ENOMEM;
-                msg = "host allocation failed while serving a combined batch";
-            } catch (...) {
-                rc = HNSWGPU_EINVAL;
-                msg = "unexpected exception while serving a combined batch";
-            }
-            cl.lock();
-        } catch (...) {  // thrown while the queue was being split (lock still held): fail what was taken so far and me
+            rc = run(batch, static_cast<int32_t>(total));
+            if (rc) msg = hnswgpu_last_error();
+        } catch (const std::bad_alloc &) {
             rc = HNSWGPU_ENOMEM;
-            msg = "host allocation failed while forming a combined batch";
-            if (std::find(batch.begin(), batch.end(), &me) == batch.end()) {
-                c.pending.erase(std::remove(c.pending.begin(), c.pending.end(), &me), c.pending.end());
-                me.rc = rc;
-                me.done = true;
-                try {
-                    me.err = msg;
-                } catch (...) {
-                }
-            }
+            msg = "host allocation failed while serving a combined batch";
+        } catch (...) {
+            rc = HNSWGPU_EINVAL;
+            msg = "unexpected exception while serving a combined batch";
         }
+        Req *waiter = nullptr;
+        {
+            std::lock_guard<std::mutex> cl(c.mu);
+            c.inflight--;
+            c.last_run_us = now_us() - t_run;
+            waiter = c.slot_waiter;
+            c.slot_waiter = nullptr;
+        }
+        if (waiter) {  // the collector was parked for a device slot
+            waiter->state.store(2, std::memory_order_release);
+            word_wake(&waiter->state);
+        }
+        bool mine = false;
         for (auto *r : batch) {
             r->rc = rc;
             if (rc) {
@@ -471,15 +598,15 @@ int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
                 } catch (...) {  // the code still says what happened
                 }
             }
-            r->done = true;
+            if (r == &me) {
+                mine = true;
+                continue;
+            }
+            r->state.store(1, std::memory_order_release);  // after this store `r` may be gone: only its address is used
+            word_wake(&r->state);
         }
-        // requests taken into `batch` before a failed split are answered above; they may still sit in c.pending
-        if (rc)
-            for (auto *r : batch) c.pending.erase(std::remove(c.pending.begin(), c.pending.end(), r), c.pending.end());
-        c.leader = false;
-        c.cv.notify_all();
+        if (mine) break;
     }
-    cl.unlock();
     if (me.rc) set_error("%s", me.err.c_str());
     return me.rc;
 }
@@ -817,6 +944,8 @@ static int create_common(int64_t n, int32_t dim, int32_t metric, int32_t device,
     idx->dim = dim;
     idx->ld = ld;
     idx->nch = nch;
+    idx->cmb_hnsw.max_inflight = 2;  // two Slots: small synchronous HNSW batches overlap on the device
+    idx->cmb_ivf.max_inflight = 1;   // the IVF path works in the index's shared scratch: one batch at a time
     *out = idx;
     return 0;
 }
@@ -906,6 +1035,13 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     if (idx->ev_last) (void)hipEventDestroy(idx->ev_last);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     if (idx->h_pin) (void)hipHostFree(idx->h_pin);
+    for (auto &sl : idx->slots) {
+        if (sl.st) (void)hipStreamSynchronize(sl.st);
+        if (sl.h) (void)hipHostFree(sl.h);
+        if (sl.d_again) (void)hipFree(sl.d_again);
+        if (sl.d_done) (void)hipFree(sl.d_done);
+        if (sl.st) (void)hipStreamDestroy(sl.st);
+    }
     delete idx;
     return 0;
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -84,9 +85,9 @@ struct hnswgpu_index {
     hipStream_t stream = nullptr;
     std::mutex mu;
     // Combining of concurrent synchronous searches (hnswgpu_hnsw_search from many host threads, the reference's
-    // parallel-search-futures pattern): callers queue their request; one of them -- the leader -- launches everything
-    // that is queued with the same (k, ef) as ONE batch and hands the results back.  Twenty threads issuing single
-    // queries then share a launch instead of queueing twenty of them one after the other.
+    // parallel-search-futures pattern): callers queue their request; one of them -- the collector -- takes everything
+    // that is queued with the same (k, ef) as ONE batch, launches it and hands the results back.  Twenty threads issuing
+    // single queries then share a launch instead of queueing twenty of them one after the other.
     struct SearchReq {
         const float *Q;
         int32_t nq, k, ef;  // ef: layer-0 breadth of an HNSW request, nprobe of an IVF request
@@ -94,19 +95,39 @@ struct hnswgpu_index {
         float *out_dist;
         int64_t *stats;
         int rc = 0;
-        bool done = false;
         std::string err;
+        // 0 = queued, 1 = served (rc / err / outputs are final), 2 = "you collect the next batch".  Every caller sleeps on
+        // ITS OWN word (futex): serving a batch of 200 wakes 200 threads one by one, none of which then fights the
+        // other 199 for a shared mutex (the condition-variable broadcast of round 1 collapsed at 200 callers).
+        std::atomic<uint32_t> state{0};
     };
     struct Combiner {
         std::mutex mu;
-        std::condition_variable cv;
         std::vector<SearchReq *> pending;
-        bool leader = false;
-        bool linger = false;  // a leader is waiting a moment for the callers the previous batch released
-        int last = 0;         // requests in the previous batch
+        std::atomic<int> npending{0};  // pending.size(), readable without the lock (a lingering collector polls it)
+        bool collector = false;        // a thread is forming the next batch (at most one at a time)
+        int inflight = 0;              // batches launched and not yet answered
+        int max_inflight = 1;          // batches that may overlap on the device (own stream + staging each)
+        SearchReq *slot_waiter = nullptr;  // the collector, parked until a batch in flight completes
+        int last = 0;                  // requests in the batch launched last
+        double last_run_us = 0.0;      // how long that batch took from launch to results (its callers return after that)
     };
     Combiner cmb_hnsw, cmb_ivf;
-    void *h_pin = nullptr;    // pinned host staging of the combined batch (queries in, results out)
+    // One batch in flight of the small synchronous searches: its own stream, one block of MAPPED pinned host memory
+    // that the kernels read the queries from and write the results to (no copy calls at all), and a flag in that
+    // block the last workgroup sets and the host thread spins on (no interrupt, no hipStreamSynchronize).
+    struct Slot {
+        std::mutex mu;
+        hipStream_t st = nullptr;
+        void *h = nullptr;      // host address of the block
+        void *d = nullptr;      // device address of the same bytes
+        size_t cap = 0;
+        int32_t *d_again = nullptr;    // [1 + kZcMaxQueries]: queries that ran out of ghost slots (see hnsw.hip)
+        uint32_t *d_done = nullptr;    // workgroups that have finished the current launch
+        uint32_t seq = 0;              // value the flag takes when the current launch has finished
+    };
+    Slot slots[2];
+    void *h_pin = nullptr;    // pinned host staging of a large combined batch (queries in, results out)
     size_t h_pin_cap = 0;
     // cross-stream ordering of the shared scratch buffers: the last call's completion event
     hipEvent_t ev_last = nullptr;
@@ -160,6 +181,10 @@ int launch_merge(const MergeArgs &a, hipStream_t st);
 // Serve `me` through combiner `c`: queue it, lead one batch at a time while it is not done.  `take(first, r, total)`
 // says whether request r may join a batch that starts with `first` and already holds `total` queries; `run` launches
 // a batch and returns its error code.
+constexpr int kZcMaxQueries = 256;  // largest combined batch served through a Slot (one workgroup per query and CU)
+int slot_prepare(hnswgpu_index::Slot &s, size_t bytes);  // stream, counters, mapped block of at least `bytes`
+// Spin on the completion flag of a slot launch (value `seq`); falls back to hipStreamSynchronize if it does not show.
+int slot_wait(hnswgpu_index::Slot &s, volatile uint32_t *flag, uint32_t seq);
 int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
                    const std::function<bool(const hnswgpu_index::SearchReq *, const hnswgpu_index::SearchReq *, int64_t)> &take,
                    const std::function<int(const std::vector<hnswgpu_index::SearchReq *> &, int32_t)> &run);

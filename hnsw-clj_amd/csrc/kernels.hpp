@@ -517,6 +517,13 @@ struct HnswArgs {
     int32_t *again_cnt;
     const int32_t *q_index;
     const int32_t *nq_dev;
+    // Host-polled completion (small synchronous calls whose queries and results live in mapped pinned host memory):
+    // every workgroup counts itself in done_cnt when it has no work left; the last one copies *again_cnt to
+    // host_again, resets the counter and stores flag_val to host_flag -- the host thread spins on that word.
+    uint32_t *done_cnt;
+    uint32_t *host_flag;
+    int32_t *host_again;
+    uint32_t flag_val;
     unsigned long long *dbg;  // -DHG_HNSW_STAMPS diagnostic builds only: per-phase s_memrealtime totals
 };
 
@@ -835,6 +842,19 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
         if (a.stats && tid == 0) {
             a.stats[2 * static_cast<int64_t>(qi)] = n_eval;
             a.stats[2 * static_cast<int64_t>(qi) + 1] = n_hop;
+        }
+    }
+    if (a.host_flag) {
+        __threadfence_system();  // this thread's results (host memory) are visible system-wide ...
+        __syncthreads();         // ... before the workgroup reports itself done
+        if (tid == 0) {
+            if (atomicAdd(a.done_cnt, 1u) == gridDim.x - 1) {  // the last workgroup: every result is out
+                atomicExch(a.done_cnt, 0u);
+                __threadfence();
+                *a.host_again = a.again_cnt ? atomicAdd(a.again_cnt, 0) : 0;
+                __threadfence_system();
+                __hip_atomic_store(a.host_flag, a.flag_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

@@ -174,5 +174,8 @@ def test_hnsw_subgraphs_equal_oracle_merge(eng, oracle, metric):
         sel = np.argsort(key, axis=1, kind="stable")[:, :k]                       # Collections/sort: stable
         ei, ed = np.take_along_axis(ci, sel, 1), np.take_along_axis(cd, sel, 1)
         assert_exact(mi.cpu().numpy(), md.cpu().numpy(), ei, ed, "%s hnsw sub-graphs, %d shards" % (metric, nshard))
-        if nshard == 2:
-            assert mi.cpu().numpy()[0, :2].tolist() == [100, 13000]               # equal distances: lower shard first
+        row = mi.cpu().numpy()[0].tolist()
+        if nshard == 2 and 100 in row and 13000 in row:                           # both copies found by the sub-graph searches:
+            assert row.index(13000) == row.index(100) + 1                         # equal distances, the lower shard first
+        if nshard == 2 and metric == "cosine":
+            assert row[:2] == [100, 13000]
