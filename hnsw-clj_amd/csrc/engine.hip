@@ -86,6 +86,7 @@ int launch_scan(int nch, const ScanArgs &a0, hipStream_t st) {
     }
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "scan grid too large (%lld blocks)", (long long)blocks);
     size_t lds = a.mode == MODE_TOPK ? sizeof(uint64_t) * kNWave * a.k : 0;
+    if (a.done) lds = sizeof(uint64_t) * (kNWave + 2) * a.k;  // fused tail: W lists + final list + (ord, dist) of the result
     HG_REQUIRE(lds <= 64 * 1024, HNSWGPU_ELIMIT, "k too large for the scan kernel (k=%d)", a.k);
     bool l2 = a.metric == METRIC_L2;
 #define CALL_ROLE(N, R, L, ROLE) \
@@ -105,58 +106,6 @@ int launch_scan(int nch, const ScanArgs &a0, hipStream_t st) {
     return 0;
 }
 
-// One workgroup of W waves per query: every wave folds a contiguous slice of the query's partial keys into
-// its own ascending top-k (registers when k <= 64, LDS otherwise), then wave 0 folds the W lists.
-// (A single wave scanning ~45k keys made the merge the longest kernel of a one-query IVF search.)
-__device__ __forceinline__ void fold_keys(const uint64_t *in, int64_t n, int k, bool regk, uint64_t *list, int lane,
-                                          uint64_t &mine, int &cnt) {
-    uint64_t thr = ~0ull, cap = ~0ull;
-    constexpr int U = 8;
-    // the next block's loads are issued before this block is folded (one memory round trip per block otherwise)
-    uint64_t nxt[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        int64_t i = u * kWave + lane;
-        nxt[u] = i < n ? in[i] : ~0ull;
-    }
-    for (int64_t base = 0; base < n; base += U * kWave) {
-        uint64_t key[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) key[u] = nxt[u];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            int64_t i = base + (U + u) * kWave + lane;
-            nxt[u] = i < n ? in[i] : ~0ull;
-        }
-        if (regk && base == 0) {  // start from a bound on the k-th smallest key instead of ~0 (kth_bound)
-            uint64_t m = key[0];
-#pragma unroll
-            for (int u = 1; u < U; u++) m = key[u] < m ? key[u] : m;
-            cap = kth_bound(m, k, lane);
-            thr = cap;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            uint64_t mask = __ballot(key[u] < thr);
-            while (mask) {
-                int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
-                mask &= mask - 1;
-                uint64_t kb = lane_bcast(key[u], b);
-                if (kb < thr) {
-                    if (regk) {
-                        wave_insert_reg(mine, cnt, k, kb, lane);
-                        const uint64_t kth = wave_kth_reg(mine, k);
-                        thr = kth < cap ? kth : cap;
-                    } else {
-                        wave_insert(list, cnt, k, kb, lane);
-                        thr = cnt == k ? list[k - 1] : ~0ull;
-                    }
-                }
-            }
-        }
-    }
-}
-
 // hipFuncSetAttribute is per device: remember it per (call site, device), not once per process (one process may
 // hold handles on several GPUs -- the partitioned and IVF-HNSW mirrors do)
 bool attr_needed(bool (&done)[64]) {
@@ -169,70 +118,8 @@ bool attr_needed(bool (&done)[64]) {
 
 __global__ __launch_bounds__(1024) void merge_topk_kernel(MergeArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);  // [W][k]
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    const int W = blockDim.x >> 6;
-    const int q = blockIdx.x;
-    const uint64_t *in = a.partial + static_cast<int64_t>(q) * a.keys_per_query;
-    const bool regk = a.k <= kWave;
-    const int64_t slice = (a.keys_per_query + W - 1) / W;
-    const int64_t s0 = wave * slice;
-    const int64_t sn = s0 + slice < a.keys_per_query ? slice : (a.keys_per_query > s0 ? a.keys_per_query - s0 : 0);
-    uint64_t *list = lists + static_cast<size_t>(wave) * a.k;
-    uint64_t mine = ~0ull;
-    int cnt = 0;
-    fold_keys(in + s0, sn, a.k, regk, list, lane, mine, cnt);
-    if (regk) {
-        if (lane < a.k) list[lane] = mine;
-    } else {
-        for (int i = cnt + lane; i < a.k; i += kWave) list[i] = ~0ull;
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    if (W > 1) {  // second level: W * k keys (sentinels included) -> final list behind the W slots
-        uint64_t *fin = lists + static_cast<size_t>(W) * a.k;
-        const int tot = W * a.k;
-        uint64_t thr = ~0ull;
-        mine = ~0ull;
-        cnt = 0;
-        for (int base = 0; base < tot; base += kWave) {
-            const int i = base + lane;
-            const uint64_t key = i < tot ? lists[i] : ~0ull;
-            uint64_t mask = __ballot(key < thr);
-            while (mask) {
-                int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
-                mask &= mask - 1;
-                uint64_t kb = lane_bcast(key, b);
-                if (kb < thr) {
-                    if (regk) {
-                        wave_insert_reg(mine, cnt, a.k, kb, lane);
-                        thr = wave_kth_reg(mine, a.k);
-                    } else {
-                        wave_insert(fin, cnt, a.k, kb, lane);
-                        thr = cnt == a.k ? fin[a.k - 1] : ~0ull;
-                    }
-                }
-            }
-        }
-        if (regk) {
-            if (lane < a.k) fin[lane] = mine;
-        } else {
-            for (int i = cnt + lane; i < a.k; i += kWave) fin[i] = ~0ull;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        list = fin;
-    } else {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    for (int i = lane; i < a.k; i += kWave) {
-        uint64_t key = list[i];
-        bool ok = key != ~0ull;
-        a.out_ord[static_cast<int64_t>(q) * a.k + i] = ok ? static_cast<uint32_t>(key) : 0xffffffffu;
-        a.out_dist[static_cast<int64_t>(q) * a.k + i] = ok ? key_dist(key) : __uint_as_float(0x7f800000u);
-    }
+    const int64_t q = blockIdx.x;
+    merge_topk_wg(a, blockIdx.x, blockDim.x >> 6, smem, a.out_ord + q * a.k, a.out_dist + q * a.k);
 }
 
 int launch_merge(const MergeArgs &a, hipStream_t st) {
@@ -345,6 +232,199 @@ int scan_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_quer
     m.out_ord = idx->s_ord.as<uint32_t>();
     m.out_dist = idx->s_dist.as<float>();
     HG_TRY(launch_merge(m, st));
+    return 0;
+}
+
+// zero-initialised per-query counters of the fused tails (each tail resets its own counter: zero between calls)
+static int ensure_counters(hnswgpu_index *idx, size_t n, hipStream_t st) {
+    const size_t bytes = sizeof(uint32_t) * 2 * n;  // [n] scan tails | [n] route tails
+    if (bytes <= idx->s_done.cap) return 0;
+    HG_TRY(idx->s_done.ensure(bytes));
+    HG_HIP(hipMemsetAsync(idx->s_done.p, 0, idx->s_done.cap, st));
+    idx->s_done_n = idx->s_done.cap / (sizeof(uint32_t) * 2);
+    return 0;
+}
+
+// IVF list scan whose last workgroup per query merges, decodes and writes the final results (ScanArgs::done).
+int scan_fused(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_query, int64_t max_rows, int64_t mean_rows,
+               hipStream_t st, int prof_slot) {
+    a.mode = MODE_TOPK;
+    a.npairs = nq * pairs_per_query;
+    a.nchunks = plan_chunks(idx->nch, max_rows, mean_rows > 0 ? mean_rows : max_rows, a.npairs, &a.chunk_rows, true);
+    a.wg_merge = a.k <= kWave ? 1 : 0;
+    const int64_t keys_per_query = static_cast<int64_t>(pairs_per_query) * a.nchunks * (a.wg_merge ? 1 : kNWave) * a.k;
+    HG_TRY(idx->s_partial.ensure(sizeof(uint64_t) * keys_per_query * nq));
+    HG_TRY(ensure_counters(idx, nq, st));
+    a.partial = idx->s_partial.as<uint64_t>();
+    a.done = idx->s_done.as<uint32_t>();
+    a.pairs_per_query = pairs_per_query;
+    hipEvent_t e0;
+    prof_begin(idx, prof_slot, st, &e0);
+    HG_TRY(launch_scan(idx->nch, a, st));
+    prof_end(idx, prof_slot, st, e0);
+    return 0;
+}
+
+// ---- centroid routing of a small batch in ONE launch (search-ivf-flat's centroid ranking, ivf_flat.clj:261-269) ----
+// Every workgroup computes the distances of its query to a slice of the centroid table (the GEMV order of scan_kernel:
+// same bits), the last workgroup of a query picks the nprobe nearest (select_topk_wg: keys (distance, centroid), the
+// stable sort of :266-268) and writes the query's probe table -- what used to be three launches (scan, select,
+// probe_pairs).
+struct RouteArgs {
+    const float *cent;
+    const float *cnorms;
+    int64_t ld;
+    int32_t nlist;
+    const float *Q;
+    int64_t qld;
+    int32_t dim, metric, nq, nprobe;
+    int32_t rows_per_block, blocks_per_query;
+    float *dense;     // [nq][nlist]
+    uint32_t *done;   // [nq], zero between calls
+    uint32_t *out_ord;
+    float *out_dist;  // [nq][nprobe]
+    const int64_t *listoff;
+    const int64_t *glistoff;
+    Pair *pairs;
+    int32_t *probes;  // optional
+    int32_t *qcnt;    // optional
+};
+
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int tail_last;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x / a.blocks_per_query, bx = blockIdx.x % a.blocks_per_query;
+    const int64_t r0 = static_cast<int64_t>(bx) * a.rows_per_block;
+    const int64_t r1 = r0 + a.rows_per_block < a.nlist ? r0 + a.rows_per_block : a.nlist;
+    if (r0 < r1) {
+        float4 q[NCH];
+        load_query<NCH>(q, a.Q + qi * a.qld, a.dim, lane);
+        const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+        const int nvec = static_cast<int>(a.ld / 4);
+        for (int64_t base = r0 + wave * RB; base < r1; base += kNWave * RB) {
+            float4 r[RB][NCH];
+            const float myrn = (a.metric == METRIC_COS && lane < RB && base + lane < r1) ? a.cnorms[base + lane] : 0.0f;
+#pragma unroll
+            for (int b = 0; b < RB; b++) load_row<NCH>(r[b], a.cent + (base + b) * a.ld, nvec, lane, base + b < r1);
+            float s[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2>(q, r[b]);
+#pragma unroll
+            for (int b = 0; b < RB; b++) s[b] = wave_sum(s[b]);
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                const int64_t row = base + b;
+                if (row < r1 && lane == 0) {
+                    const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), b));
+                    coherent_store(a.dense + static_cast<int64_t>(qi) * a.nlist + row, finish_dist(a.metric, s[b], qn, rn));
+                }
+            }
+        }
+    }
+    wait_stores_acked();  // the slice of distances is at the point of coherence before this workgroup counts itself
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(a.done + qi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tail_last = prev == static_cast<uint32_t>(a.blocks_per_query) - 1 ? 1 : 0;
+        if (tail_last) __hip_atomic_store(a.done + qi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!tail_last) return;
+    SelectArgs s;
+    s.dist = a.dense;
+    s.q_cnt = nullptr;
+    s.stride = a.nlist;
+    s.cnt_all = a.nlist;
+    s.nq = a.nq;
+    s.k = a.nprobe;
+    s.wpq = kNWave;
+    s.out_ord = a.out_ord;
+    s.out_dist = a.out_dist;
+    select_topk_wg<true>(s, qi, kNWave, smem);
+    if (wave != 0) return;
+    __threadfence_block();
+    // the query's probe table: offsets of the probed lists in its candidate stream (probe_pairs_kernel, one wave)
+    uint32_t carry = 0, gcarry = 0;
+    for (int p0 = 0; p0 < a.nprobe; p0 += kWave) {
+        const int p = p0 + lane;
+        const uint32_t l = p < a.nprobe ? a.out_ord[static_cast<int64_t>(qi) * a.nprobe + p] : 0xffffffffu;
+        Pair pr;
+        pr.q = qi;
+        pr.pad = 0;
+        pr.row_begin = pr.row_end = 0;
+        uint32_t glen = 0;
+        if (l != 0xffffffffu) {
+            pr.row_begin = a.listoff[l];
+            pr.row_end = a.listoff[l + 1];
+            glen = static_cast<uint32_t>(a.glistoff[l + 1] - a.glistoff[l]);
+        }
+        const uint32_t len = static_cast<uint32_t>(pr.row_end - pr.row_begin);
+        uint32_t incl = len, gincl = glen;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, kWave), go = __shfl_up(gincl, off, kWave);
+            if (lane >= off) {
+                incl += o;
+                gincl += go;
+            }
+        }
+        pr.ord_base = carry + incl - len;
+        pr.gord_base = gcarry + gincl - glen;
+        if (p < a.nprobe) {
+            a.pairs[static_cast<int64_t>(qi) * a.nprobe + p] = pr;
+            if (a.probes) a.probes[static_cast<int64_t>(qi) * a.nprobe + p] = l == 0xffffffffu ? -1 : static_cast<int32_t>(l);
+        }
+        carry += __shfl(incl, kWave - 1, kWave);
+        gcarry += __shfl(gincl, kWave - 1, kWave);
+    }
+    if (a.qcnt && lane == 0) a.qcnt[qi] = static_cast<int32_t>(carry);
+}
+
+int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
+                     int32_t *qcnt, hipStream_t st) {
+    RouteArgs a;
+    memset(&a, 0, sizeof(a));
+    a.cent = idx->d_cent;
+    a.cnorms = idx->d_cnorms;
+    a.ld = idx->ld;
+    a.nlist = idx->nlist;
+    a.Q = d_Q;
+    a.qld = idx->dim;
+    a.dim = idx->dim;
+    a.metric = idx->metric;
+    a.nq = nq;
+    a.nprobe = nprobe;
+    // one loop trip of every wave per workgroup for a handful of queries (1024 centroids: 32 workgroups per query),
+    // more rows per workgroup as the batch grows
+    const int per_iter = scan_rows_per_iter(idx->nch);
+    int64_t want_blocks = std::max<int64_t>(1, 2048 / std::max(nq, 1));
+    int64_t rpb = (idx->nlist + want_blocks - 1) / want_blocks;
+    rpb = std::max<int64_t>(per_iter, (rpb + per_iter - 1) / per_iter * per_iter);
+    a.rows_per_block = static_cast<int32_t>(rpb);
+    a.blocks_per_query = static_cast<int32_t>((idx->nlist + rpb - 1) / rpb);
+    HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(nq) * idx->nlist));
+    HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * nprobe));
+    HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * nprobe));
+    HG_TRY(ensure_counters(idx, nq, st));
+    a.dense = idx->s_tile.as<float>();
+    a.done = idx->s_done.as<uint32_t>() + idx->s_done_n;
+    a.out_ord = idx->s_ord.as<uint32_t>();
+    a.out_dist = idx->s_dist.as<float>();
+    a.listoff = idx->d_listoff;
+    a.glistoff = idx->d_glistoff ? idx->d_glistoff : idx->d_listoff;
+    a.pairs = pairs;
+    a.probes = probes;
+    a.qcnt = qcnt;
+    const size_t lds = sizeof(uint64_t) * (kNWave + 1) * nprobe;
+    HG_REQUIRE(lds <= 48 * 1024, HNSWGPU_ELIMIT, "nprobe too large for the fused routing kernel");
+    const int64_t blocks = static_cast<int64_t>(nq) * a.blocks_per_query;
+    const bool l2 = a.metric == METRIC_L2;
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a)
+    HG_DISPATCH(idx->nch, l2, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
     return 0;
 }
 
@@ -1025,7 +1105,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf *bufs[] = {&idx->s_q,   &idx->s_partial, &idx->s_ord,   &idx->s_dist, &idx->s_pairs, &idx->s_ids,
-                      &idx->s_outd, &idx->s_probes,  &idx->s_stats, &idx->s_misc, &idx->s_misc2, &idx->s_vis, &idx->s_qp, &idx->s_qn, &idx->s_tile, &idx->s_grp};
+                      &idx->s_outd, &idx->s_probes,  &idx->s_stats, &idx->s_misc, &idx->s_misc2, &idx->s_vis, &idx->s_qp, &idx->s_qn, &idx->s_tile, &idx->s_grp, &idx->s_done};
     for (DevBuf *b : bufs) b->release();
     for (int s = 0; s < PROF_N; s++)
         for (auto &pr : idx->prof_ev[s]) {

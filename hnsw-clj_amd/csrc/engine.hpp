@@ -158,7 +158,8 @@ struct hnswgpu_index {
     std::vector<int32_t> h_listids;
 
     // scratch (grown on demand, reused across calls; calls are serialised by `mu`)
-    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2, s_vis, s_qp, s_qn, s_tile, s_grp;
+    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2, s_vis, s_qp, s_qn, s_tile, s_grp, s_done;
+    size_t s_done_n = 0;  // counters per half of s_done (scan tails | route tails)
     uint32_t vis_gen = 0;  // last generation number handed to an HBM visited slab
 
     // profiling
@@ -191,6 +192,11 @@ int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
 // pinned staging block of a combined batch (grown on demand)
 int ensure_pinned(hnswgpu_index *idx, size_t bytes);
 int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st);
+// small IVF batches: routing in one launch, list scan with the merge / decode folded into its last workgroups
+int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
+                     int32_t *qcnt, hipStream_t st);
+int scan_fused(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_query, int64_t max_rows, int64_t mean_rows,
+               hipStream_t st, int prof_slot);
 extern unsigned long long *g_tile_dbg_buf;
 int launch_gather(int nch, GatherArgs a, int32_t nq, hipStream_t st);
 int scan_rows_per_iter(int nch);  // kNWave * RB

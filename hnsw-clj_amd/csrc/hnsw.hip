@@ -13,7 +13,6 @@
 #include <vector>
 
 #include "engine.hpp"
-#include "hnsw_latency.hpp"
 #include "javarandom.hpp"
 
 namespace hg {
@@ -40,66 +39,11 @@ static int g_force_vg = []() {
     return (e && e[0] == 'g') ? 1 : 0;
 }();
 
-// tuning overrides of the latency kernel: HNSWGPU_LATENCY_KERNEL=0 (never), HNSWGPU_LAT_NW=4|8 (waves per query)
-static const int g_lat_mode = []() {
-    const char *e = getenv("HNSWGPU_LATENCY_KERNEL");
-    return e ? atoi(e) : 1;
-}();
-static const int g_lat_nw = []() {
-    const char *e = getenv("HNSWGPU_LAT_NW");
-    const int v = e ? atoi(e) : 0;
-    return (v == 4 || v == 8) ? v : 0;
-}();
-constexpr int kLatencyMaxQueries = 768;  // beyond one resident round of workgroups the throughput kernel wins
-
-// A handful of queries (searches, LDS visited set): the kernel pipelined across expansions (hnsw_latency.hpp).
-static int launch_hnsw_latency(hnswgpu_index *idx, HnswArgs a, hipStream_t st, bool *launched) {
-    *launched = false;
-    const int nch = idx->nch;
-    const int rb = nch <= 3 ? 8 : (nch <= 6 ? 4 : 2);
-    const int nw = g_lat_nw ? g_lat_nw : (rb >= 8 ? 4 : 8);
-    const size_t lds = hnsw_latency_lds_bytes(a.cap, a.nwords, nw);
-    if (lds > kMaxLds) return 0;  // the other kernel's (smaller) state may still fit: let it try
-    const bool l2 = a.metric == METRIC_L2;
-#define CALL_K(N, R, L, W)                                                                                       \
-    do {                                                                                                         \
-        if (lds > 48 * 1024)                                                                                     \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_latency_kernel<N, R, L, W>),         \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
-        hipLaunchKernelGGL((hnsw_latency_kernel<N, R, L, W>), dim3(a.nq), dim3(W * kWave), lds, st, a);          \
-    } while (0)
-#define CALL(N, R, L)                   \
-    do {                                \
-        if (nw == 4) CALL_K(N, R, L, 4); \
-        else CALL_K(N, R, L, 8);         \
-    } while (0)
-    switch (nch) {
-        case 1: if (l2) CALL(1, 8, true); else CALL(1, 8, false); break;
-        case 2: if (l2) CALL(2, 8, true); else CALL(2, 8, false); break;
-        case 3: if (l2) CALL(3, 8, true); else CALL(3, 8, false); break;
-        case 4: if (l2) CALL(4, 4, true); else CALL(4, 4, false); break;
-        case 6: if (l2) CALL(6, 4, true); else CALL(6, 4, false); break;
-        case 8: if (l2) CALL(8, 2, true); else CALL(8, 2, false); break;
-        case 12: if (l2) CALL(12, 2, true); else CALL(12, 2, false); break;
-        default: set_error("unsupported row length"); return HNSWGPU_ELIMIT;
-    }
-#undef CALL
-#undef CALL_K
-    HG_HIP(hipGetLastError());
-    *launched = true;
-    return 0;
-}
-
 int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions; read only by -DHG_HNSW_STAMPS builds
     if (a.nq <= 0) return 0;
     const int nch = idx->nch;
     const bool vg = g_force_vg || a.n > kLdsVisitedMaxRows;
-    if (g_lat_mode && !vg && !a.q_rows && !a.q_index && a.nq <= kLatencyMaxQueries && g_hnsw_nw == 0) {
-        bool launched = false;
-        HG_TRY(launch_hnsw_latency(idx, a, st, &launched));
-        if (launched) return 0;
-    }
     // waves per query.  Measured on 31k x 768, ef 128 (tools/tune_hnsw.py): a query takes 1.1 / 1.4 / 2.0 ms
     // with 4 / 2 / 1 waves, and a CU holds 3 / 6 / 12 such workgroups (VGPR-limited), so once a batch
     // exceeds one residency round fewer waves per query win: 10,000 queries run at 601k / 776k / 802k QPS.

@@ -552,6 +552,15 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         const char *e = getenv("HNSWGPU_SCAN_ORDER");  // 0 = never (A/B)
         return e ? atoi(e) : 1;
     }();
+    // A handful of queries: the launches around the list scan (select, probe table, merge, decode, copy) cost as much as
+    // the scan, so their work is folded into the routing and scan kernels' last workgroups (two launches instead of
+    // seven; 1M x 768, one query: 99 -> 88 us per call, 78 -> 74 us back to back).  Larger batches keep the separate
+    // launches: their merge runs one workgroup per query in parallel, and a tail would only lengthen the scan kernel.
+    static const int fused_env = []() {
+        const char *e = getenv("HNSWGPU_IVF_FUSED");  // 0 = never, 1 = small batches (default), 2 = every GEMV-path batch
+        return e ? atoi(e) : 1;
+    }();
+    const bool fused_mode = fused_env == 2 || (fused_env == 1 && nq <= 8);
     const bool use_order = !use_tile && order_mode && idx->nlist <= kOrderMaxLists && npairs * 2 >= idx->nlist &&
                            npairs <= (1 << 22);
     int32_t *order_buf = nullptr;
@@ -578,6 +587,10 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     a.metric = idx->metric;
     a.k = nprobe;
     a.role = ROLE_ROUTE;
+    if (!use_tile && fused_mode && static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20)) {
+        // small batches: distances to the centroids, the choice of the nprobe nearest and the probe table in ONE launch
+        HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st));
+    } else {
     if (use_tile)  // every query against the centroid table on the tile kernel as well
         HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
                              nprobe, st, -1));
@@ -588,6 +601,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st, idx->s_ord.as<uint32_t>(), nq,
                        nprobe, idx->d_listoff, glistoff, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf);
     HG_HIP(hipGetLastError());
+    }
     }
     // 2. scan the probed lists (:217-234) and merge (:291-294)
     memset(&a, 0, sizeof(a));
@@ -620,6 +634,16 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
             // all the pairs of a list in one run (one XCD) while a run stays a small part of an XCD's share
             a.run = 8;
             while (a.run < 64 && static_cast<int64_t>(a.run) * idx->nlist < npairs) a.run *= 2;
+        }
+        if (fused_mode) {
+            // the scan's last workgroup per query merges the partial lists, maps the winners to row ids and writes the
+            // results: no merge, decode or copy launch behind the scan
+            a.listids = idx->d_listids;
+            a.out_ids = d_out_ids;
+            a.out_dist = d_out_dist;
+            a.out_gord = d_out_gord;
+            return scan_fused(idx, a, nq, nprobe, idx->max_list_len, std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1)), st,
+                              PROF_IVF_SCAN);
         }
         HG_TRY(scan_topk(idx, a, nq, nprobe, idx->max_list_len, st, PROF_IVF_SCAN,
                          std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1))));

@@ -110,6 +110,21 @@ __device__ __forceinline__ float key_dist(uint64_t key) {
     return __uint_as_float(u);
 }
 
+// Data handed from one workgroup to another INSIDE a launch (the fused tails: "last workgroup of a query finishes the
+// job"): the eight XCDs' L2s are not coherent with each other, and a device-scope fence costs a write-back plus an
+// invalidate of a whole L2 per workgroup (measured: the fused IVF search ran 3-5x slower with __threadfence() pairs).
+// Instead the handful of words exchanged are written and read with agent-scope (sc1) accesses, which go to the point
+// of coherence themselves; the writer waits for their acknowledgement (vmcnt) before it bumps the counter.
+template <class T>
+__device__ __forceinline__ void coherent_store(T *p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ T coherent_load(const T *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wait_stores_acked() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Insert `key` (wave-uniform) into the ascending list of `cnt` (<= k) keys kept in LDS by one wave.
 __device__ __forceinline__ void wave_insert(uint64_t *list, int &cnt, int k, uint64_t key, int lane) {
     int pos = 0;
@@ -236,6 +251,142 @@ __global__ __launch_bounds__(kWG) void row_norms_kernel(const float *rows, int64
     if (lane == 0) out[row] = __builtin_sqrtf(s);
 }
 
+// Merge the partial top-k lists of one query (contiguous keys) into its final ascending top-k.
+// One wave per query.  out_ord / out_dist: [nq][k], padded with 0xffffffff / +inf.
+struct MergeArgs {
+    const uint64_t *partial;
+    int64_t keys_per_query;
+    int32_t nq, k;
+    uint32_t *out_ord;
+    float *out_dist;
+};
+
+// One workgroup of W waves per query: every wave folds a contiguous slice of the query's partial keys into
+// its own ascending top-k (registers when k <= 64, LDS otherwise), then wave 0 folds the W lists.
+// (A single wave scanning ~45k keys made the merge the longest kernel of a one-query IVF search.)
+template <bool COH = false>
+__device__ __forceinline__ void fold_keys(const uint64_t *in, int64_t n, int k, bool regk, uint64_t *list, int lane,
+                                          uint64_t &mine, int &cnt) {
+    uint64_t thr = ~0ull, cap = ~0ull;
+    constexpr int U = 8;
+    // the next block's loads are issued before this block is folded (one memory round trip per block otherwise)
+    uint64_t nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        int64_t i = u * kWave + lane;
+        nxt[u] = i < n ? (COH ? coherent_load(in + i) : in[i]) : ~0ull;
+    }
+    for (int64_t base = 0; base < n; base += U * kWave) {
+        uint64_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) key[u] = nxt[u];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int64_t i = base + (U + u) * kWave + lane;
+            nxt[u] = i < n ? (COH ? coherent_load(in + i) : in[i]) : ~0ull;
+        }
+        if (regk && base == 0) {  // start from a bound on the k-th smallest key instead of ~0 (kth_bound)
+            uint64_t m = key[0];
+#pragma unroll
+            for (int u = 1; u < U; u++) m = key[u] < m ? key[u] : m;
+            cap = kth_bound(m, k, lane);
+            thr = cap;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint64_t mask = __ballot(key[u] < thr);
+            while (mask) {
+                int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+                mask &= mask - 1;
+                uint64_t kb = lane_bcast(key[u], b);
+                if (kb < thr) {
+                    if (regk) {
+                        wave_insert_reg(mine, cnt, k, kb, lane);
+                        const uint64_t kth = wave_kth_reg(mine, k);
+                        thr = kth < cap ? kth : cap;
+                    } else {
+                        wave_insert(list, cnt, k, kb, lane);
+                        thr = cnt == k ? list[k - 1] : ~0ull;
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// Merge the partial top-k lists of query q (a.keys_per_query contiguous keys) with the W waves of this workgroup: every
+// wave folds a slice into its own ascending top-k, wave 0 folds the W lists.  out_ord / out_dist: query q's k slots
+// (0xffffffff / +inf padded).  The body of merge_topk_kernel, and the tail of a fused list scan (scan_kernel).
+template <bool COH = false>
+__device__ __forceinline__ void merge_topk_wg(const MergeArgs &a, int q, int W, unsigned char *smem, uint32_t *out_ord,
+                                              float *out_dist) {
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);  // [W][k] (+ [k] for the final list when W > 1)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const uint64_t *in = a.partial + static_cast<int64_t>(q) * a.keys_per_query;
+    const bool regk = a.k <= kWave;
+    const int64_t slice = (a.keys_per_query + W - 1) / W;
+    const int64_t s0 = wave * slice;
+    const int64_t sn = s0 + slice < a.keys_per_query ? slice : (a.keys_per_query > s0 ? a.keys_per_query - s0 : 0);
+    uint64_t *list = lists + static_cast<size_t>(wave) * a.k;
+    uint64_t mine = ~0ull;
+    int cnt = 0;
+    if (wave < W) {
+        fold_keys<COH>(in + s0, sn, a.k, regk, list, lane, mine, cnt);
+        if (regk) {
+            if (lane < a.k) list[lane] = mine;
+        } else {
+            for (int i = cnt + lane; i < a.k; i += kWave) list[i] = ~0ull;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    if (W > 1) {  // second level: W * k keys (sentinels included) -> final list behind the W slots
+        uint64_t *fin = lists + static_cast<size_t>(W) * a.k;
+        const int tot = W * a.k;
+        uint64_t thr = ~0ull;
+        mine = ~0ull;
+        cnt = 0;
+        for (int base = 0; base < tot; base += kWave) {
+            const int i = base + lane;
+            const uint64_t key = i < tot ? lists[i] : ~0ull;
+            uint64_t mask = __ballot(key < thr);
+            while (mask) {
+                int b = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+                mask &= mask - 1;
+                uint64_t kb = lane_bcast(key, b);
+                if (kb < thr) {
+                    if (regk) {
+                        wave_insert_reg(mine, cnt, a.k, kb, lane);
+                        thr = wave_kth_reg(mine, a.k);
+                    } else {
+                        wave_insert(fin, cnt, a.k, kb, lane);
+                        thr = cnt == a.k ? fin[a.k - 1] : ~0ull;
+                    }
+                }
+            }
+        }
+        if (regk) {
+            if (lane < a.k) fin[lane] = mine;
+        } else {
+            for (int i = cnt + lane; i < a.k; i += kWave) fin[i] = ~0ull;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        list = fin;
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int i = lane; i < a.k; i += kWave) {
+        uint64_t key = list[i];
+        bool ok = key != ~0ull;
+        out_ord[i] = ok ? static_cast<uint32_t>(key) : 0xffffffffu;
+        out_dist[i] = ok ? key_dist(key) : __uint_as_float(0x7f800000u);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Scan: for each (query, contiguous row range) pair, stream the rows and either keep the per-wave
 // top-k (MODE_TOPK), store the distances (MODE_STORE) or fold them into a running minimum
@@ -276,9 +427,22 @@ struct ScanArgs {
     int32_t nchunks;
     int32_t k;
     int32_t role;       // ROLE_* (profiling label only)
-    uint64_t *partial;  // TOPK: [pair][chunk][wave][k]
+    uint64_t *partial;  // TOPK: [pair][chunk][wave][k] ([pair][chunk][k] with wg_merge)
     float *out;         // STORE: out[pair * out_stride + (row - row_begin)]; MINUPD: out[row]
     int64_t out_stride;
+    // TOPK, k <= 64: the four per-wave lists of a workgroup are merged in LDS and ONE list is written -- a quarter of the
+    // keys for whoever merges them
+    int32_t wg_merge;
+    // Fused tail of the IVF list scan (small batches: the launches around the scan cost as much as the scan): every
+    // workgroup counts itself in done[q] after writing its partial list; the last one of a query merges that query's
+    // partial lists, maps the winners to row ids (ivf_flat.clj:291-294) and writes the final results -- no merge,
+    // decode or copy launch.  done[] is zero between calls (the last workgroup resets its counter).
+    uint32_t *done;            // nullptr = no fused tail
+    int32_t pairs_per_query;   // = nprobe; a query's workgroups: pairs_per_query * nchunks
+    const int32_t *listids;
+    int32_t *out_ids;          // [nq][k]
+    float *out_dist;           // [nq][k]
+    uint32_t *out_gord;        // optional [nq][k]: position in the candidate stream of the whole (sharded) index
 };
 
 // ROLE only names the caller in profiler output (rocprofv3 groups dispatches by kernel name); the
@@ -377,24 +541,85 @@ __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
         }
     }
     if (a.mode == MODE_TOPK) {
-        uint64_t *dst = a.partial + ((static_cast<int64_t>(pair) * a.nchunks + chunk) * kNWave + wave) * a.k;
-        if (regk) {
-            if (lane < a.k) dst[lane] = mine;
+        if (a.wg_merge && regk) {
+            // the workgroup's four lists -> one: wave 0 inserts the other waves' keys (ascending: stop at the first
+            // key that no longer fits) into its own register list
+            if (wave != 0 && lane < a.k) lists[wave * a.k + lane] = mine;
+            __syncthreads();
+            if (wave == 0) {
+                for (int w = 1; w < kNWave; w++)
+                    for (int j = 0; j < a.k; j++) {
+                        const uint64_t key = lists[w * a.k + j];  // uniform address: an LDS broadcast
+                        if (!(key < thr)) break;
+                        wave_insert_reg(mine, cnt, a.k, key, lane);
+                        thr = wave_kth_reg(mine, a.k);
+                    }
+                uint64_t *dst = a.partial + (static_cast<int64_t>(pair) * a.nchunks + chunk) * a.k;
+                if (lane < a.k) {
+                    if (a.done) coherent_store(dst + lane, mine);  // read by another workgroup of this launch
+                    else dst[lane] = mine;
+                }
+            }
         } else {
-            for (int i = lane; i < a.k; i += kWave) dst[i] = i < cnt ? mylist[i] : ~0ull;
+            uint64_t *dst = a.partial + ((static_cast<int64_t>(pair) * a.nchunks + chunk) * kNWave + wave) * a.k;
+            if (regk) {
+                if (lane < a.k) {
+                    if (a.done) coherent_store(dst + lane, mine);
+                    else dst[lane] = mine;
+                }
+            } else {
+                for (int i = lane; i < a.k; i += kWave) {
+                    const uint64_t v = i < cnt ? mylist[i] : ~0ull;
+                    if (a.done) coherent_store(dst + i, v);
+                    else dst[i] = v;
+                }
+            }
+        }
+        if (a.done) {
+            // ---- fused tail: am I the last workgroup of query qi?
+            __shared__ int tail_last;
+            wait_stores_acked();  // this workgroup's partial list has reached the point of coherence ...
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t total = static_cast<uint32_t>(a.pairs_per_query) * static_cast<uint32_t>(a.nchunks);
+                // ... before it counts itself; the last one reads every list with coherent loads (kernels.hpp, top)
+                const uint32_t prev = __hip_atomic_fetch_add(a.done + qi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tail_last = prev == total - 1 ? 1 : 0;
+                if (tail_last) __hip_atomic_store(a.done + qi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (!tail_last) return;
+            MergeArgs m;
+            m.partial = a.partial;
+            m.keys_per_query = static_cast<int64_t>(a.pairs_per_query) * a.nchunks * ((a.wg_merge && regk) ? 1 : kNWave) * a.k;
+            m.nq = 0;
+            m.k = a.k;
+            m.out_ord = nullptr;
+            m.out_dist = nullptr;
+            uint32_t *ord_s = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (kNWave + 1) * a.k);  // [k]
+            float *dist_s = reinterpret_cast<float *>(ord_s + a.k);                                         // [k]
+            merge_topk_wg<true>(m, qi, kNWave, smem, ord_s, dist_s);  // waves 1..3 return from it after its barrier
+            if (wave != 0) return;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const Pair *pp = a.pairs + static_cast<int64_t>(qi) * a.pairs_per_query;
+            for (int i = lane; i < a.k; i += kWave) {
+                const uint32_t o = ord_s[i];
+                uint32_t go = 0xffffffffu;
+                int32_t id = -1;
+                if (o != 0xffffffffu) {
+                    int p = 0;
+                    while (p + 1 < a.pairs_per_query && pp[p + 1].ord_base <= o) p++;  // as ivf_decode_kernel
+                    id = a.listids[pp[p].row_begin + (o - pp[p].ord_base)];
+                    go = pp[p].gord_base + (o - pp[p].ord_base);
+                }
+                a.out_ids[static_cast<int64_t>(qi) * a.k + i] = id;
+                a.out_dist[static_cast<int64_t>(qi) * a.k + i] = dist_s[i];
+                if (a.out_gord) a.out_gord[static_cast<int64_t>(qi) * a.k + i] = go;
+            }
         }
     }
 }
-
-// Merge the partial top-k lists of one query (contiguous keys) into its final ascending top-k.
-// One wave per query.  out_ord / out_dist: [nq][k], padded with 0xffffffff / +inf.
-struct MergeArgs {
-    const uint64_t *partial;
-    int64_t keys_per_query;
-    int32_t nq, k;
-    uint32_t *out_ord;
-    float *out_dist;
-};
 
 // ------------------------------------------------------------------------------------------------
 // Gather-dot: distances from one query to base rows ids[0..m) -- the per-hop neighbour expansion

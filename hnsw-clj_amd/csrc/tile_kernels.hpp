@@ -431,13 +431,12 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
 // (One wave per query left a batch of 1024 queries with four waves per CU, each walking 31k candidates through
 // ~60 dependent load round trips: 143 us per launch, twice per batched IVF search.)  Keys are a total order on
 // (distance, position), so the result does not depend on W.
-__global__ __launch_bounds__(1024) void select_topk_kernel(SelectArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
+// The body of select_topk_kernel for query q served by W waves of this workgroup (W = 1: this wave alone).  Also the
+// tail of ivf_route_kernel (ivf.hip), whose last workgroup per query picks the probed lists in the same launch.
+template <bool COH = false>
+__device__ __forceinline__ void select_topk_wg(const SelectArgs &a, int q, int W, unsigned char *smem) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    const int W = a.wpq;
-    const int q = W == 1 ? blockIdx.x * kNWave + wave : blockIdx.x;
-    if (q >= a.nq) return;  // W > 1: uniform over the workgroup
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
     uint64_t *list = lists + static_cast<size_t>(wave) * a.k;
     const float *in = a.dist + static_cast<int64_t>(q) * a.stride;
@@ -456,7 +455,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(SelectArgs a) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int64_t i = first + u * kWave + lane;
-        vn[u] = i < n ? in[i] : __uint_as_float(0x7fc00000u);
+        vn[u] = i < n ? (COH ? coherent_load(in + i) : in[i]) : __uint_as_float(0x7fc00000u);
     }
     for (int64_t base = first; base < n; base += step) {
         float v[U];
@@ -465,7 +464,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(SelectArgs a) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int64_t i = base + step + u * kWave + lane;
-            vn[u] = i < n ? in[i] : __uint_as_float(0x7fc00000u);
+            vn[u] = i < n ? (COH ? coherent_load(in + i) : in[i]) : __uint_as_float(0x7fc00000u);
         }
         uint64_t key[U];
 #pragma unroll
@@ -548,6 +547,14 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(SelectArgs a) {
         a.out_ord[static_cast<int64_t>(q) * a.k + i] = ok ? static_cast<uint32_t>(key) : 0xffffffffu;
         a.out_dist[static_cast<int64_t>(q) * a.k + i] = ok ? key_dist(key) : __uint_as_float(0x7f800000u);
     }
+}
+
+__global__ __launch_bounds__(1024) void select_topk_kernel(SelectArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int W = a.wpq;
+    const int q = W == 1 ? blockIdx.x * kNWave + (threadIdx.x >> 6) : blockIdx.x;
+    if (q >= a.nq) return;  // W > 1: uniform over the workgroup
+    select_topk_wg(a, q, W, smem);
 }
 
 }  // namespace hg

@@ -28,9 +28,6 @@ L.hnswgpu_debug_set_tile_stamps.argtypes = [C.c_void_p]
 L.hnswgpu_debug_set_tile_stamps(buf.data_ptr())
 names = ["level set-up", "select+adjacency+visited", "row gather+distances", "merge 1 (rank)", "merge 2 (admit)",
          "merge 3 (scatter)", "epilogue"]
-if nq <= 768 and os.environ.get("HNSWGPU_LATENCY_KERNEL", "1") != "0":     # the pipelined kernel's phases (hnsw_latency.hpp)
-    names = ["level set-up + first candidate", "wait for rows in flight + reduce", "barrier", "next candidate+adjacency+filter",
-             "issue next rows", "merge", "epilogue"]
 for rep in range(3):
     lat = []
     for i in range(20):
@@ -43,7 +40,6 @@ for rep in range(3):
     tot = float(b[:7].sum()) * 10e-3  # us
     print("nq=%d ef=%d hops=%d kernel-side total %.1f us (%.2f us/hop)  wall p50 %.3f ms" % (
         nq, ef, hops, tot, tot / max(hops, 1), sorted(lat)[10]))
-    print("   adjacency rows fetched on demand (not prefetched): %d of %d expansions" % (b[8], hops))
     print("   shader clock during the query: %.0f MHz (%d cycles in %.1f us)" % (b[10] / max(b[11] * 10e-3, 1e-9), b[10], b[11] * 10e-3))
     for n, v in zip(names, b[:7]):
         print("   %-28s %8.1f us  %5.1f %%   %.2f us/hop" % (n, v * 10e-3, 100.0 * v / max(b[:7].sum(), 1), v * 10e-3 / max(hops, 1)))
