@@ -341,6 +341,7 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
     s.nq = a.nq;
     s.k = a.nprobe;
     s.wpq = kNWave;
+    s.vec4 = 0;
     s.out_ord = a.out_ord;
     s.out_dist = a.out_dist;
     select_topk_wg<true>(s, qi, kNWave, smem);
@@ -712,6 +713,11 @@ int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t s
     // explicit work list: workgroup b serves item (b % 8) * ceil(nitems / 8) + b / 8 (one contiguous eighth of the
     // list per XCD), so the grid must cover 8 * ceil(nitems / 8) workgroups, not just nitems
     if (a.members) blocks = (blocks + 7) & ~7LL;
+    if (a.work_ctr) {  // persistent: one workgroup per CU (its LDS slot fills a CU) pulling items off the queue
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        blocks = std::min<int64_t>(blocks, std::max(cus, 8));
+    }
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "tile grid too large");
     if (a.metric == METRIC_L2) {  // same groups, work list and outputs; rows in registers instead of MFMA tiles
         const size_t l2lds = l2_group_lds_bytes(a.ld);
@@ -768,6 +774,7 @@ int launch_select(const SelectArgs &a0, hipStream_t st) {
     if (const char *e = getenv("HNSWGPU_SELECT_W")) w = std::max(1, std::min(16, atoi(e)));  // tuning override
     while (w & (w - 1)) w &= w - 1;
     a.wpq = w;
+    a.vec4 = (a.stride % 4 == 0 && reinterpret_cast<uintptr_t>(a.dist) % 16 == 0) ? 1 : 0;
     const size_t lds = sizeof(uint64_t) * (w == 1 ? kNWave : w + 1) * a.k;
     HG_REQUIRE(lds <= 150 * 1024, HNSWGPU_ELIMIT, "k too large for the select kernel");
     if (lds > 48 * 1024) {

@@ -108,11 +108,13 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *cnt, int 
                                                         int32_t *fill, int32_t *grp_seg, int32_t *grp_mem_begin,
                                                         int32_t *grp_mem_cnt, int32_t *ngroups, int tq,
                                                         const int64_t *list_off, int64_t chunk_rows, int max_chunks,
-                                                        int32_t *wi_group, int32_t *wi_chunk, int32_t *nitems) {
+                                                        int32_t *wi_group, int32_t *wi_chunk, int32_t *nitems,
+                                                        int32_t *work_ctr) {
     __shared__ int32_t sm[1024], sg[1024], sw[1024];
     __shared__ int32_t carry_m, carry_g, carry_w;
     const int tid = threadIdx.x;
     if (tid == 0) carry_m = carry_g = carry_w = 0;
+    if (tid < 8 && work_ctr) work_ctr[tid] = 0;  // the persistent tile scan's per-XCD item counters
     __syncthreads();
     for (int l0 = 0; l0 < nlist; l0 += 1024) {
         const int l = l0 + tid;
@@ -454,7 +456,8 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
                          const int32_t *d_probes, const int32_t *d_qcnt, hipStream_t st) {
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
     const int nlist = idx->nlist;
-    const int64_t stride = static_cast<int64_t>(nprobe) * idx->max_list_len;  // candidates per query, upper bound
+    // candidates per query, upper bound; a multiple of 4 so that every query's array is 16-B aligned (float4 select)
+    const int64_t stride = (static_cast<int64_t>(nprobe) * idx->max_list_len + 3) / 4 * 4;
     const int tq = tile_tq(idx->dim);
     const int64_t gbound = npairs / tq + nlist;                                // sum_l ceil(cnt_l / tq) <= this
     HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(nq) * stride));  // queries already padded
@@ -466,24 +469,33 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
         const char *e = getenv("HNSWGPU_TILE_WGS");  // tuning override
         return e ? atoll(e) : 2048LL;
     }();
+    // persistent workgroups pulling items off a queue (tile_scan_kernel): items of up to `ptiles` tiles, however many
+    // there are -- the queue balances them.  0 = one workgroup per item, items sized to fill the chip (round 1)
+    static const int64_t ptiles_env = []() {
+        const char *e = getenv("HNSWGPU_TILE_PERSIST");
+        return e ? atoll(e) : 4LL;
+    }();
+    // the L2 group kernel takes one item per workgroup; few groups: shorter items, so that every CU has several
+    const int64_t ptiles = idx->metric == METRIC_L2 ? 0 : (ptiles_env == 4 && est_groups < 1200 ? 2 : ptiles_env);
     int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + est_groups - 1) / est_groups));
-    const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows;
+    int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows;
+    if (ptiles > 0) cr = std::max<int64_t>(1, std::min<int64_t>(ptiles, mean_tiles)) * kTileRows;
     const int64_t max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows, tpc = cr / kTileRows;
     const int32_t max_chunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
     const int64_t wbound = gbound * max_chunks;
     // int32 scratch: cnt | list_mem_begin | fill [nlist each] | grp_seg | grp_mem_begin | grp_mem_cnt [gbound each] |
     //                wi_group | wi_chunk [wbound each] | ngroups | nitems
-    size_t ints = 3 * static_cast<size_t>(nlist) + 3 * static_cast<size_t>(gbound) + 2 * static_cast<size_t>(wbound) + 4;
+    size_t ints = 3 * static_cast<size_t>(nlist) + 3 * static_cast<size_t>(gbound) + 2 * static_cast<size_t>(wbound) + 4 + 8;
     HG_TRY(idx->s_misc.ensure(sizeof(int32_t) * ints));
     HG_TRY(idx->s_misc2.ensure(sizeof(GroupMember) * static_cast<size_t>(npairs)));
     int32_t *cnt = idx->s_misc.as<int32_t>();
     int32_t *lmb = cnt + nlist, *fill = lmb + nlist, *gseg = fill + nlist, *gmb = gseg + gbound, *gmc = gmb + gbound,
-            *wig = gmc + gbound, *wic = wig + wbound, *ngr = wic + wbound, *nit = ngr + 1;
+            *wig = gmc + gbound, *wic = wig + wbound, *ngr = wic + wbound, *nit = ngr + 1, *wctr = ngr + 4;
     HG_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nlist, st));
     hipLaunchKernelGGL(ivf_hist_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st, d_probes,
                        npairs, cnt);
     hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr, tq,
-                       idx->d_listoff, cr, max_chunks, wig, wic, nit);
+                       idx->d_listoff, cr, max_chunks, wig, wic, nit, ptiles > 0 ? wctr : nullptr);
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st,
                        idx->s_pairs.as<Pair>(), d_probes, npairs, stride, lmb, fill, idx->s_misc2.as<GroupMember>());
     HG_HIP(hipGetLastError());
@@ -506,6 +518,7 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     t.wi_group = wig;
     t.wi_chunk = wic;
     t.nitems = nit;
+    t.work_ctr = ptiles > 0 ? wctr : nullptr;
     t.chunk_rows = static_cast<int32_t>(cr);
     t.nchunks = max_chunks;
     t.out = idx->s_tile.as<float>();

@@ -53,7 +53,7 @@ __host__ __device__ inline int64_t tile_nchunks(int64_t rows, int64_t chunk_rows
 }
 __host__ inline size_t tile_lds_bytes(int dim) {
     return sizeof(float) * (static_cast<size_t>(tile_tq(dim)) * tile_ldq(dim) + kTileRows * kTileLdA) +
-           sizeof(float) * kTileQ + sizeof(int64_t) * kTileQ + sizeof(float) * kTileRows + sizeof(int32_t) * kTileQ;
+           sizeof(float) * kTileQ + sizeof(int64_t) * kTileQ + sizeof(float) * kTileRows + sizeof(int32_t) * kTileQ + 16;
 }
 
 struct GroupMember {
@@ -81,6 +81,7 @@ struct TileArgs {
     const int32_t *wi_group;
     const int32_t *wi_chunk;
     const int32_t *nitems;
+    int32_t *work_ctr;  // persistent mode: 8 per-XCD item counters (zeroed by the plan kernel); nullptr = one item per workgroup
     const GroupMember *members;
     const int64_t *seg_off;  // row range of segment s = [seg_off[s], seg_off[s+1])
     // implicit groups (assignment / exact kNN): group g = queries [tq*g, tq*g + tq), every group scans rows
@@ -108,6 +109,7 @@ struct SelectArgs {
     int64_t cnt_all;
     int32_t nq, k;
     int32_t wpq;  // waves per query (set by launch_select)
+    int32_t vec4;  // candidates read as float4 (set by launch_select when every query's array is 16-B aligned)
     uint32_t *out_ord;
     float *out_dist;
 };

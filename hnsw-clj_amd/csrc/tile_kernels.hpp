@@ -23,8 +23,34 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
+    // Persistent mode (a.work_ctr, the IVF work list): a workgroup per CU takes work items off per-XCD counters until
+    // the list is empty -- no launch gap between items, no idle CU while another still has several items queued, and
+    // the list can be cut into fewer, longer items (one query-group fill per 4 tiles instead of per 2).  Each XCD
+    // first drains ITS contiguous eighth of the list (the groups that scan the same rows run side by side on one L2),
+    // then helps the others.
+    int32_t *s_item_p = qi_s + kTileQ;  // [1] the work item in hand (dynamic LDS: the static budget is spoken for)
+    for (int iter = 0;; iter++) {
     int g, chunk;
-    if (a.members) {
+    if (a.work_ctr) {
+        __syncthreads();  // every wave is done with the previous item's LDS (query group, slot tables)
+        if (tid == 0) {
+            const int nitems = *a.nitems, per_xcd = (nitems + 7) >> 3;
+            int got = -1;
+            for (int t = 0; t < 8 && got < 0; t++) {
+                const int x = (static_cast<int>(blockIdx.x) + t) & 7;
+                const int i = atomicAdd(a.work_ctr + x, 1);
+                if (i < per_xcd && x * per_xcd + i < nitems) got = x * per_xcd + i;
+            }
+            *s_item_p = got;
+        }
+        __syncthreads();
+        const int item = *s_item_p;
+        if (item < 0) break;
+        g = a.wi_group[item];
+        chunk = a.wi_chunk[item];
+    } else if (iter > 0) {
+        break;
+    } else if (a.members) {
         // The work list is ordered (list, chunk, group): the groups that scan the SAME rows are neighbours.
         // Workgroups are dealt to the 8 XCDs round-robin, so neighbours in blockIdx would land on eight different
         // L2s and every group would pull its rows over the fabric again.  Give each XCD one contiguous eighth of
@@ -35,10 +61,10 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
         if (!(a.dbg & 1)) {
             const int per_xcd = (nitems + 7) >> 3;
             const int slot = blockIdx.x >> 3;
-            if (slot >= per_xcd) return;
+            if (slot >= per_xcd) break;
             item = (blockIdx.x & 7) * per_xcd + slot;
         }
-        if (item >= nitems) return;
+        if (item >= nitems) break;
         g = a.wi_group[item];
         chunk = a.wi_chunk[item];
     } else {
@@ -49,7 +75,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     int64_t rb0, rb1;
     int cnt;
     if (a.members) {
-        if (g >= *a.ngroups) return;
+        if (g >= *a.ngroups) continue;
         int s = a.grp_seg[g];
         rb0 = a.seg_off[s];
         rb1 = a.seg_off[s + 1];
@@ -63,11 +89,11 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
     // that would reload the query group for a handful of rows); a.nchunks is the bound for the longest segment
     const int64_t tiles = (rb1 - rb0 + kTileRows - 1) / kTileRows;
     const int64_t nch = tile_nchunks(rb1 - rb0, a.chunk_rows, a.nchunks);
-    if (chunk >= nch) return;
+    if (chunk >= nch) continue;
     const int64_t per = (tiles + nch - 1) / nch * kTileRows;
     const int64_t r0 = rb0 + static_cast<int64_t>(chunk) * per;
     const int64_t r1 = r0 + per < rb1 ? r0 + per : rb1;
-    if (r0 >= r1 || cnt <= 0) return;
+    if (r0 >= r1 || cnt <= 0) continue;
     unsigned long long t_start = 0, c_start = 0;
     if (a.dbg_buf) {
         t_start = __builtin_amdgcn_s_memrealtime();
@@ -424,6 +450,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
             o[3] = static_cast<unsigned long long>((r1 - r0 + kTileRows - 1) / kTileRows) | (static_cast<unsigned long long>(cnt) << 32);
         }
     }
+    }  // work items
 }
 
 // W = a.wpq waves per query.  W = 1: four queries per 256-thread workgroup, one wave each.  W > 1: one query per
@@ -451,25 +478,43 @@ __device__ __forceinline__ void select_topk_wg(const SelectArgs &a, int q, int W
     // the next block's loads are issued before this block is folded: one memory round trip per block would
     // otherwise sit between every two folds (15 blocks per wave at 31k candidates and 4 waves)
     const int64_t step = static_cast<int64_t>(W) * U * kWave;
-    float vn[U];
+    // element u of a lane's block: candidate base + idx_of(u).  Scalar form: u * 64 + lane (one 4-byte load per lane and
+    // instruction: 256 B per wave instruction); vector form (a.vec4: rows 16-B aligned): two float4 per lane,
+    // (u / 4) * 256 + lane * 4 + u % 4 -- a quarter of the load instructions for the same 512 candidates.  Keys carry
+    // their own position, so the order in which a block is walked does not matter.
+    const bool vec = a.vec4 != 0 && !COH;
+    auto idx_of = [&](int u) -> int64_t { return vec ? (u >> 2) * (4 * kWave) + lane * 4 + (u & 3) : u * kWave + lane; };
+    auto load_block = [&](float (&dst)[U], int64_t base) {
+        if (vec) {
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int64_t i = first + u * kWave + lane;
-        vn[u] = i < n ? (COH ? coherent_load(in + i) : in[i]) : __uint_as_float(0x7fc00000u);
-    }
+            for (int g4 = 0; g4 < U / 4; g4++) {
+                const int64_t i = base + g4 * (4 * kWave) + lane * 4;
+                // a float4 may straddle the end of the query's candidates (never the end of the buffer: DevBuf slack)
+                const float4 t = i < n ? *reinterpret_cast<const float4 *>(in + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[4 * g4 + 0] = t.x;
+                dst[4 * g4 + 1] = t.y;
+                dst[4 * g4 + 2] = t.z;
+                dst[4 * g4 + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = base + u * kWave + lane;
+                dst[u] = i < n ? (COH ? coherent_load(in + i) : in[i]) : __uint_as_float(0x7fc00000u);
+            }
+        }
+    };
+    float vn[U];
+    load_block(vn, first);
     for (int64_t base = first; base < n; base += step) {
         float v[U];
 #pragma unroll
         for (int u = 0; u < U; u++) v[u] = vn[u];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int64_t i = base + step + u * kWave + lane;
-            vn[u] = i < n ? (COH ? coherent_load(in + i) : in[i]) : __uint_as_float(0x7fc00000u);
-        }
+        load_block(vn, base + step);
         uint64_t key[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            int64_t i = base + u * kWave + lane;
+            const int64_t i = base + idx_of(u);
             key[u] = i < n ? make_key(v[u], static_cast<uint32_t>(i)) : ~0ull;
         }
         if (regk && base == first) {
