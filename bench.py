@@ -495,7 +495,12 @@ def ivf_roofline(engine, dev, args, traffic):
                             "workload": "same index, batch of 1024 queries per launch, pairs grouped by list",
                             "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                             "avg_launch_ms": b["avg_scan_ms"], "qps_end_to_end": b["qps"],
-                            "algorithmic_GBs": b["algorithmic_GBs"], "unique_GB": b["unique_GB"]},
+                            "algorithmic_GBs": b["algorithmic_GBs"], "unique_GB": b["unique_GB"],
+                            "unique_GBs": b["unique_GBs"], "frac_unique_of_hbm": round(b["unique_GBs"] / HBM_PEAK_GBS, 4),
+                            "note": "a group of <= 32 queries shares one fetch of a row: 2 * 32 * 768 flop per 3 KB = 16 flop/B, "
+                                    "below the machine balance (157 TFLOP/s / 6.3 TB/s = 25 flop/B) -- at this batch the kernel is "
+                                    "HBM-bound as well: every list is read at least once (unique_GBs is that lower bound of the "
+                                    "traffic; the PMC pass in profiles/ has the measured bytes: 4.3 GB per launch = 5.2 TB/s)"},
            "ivf_recall_at_10": round(rec, 4), "ivf_build_s": round(build_s, 1),
            "mean_list_len": float(lens.mean()), "max_list_len": int(lens.max())}
     if traffic:
