@@ -147,3 +147,20 @@ def test_load_rejects_damaged_headers_before_touching_anything(native_lib, tmp_p
         assert h.value is None and L.hnswgpu_last_error()
     open(str(tmp_path / "tiny.bin"), "wb").write(b"HNSW")
     assert L.hnswgpu_load(str(tmp_path / "tiny.bin").encode(), 0, ctypes.byref(ctypes.c_void_p(None))) == -1
+
+
+def test_multi_gpu_entry_points_validate_their_arguments(native_lib):
+    """The entry points of the sharded IVF path refuse bad sizes and null pointers with a code and a message before any
+    device call (so this runs without a GPU): nothing crosses the C boundary as a crash."""
+    L = native_lib.lib()
+    one = ctypes.c_void_p(8)           # a non-null token; never dereferenced on these paths
+    assert L.hnswgpu_merge_keyed_dev(0, one, one, one, 0, 4, 10, one, one, None) == -1        # nshard < 1
+    assert L.hnswgpu_merge_keyed_dev(0, one, one, one, 2, 4, 0, one, one, None) == -1         # k < 1
+    assert L.hnswgpu_merge_keyed_dev(0, one, one, one, 2, 4, 2000, one, one, None) == -5      # k > 1024: HNSWGPU_ELIMIT
+    assert b"1024" in L.hnswgpu_last_error()
+    assert L.hnswgpu_merge_keyed_dev(0, one, one, one, 2, 0, 10, one, one, None) == 0         # no queries: nothing to do
+    assert L.hnswgpu_merge_keyed_dev(0, None, one, one, 2, 4, 10, one, one, None) == -1       # null input
+    assert L.hnswgpu_merge_topk_dev(0, one, one, 0, 4, 10, one, one, None) == -1
+    assert L.hnswgpu_set_ivf_shard(None, one, 4, one, one, one) == -1                         # null handle / lengths
+    assert L.hnswgpu_list_sums(None, 4, one, one, one) == -1
+    assert L.hnswgpu_ivf_search_shard_dev(None, one, 1, 1, 1, one, one, one, None) == -1
