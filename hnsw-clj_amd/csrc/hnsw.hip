@@ -39,11 +39,22 @@ static int g_force_vg = []() {
     return (e && e[0] == 'g') ? 1 : 0;
 }();
 
+// helper workgroups per query that prefetch neighbour rows into the query's XCD L2 (kernels.hpp, HnswArgs::pf_mail);
+// HNSWGPU_PREFETCH=<G> overrides (0 = off)
+static const int g_pf_groups = []() {
+    const char *e = getenv("HNSWGPU_PREFETCH");
+    const int v = e ? atoi(e) : 4;
+    return v < 0 ? 0 : (v > 16 ? 16 : v);
+}();
+constexpr int kPfMaxQueries = 16;  // beyond a handful of queries the chip is busy anyway
+
 int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions; read only by -DHG_HNSW_STAMPS builds
     if (a.nq <= 0) return 0;
     const int nch = idx->nch;
     const bool vg = g_force_vg || a.n > kLdsVisitedMaxRows;
+    const bool pf = g_pf_groups > 0 && !vg && !a.q_rows && !a.q_index && a.nq <= kPfMaxQueries && g_hnsw_nw == 0 &&
+                    a.n < (1LL << 31) && a.M0 <= kMaxDeg;
     // waves per query.  Measured on 31k x 768, ef 128 (tools/tune_hnsw.py): a query takes 1.1 / 1.4 / 2.0 ms
     // with 4 / 2 / 1 waves, and a CU holds 3 / 6 / 12 such workgroups (VGPR-limited), so once a batch
     // exceeds one residency round fewer waves per query win: 10,000 queries run at 601k / 776k / 802k QPS.
@@ -52,6 +63,21 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     if (a.q_index) {  // repeat pass: few (usually no) work items, one large-list workgroup per CU at most
         nw = 4;
         grid = std::min(a.nq, 256);
+    }
+    if (pf) {
+        // one mailbox per query; four regions in rotation, so that launches in flight (two Slots) never share one
+        nw = 4;
+        a.pf_groups = g_pf_groups;
+        grid = 8 * ((a.nq + 7) / 8) * (1 + g_pf_groups);
+        const size_t region = sizeof(uint32_t) * kPfMailWords * kPfMaxQueries;
+        if (idx->s_pf.cap < 4 * region) {
+            HG_TRY(idx->s_pf.ensure(4 * region));
+            HG_HIP(hipMemsetAsync(idx->s_pf.p, 0, idx->s_pf.cap, st));
+        }
+        idx->pf_seq = (idx->pf_seq + 1) & 0xffffff;
+        if (idx->pf_seq == 0) idx->pf_seq = 1;
+        a.pf_seq = idx->pf_seq;
+        a.pf_mail = reinterpret_cast<uint32_t *>(static_cast<char *>(idx->s_pf.p) + (idx->pf_seq & 3) * region);
     }
     if (vg) {
         a.nwords = 0;
@@ -92,9 +118,17 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
         if (vg) CALL_K(N, R, L, W, true); \
         else CALL_K(N, R, L, W, false);   \
     } while (0)
+#define CALL_PF(N, R, L)                                                                                          \
+    do {                                                                                                         \
+        if (lds > 48 * 1024)                                                                                     \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<N, R, L, 4, false, true>), \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
+        hipLaunchKernelGGL((hnsw_search_kernel<N, R, L, 4, false, true>), dim3(grid), dim3(4 * kWave), lds, st, a); \
+    } while (0)
 #define CALL(N, R, L)                        \
     do {                                     \
-        if (nw == 1) CALL_NW(N, R, L, 1);    \
+        if (pf) CALL_PF(N, R, L);            \
+        else if (nw == 1) CALL_NW(N, R, L, 1);    \
         else if (nw == 2) CALL_NW(N, R, L, 2); \
         else CALL_NW(N, R, L, 4);            \
     } while (0)
@@ -109,6 +143,7 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
         default: set_error("unsupported row length"); return HNSWGPU_ELIMIT;
     }
 #undef CALL
+#undef CALL_PF
 #undef CALL_NW
 #undef CALL_K
     HG_HIP(hipGetLastError());
