@@ -14,7 +14,7 @@ import sys
 
 def short(name):
     name = name.replace("void ", "")
-    return name.split("(")[0][:48]
+    return name.split("(")[0][:56]
 
 
 def main(d):
@@ -31,7 +31,7 @@ def main(d):
         for f in glob.glob(d + "/" + tag + "/*/*_counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 pmc[(short(r["Kernel_Name"]), int(r.get("Grid_Size") or r["Grid_Size_X"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    print("%-50s %10s %6s %12s %6s %7s %14s %14s" % ("kernel", "grid", "calls", "avg_us", "vgpr", "lds", "HBM read MB", "HBM write MB"))
+    print("%-58s %10s %6s %12s %6s %7s %14s %14s" % ("kernel", "grid", "calls", "avg_us", "vgpr", "lds", "HBM read MB", "HBM write MB"))
     for (k, grid), g in sorted(groups.items(), key=lambda kv: -kv[1]["ns"]):
         if not k.startswith("hg::"):
             continue
@@ -40,7 +40,7 @@ def main(d):
         wr = p.get("WRITE_SIZE")
         rd = "%.2f" % (2 * sum(fe) / len(fe) * 1024 / 1e6) if fe else "-"
         ww = "%.2f" % (sum(wr) / len(wr) * 1024 / 1e6) if wr else "-"
-        print("%-50s %10d %6d %12.1f %6s %7s %14s %14s" % (k, grid, g["n"], g["ns"] / g["n"] / 1e3, g["vgpr"], g["lds"], rd, ww))
+        print("%-58s %10d %6d %12.1f %6s %7s %14s %14s" % (k, grid, g["n"], g["ns"] / g["n"] / 1e3, g["vgpr"], g["lds"], rd, ww))
 
 
 if __name__ == "__main__":

@@ -1243,7 +1243,25 @@ def test_reference_api_mirror(eng, oracle):
     batch = parallel_search.parallel_search_futures(index, list(vecs[:20]), 10, ultra_fast.search_knn, 8)
     assert len(batch) == 20 and all(len(r) == 10 for r in batch)     # core_test.clj:112-121
     assert batch[3] == ultra_fast.search_knn(index, vecs[3], 10)
-    assert protocol.GpuHnswIndex(index).search_batch_star(vecs[:3], 4)[2] == ultra_fast.search_knn(index, vecs[2], 4)
+    # a user's own search-fn: the reference's protocol as written (a pool of threads, one task per query), served by
+    # combined launches -- same results, in query order
+    calls = []
+
+    def my_search(idx_, q, k_):
+        calls.append(1)
+        return ultra_fast.search_knn(idx_, q, k_, ef=64)
+
+    threaded = parallel_search.parallel_search_futures(index, list(vecs[:20]), 10, my_search, 8)
+    assert len(calls) == 20 and threaded == [ultra_fast.search_knn(index, v, 10, ef=64) for v in vecs[:20]]
+    bm = parallel_search.benchmark_parallel_search(index, list(vecs[:30]), 5, my_search, 4)
+    assert bm["completed"] == 30 and bm["threads"] == 4 and bm["qps"] > 0
+    gp = protocol.GpuHnswIndex(index)
+    assert gp.search_batch_star(vecs[:3], 4)[2] == ultra_fast.search_knn(index, vecs[2], 4)
+    assert protocol.default_batch_search(gp, vecs[:3], 4, None) == gp.search_batch_star(vecs[:3], 4)   # protocol.clj:92-95
+    even = protocol.default_filtered_search(gp, vecs[8], 3, lambda i: int(i.split("_")[1]) % 2 == 0, None)   # :96-101
+    assert [r["id"] for r in even][0] == "vec_8" and all(int(r["id"].split("_")[1]) % 2 == 0 for r in even) and len(even) <= 3
+    assert even == [r for r in ultra_fast.search_knn(index, vecs[8], 9) if int(r["id"].split("_")[1]) % 2 == 0][:3]
+    assert protocol.supports_batch_search(gp) and protocol.supports_persistence(gp)
     assert ultra_fast.graph_info(index)["num-elements"] == 100
     index.close()
     l2 = ultra_fast.build_index(data, distance_fn=simd_optimized.euclidean_distance, show_progress=False)
