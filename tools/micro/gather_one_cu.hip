@@ -42,6 +42,50 @@ __global__ __launch_bounds__(1024) void gather(const float *table, const int *id
     if (acc == 12345.678f) out[0] = acc;
 }
 
+// The same gather with LDS-direct loads (global_load_lds_dwordx4: no VGPR destination): does a lone CU keep more bytes in
+// flight that way?  Each wave lands its rows in its own LDS area (RB rows x 3 KB), waits, and reads them back.
+template <int RB>
+__global__ __launch_bounds__(1024) void gather_lds(const float *table, const int *ids, int rows_per_step, int steps, int ld, float *out,
+                                                   int dependent) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float *area = reinterpret_cast<float *>(smem) + (size_t)wave * RB * 768;
+    float acc = 0.f;
+    int off = 0;
+    for (int s = 0; s < steps; s++) {
+        const int *row_ids = ids + (size_t)s * rows_per_step;
+        for (int j0 = wave * RB; j0 < rows_per_step; j0 += nw * RB) {
+#pragma unroll
+            for (int x = 0; x < RB; x++) {
+                if (j0 + x < rows_per_step) {
+                    const int id = (row_ids[j0 + x] + off) & 0x7fff;
+                    const float *rp = table + (size_t)id * ld;
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        __builtin_amdgcn_global_load_lds(rp + c * 256 + lane * 4, (__attribute__((address_space(3))) void *)(area + x * 768 + c * 256),
+                                                         16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int x = 0; x < RB; x++)
+                if (j0 + x < rows_per_step) {
+                    const float4 a = *reinterpret_cast<const float4 *>(area + x * 768 + lane * 4);
+                    const float4 b = *reinterpret_cast<const float4 *>(area + x * 768 + 256 + lane * 4);
+                    const float4 c = *reinterpret_cast<const float4 *>(area + x * 768 + 512 + lane * 4);
+                    acc += a.x + b.y + c.z;
+                }
+        }
+        if (dependent) {
+            float v = acc;
+            for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+            off = (__float_as_int(v) >> 3) & 1;
+            __syncthreads();
+        }
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
 // optional background load: does the lone workgroup's memory latency depend on how busy the rest of the chip is?
 __global__ void stream_bg(const float4 *src, size_t n4, float *out, int iters) {
     float acc = 0.f;
@@ -87,6 +131,16 @@ int main(int argc, char **argv) {
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
             if (bg) CK(hipStreamSynchronize(st2));
+            if (rep && !bg && waves <= 6) {  // the LDS-direct form: 8 rows x 3 KB per wave of LDS
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_lds<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(gather_lds<8>, dim3(1), dim3(waves * 64), (size_t)waves * 8 * 768 * 4, 0, table, ids, rps, steps, ld, out, dep);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms2;
+                CK(hipEventElapsedTime(&ms2, e0, e1));
+                printf("   LDS-direct loads (global_load_lds_dwordx4): %.2f us per step = %.1f GB/s\n", ms2 * 1e3 / steps, rps * 3072.0 * steps / (ms2 * 1e-3) / 1e9);
+            }
             if (rep) printf("[bg %d%s] %s steps, %d rows x 3 KB per step, %d waves, %d MB table: %.2f us per step = %.1f GB/s on one CU\n",
                             bg, seq ? " seq" : "", dep ? "dependent" : "independent", rps, waves, mb, ms * 1e3 / steps, rps * 3072.0 * steps / (ms * 1e-3) / 1e9);
         }
