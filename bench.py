@@ -619,7 +619,7 @@ def sharded_ivf(engine, dev, rank, world, args):
     Q = centers[qw] + 0.3 * torch.randn(nq, DIM, generator=g, device=dev)
     Q /= Q.norm(dim=1, keepdim=True)
     x = rows_of(rank)
-    comm = Comm(device=dev)
+    comm = Comm(device=dev, always_collective=True)    # with one rank too: the RCCL calls of the N > 1 path are issued
     t0 = time.time()
     idx = ShardedIVF.build(x, "cosine", nlist, 10, 42, comm=comm)
     torch.cuda.synchronize()
@@ -702,8 +702,8 @@ def sharded_hnsw(engine, dev, rank, world, args):
     t0 = time.time()
     idx.hnsw_build(M, EFC, 42)
     build_s = time.time() - t0
-    s = ShardedSearcher(lambda q, k: idx.hnsw_search_dev(q, k, ef), rank * n)
-    truth = ShardedSearcher(lambda q, k: idx.exact_knn_dev(q, k), rank * n)
+    s = ShardedSearcher(lambda q, k: idx.hnsw_search_dev(q, k, ef), rank * n, always_collective=True)
+    truth = ShardedSearcher(lambda q, k: idx.exact_knn_dev(q, k), rank * n, always_collective=True)
     ti, _ = truth.search(Q[:256].contiguous(), K)
     for _ in range(2):
         ids, d = s.search(Q, K)

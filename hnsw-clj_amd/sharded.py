@@ -69,13 +69,16 @@ class Comm:
     under "gloo" (CPU rehearsals and tests: N ranks on one GPU or none) the same calls stage through host
     memory.  Without an initialised process group it is the single-rank identity."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, always_collective=False):
         self.group = group
         self.on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
         self.host = (not self.on) or dist.get_backend(group) == "gloo"
         self.device = device
+        # a one-rank group normally short-cuts every collective; `always_collective` issues them anyway (bench.py
+        # --sharded on one GPU: the RCCL calls of the N > 1 path run, with one rank, on the hardware that is there)
+        self.single = self.world == 1 and not (always_collective and self.on)
 
     def _wire(self, t):
         t = torch.as_tensor(t)
@@ -83,14 +86,14 @@ class Comm:
 
     def all_reduce_sum(self, a):
         """numpy in, numpy out (small tables: list sums and counts)."""
-        if self.world == 1:
+        if self.single:
             return np.asarray(a)
         t = self._wire(np.ascontiguousarray(a))
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
 
     def broadcast(self, a, src=0):
-        if self.world == 1:
+        if self.single:
             return np.asarray(a)
         t = self._wire(np.ascontiguousarray(a))
         dist.broadcast(t, src, group=self.group)
@@ -98,7 +101,7 @@ class Comm:
 
     def all_gather(self, t):
         """tensor [..] (same shape on every rank) -> [world, ..] on t's device."""
-        if self.world == 1:
+        if self.single:
             return t.unsqueeze(0)
         w = self._wire(t)
         out = torch.empty((self.world,) + tuple(w.shape), dtype=w.dtype, device=w.device)
@@ -108,7 +111,7 @@ class Comm:
     def all_to_all_rows(self, send, send_counts, recv_counts):
         """send: [sum(send_counts), width] rows grouped by destination rank -> [sum(recv_counts), width] rows grouped
         by source rank (RCCL all-to-all; peer-to-peer sends under gloo)."""
-        if self.world == 1:
+        if self.single:
             return send
         w = self._wire(send)
         out = torch.empty((int(sum(recv_counts)),) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
@@ -269,18 +272,19 @@ class ShardedSearcher:
     """Independent sub-indexes over contiguous row ranges.
     local_search(Q, k) -> (ids int32 [nq,k] local row ids, -1 padded; dist float32 [nq,k])."""
 
-    def __init__(self, local_search, row_offset, group=None, merge_fn=None):
+    def __init__(self, local_search, row_offset, group=None, merge_fn=None, always_collective=False):
         self.local_search = local_search
         self.row_offset = int(row_offset)
         self.group = group
         self.merge_fn = merge_fn
+        self.always_collective = always_collective
 
     def search(self, Q, k):
         ids, d = self.local_search(Q, k)
         gids = torch.where(ids >= 0, ids + self.row_offset, ids)  # local row -> global row id
         # ONE collective per batch: (id, distance bits) packed as int32 pairs, nq * k * 8 bytes per rank
         mine = torch.stack((gids, d.contiguous().view(torch.int32)), dim=0).contiguous()      # [2, nq, k]
-        both = Comm(self.group, mine.device if mine.is_cuda else None).all_gather(mine)       # [world, 2, nq, k]
+        both = Comm(self.group, mine.device if mine.is_cuda else None, self.always_collective).all_gather(mine)  # [world, 2, nq, k]
         all_ids = both[:, 0].contiguous()                   # [world, nq, k]: the merge kernel's layout
         all_d = both[:, 1].contiguous().view(torch.float32)
         merge = self.merge_fn
