@@ -780,6 +780,96 @@ constexpr uint32_t kExpanded = 0x80000000u;
 // The grid is persistent: workgroup b serves queries b, b + gridDim.x, ...
 constexpr int kPfMailWords = 160, kPfRing = 64;  // 32-bit words per query's mailbox; ring entries
 
+// ---- L2 prefetch helpers of a handful of queries (HnswArgs::pf_mail) ------------------------------------------------
+// Workgroup b sits on XCD b % 8; query t and its helpers share XCD t % 8:
+//     b = (t % 8) + 8 * ((t / 8) * (1 + G) + role), role 0 = the traversal, 1..G = helpers
+__device__ __forceinline__ void pf_place(const HnswArgs &a, int nq_eff, int &role, int &query, uint32_t *&mail) {
+    const int u = blockIdx.x >> 3, team = 1 + a.pf_groups;
+    role = u % team;
+    query = (u / team) * 8 + (blockIdx.x & 7);
+    mail = query < nq_eff ? a.pf_mail + static_cast<int64_t>(query) * kPfMailWords : nullptr;
+}
+
+// A helper: follow the query's ring until the traversal is done (or 20 ms have passed: never hang), reading ITS slice
+// of every posted node's neighbour rows -- and throwing them away: they are in the XCD's L2 afterwards.
+template <int NCH, int RB, int NW>
+__device__ __forceinline__ void pf_helper(const HnswArgs &a, uint32_t *mail, int pf_role) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int nvec = static_cast<int>(a.ld / 4);
+    const unsigned long long t_begin = wall_clock64();
+    auto timed_out = [&]() { return wall_clock64() - t_begin > 2000000ull; };
+    // the ring: the best unexpanded list entries, posted by wave 1 while wave 0 selects the next candidate.  (A second
+    // ring with the closest fresh neighbour of every expansion, posted as soon as its distance was known, made the
+    // search SLOWER -- 448 us against 426: dropped.)
+    const unsigned long long *ring = reinterpret_cast<const unsigned long long *>(mail + 16);
+    uint32_t e = 0;  // every helper follows every entry and fetches ITS slice of the node's neighbours
+    for (;;) {
+        const bool done = coherent_load(mail + 2) == a.pf_seq;
+        const unsigned long long v = coherent_load(ring + (e % kPfRing));
+        const uint32_t tag = static_cast<uint32_t>(v >> 32), node = static_cast<uint32_t>(v);
+        // an entry of a LATER lap than the one I wait for: the traversal has lapped me, take up what is there
+        // (an earlier lap: my entry has not been written yet)
+        const uint32_t ahead = ((tag & 0xff) - ((e / kPfRing) & 0xff)) & 0xff;
+        if ((tag >> 8) == a.pf_seq && ahead < 128) {
+            e += ahead * kPfRing + 1;
+            if (node < static_cast<uint32_t>(a.n)) {
+                const int nb = a.l0_adj[static_cast<int64_t>(node) * a.M0 + (lane < a.M0 ? lane : a.M0 - 1)];
+                // neighbours [lo, hi) are this helper's; its waves take them RB at a time
+                const int per = (a.M0 + a.pf_groups - 1) / a.pf_groups, lo = (pf_role - 1) * per;
+                const int hi = lo + per < a.M0 ? lo + per : a.M0;
+                for (int j0 = lo + wave * RB; j0 < hi; j0 += NW * RB) {
+                    float4 r[RB][NCH];
+#pragma unroll
+                    for (int x = 0; x < RB; x++) {
+                        const int j = j0 + x < hi ? j0 + x : hi - 1;
+                        int32_t rid = __builtin_amdgcn_readlane(nb, j);
+                        rid = (rid >= 0 && rid < a.n) ? rid : static_cast<int32_t>(node);
+                        const float4 *rp = reinterpret_cast<const float4 *>(a.rows + static_cast<int64_t>(rid) * a.ld);
+#pragma unroll
+                        for (int cc = 0; cc < NCH; cc++) {
+                            const int i = cc * kWave + lane;
+                            r[x][cc] = rp[i < nvec ? i : nvec - 1];
+                        }
+                    }
+#pragma unroll
+                    for (int x = 0; x < RB; x++)
+#pragma unroll
+                        for (int cc = 0; cc < NCH; cc++) asm volatile("" ::"v"(r[x][cc].x));  // the loads must happen
+                }
+            }
+            continue;  // look at the next entry right away
+        }
+        if (done || timed_out()) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+// One wave of the traversal: post the best few unexpanded entries of `list` (from `start`) that were not posted a
+// moment ago.  head / recent are that wave's posting state (recent: lane l holds the l-th recent node).  Data-tagged
+// 8-byte entries: one agent-scope store each, nothing to wait for.
+constexpr uint32_t kExpandedFlag = 0x80000000u;
+__device__ __forceinline__ void pf_post(const HnswArgs &a, uint32_t *mail, const uint2 *list, int start, int len,
+                                        uint32_t &head, uint32_t &recent, int lane) {
+    int posted = 0;
+    for (int base = start; base < len && posted < 4; base += kWave) {
+        const int i = base + lane;
+        const uint32_t y = i < len ? list[i].y : kExpandedFlag;
+        uint64_t m = __ballot(!(y & kExpandedFlag));
+        for (; m && posted < 4; m &= m - 1) {
+            const int j = __ffsll(static_cast<unsigned long long>(m)) - 1;
+            const uint32_t node = __builtin_amdgcn_readlane(y, j);
+            posted++;
+            if (__ballot(recent == node)) continue;  // hinted a moment ago
+            if (lane == 0) {
+                const unsigned long long tagv = (static_cast<unsigned long long>(a.pf_seq) << 8) | ((head / kPfRing) & 0xff);
+                coherent_store(reinterpret_cast<unsigned long long *>(mail + 16) + (head % kPfRing), (tagv << 32) | node);
+            }
+            if (lane == static_cast<int>(head % kWave)) recent = node;
+            head++;
+        }
+    }
+}
+
 template <int NCH, int RB, bool L2, int NW, bool VG, bool PF = false>
 __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
     constexpr int kThreads = NW * kWave;
@@ -802,69 +892,12 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
     uint32_t gen = a.gen_base;
 
     const int nq_eff = a.nq_dev ? (*a.nq_dev < a.nq ? *a.nq_dev : a.nq) : a.nq;
-    // PF: workgroup b sits on XCD b % 8; query t and its helpers share XCD t % 8:
-    //     b = (t % 8) + 8 * ((t / 8) * (1 + G) + role), role 0 = the traversal, 1..G = helpers
     int pf_role = 0, wi0 = blockIdx.x, wi_step = gridDim.x;
     uint32_t *mail = nullptr;
     if (PF) {
-        const int u = blockIdx.x >> 3, team = 1 + a.pf_groups;
-        pf_role = u % team;
-        wi0 = (u / team) * 8 + (blockIdx.x & 7);
+        pf_place(a, nq_eff, pf_role, wi0, mail);
         wi_step = 0x40000000;  // one query per traversal workgroup
-        if (wi0 < nq_eff) mail = a.pf_mail + static_cast<int64_t>(wi0) * kPfMailWords;
-        if (pf_role > 0 && wi0 < nq_eff) {
-            // ---- helper: follow the mailbox until the traversal is done (or 20 ms have passed: never hang)
-            const unsigned long long t_begin = wall_clock64();
-            auto timed_out = [&]() { return wall_clock64() - t_begin > 2000000ull; };
-            // the ring: the best unexpanded list entries, posted by wave 1 while wave 0 selects the next candidate.  (A second
-            // ring with the closest fresh neighbour of every expansion, posted as soon as its distance was known, made the
-            // search SLOWER -- 448 us against 426: dropped.)
-            const unsigned long long *rings = reinterpret_cast<const unsigned long long *>(mail + 16);
-            uint32_t cur[1] = {0};  // every helper follows every entry and fetches ITS slice of the node's neighbours
-            for (;;) {
-                const bool done = coherent_load(mail + 2) == a.pf_seq;
-                bool any = false;
-                for (int rg = 0; rg < 1; rg++) {
-                    uint32_t &e = cur[rg];
-                    const unsigned long long v = coherent_load(rings + rg * kPfRing + (e % kPfRing));
-                    const uint32_t tag = static_cast<uint32_t>(v >> 32), node = static_cast<uint32_t>(v);
-                    if ((tag >> 8) != a.pf_seq) continue;
-                    // an entry of a LATER lap than the one I wait for: the traversal has lapped me, take up what is there
-                    // (an earlier lap: my entry has not been written yet)
-                    const uint32_t ahead = ((tag & 0xff) - ((e / kPfRing) & 0xff)) & 0xff;
-                    if (ahead >= 128) continue;
-                    e += ahead * kPfRing + 1;
-                    any = true;
-                    if (node >= static_cast<uint32_t>(a.n)) continue;
-                    const int nb = a.l0_adj[static_cast<int64_t>(node) * a.M0 + (lane < a.M0 ? lane : a.M0 - 1)];
-                    // neighbours [lo, hi) are this helper's; its waves take them RB at a time
-                    const int per = (a.M0 + a.pf_groups - 1) / a.pf_groups, lo = (pf_role - 1) * per;
-                    const int hi = lo + per < a.M0 ? lo + per : a.M0;
-                    for (int j0 = lo + wave * RB; j0 < hi; j0 += NW * RB) {
-                        float4 r[RB][NCH];
-#pragma unroll
-                        for (int x = 0; x < RB; x++) {
-                            const int j = j0 + x < hi ? j0 + x : hi - 1;
-                            int32_t rid = __builtin_amdgcn_readlane(nb, j);
-                            rid = (rid >= 0 && rid < a.n) ? rid : static_cast<int32_t>(node);
-                            const float4 *rp = reinterpret_cast<const float4 *>(a.rows + static_cast<int64_t>(rid) * a.ld);
-#pragma unroll
-                            for (int cc = 0; cc < NCH; cc++) {
-                                const int i = cc * kWave + lane;
-                                r[x][cc] = rp[i < nvec ? i : nvec - 1];
-                            }
-                        }
-#pragma unroll
-                        for (int x = 0; x < RB; x++)
-#pragma unroll
-                            for (int cc = 0; cc < NCH; cc++) asm volatile("" ::"v"(r[x][cc].x));  // the loads must happen
-                    }
-                }
-                if (any) continue;  // look at the next entries right away
-                if (done || timed_out()) break;
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
+        if (pf_role > 0 && wi0 < nq_eff) pf_helper<NCH, RB, NW>(a, mail, pf_role);
         if (pf_role > 0) wi0 = nq_eff;  // helpers (and spare workgroups) take no query
     }
     for (int wi = wi0; wi < nq_eff; wi += wi_step) {
@@ -958,28 +991,10 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                         sc[1] = ncand;
                     }
                 }
-                if (PF && NW > 1 && wave == 1 && level == 0) {
+                if (PF && NW > 1 && wave == 1 && level == 0)
                     // meanwhile (wave 1 idles here): post the best few unexpanded candidates to the helpers.  It reads
                     // the list while wave 0 flags its pick -- a stale flag only costs a redundant hint.
-                    int posted = 0;
-                    for (int base = cur_start; base < len && posted < 4; base += kWave) {
-                        const int i = base + lane;
-                        const uint32_t y = i < len ? curA[i].y : kExpanded;
-                        uint64_t m = __ballot(!(y & kExpanded));
-                        for (; m && posted < 4; m &= m - 1) {
-                            const int j = __ffsll(static_cast<unsigned long long>(m)) - 1;
-                            const uint32_t node = __builtin_amdgcn_readlane(y, j);
-                            posted++;
-                            if (__ballot(pf_recent == node)) continue;  // hinted a moment ago
-                            if (lane == 0) {  // data-tagged entry: one 8-byte store, nothing to wait for
-                                const unsigned long long tagv = (static_cast<unsigned long long>(a.pf_seq) << 8) | ((pf_head / kPfRing) & 0xff);
-                                coherent_store(reinterpret_cast<unsigned long long *>(mail + 16) + (pf_head % kPfRing), (tagv << 32) | node);
-                            }
-                            if (lane == static_cast<int>(pf_head % kWave)) pf_recent = node;
-                            pf_head++;
-                        }
-                    }
-                }
+                    pf_post(a, mail, curA, cur_start, len, pf_head, pf_recent, lane);
                 __syncthreads();
                 HG_STAMP(1);  // select + adjacency + visited filter
                 const int c = sc[0];
