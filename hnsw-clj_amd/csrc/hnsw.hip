@@ -68,6 +68,12 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
         // one mailbox per query; four regions in rotation, so that launches in flight (two Slots) never share one
         nw = 4;
         a.pf_groups = g_pf_groups;
+        static const int hints = []() {
+            const char *e = getenv("HNSWGPU_PF_HINTS");
+            const int v = e ? atoi(e) : 4;
+            return v < 1 ? 1 : (v > 32 ? 32 : v);
+        }();
+        a.pf_hints = hints;
         grid = 8 * ((a.nq + 7) / 8) * (1 + g_pf_groups);
         const size_t region = sizeof(uint32_t) * kPfMailWords * kPfMaxQueries;
         if (idx->s_pf.cap < 4 * region) {

@@ -750,6 +750,7 @@ struct HnswArgs {
     // for its own stores --, so results and counters cannot depend on them.
     uint32_t *pf_mail;
     int32_t pf_groups;
+    int32_t pf_hints;  // unexpanded entries looked at per expansion (the best pf_hints of the list)
     uint32_t pf_seq;
     // Host-polled completion (small synchronous calls whose queries and results live in mapped pinned host memory):
     // every workgroup counts itself in done_cnt when it has no work left; the last one copies *again_cnt to
@@ -851,11 +852,12 @@ constexpr uint32_t kExpandedFlag = 0x80000000u;
 __device__ __forceinline__ void pf_post(const HnswArgs &a, uint32_t *mail, const uint2 *list, int start, int len,
                                         uint32_t &head, uint32_t &recent, int lane) {
     int posted = 0;
-    for (int base = start; base < len && posted < 4; base += kWave) {
+    const int want = a.pf_hints;
+    for (int base = start; base < len && posted < want; base += kWave) {
         const int i = base + lane;
         const uint32_t y = i < len ? list[i].y : kExpandedFlag;
         uint64_t m = __ballot(!(y & kExpandedFlag));
-        for (; m && posted < 4; m &= m - 1) {
+        for (; m && posted < want; m &= m - 1) {
             const int j = __ffsll(static_cast<unsigned long long>(m)) - 1;
             const uint32_t node = __builtin_amdgcn_readlane(y, j);
             posted++;
