@@ -719,20 +719,27 @@ int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t s
         blocks = std::min<int64_t>(blocks, std::max(cus, 8));
     }
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "tile grid too large");
-    if (a.metric == METRIC_L2) {  // same groups, work list and outputs; rows in registers instead of MFMA tiles
+    if (a.metric == METRIC_L2 || a.gemv_order) {  // same groups, work list and outputs; rows in registers instead of MFMA tiles
         const size_t l2lds = l2_group_lds_bytes(a.ld);
         const int nch = static_cast<int>((a.ld / 4 + kWave - 1) / kWave);
-        HG_REQUIRE(nch >= 1 && nch <= 4, HNSWGPU_ELIMIT, "L2 group scan supports dim <= %d", kL2MaxDim);
+        HG_REQUIRE(nch >= 1 && nch <= 4, HNSWGPU_ELIMIT, "the register-row group scan supports dim <= %d", kL2MaxDim);
         TileArgs b2 = a;
         b2.dbg = 0;
         b2.dbg_buf = nullptr;
-#define CALL_L2(N, R)                                                                                            \
+        HG_REQUIRE(!b2.work_ctr, HNSWGPU_EINVAL, "the group kernel takes one work item per workgroup");
+        const bool l2m = a.metric == METRIC_L2;
+#define CALL_L2M(N, R, LM)                                                                                       \
     do {                                                                                                         \
         static bool l2_attr_done[64] = {};                                                                       \
         if (attr_needed(l2_attr_done))                                                                           \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_group_kernel<N, R>),                   \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_group_kernel<N, R, LM>),               \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
-        hipLaunchKernelGGL((l2_group_kernel<N, R>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), l2lds, st, b2); \
+        hipLaunchKernelGGL((l2_group_kernel<N, R, LM>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), l2lds, st, b2); \
+    } while (0)
+#define CALL_L2(N, R)                 \
+    do {                              \
+        if (l2m) CALL_L2M(N, R, true); \
+        else CALL_L2M(N, R, false);    \
     } while (0)
         switch (nch) {
             case 1: CALL_L2(1, 8); break;
@@ -741,6 +748,7 @@ int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t s
             default: CALL_L2(4, 4); break;
         }
 #undef CALL_L2
+#undef CALL_L2M
         HG_HIP(hipGetLastError());
         return 0;
     }

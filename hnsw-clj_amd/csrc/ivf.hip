@@ -453,7 +453,7 @@ static int kmeanspp_device(hnswgpu_index *idx, int32_t nlist, int64_t seed, std:
 // and stream the list through the MFMA tile kernel once per group; distances land in a dense
 // per-query candidate array (position = the pair's order key), then one select pass per query.
 static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
-                         const int32_t *d_probes, const int32_t *d_qcnt, hipStream_t st) {
+                         const int32_t *d_probes, const int32_t *d_qcnt, hipStream_t st, bool gemv_order = false) {
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
     const int nlist = idx->nlist;
     // candidates per query, upper bound; a multiple of 4 so that every query's array is 16-B aligned (float4 select)
@@ -476,7 +476,8 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
         return e ? atoll(e) : 4LL;
     }();
     // the L2 group kernel takes one item per workgroup; few groups: shorter items, so that every CU has several
-    const int64_t ptiles = idx->metric == METRIC_L2 ? 0 : (ptiles_env == 4 && est_groups < 1200 ? 2 : ptiles_env);
+    const int64_t ptiles =
+        idx->metric == METRIC_L2 || gemv_order ? 0 : (ptiles_env == 4 && est_groups < 1200 ? 2 : ptiles_env);
     int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + est_groups - 1) / est_groups));
     int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows;
     if (ptiles > 0) cr = std::max<int64_t>(1, std::min<int64_t>(ptiles, mean_tiles)) * kTileRows;
@@ -506,6 +507,7 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     t.ld = idx->ld;
     t.dim = idx->dim;
     t.metric = idx->metric;
+    t.gemv_order = gemv_order ? 1 : 0;
     t.Qp = idx->s_qp.as<float>();
     t.q_norms = idx->s_qn.as<float>();
     t.grp_seg = gseg;
@@ -574,16 +576,28 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         return e ? atoi(e) : 1;
     }();
     const bool fused_mode = fused_env == 2 || (fused_env == 1 && nq <= 8);
-    const bool use_order = !use_tile && order_mode && idx->nlist <= kOrderMaxLists && npairs * 2 >= idx->nlist &&
-                           npairs <= (1 << 22);
+    // Just below that: 1.5 to 2 pairs per list.  The register-row group kernel (l2_kernels.hpp) fetches a list once for
+    // all the queries probing it and keeps the GEMV summation order, so the results stay bit-identical to the GEMV
+    // scan's (the contract up to 2 pairs per list) while the second and third readers of a list cost no traffic.
+    // Same index, GEMV vs group, list-scan kernel / end to end: batch 32: 0.356 / 0.423 vs 0.331 / 0.423 ms;
+    // 48: 0.464 / 0.531 vs 0.431 / 0.527; 64: 0.572 / 0.643 vs 0.488 / 0.589 (about 885 distinct lists x 3 MB at
+    // ~5.5 TB/s).  The three extra launches (histogram, plan, scatter) cost what the kernel gains below 1.5 pairs per list.
+    static const int group_env = []() {
+        const char *e = getenv("HNSWGPU_IVF_GROUP");  // 0 = never (A/B), 2 = from half a pair per list
+        return e ? atoi(e) : 1;
+    }();
+    const bool use_group = !use_tile && !fused_mode && group_env && tm != 0 && idx->dim <= kL2MaxDim &&
+                           (group_env == 2 ? npairs * 2 >= idx->nlist : npairs * 2 >= 3LL * idx->nlist);
+    const bool use_order = !use_tile && !use_group && order_mode && idx->nlist <= kOrderMaxLists &&
+                           npairs * 2 >= idx->nlist && npairs <= (1 << 22);
     int32_t *order_buf = nullptr;
-    if (use_tile || use_order) {
+    if (use_tile || use_group || use_order) {
         HG_TRY(idx->s_grp.ensure(sizeof(int32_t) * (2 * npairs + nq + 16)));
         if (!probes_buf) probes_buf = idx->s_grp.as<int32_t>();
-        qcnt_buf = use_tile ? idx->s_grp.as<int32_t>() + npairs : nullptr;
+        qcnt_buf = use_tile || use_group ? idx->s_grp.as<int32_t>() + npairs : nullptr;
         order_buf = idx->s_grp.as<int32_t>() + npairs + nq + 16;
     }
-    if (use_tile) HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
+    if (use_tile || use_group) HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
     if (d_given_probes) {  // caller-chosen lists (the :turbo mode's random partitions, :271-272); -1 = none
         hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st,
                            reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff, glistoff,
@@ -628,8 +642,8 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     a.pairs = idx->s_pairs.as<Pair>();
     a.k = k;
     a.role = ROLE_LIST_SCAN;
-    if (use_tile) {
-        HG_TRY(ivf_tile_scan(idx, d_Q, nq, k, nprobe, probes_buf, qcnt_buf, st));
+    if (use_tile || use_group) {
+        HG_TRY(ivf_tile_scan(idx, d_Q, nq, k, nprobe, probes_buf, qcnt_buf, st, use_group));
     } else {
         if (use_order) {
             const size_t olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);

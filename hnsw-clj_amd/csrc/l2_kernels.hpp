@@ -9,25 +9,30 @@
 // lane_partial + wave_sum + sqrt, so the distances are bit-identical to scan_kernel's (oracle/oracle.c "device order").
 // VALU-bound (63 % of the VALU issue rate by SQ_INSTS_VALU at batch 1024); pairing rows for v_pk_add_f32 /
 // v_pk_fma_f32 changed neither the counted instructions nor the time and was dropped.
+//
+// Round 2: the same kernel serves cosine / dot (template flag L2M = false) for the MID-SIZE batches of the IVF search --
+// 0.5 to 2 (query, list) pairs per list, where the GEMV scan streams a list once per pair (the second reader at best
+// finds the first one's lines in L2) and the MFMA tile kernel would change the summation order: here a list is
+// fetched once per group and every distance keeps the GEMV order, bit for bit.
 #pragma once
 #include "kernels.hpp"
 #include "tile_args.hpp"
 
 namespace hg {
 
-constexpr int kL2MaxDim = 1024;  // 32 resident queries x 4 KiB
-
 __host__ inline size_t l2_group_lds_bytes(int64_t ld) {
-    return sizeof(float) * kTileQ * static_cast<size_t>(ld) + sizeof(int64_t) * kTileQ + sizeof(int32_t) * kTileQ;
+    return sizeof(float) * kTileQ * static_cast<size_t>(ld) + sizeof(int64_t) * kTileQ + sizeof(int32_t) * kTileQ +
+           sizeof(float) * kTileQ;
 }
 
-template <int NCH, int RB>
+template <int NCH, int RB, bool L2M = true>
 __global__ __launch_bounds__(kTileThreads) void l2_group_kernel(TileArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int nvec = static_cast<int>(a.ld / 4);
     float4 *Bs = reinterpret_cast<float4 *>(smem);                             // [32][nvec] resident query group
     int64_t *ob_s = reinterpret_cast<int64_t *>(Bs + kTileQ * nvec);           // [32] output bases (-1 = empty slot)
     int32_t *qi_s = reinterpret_cast<int32_t *>(ob_s + kTileQ);                // [32] query index (-1 = empty)
+    float *qn_s = reinterpret_cast<float *>(qi_s + kTileQ);                    // [32] query norms (cosine)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(kTileThreads) void l2_group_kernel(TileArgs a) {
         }
         qi_s[tid] = qi;
         ob_s[tid] = ob;
+        qn_s[tid] = (!L2M && a.metric == METRIC_COS && qi >= 0 && a.q_norms) ? a.q_norms[qi] : 0.0f;
     }
     __syncthreads();
     {
@@ -110,9 +116,12 @@ __global__ __launch_bounds__(kTileThreads) void l2_group_kernel(TileArgs a) {
     uint64_t best = ~0ull;  // argmin mode: lane q keeps the best (distance, row) of query slot q over this wave's rows
     for (int64_t base = r0 + wave * RB; base < r1; base += kTileWaves * RB) {
         float4 r[RB][NCH];
+        // lane b fetches row b's precomputed norm with the rows (cosine), as scan_kernel does
+        const float myrn = (!L2M && a.metric == METRIC_COS && lane < RB && base + lane < r1) ? a.row_norms[base + lane] : 0.0f;
 #pragma unroll
         for (int b = 0; b < RB; b++) load_row<NCH>(r[b], a.rows + (base + b) * a.ld, nvec, lane, base + b < r1);
         for (int q = 0; q < cnt; q++) {
+            const float qn = L2M ? 0.0f : qn_s[q];
             float4 qv[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(kTileThreads) void l2_group_kernel(TileArgs a) {
             }
             float s[RB];
 #pragma unroll
-            for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, true>(qv, r[b]);
+            for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2M>(qv, r[b]);
 #pragma unroll
             for (int b = 0; b < RB; b++) s[b] = wave_sum(s[b]);
             if (a.out_key) {  // first minimum wins (strict <, ivf_flat.clj:86-89) = smallest (distance, row)
@@ -129,7 +138,9 @@ __global__ __launch_bounds__(kTileThreads) void l2_group_kernel(TileArgs a) {
 #pragma unroll
                 for (int b = 0; b < RB; b++) {
                     const int64_t row = base + b;
-                    const uint64_t key = row < r1 ? make_key(__builtin_sqrtf(s[b]), static_cast<uint32_t>(row - rb0)) : ~0ull;
+                    const float rn = L2M ? 0.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), b));
+                    const float dv = L2M ? __builtin_sqrtf(s[b]) : finish_dist(a.metric, s[b], qn, rn);
+                    const uint64_t key = row < r1 ? make_key(dv, static_cast<uint32_t>(row - rb0)) : ~0ull;
                     kmin = key < kmin ? key : kmin;
                 }
                 if (lane == q) best = kmin < best ? kmin : best;
@@ -137,7 +148,9 @@ __global__ __launch_bounds__(kTileThreads) void l2_group_kernel(TileArgs a) {
                 float mine = 0.0f;  // lane b takes row b's distance: RB consecutive floats of the query's array
 #pragma unroll
                 for (int b = 0; b < RB; b++) mine = lane == b ? s[b] : mine;
-                if (lane < RB && base + lane < r1) a.out[ob_s[q] + (base + lane - rb0)] = __builtin_sqrtf(mine);
+                // lane b holds row b's norm already: the distance is finished where it is stored
+                if (lane < RB && base + lane < r1)
+                    a.out[ob_s[q] + (base + lane - rb0)] = L2M ? __builtin_sqrtf(mine) : finish_dist(a.metric, mine, qn, myrn);
             }
         }
     }

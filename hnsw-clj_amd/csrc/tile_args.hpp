@@ -26,6 +26,7 @@ constexpr int kTileRows = 32 * kTileWaves;  // rows per tile
 constexpr int kTileQ = 32;      // MFMA N: queries per group
 constexpr int kTileK = 32;      // K per staging step
 constexpr int kTileLdA = kTileK + 4;  // padded LDS row of the A (rows) tile: conflict-free ds_read_b128
+constexpr int kL2MaxDim = 1024;      // register-row group kernel (l2_kernels.hpp): 32 resident queries x 4 KiB
 constexpr int kTileMaxDim = 3072;     // rows up to this length are supported by the callers' row loaders
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -96,6 +97,7 @@ struct TileArgs {
     // best make_key(distance, row) is folded in registers and merged with one 64-bit atomicMin per wave
     // (implicit groups only; the caller presets out_key[q] = ~0)
     unsigned long long *out_key;
+    int32_t gemv_order;  // cosine / dot through the register-row group kernel (GEMV summation order) instead of MFMA tiles
     int32_t dbg;  // developer ablation switches (HNSWGPU_TILE_DBG); 0 in production
     unsigned long long *dbg_buf;  // diagnostic builds only: per-workgroup {start, end, hw id, tiles} stamps
 };

@@ -130,7 +130,8 @@ int hnswgpu_hnsw_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, in
  *   queries: centroid routing (:261-269), brute-force scan of the probed lists with precomputed
  *   norms (:217-234), merge, take k.  out_probes optional (nq x nprobe list ids).
  *   Two summation orders serve this call (cosine / dot): up to 2 (query, list) pairs per list (nq * nprobe <=
- *   2 * nlist) every pair is one GEMV (wave-strided f32 chain + butterfly); larger batches are grouped by list and
+ *   2 * nlist) every pair is one GEMV (wave-strided f32 chain + butterfly; from 1.5 pairs per list the pairs of a list
+ *   share one pass over its rows, same chain, same bits); larger batches are grouped by list and
  *   scanned by the f32-MFMA tile kernel (k-ordered f32 chain).  Both are within 1e-6 of the f64 reference, but a
  *   query's distance BITS (and the order of candidates that tie within that) depend on which kernel its batch
  *   selects: search-batch* over nq queries is not bit for bit nq single search-knn calls.  Calls combined from

@@ -640,6 +640,26 @@ def test_ivf_tile_path_small_work_lists(eng, oracle, nlist, n):
                 assert_exact(ids, d, oi, od, "nlist=%d nq=%d nprobe=%d k=%d mode=%d" % (nlist, nq, nprobe, k, mode))
 
 
+@pytest.mark.parametrize("dim", [72, 300, 768, 1024, 1100])
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_ivf_group_regime_keeps_gemv_bits(eng, oracle, metric, dim):
+    """1.5 to 2 (query, list) pairs per list: the register-row group kernel serves the scan (ivf.hip: use_group; every
+    row-loader width, and dim 1100 which is past it and stays on the GEMV scan).  Lists are read once per group instead
+    of once per pair, but the summation order -- and so every bit of the result -- is the GEMV scan's."""
+    O = oracle
+    base = _data(O, 4000, dim, "clustered", seed=5)
+    Q = _data(O, 16, dim, "clustered", seed=6)
+    with eng.Index(base, ["cosine", "l2", "dot"][metric]) as idx:
+        idx.ivf_build(32, 3, 42)
+        cen, off, lids = idx.get_ivf()
+        for nq, nprobe, k in [(12, 4, 10), (16, 4, 10), (13, 4, 200), (16, 3, 1)]:
+            assert nq * nprobe <= 2 * 32                      # the GEMV-order contract's side of the boundary
+            ids, d, pr = idx.ivf_search(Q[:nq], k, nprobe, want_probes=True)
+            oi, od, opr = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=metric, mode=O.MODE_DEV)
+            np.testing.assert_array_equal(pr, opr)
+            assert_exact(ids, d, oi, od, "group regime metric=%d dim=%d nq=%d" % (metric, dim, nq))
+
+
 @pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
 def test_ivf_many_equal_distances(eng, oracle, metric):
     """Hundreds of candidates tie on the distance bits (duplicated rows, the query among them): every top-k fold
