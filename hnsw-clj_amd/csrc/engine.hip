@@ -76,6 +76,21 @@ int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, 
     return 0;
 }
 
+// The int8 rows of the traversal's rejection test: once per handle (the base rows never change), on the first graph.
+int ensure_qrows(hnswgpu_index *idx, hipStream_t st) {
+    if (idx->rejection_mode == 0 || idx->d_qrows || idx->n <= 0) return 0;
+    const int64_t n = idx->n;
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_qrows), sizeof(uint32_t) * kWave * idx->nch * n));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_qmeta), sizeof(float4) * n));
+    unsigned grid = static_cast<unsigned>((n + kNWave - 1) / kNWave);
+#define CALL(N, R, L) \
+    hipLaunchKernelGGL((quantize_rows_kernel<N>), dim3(grid), dim3(kWG), 0, st, idx->d_base, idx->ld, n, idx->metric, idx->d_qrows, idx->d_qmeta)
+    HG_DISPATCH(idx->nch, false, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_scan(int nch, const ScanArgs &a0, hipStream_t st) {
     ScanArgs a = a0;
     int64_t blocks = static_cast<int64_t>(a.npairs) * a.nchunks;
@@ -1039,6 +1054,14 @@ static int create_common(int64_t n, int32_t dim, int32_t metric, int32_t device,
     idx->dim = dim;
     idx->ld = ld;
     idx->nch = nch;
+    static const int rejection_env = []() {
+        const char *e = getenv("HNSWGPU_PREFILTER");  // default of hnswgpu_set_rejection_test
+        const int v = e ? atoi(e) : 1;
+        return v < 0 || v > 2 ? 1 : v;
+    }();
+    idx->rejection_mode = rejection_env;
+    (void)hipDeviceGetAttribute(&idx->cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (idx->cus <= 0) idx->cus = 256;
     idx->cmb_hnsw.max_inflight = 2;  // two Slots: small synchronous HNSW batches overlap on the device
     idx->cmb_ivf.max_inflight = 1;   // the IVF path works in the index's shared scratch: one batch at a time
     *out = idx;
@@ -1115,7 +1138,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows in place: freed once, below
-    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
+    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
                     idx->d_cent,  idx->d_cnorms, idx->d_lrows,  idx->d_lnorms,  idx->d_listoff, idx->d_listids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1510,6 +1533,49 @@ int hnswgpu_dense_distances(hnswgpu_index *idx, const float *Q, int32_t nq, floa
     HG_HIP(hipMemcpyAsync(out, idx->s_tile.p, bytes, hipMemcpyDeviceToHost, st));
     HG_TRY(end_call(idx, st));
     HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// Measurement / test entry: the lower bounds the HNSW traversal's rejection test (kernels.hpp: quantize_rows_kernel)
+// computes for query q against rows ids[0..m), by the traversal's own device functions.  NaN = "no bound".
+int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out) {
+    HG_REQUIRE(idx && q && ids && out && m >= 1, HNSWGPU_EINVAL, "null argument");
+    for (int32_t i = 0; i < m; i++) HG_REQUIRE(ids[i] >= 0 && ids[i] < idx->n, HNSWGPU_EINVAL, "id out of range");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(ensure_qrows(idx, st));
+    HG_REQUIRE(idx->d_qrows, HNSWGPU_EINVAL, "the rejection test is switched off (hnswgpu_set_rejection_test)");
+    HG_TRY(upload_queries(idx, q, 1, st));
+    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * m));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * m));
+    HG_HIP(hipMemcpyAsync(idx->s_ids.p, ids, sizeof(int32_t) * m, hipMemcpyHostToDevice, st));
+#define CALL(N, R, L)                                                                                                \
+    hipLaunchKernelGGL((code_bound_kernel<N>), dim3((m + 7) / 8), dim3(kWave), 0, st, idx->s_q.as<float>(), idx->dim, \
+                       idx->metric, idx->d_qrows, idx->d_qmeta, idx->d_norms, idx->s_ids.as<int32_t>(), m, idx->s_outd.as<float>())
+    HG_DISPATCH(idx->nch, false, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    HG_HIP(hipMemcpyAsync(out, idx->s_outd.p, sizeof(float) * m, hipMemcpyDeviceToHost, st));
+    HG_TRY(end_call(idx, st));
+    HG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(mode >= 0 && mode <= 2, HNSWGPU_EINVAL, "mode must be 0 (off), 1 (large batches) or 2 (always)");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    idx->rejection_mode = mode;
+    if (mode != 0 && idx->has_graph) {  // an index that has a graph gets its int8 rows now, any other with its graph
+        hipStream_t st = idx->stream;
+        HG_TRY(begin_call(idx, st));
+        HG_TRY(ensure_qrows(idx, st));
+        HG_TRY(end_call(idx, st));
+        HG_HIP(hipStreamSynchronize(st));
+    }
     return 0;
 }
 

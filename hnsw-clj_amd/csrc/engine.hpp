@@ -82,6 +82,12 @@ struct hnswgpu_index {
     int nch = 0;     // 256-float chunks per row (template parameter NCH)
     float *d_base = nullptr;
     float *d_norms = nullptr;
+    // int8 copy of the rows + per-row (scale, error bound) for the HNSW traversal's rejection test (kernels.hpp:
+    // quantize_rows_kernel); made when a graph is installed or built, null while rejection_mode is 0
+    uint32_t *d_qrows = nullptr;
+    float4 *d_qmeta = nullptr;
+    int rejection_mode = 1;  // 0 = off, 1 = batches that fill the chip (launch_hnsw_idx), 2 = every launch
+    int cus = 256;
     hipStream_t stream = nullptr;
     std::mutex mu;
     // Combining of concurrent synchronous searches (hnswgpu_hnsw_search from many host threads, the reference's
@@ -178,6 +184,7 @@ bool attr_needed(bool (&done)[64]);
 
 // launch wrappers (engine.hip / hnsw.hip)
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);
+int ensure_qrows(hnswgpu_index *idx, hipStream_t st);
 int launch_scan(int nch, const ScanArgs &a, hipStream_t st);
 int launch_merge(const MergeArgs &a, hipStream_t st);
 // Serve `me` through combiner `c`: queue it, lead one batch at a time while it is not done.  `take(first, r, total)`

@@ -49,9 +49,14 @@ static const int g_pf_groups = []() {
 constexpr int kPfMaxQueries = 16;  // beyond a handful of queries the chip is busy anyway
 
 int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
-    a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions; read only by -DHG_HNSW_STAMPS builds
+    a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions
     if (a.nq <= 0) return 0;
     const int nch = idx->nch;
+    // The rejection test on int8 rows (kernels.hpp: quantize_rows_kernel) turns one memory round trip per hop into two
+    // shorter ones: 2.2x the throughput once the chip is bandwidth-bound, ~5 % slower while a launch is latency-bound.
+    // 31k x 768, ef 100, ms per launch without / with: 256 queries 0.537 / 0.571, 512: 0.607 / 0.590, 768: 0.817 /
+    // 0.611, 1024: 1.05 / 0.74, 10000: 9.9 / 4.4 (tools/hnsw_batch_sweep.py) -- on from two queries per CU.
+    if (!(idx->rejection_mode == 2 || (idx->rejection_mode == 1 && a.nq >= 2 * idx->cus))) a.qrows = nullptr;
     const bool vg = g_force_vg || a.n > kLdsVisitedMaxRows;
     const bool pf = g_pf_groups > 0 && !vg && !a.q_rows && !a.q_index && a.nq <= kPfMaxQueries && g_hnsw_nw == 0 &&
                     a.n < (1LL << 31) && a.M0 <= kMaxDeg;
@@ -181,6 +186,8 @@ static void fill_args(const hnswgpu_index *idx, HnswArgs &a) {
     memset(&a, 0, sizeof(a));
     a.rows = idx->d_base;
     a.row_norms = idx->d_norms;
+    a.qrows = idx->d_qrows;
+    a.qmeta = idx->d_qmeta;
     a.ld = idx->ld;
     a.n = idx->n;
     a.dim = idx->dim;
@@ -558,6 +565,7 @@ int hnswgpu_set_graph(hnswgpu_index *idx, const int32_t *levels, const int32_t *
     HG_HIP(hipStreamSynchronize(st));
     free_graph(idx);
     HG_TRY(alloc_graph(idx, M, M0, blocks));
+    HG_TRY(ensure_qrows(idx, st));
     if (n > 0) {
         HG_HIP(hipMemcpyAsync(idx->d_levels, levels, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
         HG_HIP(hipMemcpyAsync(idx->d_l0, l0_adj, sizeof(int32_t) * n * M0, hipMemcpyHostToDevice, st));
@@ -826,6 +834,7 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
     HG_HIP(hipStreamSynchronize(st));  // as in hnswgpu_set_graph
     free_graph(idx);
     HG_TRY(alloc_graph(idx, M, M0, blocks));
+    HG_TRY(ensure_qrows(idx, st));
     if (n == 0) {
         idx->h_levels.clear();
         idx->h_l0.clear();

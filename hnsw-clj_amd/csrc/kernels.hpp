@@ -680,6 +680,223 @@ __global__ __launch_bounds__(kWG) void gather_dist_kernel(GatherArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Compressed rows for the traversal's rejection test.
+//
+// search-layer-ultra admits a neighbour only if the result list is not full or its distance is BELOW the list's worst
+// (ultra_fast.clj:195-198, strict <); with ef = 100 on the bench's 31k x 768 index that is 15.5 % of the 2,400
+// distances a query evaluates (tools/prefilter_study.py) -- the other 84.5 % are computed, compared and dropped.  A
+// rejected neighbour's distance is never stored or looked at again, so a LOWER BOUND that is already >= the worst
+// decides it just as well, and a lower bound needs a quarter of the bytes and an eighth of the arithmetic: every row
+// also exists as int8 codes c = round(v / s_v), s_v = max|v| / 127 (v' = s_v c) with its exact residual r_v = |v - v'|,
+// the query is coded the same way once per search (q' = s_q a, r_q = |q - q'|), and a . c is an exact integer from
+// v_dot4c_i32_i8.  Since |q . v - q' . v'| <= |q| r_v + r_q |v'| and | |q - v| - |q' - v'| | <= r_q + r_v:
+//     cosine:  d(q, v) >= 1 - q'.v' / (|q||v|) - r_v / |v| - (r_q / |q|) (1 + r_v / |v|)
+//     dot:     d(q, v) >= -q'.v' - |q| r_v - r_q (|v| + r_v)
+//     L2:      d(q, v) >= |q' - v'| - r_q - r_v,      |q' - v'|^2 = s_q^2 a.a - 2 s_q s_v a.c + s_v^2 c.c
+// Every residual is inflated by 1 % and an allowance two orders of magnitude above the f32 rounding of either side (the
+// exact path's chain of <= 18 roundings per lane sum is < 1.2e-6 relative to |q||v|) is added, so "bound >= worst"
+// implies "the f32 distance the exact path would compute is >= worst": the traversal, its results and its counters are
+// unchanged bit for bit -- only rows that may be admitted are fetched in f32.  NaN / infinity anywhere makes the
+// comparison false and the row takes the exact path.
+//
+// Layout: lane l of a wave owns the same elements of a row as in the f32 kernels (float4 number c * 64 + l, c < NCH);
+// its NCH code words are stored side by side, 64 * NCH dwords per row, so a row is ONE coalesced load of NCH dwords
+// per lane (768 B at dim 768 against 3 KB).  qmeta[row] = (s_v, E, Z, 0): E = the row's share of the bound, Z = the
+// metric's second per-row term (dot: 1.01 (|v| + r_v); L2: c.c; cosine: unused).
+// ------------------------------------------------------------------------------------------------
+// codes of this lane's elements of a row or query held as float4 r[NCH]: returns max|.| over the wave first
+template <int NCH>
+__device__ __forceinline__ float wave_absmax(const float4 (&r)[NCH], bool &bad) {
+    float mx = 0.0f;
+    bool b = false;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const float e[4] = {r[c].x, r[c].y, r[c].z, r[c].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float m = __builtin_fabsf(e[j]);
+            b = b || !(m <= 3.0e38f);  // NaN or infinity
+            mx = m > mx ? m : mx;
+        }
+    }
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float o = __shfl_xor(mx, off, kWave);
+        mx = o > mx ? o : mx;
+    }
+    bad = __ballot(b) != 0;
+    return mx;
+}
+
+// w = the int8 codes (4 per dword), res = this lane's share of |x - s code|^2, c2 = of code . code
+template <int NCH>
+__device__ __forceinline__ void encode_lane(const float4 (&r)[NCH], float mx, bool bad, uint32_t (&w)[NCH], float &res, int &c2) {
+    const float sc = mx / 127.0f, inv = mx > 0.0f ? 127.0f / mx : 0.0f;
+    res = 0.0f;
+    c2 = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const float e[4] = {r[c].x, r[c].y, r[c].z, r[c].w};
+        w[c] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float t = __builtin_rintf(e[j] * inv);
+            t = t > 127.0f ? 127.0f : (t < -127.0f ? -127.0f : t);
+            const int code = bad ? 0 : static_cast<int>(t);
+            const float d = e[j] - sc * static_cast<float>(code);  // against the value the test reconstructs
+            res = __builtin_fmaf(d, d, res);
+            c2 += code * code;
+            w[c] |= (static_cast<uint32_t>(code) & 0xffu) << (8 * j);
+        }
+    }
+}
+
+__device__ __forceinline__ int wave_sum_int(int x) {
+    for (int off = 1; off < kWave; off <<= 1) x += __shfl_xor(x, off, kWave);
+    return x;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(kWG) void quantize_rows_kernel(const float *rows, int64_t ld, int64_t n, int metric,
+                                                            uint32_t *qrows, float4 *qmeta) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kNWave + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float4 r[NCH];
+    load_row<NCH>(r, rows + row * ld, static_cast<int>(ld / 4), lane, true);
+    bool bad;
+    const float mx = wave_absmax<NCH>(r, bad);
+    uint32_t w[NCH];
+    float res;
+    int c2;
+    encode_lane<NCH>(r, mx, bad, w, res, c2);
+    res = __builtin_sqrtf(wave_sum(res));
+    c2 = wave_sum_int(c2);
+    const float nv = __builtin_sqrtf(wave_sum(lane_partial<NCH, false>(r, r)));
+    uint32_t *dst = qrows + (row * kWave + lane) * NCH;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) dst[c] = w[c];
+    if (lane == 0) {
+        float E, Z = 0.0f;
+        if (metric == METRIC_COS) {
+            E = 1.01f * res / nv + 1.0e-4f;  // nv == 0: NaN or infinity -> exact path
+        } else if (metric == METRIC_DOT) {
+            E = 1.01f * res + 2.0e-5f * nv;  // times |q| at the point of use
+            Z = 1.01f * (nv + res);          // times r_q
+        } else {
+            E = 1.01f * res + 4.0e-6f * nv;
+            Z = static_cast<float>(c2);
+        }
+        if (bad || !(E >= 0.0f)) E = __uint_as_float(0x7fc00000u);  // NaN: the comparison fails, exact path
+        qmeta[row] = make_float4(mx / 127.0f, E, Z, 0.0f);
+    }
+}
+
+// The query's side of the test, once per search and wave: codes in the row layout + the scalars of the bounds.
+template <int NCH>
+struct QueryCode {
+    uint32_t a[NCH];
+    float s;    // scale s_q
+    float qn;   // |q|
+    float rq;   // 1.01 r_q (NaN for a query with NaN / infinity: every neighbour takes the exact path)
+    float eq;   // 1.01 r_q / |q|   (cosine)
+    float a2;   // s_q^2 a.a = |q'|^2  (L2)
+};
+
+template <int NCH>
+__device__ __forceinline__ void encode_query(const float4 (&q)[NCH], QueryCode<NCH> &qc) {
+    bool bad;
+    const float mx = wave_absmax<NCH>(q, bad);
+    float res;
+    int c2;
+    encode_lane<NCH>(q, mx, bad, qc.a, res, c2);
+    qc.s = mx / 127.0f;
+    qc.qn = __builtin_sqrtf(wave_sum(lane_partial<NCH, false>(q, q)));
+    qc.rq = bad ? __uint_as_float(0x7fc00000u) : 1.01f * __builtin_sqrtf(wave_sum(res));
+    qc.eq = qc.rq / qc.qn;
+    qc.a2 = qc.s * qc.s * static_cast<float>(wave_sum_int(c2));
+}
+
+// a . c over this lane's elements (exact)
+template <int NCH>
+__device__ __forceinline__ int code_dot(const uint32_t (&a)[NCH], const uint32_t (&w)[NCH]) {
+    int acc = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) acc = __builtin_amdgcn_sdot4(static_cast<int>(a[c]), static_cast<int>(w[c]), acc, false);
+    return acc;
+}
+
+// Eight per-lane integers -> their eight wave totals, one per group of eight lanes: lane l ends up with the total of
+// x[(l >> 3) & 7].  Halving exchange: v_permlane32_swap / v_permlane16_swap trade the half a lane does not keep for
+// the half it does (4 + 2 swaps), one row_ror:8 DPP add, then three DPP adds inside the group of eight -- 17
+// instructions for eight rows instead of eight six-step butterflies.  Integer sums: the order is irrelevant.
+__device__ __forceinline__ int wave_sum8_int(const int (&x)[8], int lane) {
+    unsigned y[4], z[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // lanes 0-31 keep rows i, lanes 32-63 rows 4 + i
+        auto p = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(x[i]), static_cast<unsigned>(x[4 + i]), false, false);
+        y[i] = p[0] + p[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {  // 16-lane rows 0 / 1 / 2 / 3 keep rows i, 2 + i, 4 + i, 6 + i
+        auto p = __builtin_amdgcn_permlane16_swap(y[i], y[2 + i], false, false);
+        z[i] = p[0] + p[1];
+    }
+    // 16-lane row R: z[0] = row 2R, z[1] = row 2R + 1
+    const bool h3 = (lane & 8) != 0;
+    const int keep = static_cast<int>(h3 ? z[1] : z[0]), send = static_cast<int>(h3 ? z[0] : z[1]);
+    int v = keep + __builtin_amdgcn_update_dpp(0, send, 0x128, 0xF, 0xF, true);  // row_ror:8 = lane ^ 8
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    return v;
+}
+// the row whose total wave_sum8_int leaves in lane l
+__device__ __forceinline__ int wave_sum8_row(int lane) { return (lane >> 3) & 7; }
+
+// the lower bound of d(q, v) from the exact code dot product (see above); NaN when nothing can be said
+template <int NCH>
+__device__ __forceinline__ float code_lower_bound(int metric, int dot, const QueryCode<NCH> &qc, float4 meta, float rn) {
+    const float dh = static_cast<float>(dot) * (qc.s * meta.x);  // q' . v'
+    if (metric == METRIC_L2) {
+        const float v2 = meta.x * meta.x * meta.z;  // |v'|^2
+        const float d2 = (qc.a2 - 2.0f * dh + v2) - 2.0e-6f * (qc.a2 + v2);
+        return __builtin_sqrtf(d2 > 0.0f ? d2 : 0.0f) - (qc.rq + 4.0e-6f * qc.qn) - meta.y;
+    }
+    if (metric == METRIC_DOT) return -dh - (qc.qn * meta.y + qc.rq * meta.z);
+    return (1.0f - dh / (qc.qn * rn)) - (meta.y + qc.eq * (1.0f + meta.y));  // qn or rn zero: NaN / infinity -> exact path
+}
+
+// Diagnostic / test entry (hnswgpu_rejection_bounds): the bound of every listed row against one query, by the very
+// functions the traversal uses.  One wave per eight rows.
+template <int NCH>
+__global__ __launch_bounds__(kWave) void code_bound_kernel(const float *Q, int dim, int metric, const uint32_t *qrows,
+                                                           const float4 *qmeta, const float *row_norms, const int32_t *ids,
+                                                           int m, float *out) {
+    const int lane = threadIdx.x;
+    float4 q[NCH];
+    load_query<NCH>(q, Q, dim, lane);
+    QueryCode<NCH> qc;
+    encode_query<NCH>(q, qc);
+    const int j0 = blockIdx.x * 8;
+    int acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const int32_t rid = ids[j0 + b < m ? j0 + b : m - 1];
+        uint32_t w[NCH];
+        const uint32_t *rp = qrows + (static_cast<int64_t>(rid) * kWave + lane) * NCH;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) w[c] = rp[c];
+        acc[b] = code_dot<NCH>(qc.a, w);
+    }
+    const int tot = wave_sum8_int(acc, lane);
+    const int j = j0 + wave_sum8_row(lane);
+    if ((lane & 7) == 0 && j < m) {
+        const int32_t rid = ids[j];
+        out[j] = code_lower_bound<NCH>(metric, tot, qc, qmeta[rid], metric == METRIC_COS ? row_norms[rid] : 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // HNSW traversal: one 256-thread workgroup per query, the whole layered search GPU-resident.
 //
 // Restates search-layer-ultra / search-knn (ultra_fast.clj:151-212, 346-374) with one sorted list:
@@ -759,7 +976,11 @@ struct HnswArgs {
     uint32_t *host_flag;
     int32_t *host_again;
     uint32_t flag_val;
-    unsigned long long *dbg;  // -DHG_HNSW_STAMPS diagnostic builds only: per-phase s_memrealtime totals
+    // int8 copy of the rows for the rejection test (quantize_rows_kernel); null = every neighbour is evaluated in f32
+    const uint32_t *qrows;
+    const float4 *qmeta;
+    unsigned long long *dbg;  // diagnostic sessions: [16] += f32 rows fetched, [17] += neighbours evaluated;
+                              // -DHG_HNSW_STAMPS builds: per-phase s_memrealtime totals in [0..11]
 };
 
 #ifdef HG_HNSW_STAMPS
@@ -818,6 +1039,23 @@ __device__ __forceinline__ void pf_helper(const HnswArgs &a, uint32_t *mail, int
                 // neighbours [lo, hi) are this helper's; its waves take them RB at a time
                 const int per = (a.M0 + a.pf_groups - 1) / a.pf_groups, lo = (pf_role - 1) * per;
                 const int hi = lo + per < a.M0 ? lo + per : a.M0;
+                if (a.qrows != nullptr) {
+                    // with the rejection test the traversal reads the int8 rows (and the rows' meta data) first, and
+                    // f32 rows only for the few neighbours that may be admitted: pull the codes
+                    for (int j = lo + wave; j < hi; j += NW) {
+                        int32_t rid = __builtin_amdgcn_readlane(nb, j);
+                        rid = (rid >= 0 && rid < a.n) ? rid : static_cast<int32_t>(node);
+                        const uint32_t *rp = a.qrows + (static_cast<int64_t>(rid) * kWave + lane) * NCH;
+                        uint32_t w[NCH];
+#pragma unroll
+                        for (int cc = 0; cc < NCH; cc++) w[cc] = rp[cc];
+                        const float mz = lane == 0 ? a.qmeta[rid].x : 0.0f;
+#pragma unroll
+                        for (int cc = 0; cc < NCH; cc++) asm volatile("" ::"v"(w[cc]));  // the loads must happen
+                        asm volatile("" ::"v"(mz));
+                    }
+                    continue;
+                }
                 for (int j0 = lo + wave * RB; j0 < hi; j0 += NW * RB) {
                     float4 r[RB][NCH];
 #pragma unroll
@@ -910,9 +1148,11 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
         float4 q[NCH];
         load_query<NCH>(q, qptr, a.dim, lane);
         float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+        QueryCode<NCH> qc;  // the query's side of the rejection test
+        if (a.qrows != nullptr) encode_query<NCH>(q, qc);
         const int qlevel = a.q_levels ? a.q_levels[qi] : -1;
 
-        int64_t n_eval = 0, n_hop = 0;
+        int64_t n_eval = 0, n_hop = 0, n_exact = 0;
         int len = 0;
 #ifdef HG_HNSW_STAMPS
         unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -991,6 +1231,8 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                     if (lane == 0) {
                         sc[0] = found;
                         sc[1] = ncand;
+                        sc[7] = 0;  // this hop's "needs the f32 row" mask (rejection test below)
+                        sc[8] = 0;
                     }
                 }
                 if (PF && NW > 1 && wave == 1 && level == 0)
@@ -1009,18 +1251,91 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                     continue;
                 }
                 n_eval += nc;
-                // ---- gather rows + distances: wave w takes candidates [w*RB + t*NW*RB, +RB)
-                for (int j0 = wave * RB; j0 < nc; j0 += NW * RB) {
+                const bool list_full = len >= ef_l;
+                const float worst0 = list_full ? __uint_as_float(curA[ef_l - 1].x) : 0.0f;
+                // ---- rejection test on the int8 rows (see quantize_rows_kernel): with a full list a neighbour whose
+                //      LOWER BOUND is already >= the worst cannot be admitted (:195-198 is a strict <, the worst only
+                //      shrinks within a hop) and its distance is never looked at again -- it gets +inf and no f32 fetch
+                uint64_t needmask = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
+                if (a.qrows != nullptr && list_full) {
+                    constexpr int G = 1;  // groups of eight code rows in flight per wave (2: 220 VGPRs at dim 768, a wave less per SIMD)
+                    uint64_t wmask = 0;
+                    const int own = wave_sum8_row(lane);  // the row of a group whose total this lane receives
+                    for (int j0 = wave * 8 * G; j0 < nc; j0 += NW * 8 * G) {
+                        // the lane that will hold row `own`'s total fetches that candidate's meta data up front
+                        int myj[G];
+                        float4 mymeta[G];
+                        float myrn[G];
+                        uint32_t w[G][8][NCH];
+#pragma unroll
+                        for (int g = 0; g < G; g++) {
+                            myj[g] = j0 + 8 * g + own;
+                            if (j0 + 8 * g >= nc) break;
+                            const bool ok = (lane & 7) == 0 && myj[g] < nc;
+                            const int32_t oid = ok ? cand_id[myj[g]] : 0;
+                            mymeta[g] = ok ? a.qmeta[oid] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            myrn[g] = (a.metric == METRIC_COS && ok) ? a.row_norms[oid] : 0.0f;
+                            const int lj = j0 + 8 * g + lane;
+                            const int32_t ids8 = cand_id[(lane < 8 && lj < nc) ? lj : j0];  // past nc: a valid row, unused
+#pragma unroll
+                            for (int b = 0; b < 8; b++) {
+                                const int32_t rid = __builtin_amdgcn_readlane(ids8, b);
+                                const uint32_t *rp = a.qrows + (static_cast<int64_t>(rid) * kWave + lane) * NCH;
+#pragma unroll
+                                for (int cc = 0; cc < NCH; cc++) w[g][b][cc] = rp[cc];
+                            }
+                        }
+#pragma unroll
+                        for (int g = 0; g < G; g++) {
+                            if (j0 + 8 * g >= nc) break;
+                            int acc[8];
+#pragma unroll
+                            for (int b = 0; b < 8; b++) acc[b] = code_dot<NCH>(qc.a, w[g][b]);
+                            const int tot = wave_sum8_int(acc, lane);
+                            const bool ok = (lane & 7) == 0 && myj[g] < nc;
+                            const float lb = code_lower_bound<NCH>(a.metric, tot, qc, mymeta[g], myrn[g]);
+                            const bool need = ok && !(lb >= worst0);  // NaN: needs the exact distance
+                            if (ok) cand_d[myj[g]] = __uint_as_float(0x7f800000u);  // overwritten below if needed
+                            // bit 8r of the ballot = row r of the group
+                            const uint64_t m8 = ((__ballot(need) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56;
+                            wmask |= m8 << (j0 + 8 * g);
+                        }
+                    }
+                    if (NW > 1) {
+                        if (lane == 0 && wmask) {
+                            if (static_cast<uint32_t>(wmask)) atomicOr(reinterpret_cast<uint32_t *>(&sc[7]), static_cast<uint32_t>(wmask));
+                            if (wmask >> 32) atomicOr(reinterpret_cast<uint32_t *>(&sc[8]), static_cast<uint32_t>(wmask >> 32));
+                        }
+                        __syncthreads();
+                        needmask = static_cast<uint32_t>(sc[7]) | (static_cast<uint64_t>(static_cast<uint32_t>(sc[8])) << 32);
+                    } else {
+                        needmask = wmask;
+                    }
+                }
+                // ---- gather rows + distances of the neighbours that need them: wave w takes the needed candidates of
+                //      rank [w*RB + t*NW*RB, +RB) (all of them while the list is filling or without int8 rows)
+                HG_STAMP(8);  // rejection test (int8 rows)
+                const int nneed = __popcll(needmask);
+                n_exact += nneed;
+                const bool isset = (needmask >> lane) & 1ull;
+                const int rank = __popcll(needmask & ((1ull << lane) - 1ull));
+                for (int t0 = wave * RB; t0 < nneed; t0 += NW * RB) {
                     float4 r[RB][NCH];
-                    // lane b fetches candidate b's id and precomputed norm up front, so that the norm's memory
-                    // round trip overlaps the row gather instead of following the reduction
-                    const int myj = j0 + lane;
-                    const int32_t myid = (lane < RB && myj < nc) ? cand_id[myj] : 0;
-                    const float myrn = (a.metric == METRIC_COS && lane < RB && myj < nc) ? a.row_norms[myid] : 0.0f;
+                    // lane b takes the candidate of rank t0 + b; it fetches that candidate's id and precomputed norm up
+                    // front, so that the norm's memory round trip overlaps the row gather instead of following the reduction
+                    int myj = -1;
+#pragma unroll
+                    for (int b = 0; b < RB; b++) {
+                        const uint64_t hit = __ballot(isset && rank == t0 + b);
+                        const int jb = hit ? __ffsll(static_cast<unsigned long long>(hit)) - 1 : -1;
+                        myj = lane == b ? jb : myj;
+                    }
+                    const int32_t myid = myj >= 0 ? cand_id[myj] : 0;
+                    const float myrn = (a.metric == METRIC_COS && myj >= 0) ? a.row_norms[myid] : 0.0f;
 #pragma unroll
                     for (int b = 0; b < RB; b++) {
                         const int32_t rid = __builtin_amdgcn_readlane(myid, b);
-                        load_row<NCH>(r[b], a.rows + static_cast<int64_t>(rid) * a.ld, nvec, lane, j0 + b < nc);
+                        load_row<NCH>(r[b], a.rows + static_cast<int64_t>(rid) * a.ld, nvec, lane, t0 + b < nneed);
                     }
                     float s[RB];
 #pragma unroll
@@ -1030,7 +1345,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                     float mine = 0.0f;  // lane b keeps candidate b's reduced sum
 #pragma unroll
                     for (int b = 0; b < RB; b++) mine = lane == b ? s[b] : mine;
-                    if (lane < RB && myj < nc) cand_d[myj] = finish_dist(a.metric, mine, qn, myrn) + 0.0f;
+                    if (myj >= 0) cand_d[myj] = finish_dist(a.metric, mine, qn, myrn) + 0.0f;
                 }
                 __syncthreads();
                 HG_STAMP(2);  // row gather + distances
@@ -1040,8 +1355,6 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                 //      survivors only, and a hop without survivors skips the merge and its three barriers.
                 const float cdist = lane < nc ? cand_d[lane] : 0.0f;
                 const int cbits = __float_as_int(cdist);
-                const bool list_full = len >= ef_l;
-                const float worst0 = list_full ? __uint_as_float(curA[ef_l - 1].x) : 0.0f;
                 const bool surv = lane < nc && (!list_full || cdist < worst0);
                 const uint64_t smask = __ballot(surv);  // identical in every wave
                 if (smask == 0) {
@@ -1184,6 +1497,12 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
             a.stats[2 * static_cast<int64_t>(qi)] = n_eval;
             a.stats[2 * static_cast<int64_t>(qi) + 1] = n_hop;
         }
+#ifndef HG_HNSW_STAMPS
+        if (a.dbg && tid == 0) {
+            atomicAdd(a.dbg + 16, static_cast<unsigned long long>(n_exact));
+            atomicAdd(a.dbg + 17, static_cast<unsigned long long>(n_eval));
+        }
+#endif
         if (PF && tid == 0) coherent_store(mail + 2, a.pf_seq);  // the helpers may go
     }
     if (a.host_flag) {

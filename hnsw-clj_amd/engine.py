@@ -126,6 +126,20 @@ class Index:
         check(lib().hnswgpu_batch_distances(self._h, _p(q), _p(ids), m, _p(out)))
         return out
 
+    def set_rejection_test(self, mode):
+        """0 = off, 1 = large batches (default), 2 = every launch: int8 rejection test of the HNSW traversal."""
+        check(lib().hnswgpu_set_rejection_test(self._h, int(mode)))
+
+    def rejection_bounds(self, q, ids):
+        """Lower bounds of d(q, row) from the int8 rows of the HNSW traversal's rejection test (NaN = no bound)."""
+        q = _f32(q).reshape(-1)
+        if len(q) != self.dim:
+            raise ValueError("query has %d elements, index dim is %d" % (len(q), self.dim))
+        ids = np.ascontiguousarray(ids, np.int32)
+        out = np.empty(len(ids), np.float32)
+        check(lib().hnswgpu_rejection_bounds(self._h, _p(q), _p(ids), len(ids), _p(out)))
+        return out
+
     def norms(self):
         out = np.empty(self.n, np.float32)
         check(lib().hnswgpu_norms(self._h, _p(out)))

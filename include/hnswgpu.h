@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HNSWGPU_VERSION 102
+#define HNSWGPU_VERSION 103
 
 #define HNSWGPU_COSINE 0
 #define HNSWGPU_L2 1
@@ -226,6 +226,16 @@ int hnswgpu_load(const char *path, int32_t device, hnswgpu_index **out);
  * launch stream.  which: 0 = IVF list scan, 1 = HNSW traversal, 2 = k-means assignment scan.
  * Returns the accumulated kernel ms and launch count since the last reset (forces a stream sync). */
 int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
+/* The HNSW traversal decides most neighbours (those that cannot enter a full result list, ultra_fast.clj:195-198) from
+ * an int8 copy of the rows: a lower bound of the distance that is already >= the list's worst needs no f32 row
+ * (hnsw-clj_amd/csrc/kernels.hpp: quantize_rows_kernel; results and counters are unchanged by construction).  This
+ * entry returns those bounds for query q[dim] against rows ids[0..m) -- out[i] <= the distance hnswgpu_batch_distances
+ * reports for the same pair, NaN where the test abstains -- so the property can be checked from outside.
+ * hnswgpu_set_rejection_test: mode 0 = off (no int8 copy is made: saves n * dim bytes; the bounds entry then fails),
+ * 1 = launches of at least two queries per CU, where the traversal is bandwidth-bound (default), 2 = every launch.
+ * HNSWGPU_PREFILTER=<mode> in the environment sets the default of new handles.  Results never depend on the mode. */
+int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out);
+int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode);
 int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int64_t *launches, int32_t reset);
 
 #ifdef __cplusplus

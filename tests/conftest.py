@@ -7,6 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# The HNSW traversal's int8 rejection test is on by default only for launches that fill the chip; the parity tests use
+# small batches, so new handles in the test processes get it on EVERY launch (mode 2): every bit-for-bit comparison
+# against the oracle below then also proves that the test rejects nothing the reference would admit.
+# test_rejection_test_modes_agree covers modes 0 and 1.
+os.environ.setdefault("HNSWGPU_PREFILTER", "2")
 
 
 def pytest_configure(config):

@@ -534,6 +534,72 @@ def test_ivf_build_golden(eng, oracle, name):
         assert all(i in members for i in ids.ravel() if i >= 0)
 
 
+@pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
+def test_rejection_test_modes_agree(eng, oracle, metric):
+    """hnswgpu_set_rejection_test: off, large batches only, every launch -- ids, distance bits and the evals / hops
+    counters of a batch large enough for mode 1 to switch the test on (>= 2 queries per CU) are identical, and equal to
+    the oracle's on a subsample.  Clustered data with duplicates: ties at the list's worst are where a bound that was
+    merely "almost" a lower bound would show."""
+    O = oracle
+    base = _data(O, 20000, 40, "clustered", seed=21)
+    base[5000:5200] = base[100]                      # 200 copies of one row
+    Q = np.concatenate([_data(O, 1400, 40, "clustered", seed=22), base[100:101], base[5:45]]).astype(np.float32)
+    code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
+    with eng.Index(base, metric) as idx:
+        idx.hnsw_build(12, 60, 42)
+        res = {}
+        for mode in (0, 1, 2):
+            idx.set_rejection_test(mode)
+            res[mode] = idx.hnsw_search(Q, 10, 64, want_stats=True)
+        for mode in (1, 2):
+            np.testing.assert_array_equal(res[mode][0], res[0][0])
+            np.testing.assert_array_equal(res[mode][1].view(np.uint32), res[0][1].view(np.uint32))
+            np.testing.assert_array_equal(res[mode][2], res[0][2])
+        small = idx.hnsw_search(Q[:3], 10, 64, want_stats=True)   # mode 2, a latency-sized launch
+        np.testing.assert_array_equal(small[0], res[0][0][:3])
+        np.testing.assert_array_equal(small[2], res[0][2][:3])
+        g = idx.get_graph()
+        sub = np.r_[0:24, len(Q) - 41:len(Q)]
+        oi, od, ost, _ = O.hnsw_search(base, g, Q[sub], 10, ef=64, metric=code, mode=O.MODE_DEV)
+        assert_exact(res[2][0][sub], res[2][1][sub], oi, od, "rejection test vs oracle, %s" % metric)
+        np.testing.assert_array_equal(res[2][2][sub], ost)
+
+
+@pytest.mark.parametrize("dim", [24, 300, 768, 1024, 1536, 3072])
+@pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
+def test_rejection_bounds_never_exceed_the_distance(eng, metric, dim):
+    """The HNSW traversal skips the f32 row of a neighbour whose int8 lower bound is already >= the list's worst
+    (kernels.hpp: quantize_rows_kernel).  That is only exact if the bound never exceeds the distance the exact path
+    computes: checked for every row-loader width and metric on rows of very different scale, a zero row, a row with
+    one huge component, duplicates of the query, a zero query and a non-finite row -- and the bound must be TIGHT
+    (within 4 % of the distance scale), or the test would silently stop rejecting anything."""
+    rs = np.random.RandomState(dim)
+    n = 800
+    base = rs.randn(n, dim).astype(np.float32) * np.exp(rs.uniform(-6, 6, (n, 1))).astype(np.float32)
+    base[:200] = rs.randn(200, dim).astype(np.float32)          # a well-behaved block for the tightness check
+    base[200] = 0.0
+    base[201, 3] = 1.0e6
+    base[202] = base[5]
+    base[203, 1] = np.inf
+    base[204, 2] = np.nan
+    ids = np.arange(n, dtype=np.int32)
+    queries = [rs.randn(dim).astype(np.float32), base[5].copy(), (base[7] * 1000).astype(np.float32),
+               np.zeros(dim, np.float32), base[201].copy()]
+    with eng.Index(base, metric) as idx:
+        for qi, q in enumerate(queries):
+            lb = idx.rejection_bounds(q, ids)
+            d = idx.batch_distances(q, ids)
+            ok = ~np.isnan(lb)
+            assert np.all(lb[ok] <= d[ok]), "metric %s dim %d query %d: bound above the distance at rows %s" % (
+                metric, dim, qi, np.nonzero(ok & ~(lb <= d))[0][:8])
+            assert np.isnan(lb[203]) and np.isnan(lb[204])            # non-finite rows abstain
+            if qi == 0:                                               # tightness on the well-behaved block
+                qn, vn = np.linalg.norm(q), np.linalg.norm(base[:200], axis=1)
+                scale = {"cosine": 1.0, "dot": qn * vn, "l2": qn + vn}[metric]
+                gap = (d[:200] - lb[:200]) / scale
+                assert ok[:200].all() and gap.max() < 0.04, gap.max()
+
+
 @pytest.mark.parametrize("n,dim,nlist,metric", [(6000, 48, 40, 0), (3000, 100, 17, 2), (2500, 32, 12, 1)])
 def test_ivf_build_exact_in_engine_arithmetic(eng, oracle, n, dim, nlist, metric):
     """hnswgpu_ivf_build against the oracle's restatement of the SAME arithmetic (f32 distances in kernel order,

@@ -26,8 +26,9 @@ buf = torch.zeros(12, dtype=torch.int64, device=dev)
 L = _native.lib()
 L.hnswgpu_debug_set_tile_stamps.argtypes = [C.c_void_p]
 L.hnswgpu_debug_set_tile_stamps(buf.data_ptr())
-names = ["level set-up", "select+adjacency+visited", "row gather+distances", "merge 1 (rank)", "merge 2 (admit)",
-         "merge 3 (scatter)", "epilogue"]
+names = ["level set-up", "select+adjacency+visited", "rejection test (int8 rows)", "f32 row gather+distances", "merge 1 (rank)",
+         "merge 2 (admit)", "merge 3 (scatter)", "epilogue"]
+slots = [0, 1, 8, 2, 3, 4, 5, 6]
 for rep in range(3):
     lat = []
     for i in range(20):
@@ -37,9 +38,9 @@ for rep in range(3):
         lat.append((time.perf_counter() - t0) * 1e3)
     b = buf.cpu().numpy()
     hops = int(b[7])
-    tot = float(b[:7].sum()) * 10e-3  # us
+    tot = float(b[slots].sum()) * 10e-3  # us
     print("nq=%d ef=%d hops=%d kernel-side total %.1f us (%.2f us/hop)  wall p50 %.3f ms" % (
         nq, ef, hops, tot, tot / max(hops, 1), sorted(lat)[10]))
     print("   shader clock during the query: %.0f MHz (%d cycles in %.1f us)" % (b[10] / max(b[11] * 10e-3, 1e-9), b[10], b[11] * 10e-3))
-    for n, v in zip(names, b[:7]):
-        print("   %-28s %8.1f us  %5.1f %%   %.2f us/hop" % (n, v * 10e-3, 100.0 * v / max(b[:7].sum(), 1), v * 10e-3 / max(hops, 1)))
+    for n, v in zip(names, b[slots]):
+        print("   %-28s %8.1f us  %5.1f %%   %.2f us/hop" % (n, v * 10e-3, 100.0 * v / max(b[slots].sum(), 1), v * 10e-3 / max(hops, 1)))
