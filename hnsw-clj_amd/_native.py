@@ -79,6 +79,7 @@ _SIGS = {
     "hnswgpu_get_profile": ["p", "i32", "p", "p", "i32"],
     "hnswgpu_rejection_bounds": ["p", "p", "p", "i32", "p"],
     "hnswgpu_set_rejection_test": ["p", "i32"],
+    "hnswgpu_get_rejection_stats": ["p", "p", "p", "i32"],
 }
 _T = {"p": C.c_void_p, "i32": C.c_int32, "i64": C.c_int64}
 

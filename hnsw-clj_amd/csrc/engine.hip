@@ -1138,7 +1138,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows in place: freed once, below
-    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
+    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_rej_stats, idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
                     idx->d_cent,  idx->d_cnorms, idx->d_lrows,  idx->d_lnorms,  idx->d_listoff, idx->d_listids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1587,6 +1587,11 @@ int hnswgpu_debug_set_tile_stamps(void *device_buffer) {
 int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on) {
     HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
     std::lock_guard<std::mutex> lk(idx->mu);
+    if (on && !idx->d_rej_stats) {
+        HG_HIP(hipSetDevice(idx->device));
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_rej_stats), 2 * sizeof(unsigned long long)));
+        HG_HIP(hipMemset(idx->d_rej_stats, 0, 2 * sizeof(unsigned long long)));
+    }
     idx->prof = on != 0;
     return 0;
 }
@@ -1611,6 +1616,21 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
         idx->prof_ms[which] = 0;
         idx->prof_cnt[which] = 0;
     }
+    return 0;
+}
+
+int hnswgpu_get_rejection_stats(hnswgpu_index *idx, int64_t *f32_rows, int64_t *neighbours, int32_t reset) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    unsigned long long v[2] = {0, 0};
+    if (idx->d_rej_stats) {
+        HG_HIP(hipDeviceSynchronize());  // measurement only: every stream that may still be counting
+        HG_HIP(hipMemcpy(v, idx->d_rej_stats, sizeof(v), hipMemcpyDeviceToHost));
+        if (reset) HG_HIP(hipMemset(idx->d_rej_stats, 0, sizeof(v)));
+    }
+    if (f32_rows) *f32_rows = static_cast<int64_t>(v[0]);
+    if (neighbours) *neighbours = static_cast<int64_t>(v[1]);
     return 0;
 }
 

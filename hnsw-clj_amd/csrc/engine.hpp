@@ -86,6 +86,7 @@ struct hnswgpu_index {
     // quantize_rows_kernel); made when a graph is installed or built, null while rejection_mode is 0
     uint32_t *d_qrows = nullptr;
     float4 *d_qmeta = nullptr;
+    unsigned long long *d_rej_stats = nullptr;  // [2], counted by the traversal while profiling is on
     int rejection_mode = 1;  // 0 = off, 1 = batches that fill the chip (launch_hnsw_idx), 2 = every launch
     int cus = 256;
     hipStream_t stream = nullptr;

@@ -50,6 +50,7 @@ constexpr int kPfMaxQueries = 16;  // beyond a handful of queries the chip is bu
 
 int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions
+    a.rej_stats = idx->prof ? idx->d_rej_stats : nullptr;
     if (a.nq <= 0) return 0;
     const int nch = idx->nch;
     // The rejection test on int8 rows (kernels.hpp: quantize_rows_kernel) turns one memory round trip per hop into two

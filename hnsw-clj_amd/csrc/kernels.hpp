@@ -979,8 +979,8 @@ struct HnswArgs {
     // int8 copy of the rows for the rejection test (quantize_rows_kernel); null = every neighbour is evaluated in f32
     const uint32_t *qrows;
     const float4 *qmeta;
-    unsigned long long *dbg;  // diagnostic sessions: [16] += f32 rows fetched, [17] += neighbours evaluated;
-                              // -DHG_HNSW_STAMPS builds: per-phase s_memrealtime totals in [0..11]
+    unsigned long long *rej_stats;  // profiling: [0] += f32 rows fetched, [1] += neighbours evaluated (null otherwise)
+    unsigned long long *dbg;  // -DHG_HNSW_STAMPS diagnostic builds only: per-phase s_memrealtime totals
 };
 
 #ifdef HG_HNSW_STAMPS
@@ -1497,12 +1497,10 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
             a.stats[2 * static_cast<int64_t>(qi)] = n_eval;
             a.stats[2 * static_cast<int64_t>(qi) + 1] = n_hop;
         }
-#ifndef HG_HNSW_STAMPS
-        if (a.dbg && tid == 0) {
-            atomicAdd(a.dbg + 16, static_cast<unsigned long long>(n_exact));
-            atomicAdd(a.dbg + 17, static_cast<unsigned long long>(n_eval));
+        if (a.rej_stats && tid == 0) {
+            atomicAdd(a.rej_stats, static_cast<unsigned long long>(n_exact));
+            atomicAdd(a.rej_stats + 1, static_cast<unsigned long long>(n_eval));
         }
-#endif
         if (PF && tid == 0) coherent_store(mail + 2, a.pf_seq);  // the helpers may go
     }
     if (a.host_flag) {

@@ -130,6 +130,12 @@ class Index:
         """0 = off, 1 = large batches (default), 2 = every launch: int8 rejection test of the HNSW traversal."""
         check(lib().hnswgpu_set_rejection_test(self._h, int(mode)))
 
+    def rejection_stats(self, reset=True):
+        """(f32 rows fetched, neighbours evaluated) by the HNSW traversals since the last reset, while profiling was on."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(lib().hnswgpu_get_rejection_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return a.value, b.value
+
     def rejection_bounds(self, q, ids):
         """Lower bounds of d(q, row) from the int8 rows of the HNSW traversal's rejection test (NaN = no bound)."""
         q = _f32(q).reshape(-1)

@@ -547,10 +547,18 @@ def test_rejection_test_modes_agree(eng, oracle, metric):
     code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
     with eng.Index(base, metric) as idx:
         idx.hnsw_build(12, 60, 42)
-        res = {}
+        res, rows = {}, {}
+        idx.set_profiling(True)
         for mode in (0, 1, 2):
             idx.set_rejection_test(mode)
+            idx.rejection_stats(reset=True)
             res[mode] = idx.hnsw_search(Q, 10, 64, want_stats=True)
+            rows[mode] = idx.rejection_stats(reset=True)
+        idx.set_profiling(False)
+        # the counters: without the test every neighbour costs an f32 row, with it a minority does (and mode 1 did
+        # switch it on for this batch); `neighbours` is the evals counter of the stats
+        assert rows[0][1] == rows[2][1] == int(res[0][2][:, 0].sum())
+        assert rows[0][0] > 0.8 * rows[0][1] and rows[2][0] < 0.85 * rows[0][0] and rows[1] == rows[2], rows
         for mode in (1, 2):
             np.testing.assert_array_equal(res[mode][0], res[0][0])
             np.testing.assert_array_equal(res[mode][1].view(np.uint32), res[0][1].view(np.uint32))
