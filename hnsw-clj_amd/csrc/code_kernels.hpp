@@ -1,0 +1,277 @@
+// code_kernels.hpp -- the IVF list scan on int8 rows: bounds first, f32 only where it can matter.
+//
+// search-partition scores every row of every probed list in f32 (ivf_flat.clj:217-234) and search-ivf-flat keeps the k
+// smallest (:291-294): 96 MB of rows per query at 1M x 768 / nprobe 32 to find ten of them.  Which ten can be decided
+// from a quarter of the bytes.  Every list row also exists as int8 codes with its exact residual (kernels.hpp,
+// quantize_rows_kernel -- the same codes and bounds as the HNSW traversal's rejection test), so for every candidate
+//     lb <= d_f32(q, v) <= ub        from one exact integer dot product (v_dot4c_i32_i8).
+// Pipeline of a batch (ivf.hip: ivf_code_scan):
+//   1. code_group_kernel: lb of every (query, candidate) into the dense candidate array (position = order key);
+//   2. select_topk_kernel on the lb values; ivf_tau_kernel: tau_q = the largest ub among the k smallest lb.  At least
+//      k candidates have d <= ub <= tau_q, so the k-th smallest distance D_k <= tau_q;
+//   3. ivf_refine_kernel: a candidate with lb > tau_q has d >= lb > tau_q >= D_k and cannot be among the k nearest --
+//      nor tie with the k-th -- and becomes +inf; every other candidate ("survivor": NaN bounds included) gets its
+//      distance by the GEMV scan's own arithmetic (lane_partial + wave butterfly + finish_dist), bit for bit;
+//   4. select_topk_kernel again: the k smallest (distance, order key) -- exactly the result of scanning everything in
+//      f32, because every candidate with d <= D_k is a survivor and carries the same bits as scan_kernel would give it.
+// One summation order (the GEMV order) for every batch size.
+#pragma once
+#include "kernels.hpp"
+#include "tile_args.hpp"
+
+namespace hg {
+
+// codes + bound scalars of a batch of queries: one wave per query.  Codes in [c][lane] order (conflict-free LDS reads)
+template <int NCH>
+__global__ __launch_bounds__(kWG) void quantize_queries_kernel(const float *Q, int64_t qld, int dim, int nq,
+                                                               uint32_t *qcodes, QueryScal *qscal) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int qi = blockIdx.x * kNWave + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    float4 q[NCH];
+    load_query<NCH>(q, Q + static_cast<int64_t>(qi) * qld, dim, lane);
+    QueryCode<NCH> qc;
+    encode_query<NCH>(q, qc);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) qcodes[(static_cast<int64_t>(qi) * NCH + c) * kWave + lane] = qc.a[c];
+    if (lane == 0) qscal[qi] = qc.sc;
+}
+
+__host__ inline size_t code_group_lds_bytes(int nch) {
+    return sizeof(uint32_t) * kTileQ * nch * kWave + sizeof(int64_t) * kTileQ + sizeof(int32_t) * kTileQ +
+           sizeof(QueryScal) * kTileQ;
+}
+
+// Same groups, work list and output positions as tile_scan_kernel / l2_group_kernel (TileArgs): a workgroup keeps the
+// codes of a group of <= 32 queries in LDS, every wave holds eight code rows in registers and walks the group's queries
+// over them; a row is fetched once per group.  Per eight (row, query) pairs: 8 * NCH v_dot4c, one halving reduction
+// (wave_sum8_int), the bound in the eight lanes that own a row, one store.
+template <int NCH>
+__global__ __launch_bounds__(kTileThreads) void code_group_kernel(TileArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *qc_s = reinterpret_cast<uint32_t *>(smem);                                  // [32][NCH][64]
+    int64_t *ob_s = reinterpret_cast<int64_t *>(qc_s + kTileQ * NCH * kWave);             // [32] output bases
+    int32_t *qi_s = reinterpret_cast<int32_t *>(ob_s + kTileQ);                           // [32] query index (-1 = empty)
+    QueryScal *qs_s = reinterpret_cast<QueryScal *>(qi_s + kTileQ);                       // [32]
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+    // ---- work item -> (group, chunk): identical to tile_scan_kernel (XCD-contiguous slices of the work list)
+    const int nitems = *a.nitems;
+    const int per_xcd = (nitems + 7) >> 3;
+    const int slot = blockIdx.x >> 3;
+    if (slot >= per_xcd) return;
+    const int item = (blockIdx.x & 7) * per_xcd + slot;
+    if (item >= nitems) return;
+    const int g = a.wi_group[item];
+    const int chunk = a.wi_chunk[item];
+    if (g >= *a.ngroups) return;
+    const int seg = a.grp_seg[g];
+    const int64_t rb0 = a.seg_off[seg], rb1 = a.seg_off[seg + 1];
+    const int cnt = a.grp_mem_cnt[g];
+    const int64_t tiles = (rb1 - rb0 + kTileRows - 1) / kTileRows;
+    const int64_t nch = tile_nchunks(rb1 - rb0, a.chunk_rows, a.nchunks);
+    if (chunk >= nch) return;
+    const int64_t per = (tiles + nch - 1) / nch * kTileRows;
+    const int64_t r0 = rb0 + static_cast<int64_t>(chunk) * per;
+    const int64_t r1 = r0 + per < rb1 ? r0 + per : rb1;
+    if (r0 >= r1 || cnt <= 0) return;
+
+    if (tid < kTileQ) {
+        int qi = -1;
+        int64_t ob = -1;
+        if (tid < cnt) {
+            const GroupMember m = a.members[a.grp_mem_begin[g] + tid];
+            qi = m.q;
+            ob = m.out_base;
+            qs_s[tid] = a.qscal[qi];
+        }
+        qi_s[tid] = qi;
+        ob_s[tid] = ob;
+    }
+    __syncthreads();
+    for (int f = tid; f < cnt * NCH * kWave; f += kTileThreads) {
+        const int s = f / (NCH * kWave);
+        qc_s[f] = a.qcodes[static_cast<int64_t>(qi_s[s]) * NCH * kWave + (f - s * NCH * kWave)];
+    }
+    __syncthreads();
+
+    const int own = wave_sum8_row(lane);  // the row of a block whose total this lane receives
+    const bool owner = (lane & 7) == 0;
+    for (int64_t base = r0 + wave * 8; base < r1; base += kTileWaves * 8) {
+        const int64_t myrow = base + own;
+        const bool mine_ok = owner && myrow < r1;
+        const float4 mymeta = mine_ok ? a.cmeta[myrow] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float myrn = (a.metric == METRIC_COS && mine_ok) ? a.row_norms[myrow] : 0.0f;
+        uint32_t w[8][NCH];
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const int64_t row = base + b < r1 ? base + b : r1 - 1;
+            const uint32_t *rp = a.crows + (row * kWave + lane) * NCH;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) w[b][c] = rp[c];
+        }
+        for (int q = 0; q < cnt; q++) {
+            uint32_t qa[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) qa[c] = qc_s[(q * NCH + c) * kWave + lane];
+            int acc[8];
+#pragma unroll
+            for (int b = 0; b < 8; b++) acc[b] = code_dot<NCH>(qa, w[b]);
+            const int tot = wave_sum8_int(acc, lane);
+            if (mine_ok) a.out[ob_s[q] + (myrow - rb0)] = code_lower_bound(a.metric, tot, qs_s[q], mymeta, myrn);
+        }
+    }
+}
+
+struct TauArgs {
+    const uint32_t *ord;   // [nq][k] order keys of the k smallest lower bounds (0xffffffff = none)
+    const float *lb;       // [nq][k]
+    const Pair *pairs;     // [nq][nprobe]
+    int32_t nq, k, nprobe;
+    int32_t metric;
+    const uint32_t *crows;
+    const float4 *cmeta;
+    const float *row_norms;
+    const uint32_t *qcodes;
+    const QueryScal *qscal;
+    float *tau;            // [nq]
+};
+
+// tau_q = the largest upper bound among the k candidates with the smallest lower bounds (+inf if there are fewer than k
+// candidates with a bound): one wave per query, eight candidates per step, bounds recomputed from the codes.
+template <int NCH>
+__global__ __launch_bounds__(kWave) void ivf_tau_kernel(TauArgs a) {
+    const int lane = threadIdx.x;
+    const int qi = blockIdx.x;
+    const uint32_t *ord = a.ord + static_cast<int64_t>(qi) * a.k;
+    const float *lbv = a.lb + static_cast<int64_t>(qi) * a.k;
+    const Pair *pp = a.pairs + static_cast<int64_t>(qi) * a.nprobe;
+    uint32_t qa[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) qa[c] = a.qcodes[(static_cast<int64_t>(qi) * NCH + c) * kWave + lane];
+    const QueryScal qs = a.qscal[qi];
+    const int own = wave_sum8_row(lane);
+    float tau = -__builtin_inff();
+    bool open = false;  // a slot of the top k without a usable bound: no candidate can be excluded
+    for (int j0 = 0; j0 < a.k; j0 += 8) {
+        // lane b < 8 resolves candidate j0 + b to its list row
+        int64_t myrow = -1;
+        if (lane < 8 && j0 + lane < a.k) {
+            const uint32_t o = ord[j0 + lane];
+            const float l = lbv[j0 + lane];
+            if (o != 0xffffffffu && l == l) {
+                int p = 0;
+                while (p + 1 < a.nprobe && pp[p + 1].ord_base <= o) p++;  // as ivf_decode_kernel
+                myrow = pp[p].row_begin + (o - pp[p].ord_base);
+            }
+        }
+        if (__ballot(lane < 8 && j0 + lane < a.k && myrow < 0)) open = true;
+        int acc[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const int64_t row = __shfl(myrow, b, kWave);
+            const uint32_t *rp = a.crows + ((row >= 0 ? row : 0) * kWave + lane) * NCH;
+            uint32_t w[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) w[c] = rp[c];
+            acc[b] = code_dot<NCH>(qa, w);
+        }
+        const int tot = wave_sum8_int(acc, lane);
+        const int64_t orow = __shfl(myrow, own, kWave);
+        float ub = -__builtin_inff();
+        if ((lane & 7) == 0 && orow >= 0) {
+            float lb;
+            code_bounds(a.metric, tot, qs, a.cmeta[orow], a.metric == METRIC_COS ? a.row_norms[orow] : 0.0f, lb, ub);
+            if (!(ub == ub)) ub = __builtin_inff();
+        }
+        for (int off = 1; off < kWave; off <<= 1) {
+            const float o = __shfl_xor(ub, off, kWave);
+            ub = o > ub ? o : ub;
+        }
+        tau = ub > tau ? ub : tau;
+    }
+    if (lane == 0) a.tau[qi] = open ? __builtin_inff() : tau;
+}
+
+struct RefineArgs {
+    float *dist;            // dense candidate array: lower bounds in, distances (or +inf) out
+    const int32_t *q_cnt;   // candidates per query
+    int64_t stride;
+    const float *tau;
+    const Pair *pairs;
+    int32_t nq, nprobe;
+    int32_t chunk;          // candidates per workgroup (multiple of 64 * waves)
+    int32_t nchunks;
+    const float *rows;      // list rows, f32
+    const float *row_norms;
+    int64_t ld;
+    const float *Q;
+    int64_t qld;
+    int32_t dim;
+    int32_t metric;
+    unsigned long long *stats;  // optional: [0] += survivors, [1] += candidates
+};
+
+// Step 3 of the pipeline.  Workgroup = (query, slice of its candidates); a wave looks at 64 candidates at a time and
+// computes the distance of each survivor with all 64 lanes (RB survivors in flight).
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void ivf_refine_kernel(RefineArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x / a.nchunks, ch = blockIdx.x % a.nchunks;
+    const int cnt = a.q_cnt[qi];
+    const int c0 = ch * a.chunk;
+    if (c0 >= cnt) return;
+    const int c1 = c0 + a.chunk < cnt ? c0 + a.chunk : cnt;
+    float *d = a.dist + static_cast<int64_t>(qi) * a.stride;
+    const Pair *pp = a.pairs + static_cast<int64_t>(qi) * a.nprobe;
+    const float tau = a.tau[qi];
+    const int nvec = static_cast<int>(a.ld / 4);
+    float4 q[NCH];
+    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+    const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+    int p = 0;  // the pair the current candidates belong to (candidates ascend)
+    unsigned long long nsurv = 0;
+    for (int base = c0 + wave * kWave; base < c1; base += kNWave * kWave) {
+        const int i = base + lane;
+        const float l = i < c1 ? d[i] : __builtin_inff();
+        const bool surv = i < c1 && !(l > tau);  // NaN (no bound) survives
+        uint64_t m = __ballot(surv);
+        nsurv += __popcll(m);
+        float mine = __builtin_inff();
+        while (m) {
+            float4 r[RB][NCH];
+            int js[RB];
+            float rn[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                js[b] = -1;
+                rn[b] = 0.0f;
+                if (m) {
+                    js[b] = __ffsll(static_cast<unsigned long long>(m)) - 1;
+                    m &= m - 1;
+                    const uint32_t o = static_cast<uint32_t>(base + js[b]);
+                    while (p + 1 < a.nprobe && pp[p + 1].ord_base <= o) p++;
+                    const int64_t row = pp[p].row_begin + (o - pp[p].ord_base);
+                    load_row<NCH>(r[b], a.rows + row * a.ld, nvec, lane, true);
+                    rn[b] = a.metric == METRIC_COS ? a.row_norms[row] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                if (js[b] < 0) break;
+                const float s = wave_sum(lane_partial<NCH, L2>(q, r[b]));
+                const float dv = finish_dist(a.metric, s, qn, rn[b]) + 0.0f;
+                mine = lane == js[b] ? dv : mine;
+            }
+        }
+        if (i < c1) d[i] = mine;
+    }
+    if (a.stats && lane == 0) {
+        atomicAdd(a.stats, nsurv);
+        if (wave == 0) atomicAdd(a.stats + 1, static_cast<unsigned long long>(c1 - c0));
+    }
+}
+
+}  // namespace hg

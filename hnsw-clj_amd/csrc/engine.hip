@@ -15,6 +15,7 @@
 #include "engine.hpp"
 #include "tile_kernels.hpp"
 #include "l2_kernels.hpp"
+#include "code_kernels.hpp"
 
 namespace hg {
 
@@ -39,32 +40,6 @@ int pick_nch(int64_t ld) {
 static int rb_of(int nch) { return nch <= 3 ? 8 : (nch <= 6 ? 4 : 2); }
 int scan_rows_per_iter(int nch) { return kNWave * rb_of(nch); }
 
-#define HG_DISPATCH(nch, l2, CALL)                                        \
-    do {                                                                  \
-        if (l2) {                                                         \
-            switch (nch) {                                                \
-                case 1: CALL(1, 8, true); break;                          \
-                case 2: CALL(2, 8, true); break;                          \
-                case 3: CALL(3, 8, true); break;                          \
-                case 4: CALL(4, 4, true); break;                          \
-                case 6: CALL(6, 4, true); break;                          \
-                case 8: CALL(8, 2, true); break;                          \
-                case 12: CALL(12, 2, true); break;                        \
-                default: set_error("unsupported row length"); return HNSWGPU_ELIMIT; \
-            }                                                             \
-        } else {                                                          \
-            switch (nch) {                                                \
-                case 1: CALL(1, 8, false); break;                         \
-                case 2: CALL(2, 8, false); break;                         \
-                case 3: CALL(3, 8, false); break;                         \
-                case 4: CALL(4, 4, false); break;                         \
-                case 6: CALL(6, 4, false); break;                         \
-                case 8: CALL(8, 2, false); break;                         \
-                case 12: CALL(12, 2, false); break;                       \
-                default: set_error("unsupported row length"); return HNSWGPU_ELIMIT; \
-            }                                                             \
-        }                                                                 \
-    } while (0)
 
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st) {
     if (n <= 0) return 0;
@@ -76,16 +51,59 @@ int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, 
     return 0;
 }
 
+// int8 codes + per-row bound terms of `n` rows (kernels.hpp: quantize_rows_kernel)
+static int quantize_rows(hnswgpu_index *idx, const float *rows, int64_t n, uint32_t **crows, float4 **cmeta, hipStream_t st) {
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(crows), sizeof(uint32_t) * kWave * idx->nch * n));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(cmeta), sizeof(float4) * n));
+    unsigned grid = static_cast<unsigned>((n + kNWave - 1) / kNWave);
+#define CALL(N, R, L) \
+    hipLaunchKernelGGL((quantize_rows_kernel<N>), dim3(grid), dim3(kWG), 0, st, rows, idx->ld, n, idx->metric, *crows, *cmeta)
+    HG_DISPATCH(idx->nch, false, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
 // The int8 rows of the traversal's rejection test: once per handle (the base rows never change), on the first graph.
 int ensure_qrows(hnswgpu_index *idx, hipStream_t st) {
     if (idx->rejection_mode == 0 || idx->d_qrows || idx->n <= 0) return 0;
-    const int64_t n = idx->n;
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_qrows), sizeof(uint32_t) * kWave * idx->nch * n));
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_qmeta), sizeof(float4) * n));
-    unsigned grid = static_cast<unsigned>((n + kNWave - 1) / kNWave);
-#define CALL(N, R, L) \
-    hipLaunchKernelGGL((quantize_rows_kernel<N>), dim3(grid), dim3(kWG), 0, st, idx->d_base, idx->ld, n, idx->metric, idx->d_qrows, idx->d_qmeta)
-    HG_DISPATCH(idx->nch, false, CALL);
+    if (idx->lrows_alias && idx->d_lcrows) {  // the IVF lists are the base rows in place and already coded
+        idx->d_qrows = idx->d_lcrows;
+        idx->d_qmeta = idx->d_lcmeta;
+        return 0;
+    }
+    HG_TRY(quantize_rows(idx, idx->d_base, idx->n, &idx->d_qrows, &idx->d_qmeta, st));
+    if (idx->lrows_alias && idx->nlist > 0 && !idx->d_lcrows) {
+        idx->d_lcrows = idx->d_qrows;
+        idx->d_lcmeta = idx->d_qmeta;
+    }
+    return 0;
+}
+
+// ... and of the IVF list scan's bounds pass (code_kernels.hpp): once per set of lists.
+int ensure_list_codes(hnswgpu_index *idx, hipStream_t st) {
+    if (idx->rejection_mode == 0 || idx->d_lcrows || idx->n <= 0 || idx->nlist <= 0) return 0;
+    if (idx->lrows_alias) {
+        HG_TRY(ensure_qrows(idx, st));  // one copy serves both (it sets d_lcrows)
+        return 0;
+    }
+    return quantize_rows(idx, idx->d_lrows, idx->n, &idx->d_lcrows, &idx->d_lcmeta, st);
+}
+
+int launch_code_group(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st) {
+    int64_t blocks = (ngroups_bound * a.nchunks + 7) & ~7LL;
+    if (blocks <= 0) return 0;
+    HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "code scan grid too large");
+    const size_t lds = code_group_lds_bytes(nch);
+#define CALL(N, R, L)                                                                                                  \
+    do {                                                                                                               \
+        static bool attr_done[64] = {};                                                                                \
+        if (lds > 48 * 1024 && attr_needed(attr_done))                                                                 \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&code_group_kernel<N>),                          \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
+        hipLaunchKernelGGL((code_group_kernel<N>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, a); \
+    } while (0)
+    HG_DISPATCH(nch, false, CALL);
 #undef CALL
     HG_HIP(hipGetLastError());
     return 0;
@@ -870,10 +888,10 @@ static int tile_argmin_all(hnswgpu_index *idx, const float *Qp, const float *q_n
 }
 
 int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int32_t nq, const float *rows,
-                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot) {
+                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot, bool gemv_order) {
     HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * k));
     HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * k));
-    if (k == 1) return tile_argmin_all(idx, Qp, q_norms, nq, rows, row_norms, nrows, st, prof_slot);
+    if (k == 1 && !gemv_order) return tile_argmin_all(idx, Qp, q_norms, nq, rows, row_norms, nrows, st, prof_slot);
     // distance scratch [qb][nrows]; bound it to ~2 GiB by batching the queries
     const int tq = tile_tq(idx->dim);
     int64_t qb = std::max<int64_t>(tq, ((2LL << 30) / (4 * std::max<int64_t>(nrows, 1))) / tq * tq);
@@ -893,6 +911,7 @@ int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int
         t.nrows_all = nrows;
         t.nq = nb;
         t.out_stride = nrows;
+        t.gemv_order = gemv_order ? 1 : 0;
         int64_t groups = (nb + tq - 1) / tq;
         int64_t tiles = (nrows + kTileRows - 1) / kTileRows;
         int64_t want = std::max<int64_t>(1, std::min<int64_t>(tiles, (2048 + groups - 1) / groups));
@@ -1138,7 +1157,8 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows in place: freed once, below
-    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_rej_stats, idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
+    if (idx->d_lcrows == idx->d_qrows) idx->d_lcrows = nullptr, idx->d_lcmeta = nullptr;  // one copy serving both
+    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_lcrows, idx->d_lcmeta, idx->d_rej_stats, idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
                     idx->d_cent,  idx->d_cnorms, idx->d_lrows,  idx->d_lnorms,  idx->d_listoff, idx->d_listids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1569,10 +1589,11 @@ int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode) {
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     idx->rejection_mode = mode;
-    if (mode != 0 && idx->has_graph) {  // an index that has a graph gets its int8 rows now, any other with its graph
+    if (mode != 0 && (idx->has_graph || idx->nlist > 0)) {  // int8 rows now for what exists, else with the graph / lists
         hipStream_t st = idx->stream;
         HG_TRY(begin_call(idx, st));
-        HG_TRY(ensure_qrows(idx, st));
+        if (idx->has_graph) HG_TRY(ensure_qrows(idx, st));
+        HG_TRY(ensure_list_codes(idx, st));
         HG_TRY(end_call(idx, st));
         HG_HIP(hipStreamSynchronize(st));
     }

@@ -86,6 +86,10 @@ struct hnswgpu_index {
     // quantize_rows_kernel); made when a graph is installed or built, null while rejection_mode is 0
     uint32_t *d_qrows = nullptr;
     float4 *d_qmeta = nullptr;
+    // the same for the IVF list rows (list order; code_kernels.hpp); alias d_qrows / d_qmeta when the lists are the
+    // base rows in place
+    uint32_t *d_lcrows = nullptr;
+    float4 *d_lcmeta = nullptr;
     unsigned long long *d_rej_stats = nullptr;  // [2], counted by the traversal while profiling is on
     int rejection_mode = 1;  // 0 = off, 1 = batches that fill the chip (launch_hnsw_idx), 2 = every launch
     int cus = 256;
@@ -184,8 +188,38 @@ int pick_nch(int64_t ld);  // 0 if unsupported
 bool attr_needed(bool (&done)[64]);
 
 // launch wrappers (engine.hip / hnsw.hip)
+// CALL(NCH, RB, L2) for the row-loader width `nch` (pick_nch) -- every kernel template's dispatch
+#define HG_DISPATCH(nch, l2, CALL)                                        \
+    do {                                                                  \
+        if (l2) {                                                         \
+            switch (nch) {                                                \
+                case 1: CALL(1, 8, true); break;                          \
+                case 2: CALL(2, 8, true); break;                          \
+                case 3: CALL(3, 8, true); break;                          \
+                case 4: CALL(4, 4, true); break;                          \
+                case 6: CALL(6, 4, true); break;                          \
+                case 8: CALL(8, 2, true); break;                          \
+                case 12: CALL(12, 2, true); break;                        \
+                default: set_error("unsupported row length"); return HNSWGPU_ELIMIT; \
+            }                                                             \
+        } else {                                                          \
+            switch (nch) {                                                \
+                case 1: CALL(1, 8, false); break;                         \
+                case 2: CALL(2, 8, false); break;                         \
+                case 3: CALL(3, 8, false); break;                         \
+                case 4: CALL(4, 4, false); break;                         \
+                case 6: CALL(6, 4, false); break;                         \
+                case 8: CALL(8, 2, false); break;                         \
+                case 12: CALL(12, 2, false); break;                       \
+                default: set_error("unsupported row length"); return HNSWGPU_ELIMIT; \
+            }                                                             \
+        }                                                                 \
+    } while (0)
+
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);
 int ensure_qrows(hnswgpu_index *idx, hipStream_t st);
+int ensure_list_codes(hnswgpu_index *idx, hipStream_t st);
+int launch_code_group(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st);
 int launch_scan(int nch, const ScanArgs &a, hipStream_t st);
 int launch_merge(const MergeArgs &a, hipStream_t st);
 // Serve `me` through combiner `c`: queue it, lead one batch at a time while it is not done.  `take(first, r, total)`
@@ -232,7 +266,7 @@ int launch_select(const SelectArgs &a, hipStream_t st);
 int pad_queries(hnswgpu_index *idx, const float *d_Q, int64_t qld, int32_t nq, hipStream_t st);
 // every query against rows [0, nrows): per-query ascending top-k into s_ord / s_dist
 int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int32_t nq, const float *rows,
-                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot);
+                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot, bool gemv_order = false);
 
 // Every entry point brackets its device work with these: a call on stream B waits for the previous
 // call's work on stream A before it may reuse the index's scratch buffers.

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "engine.hpp"
+#include "code_kernels.hpp"
 #include "javarandom.hpp"
 
 namespace hg {
@@ -281,10 +282,14 @@ static int validate_lists(int64_t n, int32_t nlist, const int64_t *off, const in
 
 static void free_ivf(hnswgpu_index *idx) {
     if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows themselves: not ours to free
-    void *ptrs[] = {idx->d_cent, idx->d_cnorms, idx->d_lrows, idx->d_lnorms, idx->d_listoff, idx->d_listids, idx->d_glistoff};
+    if (idx->d_lcrows == idx->d_qrows) idx->d_lcrows = nullptr, idx->d_lcmeta = nullptr;  // the traversal's copy: stays
+    void *ptrs[] = {idx->d_cent, idx->d_cnorms, idx->d_lrows, idx->d_lnorms, idx->d_listoff, idx->d_listids, idx->d_glistoff,
+                    idx->d_lcrows, idx->d_lcmeta};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     idx->d_cent = idx->d_cnorms = idx->d_lrows = idx->d_lnorms = nullptr;
+    idx->d_lcrows = nullptr;
+    idx->d_lcmeta = nullptr;
     idx->d_listoff = idx->d_glistoff = nullptr;
     idx->d_listids = nullptr;
     idx->lrows_alias = false;
@@ -322,6 +327,7 @@ static int install_lists(hnswgpu_index *idx, int32_t nlist, const int64_t *off, 
     idx->max_list_len = 0;
     for (int l = 0; l < nlist; l++) idx->max_list_len = std::max(idx->max_list_len, off[l + 1] - off[l]);
     idx->nlist = nlist;
+    HG_TRY(ensure_list_codes(idx, st));
     HG_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -452,8 +458,11 @@ static int kmeanspp_device(hnswgpu_index *idx, int32_t nlist, int64_t seed, std:
 // Large batches: group the (query, list) pairs by list, keep each group of <= 32 queries resident in LDS
 // and stream the list through the MFMA tile kernel once per group; distances land in a dense
 // per-query candidate array (position = the pair's order key), then one select pass per query.
+// scan_mode 0 = that; 1 = the register-row group kernel (GEMV order); 2 = bounds on int8 rows first, f32 distances
+// (GEMV order) for the candidates that can still be among the k nearest (code_kernels.hpp)
 static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
-                         const int32_t *d_probes, const int32_t *d_qcnt, hipStream_t st, bool gemv_order = false) {
+                         const int32_t *d_probes, const int32_t *d_qcnt, hipStream_t st, int scan_mode = 0) {
+    const bool gemv_order = scan_mode == 1, coded = scan_mode == 2;
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
     const int nlist = idx->nlist;
     // candidates per query, upper bound; a multiple of 4 so that every query's array is 16-B aligned (float4 select)
@@ -477,7 +486,7 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     }();
     // the L2 group kernel takes one item per workgroup; few groups: shorter items, so that every CU has several
     const int64_t ptiles =
-        idx->metric == METRIC_L2 || gemv_order ? 0 : (ptiles_env == 4 && est_groups < 1200 ? 2 : ptiles_env);
+        idx->metric == METRIC_L2 || gemv_order || coded ? 0 : (ptiles_env == 4 && est_groups < 1200 ? 2 : ptiles_env);
     int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + est_groups - 1) / est_groups));
     int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows;
     if (ptiles > 0) cr = std::max<int64_t>(1, std::min<int64_t>(ptiles, mean_tiles)) * kTileRows;
@@ -525,9 +534,6 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     t.nchunks = max_chunks;
     t.out = idx->s_tile.as<float>();
     hipEvent_t e0;
-    prof_begin(idx, PROF_IVF_SCAN, st, &e0);
-    HG_TRY(launch_tile(t, gbound, idx->dim, st));
-    prof_end(idx, PROF_IVF_SCAN, st, e0);
     HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * k));
     HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * k));
     SelectArgs s;
@@ -539,6 +545,80 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     s.k = k;
     s.out_ord = idx->s_ord.as<uint32_t>();
     s.out_dist = idx->s_dist.as<float>();
+    if (coded) {
+        // 1. query codes, then the lower bound of every candidate
+        const size_t cw = sizeof(uint32_t) * kWave * idx->nch;
+        HG_TRY(idx->s_qp.ensure(cw * static_cast<size_t>(nq)));
+        HG_TRY(idx->s_qn.ensure(sizeof(QueryScal) * static_cast<size_t>(nq) + sizeof(float) * static_cast<size_t>(nq)));
+        QueryScal *qscal = idx->s_qn.as<QueryScal>();
+        float *tau = reinterpret_cast<float *>(qscal + nq);
+#define CALL(N, R, L)                                                                                                  \
+    hipLaunchKernelGGL((quantize_queries_kernel<N>), dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st, d_Q,         \
+                       static_cast<int64_t>(idx->dim), idx->dim, nq, idx->s_qp.as<uint32_t>(), qscal)
+        HG_DISPATCH(idx->nch, false, CALL);
+#undef CALL
+        HG_HIP(hipGetLastError());
+        t.crows = idx->d_lcrows;
+        t.cmeta = idx->d_lcmeta;
+        t.qcodes = idx->s_qp.as<uint32_t>();
+        t.qscal = qscal;
+        prof_begin(idx, PROF_IVF_SCAN, st, &e0);
+        HG_TRY(launch_code_group(t, gbound, idx->nch, st));
+        prof_end(idx, PROF_IVF_SCAN, st, e0);
+        // 2. the k smallest lower bounds -> tau
+        HG_TRY(launch_select(s, st));
+        TauArgs ta;
+        memset(&ta, 0, sizeof(ta));
+        ta.ord = s.out_ord;
+        ta.lb = s.out_dist;
+        ta.pairs = idx->s_pairs.as<Pair>();
+        ta.nq = nq;
+        ta.k = k;
+        ta.nprobe = nprobe;
+        ta.metric = idx->metric;
+        ta.crows = idx->d_lcrows;
+        ta.cmeta = idx->d_lcmeta;
+        ta.row_norms = idx->d_lnorms;
+        ta.qcodes = t.qcodes;
+        ta.qscal = qscal;
+        ta.tau = tau;
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_tau_kernel<N>), dim3(nq), dim3(kWave), 0, st, ta)
+        HG_DISPATCH(idx->nch, false, CALL);
+#undef CALL
+        HG_HIP(hipGetLastError());
+        // 3. f32 distances of the survivors, +inf for the rest
+        RefineArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.dist = t.out;
+        ra.q_cnt = d_qcnt;
+        ra.stride = stride;
+        ra.tau = tau;
+        ra.pairs = ta.pairs;
+        ra.nq = nq;
+        ra.nprobe = nprobe;
+        ra.chunk = 4096;
+        ra.nchunks = static_cast<int32_t>((stride + ra.chunk - 1) / ra.chunk);
+        ra.rows = idx->d_lrows;
+        ra.row_norms = idx->d_lnorms;
+        ra.ld = idx->ld;
+        ra.Q = d_Q;
+        ra.qld = idx->dim;
+        ra.dim = idx->dim;
+        ra.metric = idx->metric;
+        ra.stats = idx->prof ? idx->d_rej_stats : nullptr;
+        const int64_t rblocks = static_cast<int64_t>(nq) * ra.nchunks;
+        HG_REQUIRE(rblocks < 2147483647LL, HNSWGPU_ELIMIT, "refine grid too large");
+#define CALL(N, R, L) \
+    hipLaunchKernelGGL((ivf_refine_kernel<N, (N <= 3 ? 4 : (N <= 6 ? 2 : 1)), L>), dim3(static_cast<unsigned>(rblocks)), dim3(kWG), 0, st, ra)
+        HG_DISPATCH(idx->nch, idx->metric == METRIC_L2, CALL);
+#undef CALL
+        HG_HIP(hipGetLastError());
+        // 4. the k nearest of what is left
+        return launch_select(s, st);
+    }
+    prof_begin(idx, PROF_IVF_SCAN, st, &e0);
+    HG_TRY(launch_tile(t, gbound, idx->dim, st));
+    prof_end(idx, PROF_IVF_SCAN, st, e0);
     return launch_select(s, st);
 }
 
@@ -558,7 +638,17 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     // GEMV vs tiled, end to end): batch 32: 0.42 vs 0.56 ms; 48: 0.54 vs 0.61; 64: 0.64 vs 0.64; 80: 0.72 vs 0.65;
     // 96: 0.82 vs 0.71; 128: 1.03 vs 0.71.
     const int tm = tile_mode();
-    const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs > 2LL * idx->nlist);
+    // Batches beyond the fused small-batch path: bounds on the int8 list rows first, f32 distances (GEMV order, the
+    // one arithmetic of every IVF search) only for the candidates that can still be among the k nearest
+    // (code_kernels.hpp).  Without the int8 rows (hnswgpu_set_rejection_test mode 0) the same bits come from the f32
+    // scans below: one GEMV per pair, or the register-row group kernel from 1.5 pairs per list.
+    static const int code_env = []() {
+        const char *e = getenv("HNSWGPU_IVF_CODES");  // 0 = never (A/B), N > 0 = from N queries per batch
+        return e ? atoi(e) : 9;
+    }();
+    const bool use_code = idx->d_lcrows != nullptr && code_env > 0 && nq >= code_env && tm != 0;
+    // the MFMA tile scan (k-ordered chain, different bits) only on request: HNSWGPU_TILE=1
+    const bool use_tile = !use_code && tile_path_ok(idx) && tm == 1;
     int32_t *probes_buf = d_out_probes;
     int32_t *qcnt_buf = nullptr;
     // GEMV scan with enough pairs for lists to be probed twice: run the pairs in list order (see ScanArgs::order).
@@ -575,7 +665,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         const char *e = getenv("HNSWGPU_IVF_FUSED");  // 0 = never, 1 = small batches (default), 2 = every GEMV-path batch
         return e ? atoi(e) : 1;
     }();
-    const bool fused_mode = fused_env == 2 || (fused_env == 1 && nq <= 8);
+    const bool fused_mode = !use_code && (fused_env == 2 || (fused_env == 1 && nq <= 8));
     // Just below that: 1.5 to 2 pairs per list.  The register-row group kernel (l2_kernels.hpp) fetches a list once for
     // all the queries probing it and keeps the GEMV summation order, so the results stay bit-identical to the GEMV
     // scan's (the contract up to 2 pairs per list) while the second and third readers of a list cost no traffic.
@@ -586,18 +676,20 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         const char *e = getenv("HNSWGPU_IVF_GROUP");  // 0 = never (A/B), 2 = from half a pair per list
         return e ? atoi(e) : 1;
     }();
-    const bool use_group = !use_tile && !fused_mode && group_env && tm != 0 && idx->dim <= kL2MaxDim &&
+    const bool use_group = !use_tile && !use_code && !fused_mode && group_env && tm != 0 && idx->dim <= kL2MaxDim &&
                            (group_env == 2 ? npairs * 2 >= idx->nlist : npairs * 2 >= 3LL * idx->nlist);
-    const bool use_order = !use_tile && !use_group && order_mode && idx->nlist <= kOrderMaxLists &&
+    const bool use_order = !use_tile && !use_group && !use_code && order_mode && idx->nlist <= kOrderMaxLists &&
                            npairs * 2 >= idx->nlist && npairs <= (1 << 22);
     int32_t *order_buf = nullptr;
-    if (use_tile || use_group || use_order) {
+    if (use_tile || use_group || use_code || use_order) {
         HG_TRY(idx->s_grp.ensure(sizeof(int32_t) * (2 * npairs + nq + 16)));
         if (!probes_buf) probes_buf = idx->s_grp.as<int32_t>();
-        qcnt_buf = use_tile || use_group ? idx->s_grp.as<int32_t>() + npairs : nullptr;
+        qcnt_buf = use_tile || use_group || use_code ? idx->s_grp.as<int32_t>() + npairs : nullptr;
         order_buf = idx->s_grp.as<int32_t>() + npairs + nq + 16;
     }
     if (use_tile || use_group) HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
+    // many queries against the centroid table: once per group of 32 instead of once per query, same (GEMV) bits
+    const bool route_group = !use_tile && !d_given_probes && nq >= 64 && idx->dim <= kL2MaxDim && tm != 0;
     if (d_given_probes) {  // caller-chosen lists (the :turbo mode's random partitions, :271-272); -1 = none
         hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st,
                            reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff, glistoff,
@@ -621,7 +713,11 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     if (use_tile)  // every query against the centroid table on the tile kernel as well
         HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
                              nprobe, st, -1));
-    else if (static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20))  // dense [nq][nlist] distances + select
+    else if (route_group) {  // the centroid table once per 32 queries, GEMV order (register-row group kernel)
+        HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
+        HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
+                             nprobe, st, -1, true));
+    } else if (static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20))  // dense [nq][nlist] distances + select
         HG_TRY(scan_dense_topk(idx, a, nq, idx->nlist, st));
     else
         HG_TRY(scan_topk(idx, a, nq, 1, idx->nlist, st, -1));
@@ -642,8 +738,8 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     a.pairs = idx->s_pairs.as<Pair>();
     a.k = k;
     a.role = ROLE_LIST_SCAN;
-    if (use_tile || use_group) {
-        HG_TRY(ivf_tile_scan(idx, d_Q, nq, k, nprobe, probes_buf, qcnt_buf, st, use_group));
+    if (use_tile || use_group || use_code) {
+        HG_TRY(ivf_tile_scan(idx, d_Q, nq, k, nprobe, probes_buf, qcnt_buf, st, use_code ? 2 : (use_group ? 1 : 0)));
     } else {
         if (use_order) {
             const size_t olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);
@@ -997,13 +1093,11 @@ int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k
         me.out_ids = out_ids;
         me.out_dist = out_dist;
         me.stats = nullptr;
-        const bool one_arith = idx->metric == METRIC_L2 || !tile_path_ok(idx) || tile_mode() == 0;
+        // one arithmetic (the GEMV order) on every path unless the MFMA tile scan was asked for (HNSWGPU_TILE=1)
+        const bool one_arith = idx->metric == METRIC_L2 || !tile_path_ok(idx) || tile_mode() != 1;
         // the kernel a batch of `total` queries gets: ivf_search_enqueue's own predicate, on the BATCH's nprobe (the
         // leader that evaluates this may have asked for another one)
-        auto tiled = [idx](int64_t total, int32_t nprobe_req) {
-            const int64_t nl = idx->nlist;
-            return total * std::min<int64_t>(nprobe_req, nl) > 2 * nl;
-        };
+        auto tiled = [](int64_t, int32_t) { return true; };  // HNSWGPU_TILE=1: every batch on the tile scan
         return combine_search(
             idx->cmb_ivf, me,
             [=](const hnswgpu_index::SearchReq *first, const hnswgpu_index::SearchReq *r, int64_t total) {

@@ -792,14 +792,18 @@ __global__ __launch_bounds__(kWG) void quantize_rows_kernel(const float *rows, i
 }
 
 // The query's side of the test, once per search and wave: codes in the row layout + the scalars of the bounds.
-template <int NCH>
-struct QueryCode {
-    uint32_t a[NCH];
+struct QueryScal {
     float s;    // scale s_q
     float qn;   // |q|
     float rq;   // 1.01 r_q (NaN for a query with NaN / infinity: every neighbour takes the exact path)
     float eq;   // 1.01 r_q / |q|   (cosine)
     float a2;   // s_q^2 a.a = |q'|^2  (L2)
+    float pad[3];
+};
+template <int NCH>
+struct QueryCode {
+    uint32_t a[NCH];
+    QueryScal sc;
 };
 
 template <int NCH>
@@ -809,11 +813,12 @@ __device__ __forceinline__ void encode_query(const float4 (&q)[NCH], QueryCode<N
     float res;
     int c2;
     encode_lane<NCH>(q, mx, bad, qc.a, res, c2);
-    qc.s = mx / 127.0f;
-    qc.qn = __builtin_sqrtf(wave_sum(lane_partial<NCH, false>(q, q)));
-    qc.rq = bad ? __uint_as_float(0x7fc00000u) : 1.01f * __builtin_sqrtf(wave_sum(res));
-    qc.eq = qc.rq / qc.qn;
-    qc.a2 = qc.s * qc.s * static_cast<float>(wave_sum_int(c2));
+    qc.sc.s = mx / 127.0f;
+    qc.sc.qn = __builtin_sqrtf(wave_sum(lane_partial<NCH, false>(q, q)));
+    qc.sc.rq = bad ? __uint_as_float(0x7fc00000u) : 1.01f * __builtin_sqrtf(wave_sum(res));
+    qc.sc.eq = qc.sc.rq / qc.sc.qn;
+    qc.sc.a2 = qc.sc.s * qc.sc.s * static_cast<float>(wave_sum_int(c2));
+    qc.sc.pad[0] = qc.sc.pad[1] = qc.sc.pad[2] = 0.0f;
 }
 
 // a . c over this lane's elements (exact)
@@ -853,17 +858,32 @@ __device__ __forceinline__ int wave_sum8_int(const int (&x)[8], int lane) {
 // the row whose total wave_sum8_int leaves in lane l
 __device__ __forceinline__ int wave_sum8_row(int lane) { return (lane >> 3) & 7; }
 
-// the lower bound of d(q, v) from the exact code dot product (see above); NaN when nothing can be said
-template <int NCH>
-__device__ __forceinline__ float code_lower_bound(int metric, int dot, const QueryCode<NCH> &qc, float4 meta, float rn) {
+// the bounds of d(q, v) from the exact code dot product (see above): lb <= the f32 distance of the exact path <= ub;
+// NaN when nothing can be said
+__device__ __forceinline__ void code_bounds(int metric, int dot, const QueryScal &qc, float4 meta, float rn, float &lb, float &ub) {
     const float dh = static_cast<float>(dot) * (qc.s * meta.x);  // q' . v'
     if (metric == METRIC_L2) {
         const float v2 = meta.x * meta.x * meta.z;  // |v'|^2
-        const float d2 = (qc.a2 - 2.0f * dh + v2) - 2.0e-6f * (qc.a2 + v2);
-        return __builtin_sqrtf(d2 > 0.0f ? d2 : 0.0f) - (qc.rq + 4.0e-6f * qc.qn) - meta.y;
+        const float d2 = qc.a2 - 2.0f * dh + v2, dl = 2.0e-6f * (qc.a2 + v2), lo = d2 - dl;
+        const float W = (qc.rq + 4.0e-6f * qc.qn) + meta.y;
+        lb = __builtin_sqrtf(lo > 0.0f ? lo : 0.0f) - W;
+        ub = __builtin_sqrtf(d2 + dl) * (1.0f + 1.0e-6f) + W;
+        return;
     }
-    if (metric == METRIC_DOT) return -dh - (qc.qn * meta.y + qc.rq * meta.z);
-    return (1.0f - dh / (qc.qn * rn)) - (meta.y + qc.eq * (1.0f + meta.y));  // qn or rn zero: NaN / infinity -> exact path
+    if (metric == METRIC_DOT) {
+        const float W = qc.qn * meta.y + qc.rq * meta.z;
+        lb = -dh - W;
+        ub = -dh + W;
+        return;
+    }
+    const float c = 1.0f - dh / (qc.qn * rn), W = meta.y + qc.eq * (1.0f + meta.y);  // qn or rn zero: NaN / infinity
+    lb = c - W;
+    ub = c + W;
+}
+__device__ __forceinline__ float code_lower_bound(int metric, int dot, const QueryScal &qc, float4 meta, float rn) {
+    float lb, ub;
+    code_bounds(metric, dot, qc, meta, rn, lb, ub);
+    return lb;
 }
 
 // Diagnostic / test entry (hnswgpu_rejection_bounds): the bound of every listed row against one query, by the very
@@ -892,7 +912,7 @@ __global__ __launch_bounds__(kWave) void code_bound_kernel(const float *Q, int d
     const int j = j0 + wave_sum8_row(lane);
     if ((lane & 7) == 0 && j < m) {
         const int32_t rid = ids[j];
-        out[j] = code_lower_bound<NCH>(metric, tot, qc, qmeta[rid], metric == METRIC_COS ? row_norms[rid] : 0.0f);
+        out[j] = code_lower_bound(metric, tot, qc.sc, qmeta[rid], metric == METRIC_COS ? row_norms[rid] : 0.0f);
     }
 }
 
@@ -1293,7 +1313,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                             for (int b = 0; b < 8; b++) acc[b] = code_dot<NCH>(qc.a, w[g][b]);
                             const int tot = wave_sum8_int(acc, lane);
                             const bool ok = (lane & 7) == 0 && myj[g] < nc;
-                            const float lb = code_lower_bound<NCH>(a.metric, tot, qc, mymeta[g], myrn[g]);
+                            const float lb = code_lower_bound(a.metric, tot, qc.sc, mymeta[g], myrn[g]);
                             const bool need = ok && !(lb >= worst0);  // NaN: needs the exact distance
                             if (ok) cand_d[myj[g]] = __uint_as_float(0x7f800000u);  // overwritten below if needed
                             // bit 8r of the ballot = row r of the group
