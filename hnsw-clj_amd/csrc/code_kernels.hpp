@@ -14,7 +14,8 @@
 //      distance by the GEMV scan's own arithmetic (lane_partial + wave butterfly + finish_dist), bit for bit;
 //   4. select_topk_kernel again: the k smallest (distance, order key) -- exactly the result of scanning everything in
 //      f32, because every candidate with d <= D_k is a survivor and carries the same bits as scan_kernel would give it.
-// One summation order (the GEMV order) for every batch size.
+// The survivors' arithmetic is the GEMV scan's, so this pipeline serves the batch sizes of the GEMV regime (up to 2
+// (query, list) pairs per list) with unchanged bits; larger batches keep the MFMA tile scan.
 #pragma once
 #include "kernels.hpp"
 #include "tile_args.hpp"
@@ -219,7 +220,9 @@ template <int NCH, int RB, bool L2>
 __global__ __launch_bounds__(kWG) void ivf_refine_kernel(RefineArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    const int qi = blockIdx.x / a.nchunks, ch = blockIdx.x % a.nchunks;
+    // slice-major: the survivors of a query sit where its nearest lists are, at the head of its candidate stream, i.e.
+    // in slice 0 -- (query-major put every busy workgroup on blockIdx = 0 mod nchunks: ONE XCD did all the work)
+    const int qi = blockIdx.x % a.nq, ch = blockIdx.x / a.nq;
     const int cnt = a.q_cnt[qi];
     const int c0 = ch * a.chunk;
     if (c0 >= cnt) return;
@@ -231,7 +234,6 @@ __global__ __launch_bounds__(kWG) void ivf_refine_kernel(RefineArgs a) {
     float4 q[NCH];
     load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
     const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
-    int p = 0;  // the pair the current candidates belong to (candidates ascend)
     unsigned long long nsurv = 0;
     for (int base = c0 + wave * kWave; base < c1; base += kNWave * kWave) {
         const int i = base + lane;
@@ -240,30 +242,42 @@ __global__ __launch_bounds__(kWG) void ivf_refine_kernel(RefineArgs a) {
         uint64_t m = __ballot(surv);
         nsurv += __popcll(m);
         float mine = __builtin_inff();
-        while (m) {
-            float4 r[RB][NCH];
-            int js[RB];
-            float rn[RB];
-#pragma unroll
-            for (int b = 0; b < RB; b++) {
-                js[b] = -1;
-                rn[b] = 0.0f;
-                if (m) {
-                    js[b] = __ffsll(static_cast<unsigned long long>(m)) - 1;
-                    m &= m - 1;
-                    const uint32_t o = static_cast<uint32_t>(base + js[b]);
-                    while (p + 1 < a.nprobe && pp[p + 1].ord_base <= o) p++;
-                    const int64_t row = pp[p].row_begin + (o - pp[p].ord_base);
-                    load_row<NCH>(r[b], a.rows + row * a.ld, nvec, lane, true);
-                    rn[b] = a.metric == METRIC_COS ? a.row_norms[row] : 0.0f;
-                }
+        if (m) {
+            // every lane resolves ITS candidate to a list row (the last pair whose ord_base <= ord: lists of length 0
+            // share an ord_base with their successor, as in ivf_decode_kernel) and fetches that row's norm: all 64
+            // look-ups side by side, nothing dependent left inside the loop below
+            int lo = 0, hi = a.nprobe - 1;
+            const uint32_t o = static_cast<uint32_t>(i);
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pp[mid].ord_base <= o) lo = mid;
+                else hi = mid - 1;
             }
+            const int64_t myrow = surv ? pp[lo].row_begin + (o - pp[lo].ord_base) : 0;
+            const float myrn = (surv && a.metric == METRIC_COS) ? a.row_norms[myrow] : 0.0f;
+            const int rlo = static_cast<int>(myrow), rhi = static_cast<int>(myrow >> 32);
+            while (m) {
+                float4 r[RB][NCH];
+                int js[RB];
 #pragma unroll
-            for (int b = 0; b < RB; b++) {
-                if (js[b] < 0) break;
-                const float s = wave_sum(lane_partial<NCH, L2>(q, r[b]));
-                const float dv = finish_dist(a.metric, s, qn, rn[b]) + 0.0f;
-                mine = lane == js[b] ? dv : mine;
+                for (int b = 0; b < RB; b++) {
+                    js[b] = -1;
+                    if (m) {
+                        js[b] = __ffsll(static_cast<unsigned long long>(m)) - 1;
+                        m &= m - 1;
+                        const int64_t row = (static_cast<int64_t>(__builtin_amdgcn_readlane(rhi, js[b])) << 32) |
+                                            static_cast<uint32_t>(__builtin_amdgcn_readlane(rlo, js[b]));
+                        load_row<NCH>(r[b], a.rows + row * a.ld, nvec, lane, true);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    if (js[b] < 0) break;
+                    const float s = wave_sum(lane_partial<NCH, L2>(q, r[b]));
+                    const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), js[b]));
+                    const float dv = finish_dist(a.metric, s, qn, rn) + 0.0f;
+                    mine = lane == js[b] ? dv : mine;
+                }
             }
         }
         if (i < c1) d[i] = mine;

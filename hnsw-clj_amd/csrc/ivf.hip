@@ -596,7 +596,7 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
         ra.pairs = ta.pairs;
         ra.nq = nq;
         ra.nprobe = nprobe;
-        ra.chunk = 4096;
+        ra.chunk = 256;  // one 64-candidate step per wave: the survivors of a query are a few dense runs (its nearest lists)
         ra.nchunks = static_cast<int32_t>((stride + ra.chunk - 1) / ra.chunk);
         ra.rows = idx->d_lrows;
         ra.row_norms = idx->d_lnorms;
@@ -609,7 +609,7 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
         const int64_t rblocks = static_cast<int64_t>(nq) * ra.nchunks;
         HG_REQUIRE(rblocks < 2147483647LL, HNSWGPU_ELIMIT, "refine grid too large");
 #define CALL(N, R, L) \
-    hipLaunchKernelGGL((ivf_refine_kernel<N, (N <= 3 ? 4 : (N <= 6 ? 2 : 1)), L>), dim3(static_cast<unsigned>(rblocks)), dim3(kWG), 0, st, ra)
+    hipLaunchKernelGGL((ivf_refine_kernel<N, (N <= 3 ? 8 : (N <= 6 ? 4 : 2)), L>), dim3(static_cast<unsigned>(rblocks)), dim3(kWG), 0, st, ra)
         HG_DISPATCH(idx->nch, idx->metric == METRIC_L2, CALL);
 #undef CALL
         HG_HIP(hipGetLastError());
@@ -638,17 +638,20 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     // GEMV vs tiled, end to end): batch 32: 0.42 vs 0.56 ms; 48: 0.54 vs 0.61; 64: 0.64 vs 0.64; 80: 0.72 vs 0.65;
     // 96: 0.82 vs 0.71; 128: 1.03 vs 0.71.
     const int tm = tile_mode();
-    // Batches beyond the fused small-batch path: bounds on the int8 list rows first, f32 distances (GEMV order, the
-    // one arithmetic of every IVF search) only for the candidates that can still be among the k nearest
-    // (code_kernels.hpp).  Without the int8 rows (hnswgpu_set_rejection_test mode 0) the same bits come from the f32
-    // scans below: one GEMV per pair, or the register-row group kernel from 1.5 pairs per list.
     static const int code_env = []() {
         const char *e = getenv("HNSWGPU_IVF_CODES");  // 0 = never (A/B), N > 0 = from N queries per batch
         return e ? atoi(e) : 9;
     }();
-    const bool use_code = idx->d_lcrows != nullptr && code_env > 0 && nq >= code_env && tm != 0;
-    // the MFMA tile scan (k-ordered chain, different bits) only on request: HNSWGPU_TILE=1
-    const bool use_tile = !use_code && tile_path_ok(idx) && tm == 1;
+    const bool codes_ok = idx->d_lcrows != nullptr && code_env > 0 && nq >= code_env && tm != 0;
+    // (Euclidean has one arithmetic at every batch size -- its "tile" path is the register-row group kernel -- so the
+    // bounds pipeline below serves all its batches: batch 1024 at 1M x 768: 4.7 -> X ms)
+    const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs > 2LL * idx->nlist) &&
+                          !(idx->metric == METRIC_L2 && codes_ok && tm != 1);
+    // Between the fused small-batch path and the tile scan: bounds on the int8 list rows first, f32 distances -- the
+    // GEMV order, so the bits of this regime are unchanged -- only for the candidates that can still be among the k
+    // nearest (code_kernels.hpp).  Without the int8 rows (hnswgpu_set_rejection_test mode 0) the same bits come from
+    // the f32 scans below: one GEMV per pair, or the register-row group kernel from 1.5 pairs per list.
+    const bool use_code = !use_tile && codes_ok;
     int32_t *probes_buf = d_out_probes;
     int32_t *qcnt_buf = nullptr;
     // GEMV scan with enough pairs for lists to be probed twice: run the pairs in list order (see ScanArgs::order).
@@ -688,8 +691,6 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         order_buf = idx->s_grp.as<int32_t>() + npairs + nq + 16;
     }
     if (use_tile || use_group) HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
-    // many queries against the centroid table: once per group of 32 instead of once per query, same (GEMV) bits
-    const bool route_group = !use_tile && !d_given_probes && nq >= 64 && idx->dim <= kL2MaxDim && tm != 0;
     if (d_given_probes) {  // caller-chosen lists (the :turbo mode's random partitions, :271-272); -1 = none
         hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st,
                            reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff, glistoff,
@@ -713,11 +714,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     if (use_tile)  // every query against the centroid table on the tile kernel as well
         HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
                              nprobe, st, -1));
-    else if (route_group) {  // the centroid table once per 32 queries, GEMV order (register-row group kernel)
-        HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
-        HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
-                             nprobe, st, -1, true));
-    } else if (static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20))  // dense [nq][nlist] distances + select
+    else if (static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20))  // dense [nq][nlist] distances + select
         HG_TRY(scan_dense_topk(idx, a, nq, idx->nlist, st));
     else
         HG_TRY(scan_topk(idx, a, nq, 1, idx->nlist, st, -1));
@@ -1093,11 +1090,13 @@ int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k
         me.out_ids = out_ids;
         me.out_dist = out_dist;
         me.stats = nullptr;
-        // one arithmetic (the GEMV order) on every path unless the MFMA tile scan was asked for (HNSWGPU_TILE=1)
-        const bool one_arith = idx->metric == METRIC_L2 || !tile_path_ok(idx) || tile_mode() != 1;
+        const bool one_arith = idx->metric == METRIC_L2 || !tile_path_ok(idx) || tile_mode() == 0;
         // the kernel a batch of `total` queries gets: ivf_search_enqueue's own predicate, on the BATCH's nprobe (the
         // leader that evaluates this may have asked for another one)
-        auto tiled = [](int64_t, int32_t) { return true; };  // HNSWGPU_TILE=1: every batch on the tile scan
+        auto tiled = [idx](int64_t total, int32_t nprobe_req) {
+            const int64_t nl = idx->nlist;
+            return total * std::min<int64_t>(nprobe_req, nl) > 2 * nl;
+        };
         return combine_search(
             idx->cmb_ivf, me,
             [=](const hnswgpu_index::SearchReq *first, const hnswgpu_index::SearchReq *r, int64_t total) {

@@ -30,10 +30,10 @@ def eng(native_lib):
 
 
 def _ivf_mode(O, metric, dim, nq, nprobe, nlist):
-    """The arithmetic of an IVF search (ivf.hip: ivf_search_enqueue): the GEMV order for every batch size -- the fused
-    small-batch scan, one GEMV per pair, the register-row group kernel and the int8-bounds pipeline (whose survivors
-    are evaluated in the GEMV order) all give the same bits."""
-    return O.MODE_DEV
+    """Which kernel serves an IVF search (ivf.hip: ivf_search_enqueue): the MFMA tile path once the batch has
+    more than 2 (query, list) pairs per list (cosine / dot), else the GEMV scan."""
+    tiled = metric != O.L2 and dim <= 3072 and nq * min(nprobe, nlist) > 2 * nlist
+    return O.MODE_MFMA if tiled else O.MODE_DEV
 
 
 def _data(oracle, n, dim, dist="gaussian", seed=42, **kw):
@@ -775,6 +775,7 @@ def test_ivf_tile_path_several_k_phases(eng, oracle, dim):
         cen, off, lids = idx.get_ivf()
         for nq, nprobe, k in [(70, 5, 10), (33, 2, 40), (7, 5, 3)]:
             mode = _ivf_mode(O, O.COSINE, dim, nq, nprobe, 5)
+            assert mode == O.MODE_MFMA
             ids, d = idx.ivf_search(Q[:nq], k, nprobe)
             oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, mode=mode)
             assert_exact(ids, d, oi, od, "dim=%d nq=%d nprobe=%d k=%d" % (dim, nq, nprobe, k))
@@ -1172,7 +1173,8 @@ def test_ivf_search_given_lists_exact(eng, oracle, metric):
                 pick = rs.permutation(nlist)[:nprobe]
                 keep = rs.rand(nprobe) < 0.8
                 probes[q, keep] = pick[keep]
-            dense = _dense_oracle(O, base, Q, m, O.MODE_DEV)       # one arithmetic at every batch size
+            tiled = m != O.L2 and nq * nprobe > 2 * nlist
+            dense = _dense_oracle(O, base, Q, m, O.MODE_MFMA if tiled else O.MODE_DEV)
             cand_ids = np.full((nq, n), -1, np.int32)
             cand_d = np.full((nq, n), np.inf, np.float32)
             for q in range(nq):

@@ -81,12 +81,13 @@ def test_config3_ivf_per_gpu_shard(eng, oracle):
         ei = ei.cpu().numpy()
         rec = np.mean([len(set(res[1024][0][r]) & set(ei[r])) / k for r in range(128)])
         assert rec >= 0.9, rec
-        # oracle, same centroids and lists, 64-query subsample: one arithmetic (the GEMV order) at every batch size --
-        # ids and distance bits
-        oi, od, _ = O.ivf_search(base, cent, off, lids, qh[:64], k, nprobe, mode=O.MODE_DEV)
-        assert_exact(res[1024][0][:64], res[1024][1][:64], oi, od, "config3 batch 1024 vs oracle")
+        # oracle, same centroids and lists, 64-query subsample: the batch-1024 answers in MFMA order, a 64-query batch
+        # (64 * 32 pairs = 2 per list: still the GEMV scan) in the GEMV order -- ids and distance bits
+        oi, od, _ = O.ivf_search(base, cent, off, lids, qh[:64], k, nprobe, mode=O.MODE_MFMA)
+        assert_exact(res[1024][0][:64], res[1024][1][:64], oi, od, "config3 batch 1024 vs oracle (MFMA order)")
         i64, d64 = idx.ivf_search(qh[:64], k, nprobe)
-        assert_exact(i64, d64, oi, od, "config3 batch 64 vs oracle")
+        oi, od, _ = O.ivf_search(base, cent, off, lids, qh[:64], k, nprobe, mode=O.MODE_DEV)
+        assert_exact(i64, d64, oi, od, "config3 batch 64 vs oracle (GEMV order)")
         fi, fd, _ = O.ivf_search(base, cent, off, lids, qh[:16], k, nprobe)           # f64 reference order
         assert_topk_parity(res[1024][0][:16], res[1024][1][:16], fi, fd, "config3 vs f64 oracle")
 

@@ -117,7 +117,9 @@ def _ivf_worker(rank, world, port, use_gpu, out):
     allp = comm.all_gather(torch.from_numpy(pad)).numpy()
     assign = np.concatenate([allp[r, :counts[r]] for r in range(world)])
     off, lids = lists_from_assign(assign, nlist)
-    mode = O.MODE_DEV                                 # one arithmetic for every batch size, on the GPU as in OracleOps
+    mode = O.MODE_DEV
+    if use_gpu:                                       # the kernel the batch selects: 7 * 5 = 35 pairs > 2 * 12 lists
+        mode = O.MODE_MFMA if len(Q) * nprobe > 2 * nlist else O.MODE_DEV
     oi, od, _ = O.ivf_search(base, idx.centroids, off, lids, Q, k, nprobe, metric=metric, mode=mode)
     out["ids_%d" % rank] = bool(np.array_equal(ids, oi))
     out["d_%d" % rank] = bool(np.array_equal(d.view(np.uint32), od.astype(np.float32).view(np.uint32)))
