@@ -432,7 +432,10 @@ def ivf_roofline(engine, dev, args, traffic):
     _, off, _ = idx.get_ivf()
     lens = np.diff(off)
     out = {}
-    for nq in (1, 32, 1024):
+    for nq in (1, 32, 1024, "32_f32"):
+        f32_only = nq == "32_f32"                      # the same batch of 32 with the int8 bounds pass switched off
+        key, nq = nq, 32 if f32_only else nq
+        idx.set_rejection_test(0 if f32_only else 1)
         Q = Qa[:nq].contiguous()
         _, _, probes = idx.ivf_search(Q.cpu().numpy(), K, nprobe, want_probes=True)
         rows = int(lens[probes.ravel()].sum())
@@ -449,16 +452,20 @@ def ivf_roofline(engine, dev, args, traffic):
         wall = (time.perf_counter() - t0) / steps      # end-to-end search, profiling events off
         idx.set_profiling(True)                        # same launches again with hipEvents around the scan kernel
         idx.get_profile(engine.PROF_IVF_SCAN, reset=True)
+        idx.rejection_stats(reset=True)
         for _ in range(steps):
             idx.ivf_search_dev(Q, K, nprobe)
         ms, cnt = idx.get_profile(engine.PROF_IVF_SCAN, reset=True)
+        surv, cand = idx.rejection_stats(reset=True)
         idx.set_profiling(False)
         avg_ms = ms / max(cnt, 1)
-        out[nq] = {"nq": nq, "avg_scan_ms": round(avg_ms, 4), "search_wall_ms": round(wall * 1e3, 4),
+        out[key] = {"nq": nq, "survivors_per_query": round(surv / max(steps * nq, 1), 1),
+                   "candidates_per_query": round(rows / nq, 1), "unique_rows": uniq, "avg_scan_ms": round(avg_ms, 4), "search_wall_ms": round(wall * 1e3, 4),
                    "qps": round(nq / wall, 1), "algorithmic_GB": round(alg_bytes / 1e9, 4),
                    "unique_GB": round(uniq * (4 * DIM + 4) / 1e9, 4),
                    "algorithmic_GBs": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
                    "unique_GBs": round(uniq * (4 * DIM + 4) / (avg_ms * 1e-3) / 1e9, 1)}
+    idx.set_rejection_test(1)
     # single query, true latency: one call, one sync, host timer
     lat = []
     o1 = (torch.empty((1, K), dtype=torch.int32, device=dev), torch.empty((1, K), dtype=torch.float32, device=dev))
@@ -481,26 +488,42 @@ def ivf_roofline(engine, dev, args, traffic):
     #  * batch 1024 (configs[3]) -> the pairs are grouped by list and scanned by the f32-MFMA tile kernel:
     #    rows are fetched once per 32-query group, so the bound is the f32 matrix rate, not HBM.
     r = out[32]
+    f = out["32_f32"]
     b = out[1024]
     o = out[1]
     flops = 2.0 * b["algorithmic_GB"] * 1e9 / (4 * DIM + 4) * DIM      # 2 * rows scanned * D
     tf = flops / (b["avg_scan_ms"] * 1e-3) / 1e12
+    code_row = 256 * ((DIM + 255) // 256) + 16 + 4                     # int8 row + (scale, bound terms) + norm
+    # what the bounds kernel has to move per launch: every probed list once (all the pairs of a list are one group at
+    # this batch size) in int8, and one lower bound per candidate written
+    req_bytes = r["unique_rows"] * code_row + 4 * r["candidates_per_query"] * r["nq"]
     tr = traffic["traffic"] if traffic else None
-    achieved = (tr / 1e9 if tr else r["unique_GB"]) / (r["avg_scan_ms"] * 1e-3)
+    achieved = (tr if tr else req_bytes) / 1e9 / (r["avg_scan_ms"] * 1e-3)
+    tr_f = traffic["traffic_f32_scan"] if traffic else None
+    ach_f = (tr_f / 1e9 if tr_f else f["unique_GB"]) / (f["avg_scan_ms"] * 1e-3)
     res = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr,
-           "achieved_from": "PMC traffic / kernel time" if tr else "unique bytes / kernel time (no PMC pass in this run: "
+           "achieved_from": "PMC traffic / kernel time" if tr else "requested bytes / kernel time (no PMC pass in this run: "
                             "--no-pmc, N > 1 or rocprofv3 unavailable; a lower bound of the traffic; profiles/ holds a PMC run)",
            "frac_of_copy_ceiling": round(achieved / 6290.0, 4),
-           "kernel": "scan_kernel<3,8,false,ROLE_LIST_SCAN>",
-           "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch "
-                       "(one GEMV per (query, probed list) pair)" % n,
-           "avg_launch_ms": r["avg_scan_ms"], "algorithmic_bytes_per_launch": int(r["algorithmic_GB"] * 1e9),
+           "kernel": "code_group_kernel<3>",
+           "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch: lower bounds of every "
+                       "candidate from the int8 list rows (then f32 distances of the %.0f survivors per query: "
+                       "ivf_refine_kernel)" % (n, r["survivors_per_query"]),
+           "avg_launch_ms": r["avg_scan_ms"], "requested_bytes_per_launch": int(req_bytes),
+           "algorithmic_bytes_per_launch": int(r["algorithmic_GB"] * 1e9),
            "algorithmic_GBs": r["algorithmic_GBs"], "frac_algorithmic": round(r["algorithmic_GBs"] / HBM_PEAK_GBS, 4),
-           "unique_bytes_GBs": r["unique_GBs"], "frac_unique": round(r["unique_GBs"] / HBM_PEAK_GBS, 4),
-           "reuse_note": "algorithmic bytes count a list once per (query, list) pair (SURVEY 8d); pairs of one batch that "
-                         "probe the same list run side by side on one XCD and share its L2, so algorithmic_GBs can exceed the "
-                         "HBM rate -- it is a throughput figure, not a roofline fraction",
+           "reuse_note": "algorithmic bytes are the reference algorithm's: every probed list in f32, once per (query, list) "
+                         "pair (SURVEY 8d).  The search reads each probed list once per batch in int8 and f32 rows only for "
+                         "the candidates whose lower bound does not exclude them from the k nearest, so algorithmic_GBs is "
+                         "a throughput figure far above any memory rate -- frac is the kernel's own traffic over its time",
+           "f32_scan": {"kernel": "scan_kernel<3,8,false,ROLE_LIST_SCAN>", "avg_launch_ms": f["avg_scan_ms"],
+                        "search_wall_ms": f["search_wall_ms"], "qps": f["qps"], "traffic": tr_f,
+                        "achieved": round(ach_f, 1), "unit": "GB/s", "frac": round(ach_f / HBM_PEAK_GBS, 4),
+                        "algorithmic_GBs": f["algorithmic_GBs"], "unique_bytes_GBs": f["unique_GBs"],
+                        "frac_unique": round(f["unique_GBs"] / HBM_PEAK_GBS, 4),
+                        "note": "the same batch with the bounds pass switched off (hnswgpu_set_rejection_test 0): one f32 GEMV "
+                                "per (query, probed list) pair -- round 1 / 2's roofline kernel, same results bit for bit"},
            "batch_32": r,
            "batch_1": {"kernel_ms": o["avg_scan_ms"], "algorithmic_bytes": int(o["algorithmic_GB"] * 1e9),
                        "achieved": o["algorithmic_GBs"], "unit": "GB/s", "frac": round(o["algorithmic_GBs"] / HBM_PEAK_GBS, 4),
@@ -523,6 +546,7 @@ def ivf_roofline(engine, dev, args, traffic):
            "mean_list_len": float(lens.mean()), "max_list_len": int(lens.max())}
     if traffic:
         res["traffic_note"] = traffic["traffic_note"]
+        res["raw_fetch_size_bytes"] = traffic["raw_fetch_size_bytes"]
     return res
 
 
@@ -542,7 +566,8 @@ def ivf_dataset(dev, n, nlist, nq_all):
     return x, Qa
 
 
-PMC_SCAN_KERNEL = "scan_kernel<3, 8, false, 0>"      # ROLE_LIST_SCAN instantiation for dim 768
+PMC_SCAN_KERNEL = "code_group_kernel<3>"             # the bounds kernel for dim 768 (default path at batch 32)
+PMC_F32_KERNEL = "scan_kernel<3, 8, false, 0>"       # ROLE_LIST_SCAN instantiation: the f32 scan (bounds pass off)
 
 
 def pmc_child(args):
@@ -558,9 +583,11 @@ def pmc_child(args):
     del x
     idx.ivf_build(1024, 10, 42)
     Q = Qa[:32].contiguous()
-    for _ in range(6):
-        idx.ivf_search_dev(Q, K, 32)
-    torch.cuda.synchronize()
+    for mode in (1, 0):                                # the bounds pipeline, then the f32 scan of the same batch
+        idx.set_rejection_test(mode)
+        for _ in range(6):
+            idx.ivf_search_dev(Q, K, 32)
+        torch.cuda.synchronize()
     idx.close()
 
 
@@ -589,26 +616,37 @@ def pmc_traffic(args):
         t0 = time.time()
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-            vals = []
+            vals, vals_f = [], []
             for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if PMC_SCAN_KERNEL in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    if row["Counter_Name"] != ctr:
+                        continue
+                    if PMC_SCAN_KERNEL in row["Kernel_Name"]:
                         vals.append(float(row["Counter_Value"]))
-            if r.returncode != 0 or not vals:
-                log("pmc: %s pass failed (rc %d, %d rows): %s" % (ctr, r.returncode, len(vals), r.stderr.decode()[-300:]))
+                    elif PMC_F32_KERNEL in row["Kernel_Name"]:
+                        vals_f.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals or not vals_f:
+                log("pmc: %s pass failed (rc %d, %d + %d rows): %s" % (ctr, r.returncode, len(vals), len(vals_f), r.stderr.decode()[-300:]))
                 return None
-            got[ctr] = (sum(vals) / len(vals) * 1024.0, len(vals))
-            log("pmc: %s pass %.0fs, %d launches of %s" % (ctr, time.time() - t0, len(vals), PMC_SCAN_KERNEL))
+            got[ctr] = (sum(vals) / len(vals) * 1024.0, len(vals), sum(vals_f) / len(vals_f) * 1024.0, len(vals_f))
+            log("pmc: %s pass %.0fs, %d launches of %s (%.0f B), %d of %s (%.0f B)" % (
+                ctr, time.time() - t0, len(vals), PMC_SCAN_KERNEL, got[ctr][0], len(vals_f), PMC_F32_KERNEL, got[ctr][2]))
         except Exception as e:  # noqa: BLE001 -- a missing profiler must not take the bench down
             log("pmc: %s pass: %s: %s" % (ctr, type(e).__name__, e))
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
+    # gfx950: FETCH_SIZE tallies a 128-B request of a wide coalesced read at 64 B (MI355X_MICROARCH.md, HBM section:
+    # calibrated there for 16 B per lane; the bounds kernel reads 12 B per lane, calibrated in profiles/README.md
+    # against its known byte count -- every probed list exactly once at this batch size); WRITE_SIZE is exact
     rd, wr = 2.0 * got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
-    return {"traffic": int(rd + wr),
-            "traffic_note": "HBM bytes per launch of the list-scan kernel at batch 32: 2 x FETCH_SIZE (gfx950 wide-read "
-                            "correction) + WRITE_SIZE, each from its own rocprofv3 --pmc pass over %d launches of the same "
-                            "index and batch in a child process (read %d B, written %d B)" % (got["FETCH_SIZE"][1], rd, wr)}
+    rd_f, wr_f = 2.0 * got["FETCH_SIZE"][2], got["WRITE_SIZE"][2]
+    return {"traffic": int(rd + wr), "traffic_f32_scan": int(rd_f + wr_f),
+            "raw_fetch_size_bytes": int(got["FETCH_SIZE"][0]), "raw_fetch_size_bytes_f32_scan": int(got["FETCH_SIZE"][2]),
+            "traffic_note": "HBM bytes per launch at batch 32: 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE, each "
+                            "from its own rocprofv3 --pmc pass over %d launches of the same index and batch in a child "
+                            "process (bounds kernel: read %d B, written %d B; f32 scan with the bounds pass off: read %d B, "
+                            "written %d B)" % (got["FETCH_SIZE"][1], rd, wr, rd_f, wr_f)}
 
 
 def sharded_ivf(engine, dev, rank, world, args):
