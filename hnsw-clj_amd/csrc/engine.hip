@@ -1648,9 +1648,12 @@ int hnswgpu_get_rejection_stats(hnswgpu_index *idx, int64_t *f32_rows, int64_t *
     HG_HIP(hipSetDevice(idx->device));
     unsigned long long v[2] = {0, 0};
     if (idx->d_rej_stats) {
-        HG_HIP(hipDeviceSynchronize());  // measurement only: every stream that may still be counting
-        HG_HIP(hipMemcpy(v, idx->d_rej_stats, sizeof(v), hipMemcpyDeviceToHost));
-        if (reset) HG_HIP(hipMemset(idx->d_rej_stats, 0, sizeof(v)));
+        hipStream_t st = idx->stream;
+        HG_TRY(begin_call(idx, st));  // every earlier call on this handle, whatever its stream, is ordered before st
+        HG_HIP(hipMemcpyAsync(v, idx->d_rej_stats, sizeof(v), hipMemcpyDeviceToHost, st));
+        if (reset) HG_HIP(hipMemsetAsync(idx->d_rej_stats, 0, sizeof(v), st));
+        HG_TRY(end_call(idx, st));
+        HG_HIP(hipStreamSynchronize(st));
     }
     if (f32_rows) *f32_rows = static_cast<int64_t>(v[0]);
     if (neighbours) *neighbours = static_cast<int64_t>(v[1]);

@@ -46,9 +46,20 @@ if sys.argv[1] == "hnsw":
             ids, _ = idx.hnsw_search_dev(Q, 10, ef)
         torch.cuda.synchronize()
         dt = (time.time() - t) / 3
-        gb = (ev * 4 * dim + hp * 4 * 32) * len(Q) / 1e9
-        print("  ef %3d  recall@10 %.4f  %d queries in %.2f ms = %.0f QPS; E %.0f H %.0f -> %.2f GB gathered = %.0f GB/s (%.2f of 8 TB/s)"
-              % (ef, bench.recall_at_k(ids[:512], ti), len(Q), dt * 1e3, len(Q) / dt, ev, hp, gb, gb / dt, gb / dt / 8000), flush=True)
+        idx.set_profiling(True)                      # one more launch with the device counters of the rejection test
+        idx.rejection_stats(reset=True)
+        idx.hnsw_search_dev(Q, 10, ef)
+        torch.cuda.synchronize()
+        f32_rows, nb = idx.rejection_stats(reset=True)
+        idx.set_profiling(False)
+        code_row = 256 * ((dim + 255) // 256) + 20
+        tested = f32_rows < 0.98 * nb
+        gb = ((nb * code_row if tested else 0) + f32_rows * (4 * dim + 4) + hp * len(Q) * 4 * 32) / 1e9
+        alg = (ev * 4 * dim + hp * 4 * 32) * len(Q) / 1e9
+        print("  ef %3d  recall@10 %.4f  %d queries in %.2f ms = %.0f QPS; E %.0f H %.0f, f32 rows fetched %.0f per query -> %.2f GB "
+              "requested = %.0f GB/s (%.2f of 8 TB/s); the reference algorithm's bytes: %.2f GB"
+              % (ef, bench.recall_at_k(ids[:512], ti), len(Q), dt * 1e3, len(Q) / dt, ev, hp, f32_rows / len(Q), gb, gb / dt,
+                 gb / dt / 8000, alg), flush=True)
 else:
     n, dim, nlist = 10_000_000, 768, 1024
     cen = torch.randn(nlist, dim, generator=g, device=dev)
@@ -65,7 +76,7 @@ else:
     qw = torch.randint(0, nlist, (1024,), generator=g, device=dev)
     Q = cen[qw] + 0.3 * torch.randn(1024, dim, generator=g, device=dev)
     Q = (Q / Q.norm(dim=1, keepdim=True)).contiguous()
-    for nq in (1, 32, 1024):
+    for nq in (1, 32, 64, 1024):
         q = Q[:nq].contiguous()
         for _ in range(2):
             idx.ivf_search_dev(q, 10, 32)
