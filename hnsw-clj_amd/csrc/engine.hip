@@ -64,9 +64,15 @@ static int quantize_rows(hnswgpu_index *idx, const float *rows, int64_t n, uint3
     return 0;
 }
 
+// An int8 row is 64 x NCH dwords (256 B at dim <= 256): below dim 128 it saves no cache line against the f32 row and the
+// bounds pass would only add a memory round trip -- mode 1 leaves such handles without codes (mode 2 forces them).
+static bool codes_wanted(const hnswgpu_index *idx) {
+    return idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128);
+}
+
 // The int8 rows of the traversal's rejection test: once per handle (the base rows never change), on the first graph.
 int ensure_qrows(hnswgpu_index *idx, hipStream_t st) {
-    if (idx->rejection_mode == 0 || idx->d_qrows || idx->n <= 0) return 0;
+    if (!codes_wanted(idx) || idx->d_qrows || idx->n <= 0) return 0;
     if (idx->lrows_alias && idx->d_lcrows) {  // the IVF lists are the base rows in place and already coded
         idx->d_qrows = idx->d_lcrows;
         idx->d_qmeta = idx->d_lcmeta;
@@ -82,7 +88,7 @@ int ensure_qrows(hnswgpu_index *idx, hipStream_t st) {
 
 // ... and of the IVF list scan's bounds pass (code_kernels.hpp): once per set of lists.
 int ensure_list_codes(hnswgpu_index *idx, hipStream_t st) {
-    if (idx->rejection_mode == 0 || idx->d_lcrows || idx->n <= 0 || idx->nlist <= 0) return 0;
+    if (!codes_wanted(idx) || idx->d_lcrows || idx->n <= 0 || idx->nlist <= 0) return 0;
     if (idx->lrows_alias) {
         HG_TRY(ensure_qrows(idx, st));  // one copy serves both (it sets d_lcrows)
         return 0;
@@ -1568,7 +1574,8 @@ int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *
     hipStream_t st = idx->stream;
     HG_TRY(begin_call(idx, st));
     HG_TRY(ensure_qrows(idx, st));
-    HG_REQUIRE(idx->d_qrows, HNSWGPU_EINVAL, "the rejection test is switched off (hnswgpu_set_rejection_test)");
+    HG_REQUIRE(idx->d_qrows, HNSWGPU_EINVAL,
+               "this handle has no int8 rows (hnswgpu_set_rejection_test: mode 0, or mode 1 with dim < 128)");
     HG_TRY(upload_queries(idx, q, 1, st));
     HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * m));
     HG_TRY(idx->s_outd.ensure(sizeof(float) * m));

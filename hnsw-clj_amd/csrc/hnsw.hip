@@ -57,7 +57,7 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     // shorter ones: 2.2x the throughput once the chip is bandwidth-bound, ~5 % slower while a launch is latency-bound.
     // 31k x 768, ef 100, ms per launch without / with: 256 queries 0.537 / 0.571, 512: 0.607 / 0.590, 768: 0.817 /
     // 0.611, 1024: 1.05 / 0.74, 10000: 9.9 / 4.4 (tools/hnsw_batch_sweep.py) -- on from two queries per CU.
-    if (!(idx->rejection_mode == 2 || (idx->rejection_mode == 1 && a.nq >= 2 * idx->cus))) a.qrows = nullptr;
+    if (!(idx->rejection_mode == 2 || (idx->rejection_mode == 1 && a.nq >= 2 * idx->cus && idx->dim >= 128))) a.qrows = nullptr;
     const bool vg = g_force_vg || a.n > kLdsVisitedMaxRows;
     const bool pf = g_pf_groups > 0 && !vg && !a.q_rows && !a.q_index && a.nq <= kPfMaxQueries && g_hnsw_nw == 0 &&
                     a.n < (1LL << 31) && a.M0 <= kMaxDeg;

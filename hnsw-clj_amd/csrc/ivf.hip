@@ -642,7 +642,8 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         const char *e = getenv("HNSWGPU_IVF_CODES");  // 0 = never (A/B), N > 0 = from N queries per batch
         return e ? atoi(e) : 9;
     }();
-    const bool codes_ok = idx->d_lcrows != nullptr && idx->rejection_mode != 0 && code_env > 0 && nq >= code_env && tm != 0;
+    const bool codes_ok = idx->d_lcrows != nullptr && (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128)) &&
+                          code_env > 0 && nq >= code_env && tm != 0;
     // (Euclidean has one arithmetic at every batch size -- its "tile" path is the register-row group kernel -- so the
     // bounds pipeline below serves all its batches: batch 1024 at 1M x 768: 4.8 -> 2.8 ms)
     const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs > 2LL * idx->nlist) &&

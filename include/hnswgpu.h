@@ -232,7 +232,9 @@ int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
  * entry returns those bounds for query q[dim] against rows ids[0..m) -- out[i] <= the distance hnswgpu_batch_distances
  * reports for the same pair, NaN where the test abstains -- so the property can be checked from outside.
  * hnswgpu_set_rejection_test: mode 0 = off (no int8 copy is made: saves n * dim bytes; the bounds entry then fails),
- * 1 = launches of at least two queries per CU, where the traversal is bandwidth-bound (default), 2 = every launch.
+ * 1 = launches of at least two queries per CU, where the traversal is bandwidth-bound, and only for dim >= 128 (an int8
+ * row of a shorter vector saves no cache line) (default), 2 = every launch, every dim.  The same int8 codes serve the
+ * IVF search's bounds pass (batches of 9 queries up to 2 (query, list) pairs per list; every Euclidean batch).
  * HNSWGPU_PREFILTER=<mode> in the environment sets the default of new handles.  Results never depend on the mode. */
 int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out);
 int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode);

@@ -541,9 +541,9 @@ def test_rejection_test_modes_agree(eng, oracle, metric):
     the oracle's on a subsample.  Clustered data with duplicates: ties at the list's worst are where a bound that was
     merely "almost" a lower bound would show."""
     O = oracle
-    base = _data(O, 20000, 40, "clustered", seed=21)
+    base = _data(O, 20000, 136, "clustered", seed=21)  # mode 1 needs dim >= 128
     base[5000:5200] = base[100]                      # 200 copies of one row
-    Q = np.concatenate([_data(O, 1400, 40, "clustered", seed=22), base[100:101], base[5:45]]).astype(np.float32)
+    Q = np.concatenate([_data(O, 1400, 136, "clustered", seed=22), base[100:101], base[5:45]]).astype(np.float32)
     code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
     with eng.Index(base, metric) as idx:
         idx.hnsw_build(12, 60, 42)
@@ -571,6 +571,39 @@ def test_rejection_test_modes_agree(eng, oracle, metric):
         oi, od, ost, _ = O.hnsw_search(base, g, Q[sub], 10, ef=64, metric=code, mode=O.MODE_DEV)
         assert_exact(res[2][0][sub], res[2][1][sub], oi, od, "rejection test vs oracle, %s" % metric)
         np.testing.assert_array_equal(res[2][2][sub], ost)
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
+def test_ivf_bounds_pass_agrees_and_rejects(eng, oracle, metric):
+    """The IVF bounds pass (code_kernels.hpp): a batch in the GEMV regime with the int8 bounds pass on (mode 2) and off
+    (mode 0) returns the same ids and distance bits, equal to the oracle's; the device counters show that the pass ran
+    and excluded most candidates; duplicated rows (ties at the k-th distance) and k beyond the candidate count included."""
+    O = oracle
+    code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
+    base = _data(O, 6000, 136, "clustered", num_clusters=30, noise_level=0.2, seed=31)
+    base[3000:3040] = base[7]                               # 40 copies of one row: ties around the k-th distance
+    Q = np.concatenate([_data(O, 15, 136, "clustered", num_clusters=30, noise_level=0.2, seed=32), base[7:8]]).astype(np.float32)
+    with eng.Index(base, metric) as idx:
+        idx.ivf_build(40, 4, 42)
+        cen, off, lids = idx.get_ivf()
+        idx.set_profiling(True)
+        for nq, nprobe, k in [(16, 4, 10), (9, 5, 30), (16, 2, 1000)]:
+            assert metric == "l2" or nq * nprobe <= 2 * 40
+            got = {}
+            for mode in (2, 0):
+                idx.set_rejection_test(mode)
+                idx.rejection_stats(reset=True)
+                got[mode] = idx.ivf_search(Q[:nq], k, nprobe)
+                surv, cand = idx.rejection_stats(reset=True)
+                if mode == 2:
+                    assert cand > 0 and (k >= 1000 or surv < 0.6 * cand), (surv, cand)   # it ran, and it rejected
+                else:
+                    assert cand == 0                                                      # the f32 scans only
+            np.testing.assert_array_equal(got[2][0], got[0][0])
+            np.testing.assert_array_equal(got[2][1].view(np.uint32), got[0][1].view(np.uint32))
+            oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=code, mode=O.MODE_DEV)
+            assert_exact(got[2][0], got[2][1], oi, od, "ivf bounds pass %s nq=%d nprobe=%d k=%d" % (metric, nq, nprobe, k))
+        idx.set_profiling(False)
 
 
 @pytest.mark.parametrize("dim", [24, 300, 768, 1024, 1536, 3072])
