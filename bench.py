@@ -268,7 +268,7 @@ def main():
     f32_q, nb_q = f32_rows * per_q, neighbours * per_q
     code_row = 256 * ((DIM + 255) // 256)                        # int8 row: 64 lanes x NCH dwords
     tested = f32_q < 0.98 * nb_q                                 # the rejection test ran (it is off for small launches)
-    moved_q = (nb_q * (code_row + 16 + 4) if tested else 0.0) + f32_q * (4 * DIM + 4) + hops * 4 * (2 * M)
+    moved_q = (nb_q * (code_row + 16) if tested else 0.0) + f32_q * (4 * DIM + 4) + hops * 4 * (2 * M)
     hnsw_gbs = moved_q * args.nq / (hnsw_avg_ms * 1e-3) / 1e9
 
     result = {
@@ -313,7 +313,7 @@ def main():
                           "requested_bytes_per_query": int(moved_q),
                           "f32_rows_per_query": round(f32_q, 1), "neighbours_per_query": round(nb_q, 1),
                           "note": "achieved = bytes the kernel REQUESTS per launch / its duration: every evaluated neighbour's "
-                                  "int8 row (+ 20 B of per-row scalars), an f32 row only for the neighbours whose lower bound "
+                                  "int8 row (+ 16 B of per-row scalars), an f32 row only for the neighbours whose lower bound "
                                   "does not already exclude them from the result list (counted on the device), and the "
                                   "adjacency rows.  algorithmic_GBs prices the same launch at the reference algorithm's bytes "
                                   "(every neighbour an f32 row) and may exceed any ceiling.  31,173 x 768: both copies (95.8 + "
@@ -493,7 +493,7 @@ def ivf_roofline(engine, dev, args, traffic):
     o = out[1]
     flops = 2.0 * b["algorithmic_GB"] * 1e9 / (4 * DIM + 4) * DIM      # 2 * rows scanned * D
     tf = flops / (b["avg_scan_ms"] * 1e-3) / 1e12
-    code_row = 256 * ((DIM + 255) // 256) + 16 + 4                     # int8 row + (scale, bound terms) + norm
+    code_row = 256 * ((DIM + 255) // 256) + 16                         # int8 row + (scale, bound terms, norm)
     # what the bounds kernel has to move per launch: every probed list once (all the pairs of a list are one group at
     # this batch size) in int8, and one lower bound per candidate written
     req_bytes = r["unique_rows"] * code_row + 4 * r["candidates_per_query"] * r["nq"]

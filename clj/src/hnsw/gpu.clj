@@ -49,6 +49,7 @@
 (def ^:private h-save     (delay (fn-handle "hnswgpu_save" (FunctionDescriptor/of I (into-array [P P])))))
 (def ^:private h-load     (delay (fn-handle "hnswgpu_load" (FunctionDescriptor/of I (into-array [P I P])))))
 (def ^:private h-info     (delay (fn-handle "hnswgpu_info" (FunctionDescriptor/of I (into-array [P P P P P P])))))
+(def ^:private h-rejmode  (delay (fn-handle "hnswgpu_set_rejection_test" (FunctionDescriptor/of I (into-array [P I])))))
 (def ^:private h-error    (delay (fn-handle "hnswgpu_last_error" (FunctionDescriptor/of P (into-array ValueLayout [])))))
 
 (defn- check [rc]
@@ -221,6 +222,14 @@
     idx))
 
 ;; ===== persistence (helper/index-io save-index / load-index, src/hnsw/helper/index_io.clj:10-80) =====
+
+(defn set-rejection-test!
+  "Tuning knob with no counterpart in the reference: the engine decides neighbours / candidates that cannot reach the
+   result from an int8 copy of the rows (+25 % memory) and reads f32 rows only for the rest; results never depend on it.
+   mode :off (no copy), :auto (default: large HNSW batches, IVF batches of 9+ queries, dim >= 128) or :always."
+  [idx mode]
+  (check (.invokeWithArguments ^MethodHandle @h-rejmode [(:handle idx) (int ({:off 0 :auto 1 :always 2} mode))]))
+  idx)
 
 (defn save
   "One flat binary file (base + graph + lists); the String ids go beside it as EDN -- the engine knows rows only."

@@ -103,7 +103,6 @@ __global__ __launch_bounds__(kTileThreads) void code_group_kernel(TileArgs a) {
         const int64_t myrow = base + own;
         const bool mine_ok = owner && myrow < r1;
         const float4 mymeta = mine_ok ? a.cmeta[myrow] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const float myrn = (a.metric == METRIC_COS && mine_ok) ? a.row_norms[myrow] : 0.0f;
         uint32_t w[8][NCH];
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(kTileThreads) void code_group_kernel(TileArgs a) {
 #pragma unroll
             for (int b = 0; b < 8; b++) acc[b] = code_dot<NCH>(qa, w[b]);
             const int tot = wave_sum8_int(acc, lane);
-            if (mine_ok) a.out[ob_s[q] + (myrow - rb0)] = code_lower_bound(a.metric, tot, qs_s[q], mymeta, myrn);
+            if (mine_ok) a.out[ob_s[q] + (myrow - rb0)] = code_lower_bound(a.metric, tot, qs_s[q], mymeta, mymeta.w);
         }
     }
 }
@@ -183,7 +182,8 @@ __global__ __launch_bounds__(kWave) void ivf_tau_kernel(TauArgs a) {
         float ub = -__builtin_inff();
         if ((lane & 7) == 0 && orow >= 0) {
             float lb;
-            code_bounds(a.metric, tot, qs, a.cmeta[orow], a.metric == METRIC_COS ? a.row_norms[orow] : 0.0f, lb, ub);
+            const float4 mt = a.cmeta[orow];
+            code_bounds(a.metric, tot, qs, mt, mt.w, lb, ub);
             if (!(ub == ub)) ub = __builtin_inff();
         }
         for (int off = 1; off < kWave; off <<= 1) {

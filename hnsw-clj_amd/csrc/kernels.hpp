@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kWG) void gather_dist_kernel(GatherArgs a) {
 //
 // Layout: lane l of a wave owns the same elements of a row as in the f32 kernels (float4 number c * 64 + l, c < NCH);
 // its NCH code words are stored side by side, 64 * NCH dwords per row, so a row is ONE coalesced load of NCH dwords
-// per lane (768 B at dim 768 against 3 KB).  qmeta[row] = (s_v, E, Z, 0): E = the row's share of the bound, Z = the
+// per lane (768 B at dim 768 against 3 KB).  qmeta[row] = (s_v, E, Z, |v|): E = the row's share of the bound, Z = the
 // metric's second per-row term (dot: 1.01 (|v| + r_v); L2: c.c; cosine: unused).
 // ------------------------------------------------------------------------------------------------
 // codes of this lane's elements of a row or query held as float4 r[NCH]: returns max|.| over the wave first
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(kWG) void quantize_rows_kernel(const float *rows, i
             Z = static_cast<float>(c2);
         }
         if (bad || !(E >= 0.0f)) E = __uint_as_float(0x7fc00000u);  // NaN: the comparison fails, exact path
-        qmeta[row] = make_float4(mx / 127.0f, E, Z, 0.0f);
+        qmeta[row] = make_float4(mx / 127.0f, E, Z, nv);  // .w = |v|: the bound needs no second random read for the norm
     }
 }
 
@@ -912,7 +912,8 @@ __global__ __launch_bounds__(kWave) void code_bound_kernel(const float *Q, int d
     const int j = j0 + wave_sum8_row(lane);
     if ((lane & 7) == 0 && j < m) {
         const int32_t rid = ids[j];
-        out[j] = code_lower_bound(metric, tot, qc.sc, qmeta[rid], metric == METRIC_COS ? row_norms[rid] : 0.0f);
+        const float4 mt = qmeta[rid];
+        out[j] = code_lower_bound(metric, tot, qc.sc, mt, mt.w);
     }
 }
 
@@ -1285,7 +1286,6 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                         // the lane that will hold row `own`'s total fetches that candidate's meta data up front
                         int myj[G];
                         float4 mymeta[G];
-                        float myrn[G];
                         uint32_t w[G][8][NCH];
 #pragma unroll
                         for (int g = 0; g < G; g++) {
@@ -1294,7 +1294,6 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                             const bool ok = (lane & 7) == 0 && myj[g] < nc;
                             const int32_t oid = ok ? cand_id[myj[g]] : 0;
                             mymeta[g] = ok ? a.qmeta[oid] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                            myrn[g] = (a.metric == METRIC_COS && ok) ? a.row_norms[oid] : 0.0f;
                             const int lj = j0 + 8 * g + lane;
                             const int32_t ids8 = cand_id[(lane < 8 && lj < nc) ? lj : j0];  // past nc: a valid row, unused
 #pragma unroll
@@ -1313,7 +1312,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                             for (int b = 0; b < 8; b++) acc[b] = code_dot<NCH>(qc.a, w[g][b]);
                             const int tot = wave_sum8_int(acc, lane);
                             const bool ok = (lane & 7) == 0 && myj[g] < nc;
-                            const float lb = code_lower_bound(a.metric, tot, qc.sc, mymeta[g], myrn[g]);
+                            const float lb = code_lower_bound(a.metric, tot, qc.sc, mymeta[g], mymeta[g].w);
                             const bool need = ok && !(lb >= worst0);  // NaN: needs the exact distance
                             if (ok) cand_d[myj[g]] = __uint_as_float(0x7f800000u);  // overwritten below if needed
                             // bit 8r of the ballot = row r of the group

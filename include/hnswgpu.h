@@ -239,7 +239,7 @@ int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
 int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out);
 int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode);
 /* While profiling is on the traversal counts the neighbours it evaluated and the f32 rows it had to fetch for them
- * (everything with the test off): the bytes a search really moved = neighbours * (int8 row + 20 B) + f32_rows * 4 * dim. */
+ * (everything with the test off): the bytes a search really moved = neighbours * (int8 row + 16 B) + f32_rows * 4 * dim. */
 int hnswgpu_get_rejection_stats(hnswgpu_index *idx, int64_t *f32_rows, int64_t *neighbours, int32_t reset);
 int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int64_t *launches, int32_t reset);
 

@@ -52,7 +52,7 @@ if sys.argv[1] == "hnsw":
         torch.cuda.synchronize()
         f32_rows, nb = idx.rejection_stats(reset=True)
         idx.set_profiling(False)
-        code_row = 256 * ((dim + 255) // 256) + 20
+        code_row = 256 * ((dim + 255) // 256) + 16
         tested = f32_rows < 0.98 * nb
         gb = ((nb * code_row if tested else 0) + f32_rows * (4 * dim + 4) + hp * len(Q) * 4 * 32) / 1e9
         alg = (ev * 4 * dim + hp * 4 * 32) * len(Q) / 1e9
