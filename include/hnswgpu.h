@@ -131,7 +131,8 @@ int hnswgpu_hnsw_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, in
  *   norms (:217-234), merge, take k.  out_probes optional (nq x nprobe list ids).
  *   Two summation orders serve this call (cosine / dot): up to 2 (query, list) pairs per list (nq * nprobe <=
  *   2 * nlist) every pair is one GEMV (wave-strided f32 chain + butterfly; from 1.5 pairs per list the pairs of a list
- *   share one pass over its rows, same chain, same bits); larger batches are grouped by list and
+ *   share one pass over its rows, and with the int8 copies of hnswgpu_set_rejection_test only the candidates whose
+ *   lower bound can still reach the k nearest are evaluated at all -- same chain, same bits); larger batches are grouped by list and
  *   scanned by the f32-MFMA tile kernel (k-ordered f32 chain).  Both are within 1e-6 of the f64 reference, but a
  *   query's distance BITS (and the order of candidates that tie within that) depend on which kernel its batch
  *   selects: search-batch* over nq queries is not bit for bit nq single search-knn calls.  Calls combined from
