@@ -202,7 +202,8 @@ struct RefineArgs {
     const float *tau;
     const Pair *pairs;
     int32_t nq, nprobe;
-    int32_t chunk;          // candidates per workgroup (multiple of 64 * waves)
+    int32_t chunk;          // candidates per workgroup (4 * span)
+    int32_t span;           // candidates per wave step: 64 or 16
     int32_t nchunks;
     const float *rows;      // list rows, f32
     const float *row_norms;
@@ -232,17 +233,26 @@ __global__ __launch_bounds__(kWG) void ivf_refine_kernel(RefineArgs a) {
     const float tau = a.tau[qi];
     const int nvec = static_cast<int>(a.ld / 4);
     float4 q[NCH];
-    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
-    const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+    float qn = 0.0f;
+    bool have_q = false;  // the query is fetched by the first window that has a survivor (most workgroups have none)
     unsigned long long nsurv = 0;
-    for (int base = c0 + wave * kWave; base < c1; base += kNWave * kWave) {
+    // a wave looks at `span` candidates per step (64, or 16 for small batches: a full window is then 16 rows per wave
+    // instead of 64, and four times as many waves share a query's survivors)
+    const int span = a.span;
+    for (int base = c0 + wave * span; base < c1; base += kNWave * span) {
         const int i = base + lane;
-        const float l = i < c1 ? d[i] : __builtin_inff();
-        const bool surv = i < c1 && !(l > tau);  // NaN (no bound) survives
+        const bool in = lane < span && i < c1;
+        const float l = in ? d[i] : __builtin_inff();
+        const bool surv = in && !(l > tau);  // NaN (no bound) survives
         uint64_t m = __ballot(surv);
         nsurv += __popcll(m);
         float mine = __builtin_inff();
         if (m) {
+            if (!have_q) {
+                load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+                qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+                have_q = true;
+            }
             // every lane resolves ITS candidate to a list row (the last pair whose ord_base <= ord: lists of length 0
             // share an ord_base with their successor, as in ivf_decode_kernel) and fetches that row's norm: all 64
             // look-ups side by side, nothing dependent left inside the loop below
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(kWG) void ivf_refine_kernel(RefineArgs a) {
                 }
             }
         }
-        if (i < c1) d[i] = mine;
+        if (in) d[i] = mine;
     }
     if (a.stats && lane == 0) {
         atomicAdd(a.stats, nsurv);

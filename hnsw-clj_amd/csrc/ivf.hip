@@ -596,7 +596,10 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
         ra.pairs = ta.pairs;
         ra.nq = nq;
         ra.nprobe = nprobe;
-        ra.chunk = 256;  // one 64-candidate step per wave: the survivors of a query are a few dense runs (its nearest lists)
+        // the survivors of a query are a few dense runs (its nearest lists): a small batch spreads them over four times
+        // as many waves (16 candidates per wave: two trips of eight rows for a full window)
+        ra.span = nq <= 32 ? 16 : 64;
+        ra.chunk = 4 * ra.span;
         ra.nchunks = static_cast<int32_t>((stride + ra.chunk - 1) / ra.chunk);
         ra.rows = idx->d_lrows;
         ra.row_norms = idx->d_lnorms;
