@@ -105,17 +105,26 @@ __global__ void ivf_hist_kernel(const int32_t *probes, int64_t npairs, int32_t *
 
 // One workgroup: exclusive scans over the lists (members, groups of <= 32) in chunks of 1024 lists, then
 // every thread writes the groups of its own list.
-__global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *cnt, int nlist, int32_t *list_mem_begin,
+// With `probes` set (batches of a few thousand pairs) the kernel also does the histogram before and the scatter of the
+// pairs into their groups after: one launch instead of a memset and three kernels.
+__global__ __launch_bounds__(1024) void ivf_plan_kernel(int32_t *cnt, int nlist, int32_t *list_mem_begin,
                                                         int32_t *fill, int32_t *grp_seg, int32_t *grp_mem_begin,
                                                         int32_t *grp_mem_cnt, int32_t *ngroups, int tq,
                                                         const int64_t *list_off, int64_t chunk_rows, int max_chunks,
                                                         int32_t *wi_group, int32_t *wi_chunk, int32_t *nitems,
-                                                        int32_t *work_ctr) {
+                                                        int32_t *work_ctr, const int32_t *probes, int64_t npairs,
+                                                        const Pair *pairs, int64_t stride, GroupMember *members) {
     __shared__ int32_t sm[1024], sg[1024], sw[1024];
     __shared__ int32_t carry_m, carry_g, carry_w;
     const int tid = threadIdx.x;
     if (tid == 0) carry_m = carry_g = carry_w = 0;
     if (tid < 8 && work_ctr) work_ctr[tid] = 0;  // the persistent tile scan's per-XCD item counters
+    if (probes) {  // histogram of the probed lists (ivf_hist_kernel's job)
+        for (int l = tid; l < nlist; l += 1024) cnt[l] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < npairs; i += 1024)
+            if (probes[i] >= 0) atomicAdd(&cnt[probes[i]], 1);
+    }
     __syncthreads();
     for (int l0 = 0; l0 < nlist; l0 += 1024) {
         const int l = l0 + tid;
@@ -164,6 +173,19 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *cnt, int 
     if (tid == 0) {
         *ngroups = carry_g;
         *nitems = carry_w;
+    }
+    if (probes) {  // ivf_scatter_kernel's job: every pair into a slot of its list's member range
+        __syncthreads();
+        for (int64_t i = tid; i < npairs; i += 1024) {
+            const int l = probes[i];
+            if (l < 0) continue;
+            const int slot = list_mem_begin[l] + atomicAdd(&fill[l], 1);
+            GroupMember m;
+            m.q = pairs[i].q;
+            m.pad = 0;
+            m.out_base = static_cast<int64_t>(pairs[i].q) * stride + pairs[i].ord_base;
+            members[slot] = m;
+        }
     }
 }
 
@@ -501,13 +523,21 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     int32_t *cnt = idx->s_misc.as<int32_t>();
     int32_t *lmb = cnt + nlist, *fill = lmb + nlist, *gseg = fill + nlist, *gmb = gseg + gbound, *gmc = gmb + gbound,
             *wig = gmc + gbound, *wic = wig + wbound, *ngr = wic + wbound, *nit = ngr + 1, *wctr = ngr + 4;
-    HG_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nlist, st));
-    hipLaunchKernelGGL(ivf_hist_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st, d_probes,
-                       npairs, cnt);
-    hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr, tq,
-                       idx->d_listoff, cr, max_chunks, wig, wic, nit, ptiles > 0 ? wctr : nullptr);
-    hipLaunchKernelGGL(ivf_scatter_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st,
-                       idx->s_pairs.as<Pair>(), d_probes, npairs, stride, lmb, fill, idx->s_misc2.as<GroupMember>());
+    if (npairs <= 8192) {  // small batches are launch-bound: histogram, plan and scatter in the one-workgroup kernel
+        hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr, tq,
+                           idx->d_listoff, cr, max_chunks, wig, wic, nit, ptiles > 0 ? wctr : nullptr, d_probes, npairs,
+                           idx->s_pairs.as<Pair>(), stride, idx->s_misc2.as<GroupMember>());
+    } else {
+        HG_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nlist, st));
+        hipLaunchKernelGGL(ivf_hist_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st, d_probes,
+                           npairs, cnt);
+        hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr, tq,
+                           idx->d_listoff, cr, max_chunks, wig, wic, nit, ptiles > 0 ? wctr : nullptr,
+                           static_cast<const int32_t *>(nullptr), static_cast<int64_t>(0), static_cast<const Pair *>(nullptr),
+                           static_cast<int64_t>(0), static_cast<GroupMember *>(nullptr));
+        hipLaunchKernelGGL(ivf_scatter_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st,
+                           idx->s_pairs.as<Pair>(), d_probes, npairs, stride, lmb, fill, idx->s_misc2.as<GroupMember>());
+    }
     HG_HIP(hipGetLastError());
     TileArgs t;
     memset(&t, 0, sizeof(t));
