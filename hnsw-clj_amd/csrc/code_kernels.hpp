@@ -132,7 +132,6 @@ struct TauArgs {
     int32_t metric;
     const uint32_t *crows;
     const float4 *cmeta;
-    const float *row_norms;
     const uint32_t *qcodes;
     const QueryScal *qscal;
     float *tau;            // [nq]

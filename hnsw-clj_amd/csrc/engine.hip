@@ -1582,7 +1582,7 @@ int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *
     HG_HIP(hipMemcpyAsync(idx->s_ids.p, ids, sizeof(int32_t) * m, hipMemcpyHostToDevice, st));
 #define CALL(N, R, L)                                                                                                \
     hipLaunchKernelGGL((code_bound_kernel<N>), dim3((m + 7) / 8), dim3(kWave), 0, st, idx->s_q.as<float>(), idx->dim, \
-                       idx->metric, idx->d_qrows, idx->d_qmeta, idx->d_norms, idx->s_ids.as<int32_t>(), m, idx->s_outd.as<float>())
+                       idx->metric, idx->d_qrows, idx->d_qmeta, idx->s_ids.as<int32_t>(), m, idx->s_outd.as<float>())
     HG_DISPATCH(idx->nch, false, CALL);
 #undef CALL
     HG_HIP(hipGetLastError());

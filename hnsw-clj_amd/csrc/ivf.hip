@@ -608,7 +608,6 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
         ta.metric = idx->metric;
         ta.crows = idx->d_lcrows;
         ta.cmeta = idx->d_lcmeta;
-        ta.row_norms = idx->d_lnorms;
         ta.qcodes = t.qcodes;
         ta.qscal = qscal;
         ta.tau = tau;

@@ -890,8 +890,7 @@ __device__ __forceinline__ float code_lower_bound(int metric, int dot, const Que
 // functions the traversal uses.  One wave per eight rows.
 template <int NCH>
 __global__ __launch_bounds__(kWave) void code_bound_kernel(const float *Q, int dim, int metric, const uint32_t *qrows,
-                                                           const float4 *qmeta, const float *row_norms, const int32_t *ids,
-                                                           int m, float *out) {
+                                                           const float4 *qmeta, const int32_t *ids, int m, float *out) {
     const int lane = threadIdx.x;
     float4 q[NCH];
     load_query<NCH>(q, Q, dim, lane);
@@ -1279,46 +1278,34 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                 //      shrinks within a hop) and its distance is never looked at again -- it gets +inf and no f32 fetch
                 uint64_t needmask = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
                 if (a.qrows != nullptr && list_full) {
-                    constexpr int G = 1;  // groups of eight code rows in flight per wave (2: 220 VGPRs at dim 768, a wave less per SIMD)
+                    // eight code rows per wave step (sixteen in flight cost 220 VGPRs at dim 768: a wave less per SIMD)
                     uint64_t wmask = 0;
-                    const int own = wave_sum8_row(lane);  // the row of a group whose total this lane receives
-                    for (int j0 = wave * 8 * G; j0 < nc; j0 += NW * 8 * G) {
+                    const int own = wave_sum8_row(lane);  // the row of a step whose total this lane receives
+                    for (int j0 = wave * 8; j0 < nc; j0 += NW * 8) {
                         // the lane that will hold row `own`'s total fetches that candidate's meta data up front
-                        int myj[G];
-                        float4 mymeta[G];
-                        uint32_t w[G][8][NCH];
+                        const int myj = j0 + own;
+                        const bool ok = (lane & 7) == 0 && myj < nc;
+                        const float4 mymeta = ok ? a.qmeta[cand_id[myj]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        const int lj = j0 + lane;
+                        const int32_t ids8 = cand_id[(lane < 8 && lj < nc) ? lj : j0];  // past nc: a valid row, unused
+                        uint32_t w[8][NCH];
 #pragma unroll
-                        for (int g = 0; g < G; g++) {
-                            myj[g] = j0 + 8 * g + own;
-                            if (j0 + 8 * g >= nc) break;
-                            const bool ok = (lane & 7) == 0 && myj[g] < nc;
-                            const int32_t oid = ok ? cand_id[myj[g]] : 0;
-                            mymeta[g] = ok ? a.qmeta[oid] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                            const int lj = j0 + 8 * g + lane;
-                            const int32_t ids8 = cand_id[(lane < 8 && lj < nc) ? lj : j0];  // past nc: a valid row, unused
+                        for (int b = 0; b < 8; b++) {
+                            const int32_t rid = __builtin_amdgcn_readlane(ids8, b);
+                            const uint32_t *rp = a.qrows + (static_cast<int64_t>(rid) * kWave + lane) * NCH;
 #pragma unroll
-                            for (int b = 0; b < 8; b++) {
-                                const int32_t rid = __builtin_amdgcn_readlane(ids8, b);
-                                const uint32_t *rp = a.qrows + (static_cast<int64_t>(rid) * kWave + lane) * NCH;
-#pragma unroll
-                                for (int cc = 0; cc < NCH; cc++) w[g][b][cc] = rp[cc];
-                            }
+                            for (int cc = 0; cc < NCH; cc++) w[b][cc] = rp[cc];
                         }
+                        int acc[8];
 #pragma unroll
-                        for (int g = 0; g < G; g++) {
-                            if (j0 + 8 * g >= nc) break;
-                            int acc[8];
-#pragma unroll
-                            for (int b = 0; b < 8; b++) acc[b] = code_dot<NCH>(qc.a, w[g][b]);
-                            const int tot = wave_sum8_int(acc, lane);
-                            const bool ok = (lane & 7) == 0 && myj[g] < nc;
-                            const float lb = code_lower_bound(a.metric, tot, qc.sc, mymeta[g], mymeta[g].w);
-                            const bool need = ok && !(lb >= worst0);  // NaN: needs the exact distance
-                            if (ok) cand_d[myj[g]] = __uint_as_float(0x7f800000u);  // overwritten below if needed
-                            // bit 8r of the ballot = row r of the group
-                            const uint64_t m8 = ((__ballot(need) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56;
-                            wmask |= m8 << (j0 + 8 * g);
-                        }
+                        for (int b = 0; b < 8; b++) acc[b] = code_dot<NCH>(qc.a, w[b]);
+                        const int tot = wave_sum8_int(acc, lane);
+                        const float lb = code_lower_bound(a.metric, tot, qc.sc, mymeta, mymeta.w);
+                        const bool need = ok && !(lb >= worst0);  // NaN: needs the exact distance
+                        if (ok) cand_d[myj] = __uint_as_float(0x7f800000u);  // overwritten below if needed
+                        // bit 8r of the ballot = row r of the step
+                        const uint64_t m8 = ((__ballot(need) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56;
+                        wmask |= m8 << j0;
                     }
                     if (NW > 1) {
                         if (lane == 0 && wmask) {
