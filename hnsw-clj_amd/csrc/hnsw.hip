@@ -145,8 +145,9 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
         else CALL_NW(N, R, L, 4);            \
     } while (0)
     // f32 rows in flight per wave: with the rejection test a hop fetches f32 rows for a handful of neighbours only, half
-    // as many in flight are plenty, and the kernel then holds a wave more per SIMD (dim 768, one wave per query: 159 ->
-    // 110 VGPRs, four waves instead of three: 10,000 queries 2.24M -> 2.42M QPS, 4,096 queries 1.89M -> 2.36M)
+    // a quarter of them in flight are plenty, and the kernel then holds more waves per SIMD (dim 768, one wave per query:
+    // 159 -> 99 VGPRs, five waves instead of three: 10,000 queries 2.24M -> 2.43M QPS, 4,096 queries 1.89M -> 2.39M,
+    // 1,024 queries 0.75 -> 0.68 ms)
 #define CALLR(N, R, RF)                                   \
     do {                                                  \
         if (a.qrows) {                                    \
@@ -160,7 +161,7 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     switch (nch) {
         case 1: CALLR(1, 8, 4); break;
         case 2: CALLR(2, 8, 4); break;
-        case 3: CALLR(3, 8, 4); break;
+        case 3: CALLR(3, 8, 2); break;
         // longer rows keep their count: at dim 1536 (HBM-resident, 1.25M rows) two rows in flight instead of four cost
         // 7 % although a third wave fits per SIMD
         case 4: CALLR(4, 4, 4); break;
