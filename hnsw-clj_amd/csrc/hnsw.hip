@@ -65,6 +65,9 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     // with 4 / 2 / 1 waves, and a CU holds 3 / 6 / 12 such workgroups (VGPR-limited), so once a batch
     // exceeds one residency round fewer waves per query win: 10,000 queries run at 601k / 776k / 802k QPS.
     int nw = g_hnsw_nw > 0 ? g_hnsw_nw : (a.nq > 1536 ? 1 : (a.nq > 768 ? 2 : 4));
+    // with the rejection test (fewer f32 rows in flight, below) a CU holds 4 / 8 / 20 such workgroups up to dim 768:
+    // 1,024 queries 0.60 / 0.68 / 0.96 ms with 4 / 2 / 1 waves, 2,048: 1.15 / 0.93 / 1.06, 3,072: 1.68 / 1.51 / 1.36
+    if (g_hnsw_nw == 0 && a.qrows && nch <= 3) nw = a.nq > 2048 ? 1 : (a.nq > 1024 ? 2 : 4);
     int grid = a.nq;
     if (a.q_index) {  // repeat pass: few (usually no) work items, one large-list workgroup per CU at most
         nw = 4;
