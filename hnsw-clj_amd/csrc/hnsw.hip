@@ -19,7 +19,7 @@ namespace hg {
 
 static size_t hnsw_lds_bytes(int cap, int nwords, int nw) {
     return sizeof(uint2) * 2 * cap + sizeof(int32_t) * 3 * kMaxDeg + sizeof(int32_t) * 16 + sizeof(int32_t) * nw * kWave +
-           sizeof(int32_t) * cap + sizeof(uint32_t) * nwords;
+           sizeof(int32_t) * cap + sizeof(uint2) * kPfRing + sizeof(uint32_t) * nwords;
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
@@ -46,7 +46,7 @@ static const int g_pf_groups = []() {
     const int v = e ? atoi(e) : 4;
     return v < 0 ? 0 : (v > 16 ? 16 : v);
 }();
-constexpr int kPfMaxQueries = 16;  // beyond a handful of queries the chip is busy anyway
+constexpr int kPfMaxQueries = 64;  // 64 x (1 + 4) workgroups still find a CU each or nearly; at 100 queries the helpers cost more than they give
 
 int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions
@@ -84,15 +84,32 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
         }();
         a.pf_hints = hints;
         grid = 8 * ((a.nq + 7) / 8) * (1 + g_pf_groups);
-        const size_t region = sizeof(uint32_t) * kPfMailWords * kPfMaxQueries;
+        // per region: the mailboxes, then the helpers' published bounds [query][ring slot][neighbour slot]
+        const size_t mail_bytes = sizeof(uint32_t) * kPfMailWords * kPfMaxQueries;
+        const size_t res_bytes = sizeof(unsigned long long) * kPfMaxQueries * kPfRing * kMaxDeg;
+        const size_t region = mail_bytes + res_bytes;
         if (idx->s_pf.cap < 4 * region) {
             HG_TRY(idx->s_pf.ensure(4 * region));
             HG_HIP(hipMemsetAsync(idx->s_pf.p, 0, idx->s_pf.cap, st));
         }
         idx->pf_seq = (idx->pf_seq + 1) & 0xffffff;
-        if (idx->pf_seq == 0) idx->pf_seq = 1;
+        if (idx->pf_seq == 0) {  // the launch numbers start over: no tag of the previous cycle may survive
+            HG_HIP(hipMemsetAsync(idx->s_pf.p, 0, idx->s_pf.cap, st));
+            idx->pf_seq = 1;
+        }
         a.pf_seq = idx->pf_seq;
-        a.pf_mail = reinterpret_cast<uint32_t *>(static_cast<char *>(idx->s_pf.p) + (idx->pf_seq & 3) * region);
+        char *reg = static_cast<char *>(idx->s_pf.p) + (idx->pf_seq & 3) * region;
+        a.pf_mail = reinterpret_cast<uint32_t *>(reg);
+        static const int pf_eval = []() {
+            const char *e = getenv("HNSWGPU_PF_EVAL");  // 0 = the helpers only warm the L2 (A/B)
+            return e ? atoi(e) : 1;
+        }();
+        if (pf_eval) {
+            // the helpers evaluate the neighbours of the hinted nodes and publish the distances (kernels.hpp: pf_res); the
+            // traversal's own int8 bounds pass stays off: for a handful of queries it costs what it saves
+            a.pf_res = reinterpret_cast<unsigned long long *>(reg + mail_bytes);
+            a.qrows = nullptr;
+        }
     }
     if (vg) {
         a.nwords = 0;

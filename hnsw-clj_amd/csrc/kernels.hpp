@@ -986,6 +986,13 @@ struct HnswArgs {
     // data-tagged entries (launch number << 8 | lap) << 32 | node): the traversal never waits for a helper -- not even
     // for its own stores --, so results and counters cannot depend on them.
     uint32_t *pf_mail;
+    // ... and the helpers do more than warm the L2: they EVALUATE.  A distance is a property of (query, row), not of the
+    // traversal's state, so one computed ahead of time by another workgroup -- with the same lane_partial + butterfly +
+    // finish_dist, hence the same bits -- is as good as one computed on the spot.  For every hinted node a helper
+    // publishes the distances of its slice of the node's neighbours: pf_res[query][ring slot][neighbour slot] =
+    // (tag << 32) | distance bits, tag = the hint's own (launch number << 8 | lap).  When the traversal expands a node
+    // whose words have arrived it reads them beside the adjacency row and gathers nothing for those neighbours.
+    unsigned long long *pf_res;
     int32_t pf_groups;
     int32_t pf_hints;  // unexpanded entries looked at per expansion (the best pf_hints of the list)
     uint32_t pf_seq;
@@ -1034,10 +1041,13 @@ __device__ __forceinline__ void pf_place(const HnswArgs &a, int nq_eff, int &rol
 
 // A helper: follow the query's ring until the traversal is done (or 20 ms have passed: never hang), reading ITS slice
 // of every posted node's neighbour rows -- and throwing them away: they are in the XCD's L2 afterwards.
-template <int NCH, int RB, int NW>
-__device__ __forceinline__ void pf_helper(const HnswArgs &a, uint32_t *mail, int pf_role) {
+template <int NCH, int RB, bool L2, int NW>
+__device__ __forceinline__ void pf_helper(const HnswArgs &a, uint32_t *mail, int pf_role, int pf_query) {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int nvec = static_cast<int>(a.ld / 4);
+    float4 hq[NCH];  // the query and its norm, exactly as the traversal holds them
+    load_query<NCH>(hq, a.Q + static_cast<int64_t>(pf_query) * a.qld, a.dim, lane);
+    const float hqn = a.metric == METRIC_COS ? query_norm<NCH>(hq) : 0.0f;
     const unsigned long long t_begin = wall_clock64();
     auto timed_out = [&]() { return wall_clock64() - t_begin > 2000000ull; };
     // the ring: the best unexpanded list entries, posted by wave 1 while wave 0 selects the next candidate.  (A second
@@ -1059,20 +1069,40 @@ __device__ __forceinline__ void pf_helper(const HnswArgs &a, uint32_t *mail, int
                 // neighbours [lo, hi) are this helper's; its waves take them RB at a time
                 const int per = (a.M0 + a.pf_groups - 1) / a.pf_groups, lo = (pf_role - 1) * per;
                 const int hi = lo + per < a.M0 ? lo + per : a.M0;
-                if (a.qrows != nullptr) {
-                    // with the rejection test the traversal reads the int8 rows (and the rows' meta data) first, and
-                    // f32 rows only for the few neighbours that may be admitted: pull the codes
-                    for (int j = lo + wave; j < hi; j += NW) {
-                        int32_t rid = __builtin_amdgcn_readlane(nb, j);
-                        rid = (rid >= 0 && rid < a.n) ? rid : static_cast<int32_t>(node);
-                        const uint32_t *rp = a.qrows + (static_cast<int64_t>(rid) * kWave + lane) * NCH;
-                        uint32_t w[NCH];
+                if (a.pf_res != nullptr) {
+                    // distances of this helper's slice of the node's neighbours, RB rows per trip, by the entry's wave
+                    if (static_cast<int>((e - 1) % NW) == wave) {
+                        const uint32_t ee = e - 1;  // the entry in hand (e already points past it)
+                        const unsigned long long tagw =
+                            ((static_cast<unsigned long long>(a.pf_seq) << 8) | ((ee / kPfRing) & 0xff)) << 32;
+                        unsigned long long *res = a.pf_res + (static_cast<int64_t>(pf_query) * kPfRing + (ee % kPfRing)) * kMaxDeg;
+                        for (int j0 = lo; j0 < hi; j0 += RB) {
+                            float4 r[RB][NCH];
+                            // lane b < RB owns row b of the trip: its neighbour id (through LDS-free v_readlane in the
+                            // unrolled loop below) and that row's norm
+                            int32_t myid = -1;
 #pragma unroll
-                        for (int cc = 0; cc < NCH; cc++) w[cc] = rp[cc];
-                        const float mz = lane == 0 ? a.qmeta[rid].x : 0.0f;
+                            for (int b = 0; b < RB; b++) {
+                                const int j = j0 + b < hi ? j0 + b : hi - 1;
+                                const int32_t t = __builtin_amdgcn_readlane(nb, j);
+                                const bool ok = t >= 0 && t < a.n && j0 + b < hi;
+                                if (lane == b) myid = ok ? t : -1;
+                                load_row<NCH>(r[b], a.rows + static_cast<int64_t>(ok ? t : static_cast<int32_t>(node)) * a.ld, nvec, lane, true);
+                            }
+                            const float myrn = (a.metric == METRIC_COS && myid >= 0) ? a.row_norms[myid] : 0.0f;
+                            float sums[RB];
 #pragma unroll
-                        for (int cc = 0; cc < NCH; cc++) asm volatile("" ::"v"(w[cc]));  // the loads must happen
-                        asm volatile("" ::"v"(mz));
+                            for (int b = 0; b < RB; b++) sums[b] = lane_partial<NCH, L2>(hq, r[b]);
+#pragma unroll
+                            for (int b = 0; b < RB; b++) sums[b] = wave_sum(sums[b]);
+                            float mine = 0.0f;
+#pragma unroll
+                            for (int b = 0; b < RB; b++) mine = lane == b ? sums[b] : mine;
+                            if (lane < RB && myid >= 0) {
+                                const float dv = finish_dist(a.metric, mine, hqn, myrn) + 0.0f;
+                                coherent_store(res + (j0 + lane), tagw | __float_as_uint(dv));
+                            }
+                        }
                     }
                     continue;
                 }
@@ -1108,7 +1138,7 @@ __device__ __forceinline__ void pf_helper(const HnswArgs &a, uint32_t *mail, int
 // 8-byte entries: one agent-scope store each, nothing to wait for.
 constexpr uint32_t kExpandedFlag = 0x80000000u;
 __device__ __forceinline__ void pf_post(const HnswArgs &a, uint32_t *mail, const uint2 *list, int start, int len,
-                                        uint32_t &head, uint32_t &recent, int lane) {
+                                        uint32_t &head, uint32_t &recent, int lane, uint2 *hint_s) {
     int posted = 0;
     const int want = a.pf_hints;
     for (int base = start; base < len && posted < want; base += kWave) {
@@ -1123,6 +1153,7 @@ __device__ __forceinline__ void pf_post(const HnswArgs &a, uint32_t *mail, const
             if (lane == 0) {
                 const unsigned long long tagv = (static_cast<unsigned long long>(a.pf_seq) << 8) | ((head / kPfRing) & 0xff);
                 coherent_store(reinterpret_cast<unsigned long long *>(mail + 16) + (head % kPfRing), (tagv << 32) | node);
+                hint_s[head % kPfRing] = make_uint2(node, head);  // the traversal's own copy of the ring: (node, entry)
             }
             if (lane == static_cast<int>(head % kWave)) recent = node;
             head++;
@@ -1142,7 +1173,8 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
     int32_t *sc = cand_P + kMaxDeg;  // scalars
     int32_t *part = sc + 16;         // [NW][64] per-wave partial counts of the merge
     int32_t *posA = part + NW * kWave;  // [cap] merged position of every list entry
-    uint32_t *bits = reinterpret_cast<uint32_t *>(posA + a.cap);
+    uint2 *hint_s = reinterpret_cast<uint2 *>(posA + a.cap);  // [kPfRing] (node, ring entry) of the hints posted (PF)
+    uint32_t *bits = reinterpret_cast<uint32_t *>(hint_s + kPfRing);
     uint32_t *stamps = VG ? a.vis + static_cast<int64_t>(blockIdx.x) * a.vis_stride : nullptr;
     // sc[0]=cursor sc[1]=ncand sc[2]=nadmit sc[3]=minP sc[4]=worst bits sc[5]=nghost sc[6]=ghost overflow (per query)
     const int tid = threadIdx.x;
@@ -1157,7 +1189,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
     if (PF) {
         pf_place(a, nq_eff, pf_role, wi0, mail);
         wi_step = 0x40000000;  // one query per traversal workgroup
-        if (pf_role > 0 && wi0 < nq_eff) pf_helper<NCH, RB, NW>(a, mail, pf_role);
+        if (pf_role > 0 && wi0 < nq_eff) pf_helper<NCH, RB, L2, NW>(a, mail, pf_role, wi0);
         if (pf_role > 0) wi0 = nq_eff;  // helpers (and spare workgroups) take no query
     }
     for (int wi = wi0; wi < nq_eff; wi += wi_step) {
@@ -1181,6 +1213,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
 #endif
         __syncthreads();  // the previous query's result readers are done with the lists
         if (tid == 0) sc[6] = 0;
+        if (PF && tid < kPfRing) hint_s[tid] = make_uint2(0xffffffffu, 0u);
         // seed: the entry point (ultra_fast.clj:358-359)
         {
             float4 r[NCH];
@@ -1232,6 +1265,29 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                         const int32_t *adj = level == 0 ? a.l0_adj + static_cast<int64_t>(node) * a.M0
                                                         : a.up_adj + (a.up_off[node] + (level - 1)) * a.M;
                         int nb = lane < deg ? adj[lane] : -1;
+                        // has a helper published the distances of this node's neighbours?  (the newest hint of the node
+                        // in the traversal's copy of the ring; its words carry the hint's own tag, read with one 64-bit load
+                        // per neighbour slot beside the adjacency row: nothing here waits for a helper)
+                        float pubd = 0.0f;
+                        bool have = false;
+                        if (PF && level == 0 && a.pf_res != nullptr) {
+                            const uint2 h = hint_s[lane];
+                            uint64_t hm = __ballot(h.x == node);
+                            if (hm) {
+                                uint32_t e_new = 0;
+                                for (; hm; hm &= hm - 1) {
+                                    const uint32_t e1 = __builtin_amdgcn_readlane(h.y, __ffsll(static_cast<unsigned long long>(hm)) - 1);
+                                    e_new = e1 > e_new ? e1 : e_new;
+                                }
+                                const uint32_t tag = (a.pf_seq << 8) | ((e_new / kPfRing) & 0xff);
+                                if (lane < deg) {
+                                    const unsigned long long wv = coherent_load(
+                                        a.pf_res + (static_cast<int64_t>(wi) * kPfRing + (e_new % kPfRing)) * kMaxDeg + lane);
+                                    have = static_cast<uint32_t>(wv >> 32) == tag;
+                                    pubd = __uint_as_float(static_cast<uint32_t>(wv));
+                                }
+                            }
+                        }
                         bool fresh = false;
                         if (nb >= 0 && nb < a.n) {
                             if (VG) {
@@ -1244,8 +1300,22 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                         }
                         uint64_t m = __ballot(fresh);
                         int pos = __popcll(m & ((1ull << lane) - 1ull));
-                        if (fresh) cand_id[pos] = nb;
+                        if (fresh) {
+                            cand_id[pos] = nb;
+                            if (PF && have) cand_d[pos] = pubd;  // (the gather below skips this candidate)
+                        }
                         ncand = __popcll(m);
+                        if (PF) {  // which compacted candidates carry a published distance
+                            uint64_t pm = __ballot(fresh && have), packed = 0;
+                            for (; pm; pm &= pm - 1) {
+                                const int l = __ffsll(static_cast<unsigned long long>(pm)) - 1;
+                                packed |= 1ull << __popcll(m & ((1ull << l) - 1ull));
+                            }
+                            if (lane == 0) {
+                                sc[9] = static_cast<int32_t>(static_cast<uint32_t>(packed));
+                                sc[10] = static_cast<int32_t>(static_cast<uint32_t>(packed >> 32));
+                            }
+                        }
                         if (lane == 0) curA[found].y = node | kExpanded;
                     }
                     if (lane == 0) {
@@ -1258,7 +1328,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                 if (PF && NW > 1 && wave == 1 && level == 0)
                     // meanwhile (wave 1 idles here): post the best few unexpanded candidates to the helpers.  It reads
                     // the list while wave 0 flags its pick -- a stale flag only costs a redundant hint.
-                    pf_post(a, mail, curA, cur_start, len, pf_head, pf_recent, lane);
+                    pf_post(a, mail, curA, cur_start, len, pf_head, pf_recent, lane, hint_s);
                 __syncthreads();
                 HG_STAMP(1);  // select + adjacency + visited filter
                 const int c = sc[0];
@@ -1277,6 +1347,9 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                 //      LOWER BOUND is already >= the worst cannot be admitted (:195-198 is a strict <, the worst only
                 //      shrinks within a hop) and its distance is never looked at again -- it gets +inf and no f32 fetch
                 uint64_t needmask = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
+                if (PF && a.pf_res != nullptr)  // distances a helper has published (cand_d holds them): nothing to gather
+                    needmask &= ~(static_cast<uint64_t>(static_cast<uint32_t>(sc[9])) |
+                                  (static_cast<uint64_t>(static_cast<uint32_t>(sc[10])) << 32));
                 if (a.qrows != nullptr && list_full) {
                     // eight code rows per wave step (sixteen in flight cost 220 VGPRs at dim 768: a wave less per SIMD)
                     uint64_t wmask = 0;

@@ -31,7 +31,7 @@ def pct(a):
     return "p50 %.1f  min %.1f  p95 %.1f us" % (a[len(a) // 2], a[0], a[int(len(a) * 0.95)])
 
 
-for nq in (1, 20, 200):
+for nq in [int(x) for x in os.environ.get("PROBE_NQ", "1,20,200").split(",")]:
     lat = []
     for i in range(80):
         t = time.perf_counter()
