@@ -534,6 +534,36 @@ def test_ivf_build_golden(eng, oracle, name):
         assert all(i in members for i in ids.ravel() if i >= 0)
 
 
+def test_helpers_evaluate_small_launches(eng, oracle):
+    """Launches of a handful of queries: helper workgroups on idle CUs evaluate the neighbours of the candidates the
+    traversal will expand next and publish the distances (kernels.hpp: pf_res); the traversal gathers only what has not
+    arrived.  Timing decides WHICH distances arrive, never what they are: ids, distance bits and both counters equal the
+    oracle's for 1 / 3 / 20 / 64 queries, several times over, and the device counters show that published distances
+    were used (the int8 test is switched off here, so every neighbour not gathered locally was published)."""
+    O = oracle
+    base = _data(O, 20000, 136, "clustered", seed=51)
+    base[9000:9100] = base[17]                                  # ties among the candidates
+    Q = np.concatenate([_data(O, 63, 136, "clustered", seed=52), base[17:18]]).astype(np.float32)
+    with eng.Index(base) as idx:
+        idx.hnsw_build(16, 80, 42)
+        g = idx.get_graph()
+        oi, od, ost, _ = O.hnsw_search(base, g, Q, 10, ef=96, mode=O.MODE_DEV)
+        idx.set_rejection_test(0)
+        idx.set_profiling(True)
+        used = 0
+        for rep in range(3):
+            for lo, hi in [(0, 1), (1, 4), (4, 24), (0, 64), (63, 64)]:
+                idx.rejection_stats(reset=True)
+                ids, d, st = idx.hnsw_search(Q[lo:hi], 10, 96, want_stats=True)
+                gathered, neighbours = idx.rejection_stats(reset=True)
+                assert_exact(ids, d, oi[lo:hi], od[lo:hi], "helpers rep %d queries %d..%d" % (rep, lo, hi))
+                np.testing.assert_array_equal(st, ost[lo:hi])
+                assert neighbours == int(ost[lo:hi, 0].sum()) and gathered <= neighbours
+                used += neighbours - gathered
+        idx.set_profiling(False)
+        assert used > 0, "no published distance was ever used"
+
+
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
 def test_rejection_test_modes_agree(eng, oracle, metric):
     """hnswgpu_set_rejection_test: off, large batches only, every launch -- ids, distance bits and the evals / hops
