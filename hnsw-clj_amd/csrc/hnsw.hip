@@ -46,7 +46,7 @@ static const int g_pf_groups = []() {
     const int v = e ? atoi(e) : 4;
     return v < 0 ? 0 : (v > 16 ? 16 : v);
 }();
-constexpr int kPfMaxQueries = 64;  // 64 x (1 + 4) workgroups still find a CU each or nearly; at 100 queries the helpers cost more than they give
+constexpr int kPfMaxQueries = 128;  // up to half a CU count of queries: every traversal and at least one helper per query get a CU
 
 int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions
@@ -76,14 +76,15 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     if (pf) {
         // one mailbox per query; four regions in rotation, so that launches in flight (two Slots) never share one
         nw = 4;
-        a.pf_groups = g_pf_groups;
+        // as many helper workgroups per query as find a CU of their own beside the traversals (at most the configured number)
+        a.pf_groups = std::max(1, std::min(g_pf_groups, idx->cus / std::max(a.nq, 1) - 1));
         static const int hints = []() {
             const char *e = getenv("HNSWGPU_PF_HINTS");
             const int v = e ? atoi(e) : 4;
             return v < 1 ? 1 : (v > 32 ? 32 : v);
         }();
         a.pf_hints = hints;
-        grid = 8 * ((a.nq + 7) / 8) * (1 + g_pf_groups);
+        grid = 8 * ((a.nq + 7) / 8) * (1 + a.pf_groups);
         // per region: the mailboxes, then the helpers' published bounds [query][ring slot][neighbour slot]
         const size_t mail_bytes = sizeof(uint32_t) * kPfMailWords * kPfMaxQueries;
         const size_t res_bytes = sizeof(unsigned long long) * kPfMaxQueries * kPfRing * kMaxDeg;
