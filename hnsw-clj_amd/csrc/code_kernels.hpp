@@ -14,7 +14,7 @@
 //      distance by the GEMV scan's own arithmetic (lane_partial + wave butterfly + finish_dist), bit for bit;
 //   4. select_topk_kernel again: the k smallest (distance, order key) -- exactly the result of scanning everything in
 //      f32, because every candidate with d <= D_k is a survivor and carries the same bits as scan_kernel would give it.
-// The survivors' arithmetic is the GEMV scan's, so this pipeline serves the batch sizes of the GEMV regime (up to 2
+// The survivors' arithmetic is the GEMV scan's, so this pipeline serves the batch sizes of the GEMV regime (up to 8
 // (query, list) pairs per list) with unchanged bits; larger batches keep the MFMA tile scan.
 #pragma once
 #include "kernels.hpp"

@@ -654,6 +654,13 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     return launch_select(s, st);
 }
 
+// (query, list) pairs per list from which the MFMA tile scan serves a cosine / dot batch -- and with it the k-ordered
+// summation.  Up to here the GEMV order: one GEMV per pair, the register-row group kernel, or bounds on the int8 rows +
+// f32 refine (same bits all three).  Measured on 1M x 768 / 1024 lists / nprobe 32, bounds pipeline vs tile scan, end to
+// end: batch 96: 0.35 vs 0.67 ms; 128: 0.40 vs 0.66; 256: 0.57 vs 0.70; 384: 0.74 vs 0.70; 512: 0.94 vs 0.72 -- the tile
+// scan reads every probed list in f32 whatever the batch, the bounds pipeline a quarter of that plus the survivors.
+constexpr int64_t kTilePairs = 8;
+
 static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
                               int32_t *d_out_ids, float *d_out_dist, int32_t *d_out_probes, hipStream_t st,
                               const int32_t *d_given_probes = nullptr, uint32_t *d_out_gord = nullptr) {
@@ -664,7 +671,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     memset(&a, 0, sizeof(a));
     HG_TRY(idx->s_pairs.ensure(sizeof(Pair) * static_cast<size_t>(nq) * nprobe));
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
-    // tiled (MFMA) list scan once the batch holds more than 2 (query, list) pairs per list: the GEMV scan streams a
+    // tiled (MFMA) list scan once the batch holds more than kTilePairs (query, list) pairs per list: the GEMV scan streams a
     // list once per pair (pairs of one list side by side on one L2, see ScanArgs::order), the tile scan once per
     // group of <= 32 pairs but at ~5 TB/s.  Measured on 1M x 768 / 1024 lists / nprobe 32 (tools/ivf_batch_time.py,
     // GEMV vs tiled, end to end): batch 32: 0.42 vs 0.56 ms; 48: 0.54 vs 0.61; 64: 0.64 vs 0.64; 80: 0.72 vs 0.65;
@@ -678,7 +685,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
                           code_env > 0 && nq >= code_env && tm != 0;
     // (Euclidean has one arithmetic at every batch size -- its "tile" path is the register-row group kernel -- so the
     // bounds pipeline below serves all its batches: batch 1024 at 1M x 768: 4.8 -> 2.8 ms)
-    const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs > 2LL * idx->nlist) &&
+    const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs > kTilePairs * idx->nlist) &&
                           !(idx->metric == METRIC_L2 && codes_ok && tm != 1);
     // Between the fused small-batch path and the tile scan: bounds on the int8 list rows first, f32 distances -- the
     // GEMV order, so the bits of this regime are unchanged -- only for the candidates that can still be among the k
@@ -702,9 +709,9 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         return e ? atoi(e) : 1;
     }();
     const bool fused_mode = !use_code && (fused_env == 2 || (fused_env == 1 && nq <= 8));
-    // Just below that: 1.5 to 2 pairs per list.  The register-row group kernel (l2_kernels.hpp) fetches a list once for
+    // Without int8 rows, from 1.5 pairs per list up to that boundary: the register-row group kernel (l2_kernels.hpp) fetches a list once for
     // all the queries probing it and keeps the GEMV summation order, so the results stay bit-identical to the GEMV
-    // scan's (the contract up to 2 pairs per list) while the second and third readers of a list cost no traffic.
+    // scan's (the contract up to kTilePairs pairs per list) while the second and third readers of a list cost no traffic.
     // Same index, GEMV vs group, list-scan kernel / end to end: batch 32: 0.356 / 0.423 vs 0.331 / 0.423 ms;
     // 48: 0.464 / 0.531 vs 0.431 / 0.527; 64: 0.572 / 0.643 vs 0.488 / 0.589 (about 885 distinct lists x 3 MB at
     // ~5.5 TB/s).  The three extra launches (histogram, plan, scatter) cost what the kernel gains below 1.5 pairs per list.
@@ -1128,7 +1135,7 @@ int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k
         // leader that evaluates this may have asked for another one)
         auto tiled = [idx](int64_t total, int32_t nprobe_req) {
             const int64_t nl = idx->nlist;
-            return total * std::min<int64_t>(nprobe_req, nl) > 2 * nl;
+            return total * std::min<int64_t>(nprobe_req, nl) > kTilePairs * nl;
         };
         return combine_search(
             idx->cmb_ivf, me,

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(native_lib):
     for n in names:
         assert hasattr(L, n), "libhnswgpu.so does not export %s" % n
     L.hnswgpu_version.restype = ctypes.c_int
-    assert L.hnswgpu_version() == 103
+    assert L.hnswgpu_version() == 104
 
 
 def test_python_binding_covers_header(native_lib):
