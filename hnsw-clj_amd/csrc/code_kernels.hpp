@@ -14,7 +14,7 @@
 //      distance by the GEMV scan's own arithmetic (lane_partial + wave butterfly + finish_dist), bit for bit;
 //   4. select_topk_kernel again: the k smallest (distance, order key) -- exactly the result of scanning everything in
 //      f32, because every candidate with d <= D_k is a survivor and carries the same bits as scan_kernel would give it.
-// The survivors' arithmetic is the GEMV scan's, so this pipeline serves the batch sizes of the GEMV regime (up to 8
+// The survivors' arithmetic is the GEMV scan's, so this pipeline serves the batch sizes of the GEMV regime (up to 12
 // (query, list) pairs per list) with unchanged bits; larger batches keep the MFMA tile scan.
 #pragma once
 #include "kernels.hpp"
@@ -57,6 +57,7 @@ __global__ __launch_bounds__(kTileThreads) void code_group_kernel(TileArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
+    if (a.sel && *a.sel != a.sel_want) return;  // the plan gave this batch to the other bounds kernel
     // ---- work item -> (group, chunk): identical to tile_scan_kernel (XCD-contiguous slices of the work list)
     const int nitems = *a.nitems;
     const int per_xcd = (nitems + 7) >> 3;
@@ -121,6 +122,157 @@ __global__ __launch_bounds__(kTileThreads) void code_group_kernel(TileArgs a) {
             const int tot = wave_sum8_int(acc, lane);
             if (mine_ok) a.out[ob_s[q] + (myrow - rb0)] = code_lower_bound(a.metric, tot, qs_s[q], mymeta, mymeta.w);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The bounds pass on the matrix cores.  A group of <= 32 queries against 32 list rows is a 32 x 32 x K integer GEMM
+// tile: v_mfma_i32_32x32x32_i8 does in 24 instructions (dim 768) what 8 * 24 v_dot4c + a 17-instruction exchange per 8
+// rows and query do on the VALU -- the dot4c kernel above is VALU-bound as soon as lists are probed by several queries
+// (Euclidean batch 1024: 1.3 ms against a 0.25 ms memory floor).  The integer dot products are exact either way, so
+// both kernels write the same bits.
+//
+// MFMA operand maps: lane l (r = l & 31, h = l >> 5) supplies 16 bytes of A row r and of B column r per step, the same
+// 16 of the step's 32 k for both operands -- WHICH k they are does not matter for a dot product as long as rows and
+// queries agree, so a step is simply bytes [32 s, 32 s + 32) of the code vectors in natural element order, half h the
+// upper or lower 16.  List rows are stored for that (tile layout): [block of 32 rows][step s][half h][row r][16 B] --
+// every A operand is ONE contiguous 1 KB wave load, no LDS on the way.  The group's query codes sit in LDS as
+// [step][half][query][16 B] (conflict-free 16-B reads).  C/D: lane l holds column l & 31 (the query), register g row
+// (g & 3) + 8 (g >> 2) + 4 (l >> 5).
+// ------------------------------------------------------------------------------------------------
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+// dword address of natural code dword g4 (elements 4 g4 .. 4 g4 + 3) of list row R in the tile layout; S = steps per row
+__host__ __device__ inline int64_t tile_code_dword(int64_t R, int g4, int S) {
+    const int s = g4 >> 3, h = (g4 >> 2) & 1, w = g4 & 3;
+    return ((((R >> 5) * S + s) * 2 + h) * 32 + (R & 31)) * 4 + w;
+}
+
+// codes of `n` rows into the tile layout (+ the same per-row meta as quantize_rows_kernel): one wave per row
+template <int NCH>
+__global__ __launch_bounds__(kWG) void quantize_rows_tile_kernel(const float *rows, int64_t ld, int64_t n, uint32_t *tile) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kNWave + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float4 r[NCH];
+    load_row<NCH>(r, rows + row * ld, static_cast<int>(ld / 4), lane, true);
+    bool bad;
+    const float mx = wave_absmax<NCH>(r, bad);
+    uint32_t w[NCH];
+    float res;
+    int c2;
+    encode_lane<NCH>(r, mx, bad, w, res, c2);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) tile[tile_code_dword(row, c * kWave + lane, NCH * 8)] = w[c];
+}
+
+__host__ inline size_t code_mfma_lds_bytes(int nch, int waves) {
+    return static_cast<size_t>(nch) * 256 * kTileQ                      // query codes [step][half][query][16 B]
+           + sizeof(int64_t) * kTileQ + sizeof(int32_t) * kTileQ + sizeof(QueryScal) * kTileQ
+           + static_cast<size_t>(waves) * (sizeof(float) * 32 * 33 + sizeof(float4) * 32);  // per wave: result tile + row meta
+}
+
+constexpr int kCodeMfmaWaves = 4;
+
+template <int NCH>
+__global__ __launch_bounds__(kCodeMfmaWaves * kWave) void code_mfma_kernel(TileArgs a) {
+    constexpr int S = NCH * 8;  // steps of 32 bytes
+    extern __shared__ __align__(16) unsigned char smem[];
+    v4i_t *qb_s = reinterpret_cast<v4i_t *>(smem);                                        // [S][2][32]
+    int64_t *ob_s = reinterpret_cast<int64_t *>(qb_s + S * 64);                           // [32] output bases
+    int32_t *qi_s = reinterpret_cast<int32_t *>(ob_s + kTileQ);                           // [32] query index (-1 = empty)
+    QueryScal *qs_s = reinterpret_cast<QueryScal *>(qi_s + kTileQ);                       // [32]
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+    float *tile_s = reinterpret_cast<float *>(qs_s + kTileQ) + wave * (32 * 33 + 4 * 32);  // [32 queries][33] bounds
+    float4 *meta_s = reinterpret_cast<float4 *>(tile_s + 32 * 33);                        // [32] row meta
+    if (a.sel && *a.sel != a.sel_want) return;  // the plan gave this batch to the other bounds kernel
+    // ---- work item -> (group, chunk): as code_group_kernel
+    const int nitems = *a.nitems;
+    const int per_xcd = (nitems + 7) >> 3;
+    const int slot = blockIdx.x >> 3;
+    if (slot >= per_xcd) return;
+    const int item = (blockIdx.x & 7) * per_xcd + slot;
+    if (item >= nitems) return;
+    const int g = a.wi_group[item];
+    const int chunk = a.wi_chunk[item];
+    if (g >= *a.ngroups) return;
+    const int seg = a.grp_seg[g];
+    const int64_t rb0 = a.seg_off[seg], rb1 = a.seg_off[seg + 1];
+    const int cnt = a.grp_mem_cnt[g];
+    const int64_t tiles = (rb1 - rb0 + kTileRows - 1) / kTileRows;
+    const int64_t nch = tile_nchunks(rb1 - rb0, a.chunk_rows, a.nchunks);
+    if (chunk >= nch) return;
+    const int64_t per = (tiles + nch - 1) / nch * kTileRows;
+    const int64_t r0 = rb0 + static_cast<int64_t>(chunk) * per;
+    const int64_t r1 = r0 + per < rb1 ? r0 + per : rb1;
+    if (r0 >= r1 || cnt <= 0) return;
+
+    if (tid < kTileQ) {
+        int qi = -1;
+        int64_t ob = -1;
+        if (tid < cnt) {
+            const GroupMember m = a.members[a.grp_mem_begin[g] + tid];
+            qi = m.q;
+            ob = m.out_base;
+            qs_s[tid] = a.qscal[qi];
+        }
+        qi_s[tid] = qi;
+        ob_s[tid] = ob;
+    }
+    __syncthreads();
+    // query codes: natural order in global memory (16-B chunk t of query q = step t / 2, half t & 1); empty slots are zero
+    for (int f = tid; f < kTileQ * S * 2; f += kCodeMfmaWaves * kWave) {
+        const int q = f / (S * 2), t = f - q * (S * 2);
+        v4i_t v = {0, 0, 0, 0};
+        if (q < cnt) v = reinterpret_cast<const v4i_t *>(a.qcodes + static_cast<int64_t>(qi_s[q]) * NCH * kWave)[t];
+        qb_s[t * 32 + q] = v;
+    }
+    __syncthreads();
+
+    const int col = lane & 31, half = lane >> 5;
+    const QueryScal myqs = col < cnt ? qs_s[col] : QueryScal{};
+    // blocks of 32 rows of the tile layout that overlap [r0, r1): the layout's blocks are aligned to the WHOLE list array,
+    // not to a list, so the first and the last block of a chunk may hold rows of the neighbours -- computed, not stored
+    const int64_t b0 = r0 >> 5, b1 = (r1 + 31) >> 5;
+    for (int64_t b = b0 + wave; b < b1; b += kCodeMfmaWaves) {
+        const v4i_t *ap = reinterpret_cast<const v4i_t *>(a.ctile) + (b * S) * 64 + lane;
+        if (lane < 32) {
+            const int64_t row = b * 32 + lane;
+            meta_s[lane] = (row >= r0 && row < r1) ? a.cmeta[row] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        v4i_t av[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) av[u] = ap[u * 64];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const v4i_t cur = av[s & 7];
+            if (s + 8 < S) av[s & 7] = ap[(s + 8) * 64];  // eight operands (8 KB per wave) in flight
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur, qb_s[(s * 2 + half) * 32 + col], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // meta_s written by lanes 0-31 above is read by every lane below
+        if (col < cnt) {  // (lanes of empty query slots have nothing to say)
+#pragma unroll
+            for (int gq = 0; gq < 16; gq++) {
+                const int i = (gq & 3) + 8 * (gq >> 2) + 4 * half;
+                const float4 mt = meta_s[i];
+                tile_s[col * 33 + i] = code_lower_bound(a.metric, acc[gq], myqs, mt, mt.w);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // store: lanes 0-31 the 32 rows of one query, lanes 32-63 of the next: whole lines per query
+        const int64_t row = b * 32 + col;
+        const bool row_ok = row >= r0 && row < r1;
+        for (int q2 = 0; q2 < cnt; q2 += 2) {
+            const int q = q2 + half;
+            if (q < cnt && row_ok) a.out[ob_s[q] + (row - rb0)] = tile_s[q * 33 + col];
+        }
+        __builtin_amdgcn_wave_barrier();  // the next block overwrites meta_s / tile_s
     }
 }
 

@@ -86,14 +86,54 @@ int ensure_qrows(hnswgpu_index *idx, hipStream_t st) {
     return 0;
 }
 
+// The list codes once more in the MFMA tile layout: blocks of 32 rows x 32-byte steps (code_mfma_kernel)
+static int ensure_list_tile(hnswgpu_index *idx, hipStream_t st) {
+    static const int on = []() {
+        const char *e = getenv("HNSWGPU_CODE_MFMA");  // 0 = the bounds pass stays on the dot4c kernel (A/B; no tile copy)
+        return e ? atoi(e) : 1;
+    }();
+    if (!on || idx->d_lctile || idx->n <= 0) return 0;
+    const int64_t n = idx->n, blocks = (n + 31) / 32;
+    const size_t bytes = static_cast<size_t>(blocks) * 32 * idx->nch * 256;
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lctile), bytes));
+    HG_HIP(hipMemsetAsync(idx->d_lctile, 0, bytes, st));
+    unsigned grid = static_cast<unsigned>((n + kNWave - 1) / kNWave);
+#define CALL(N, R, L) \
+    hipLaunchKernelGGL((quantize_rows_tile_kernel<N>), dim3(grid), dim3(kWG), 0, st, idx->d_lrows, idx->ld, n, idx->d_lctile)
+    HG_DISPATCH(idx->nch, false, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
 // ... and of the IVF list scan's bounds pass (code_kernels.hpp): once per set of lists.
 int ensure_list_codes(hnswgpu_index *idx, hipStream_t st) {
     if (!codes_wanted(idx) || idx->d_lcrows || idx->n <= 0 || idx->nlist <= 0) return 0;
     if (idx->lrows_alias) {
         HG_TRY(ensure_qrows(idx, st));  // one copy serves both (it sets d_lcrows)
-        return 0;
+        return ensure_list_tile(idx, st);
     }
-    return quantize_rows(idx, idx->d_lrows, idx->n, &idx->d_lcrows, &idx->d_lcmeta, st);
+    HG_TRY(quantize_rows(idx, idx->d_lrows, idx->n, &idx->d_lcrows, &idx->d_lcmeta, st));
+    return ensure_list_tile(idx, st);
+}
+
+int launch_code_mfma(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st) {
+    int64_t blocks = (ngroups_bound * a.nchunks + 7) & ~7LL;
+    if (blocks <= 0) return 0;
+    HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "code scan grid too large");
+    const size_t lds = code_mfma_lds_bytes(nch, kCodeMfmaWaves);
+#define CALL(N, R, L)                                                                                                  \
+    do {                                                                                                               \
+        static bool attr_done[64] = {};                                                                                \
+        if (lds > 48 * 1024 && attr_needed(attr_done))                                                                 \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&code_mfma_kernel<N>),                           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
+        hipLaunchKernelGGL((code_mfma_kernel<N>), dim3(static_cast<unsigned>(blocks)), dim3(kCodeMfmaWaves * kWave), lds, st, a); \
+    } while (0)
+    HG_DISPATCH(nch, false, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_code_group(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st) {
@@ -1166,7 +1206,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows in place: freed once, below
     if (idx->d_lcrows == idx->d_qrows) idx->d_lcrows = nullptr, idx->d_lcmeta = nullptr;  // one copy serving both
-    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_lcrows, idx->d_lcmeta, idx->d_rej_stats, idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
+    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_lcrows, idx->d_lcmeta, idx->d_lctile, idx->d_rej_stats, idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
                     idx->d_cent,  idx->d_cnorms, idx->d_lrows,  idx->d_lnorms,  idx->d_listoff, idx->d_listids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

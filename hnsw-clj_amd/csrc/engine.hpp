@@ -90,6 +90,7 @@ struct hnswgpu_index {
     // base rows in place
     uint32_t *d_lcrows = nullptr;
     float4 *d_lcmeta = nullptr;
+    uint32_t *d_lctile = nullptr;  // the list codes once more, in the MFMA tile layout (code_kernels.hpp: code_mfma_kernel)
     unsigned long long *d_rej_stats = nullptr;  // [2], counted by the traversal while profiling is on
     int rejection_mode = 1;  // 0 = off, 1 = batches that fill the chip (launch_hnsw_idx), 2 = every launch
     int cus = 256;
@@ -220,6 +221,7 @@ int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, 
 int ensure_qrows(hnswgpu_index *idx, hipStream_t st);
 int ensure_list_codes(hnswgpu_index *idx, hipStream_t st);
 int launch_code_group(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st);
+int launch_code_mfma(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st);
 int launch_scan(int nch, const ScanArgs &a, hipStream_t st);
 int launch_merge(const MergeArgs &a, hipStream_t st);
 // Serve `me` through combiner `c`: queue it, lead one batch at a time while it is not done.  `take(first, r, total)`

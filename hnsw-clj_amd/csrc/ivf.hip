@@ -173,6 +173,10 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(int32_t *cnt, int nlist,
     if (tid == 0) {
         *ngroups = carry_g;
         *nitems = carry_w;
+        // which bounds kernel serves the batch (code_kernels.hpp): the matrix cores once a list is probed by six queries
+        // or more on average (a 32 x 32 MFMA tile costs the same for one query as for 32; measured on 1M x 768: 4 per
+        // list 0.20 vs 0.17 ms for the dot4c kernel, 8 per list 0.18 vs 0.23, Euclidean batch 1024: 0.39 vs 1.31)
+        ngroups[2] = carry_m >= 6 * carry_g ? 1 : 0;
     }
     if (probes) {  // ivf_scatter_kernel's job: every pair into a slot of its list's member range
         __syncthreads();
@@ -306,12 +310,13 @@ static void free_ivf(hnswgpu_index *idx) {
     if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows themselves: not ours to free
     if (idx->d_lcrows == idx->d_qrows) idx->d_lcrows = nullptr, idx->d_lcmeta = nullptr;  // the traversal's copy: stays
     void *ptrs[] = {idx->d_cent, idx->d_cnorms, idx->d_lrows, idx->d_lnorms, idx->d_listoff, idx->d_listids, idx->d_glistoff,
-                    idx->d_lcrows, idx->d_lcmeta};
+                    idx->d_lcrows, idx->d_lcmeta, idx->d_lctile};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     idx->d_cent = idx->d_cnorms = idx->d_lrows = idx->d_lnorms = nullptr;
     idx->d_lcrows = nullptr;
     idx->d_lcmeta = nullptr;
+    idx->d_lctile = nullptr;
     idx->d_listoff = idx->d_glistoff = nullptr;
     idx->d_listids = nullptr;
     idx->lrows_alias = false;
@@ -592,7 +597,14 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
         t.cmeta = idx->d_lcmeta;
         t.qcodes = idx->s_qp.as<uint32_t>();
         t.qscal = qscal;
+        t.ctile = idx->d_lctile;
         prof_begin(idx, PROF_IVF_SCAN, st, &e0);
+        if (t.ctile) {  // both layouts: both kernels are enqueued, the plan's choice (ngr[2]) runs, the other returns at once
+            t.sel = ngr + 2;
+            t.sel_want = 1;
+            HG_TRY(launch_code_mfma(t, gbound, idx->nch, st));
+            t.sel_want = 0;
+        }
         HG_TRY(launch_code_group(t, gbound, idx->nch, st));
         prof_end(idx, PROF_IVF_SCAN, st, e0);
         // 2. the k smallest lower bounds -> tau
@@ -657,9 +669,10 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
 // (query, list) pairs per list from which the MFMA tile scan serves a cosine / dot batch -- and with it the k-ordered
 // summation.  Up to here the GEMV order: one GEMV per pair, the register-row group kernel, or bounds on the int8 rows +
 // f32 refine (same bits all three).  Measured on 1M x 768 / 1024 lists / nprobe 32, bounds pipeline vs tile scan, end to
-// end: batch 96: 0.35 vs 0.67 ms; 128: 0.40 vs 0.66; 256: 0.57 vs 0.70; 384: 0.74 vs 0.70; 512: 0.94 vs 0.72 -- the tile
-// scan reads every probed list in f32 whatever the batch, the bounds pipeline a quarter of that plus the survivors.
-constexpr int64_t kTilePairs = 8;
+// end: batch 96: 0.35 vs 0.67 ms; 128: 0.40 vs 0.66; 256: 0.55 vs 0.70; 320: 0.62 vs 0.76; 384: 0.68 vs 0.78; 512: 0.80 vs
+// 0.80; 768: 1.04 vs 0.89 -- the tile scan reads every probed list in f32 whatever the batch, the bounds pipeline a quarter
+// of that (on the matrix cores from six queries per list) plus the survivors.
+constexpr int64_t kTilePairs = 12;
 
 static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
                               int32_t *d_out_ids, float *d_out_dist, int32_t *d_out_probes, hipStream_t st,
@@ -685,7 +698,11 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
                           code_env > 0 && nq >= code_env && tm != 0;
     // (Euclidean has one arithmetic at every batch size -- its "tile" path is the register-row group kernel -- so the
     // bounds pipeline below serves all its batches: batch 1024 at 1M x 768: 4.8 -> 2.8 ms)
-    const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs > kTilePairs * idx->nlist) &&
+    static const int64_t tile_pairs = []() {
+        const char *e = getenv("HNSWGPU_TILE_PAIRS");  // measurement only: it moves the boundary between the two summation orders
+        return e ? atoll(e) : kTilePairs;
+    }();
+    const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs > tile_pairs * idx->nlist) &&
                           !(idx->metric == METRIC_L2 && codes_ok && tm != 1);
     // Between the fused small-batch path and the tile scan: bounds on the int8 list rows first, f32 distances -- the
     // GEMV order, so the bits of this regime are unchanged -- only for the candidates that can still be among the k

@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kWG) void gather_dist_kernel(GatherArgs a) {
 //
 // Layout: lane l of a wave owns the same elements of a row as in the f32 kernels (float4 number c * 64 + l, c < NCH);
 // its NCH code words are stored side by side, 64 * NCH dwords per row, so a row is ONE coalesced load of NCH dwords
-// per lane (768 B at dim 768 against 3 KB).  qmeta[row] = (s_v, E, Z, |v|): E = the row's share of the bound, Z = the
+// per lane (768 B at dim 768 against 3 KB).  qmeta[row] = (s_v, E, Z, 1 / |v|): E = the row's share of the bound, Z = the
 // metric's second per-row term (dot: 1.01 (|v| + r_v); L2: c.c; cosine: unused).
 // ------------------------------------------------------------------------------------------------
 // codes of this lane's elements of a row or query held as float4 r[NCH]: returns max|.| over the wave first
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(kWG) void quantize_rows_kernel(const float *rows, i
             Z = static_cast<float>(c2);
         }
         if (bad || !(E >= 0.0f)) E = __uint_as_float(0x7fc00000u);  // NaN: the comparison fails, exact path
-        qmeta[row] = make_float4(mx / 127.0f, E, Z, nv);  // .w = |v|: the bound needs no second random read for the norm
+        qmeta[row] = make_float4(mx / 127.0f, E, Z, 1.0f / nv);  // .w = 1 / |v|: no second random read for the norm, no division in the bound
     }
 }
 
@@ -798,7 +798,8 @@ struct QueryScal {
     float rq;   // 1.01 r_q (NaN for a query with NaN / infinity: every neighbour takes the exact path)
     float eq;   // 1.01 r_q / |q|   (cosine)
     float a2;   // s_q^2 a.a = |q'|^2  (L2)
-    float pad[3];
+    float iqn;  // 1 / |q|   (cosine: the bound multiplies, the reciprocals' roundings are far inside its allowance)
+    float pad[2];
 };
 template <int NCH>
 struct QueryCode {
@@ -818,7 +819,8 @@ __device__ __forceinline__ void encode_query(const float4 (&q)[NCH], QueryCode<N
     qc.sc.rq = bad ? __uint_as_float(0x7fc00000u) : 1.01f * __builtin_sqrtf(wave_sum(res));
     qc.sc.eq = qc.sc.rq / qc.sc.qn;
     qc.sc.a2 = qc.sc.s * qc.sc.s * static_cast<float>(wave_sum_int(c2));
-    qc.sc.pad[0] = qc.sc.pad[1] = qc.sc.pad[2] = 0.0f;
+    qc.sc.iqn = 1.0f / qc.sc.qn;
+    qc.sc.pad[0] = qc.sc.pad[1] = 0.0f;
 }
 
 // a . c over this lane's elements (exact)
@@ -860,7 +862,7 @@ __device__ __forceinline__ int wave_sum8_row(int lane) { return (lane >> 3) & 7;
 
 // the bounds of d(q, v) from the exact code dot product (see above): lb <= the f32 distance of the exact path <= ub;
 // NaN when nothing can be said
-__device__ __forceinline__ void code_bounds(int metric, int dot, const QueryScal &qc, float4 meta, float rn, float &lb, float &ub) {
+__device__ __forceinline__ void code_bounds(int metric, int dot, const QueryScal &qc, float4 meta, float irn, float &lb, float &ub) {
     const float dh = static_cast<float>(dot) * (qc.s * meta.x);  // q' . v'
     if (metric == METRIC_L2) {
         const float v2 = meta.x * meta.x * meta.z;  // |v'|^2
@@ -876,13 +878,13 @@ __device__ __forceinline__ void code_bounds(int metric, int dot, const QueryScal
         ub = -dh + W;
         return;
     }
-    const float c = 1.0f - dh / (qc.qn * rn), W = meta.y + qc.eq * (1.0f + meta.y);  // qn or rn zero: NaN / infinity
+    const float c = 1.0f - dh * (qc.iqn * irn), W = meta.y + qc.eq * (1.0f + meta.y);  // |q| or |v| zero: NaN / infinity
     lb = c - W;
     ub = c + W;
 }
-__device__ __forceinline__ float code_lower_bound(int metric, int dot, const QueryScal &qc, float4 meta, float rn) {
+__device__ __forceinline__ float code_lower_bound(int metric, int dot, const QueryScal &qc, float4 meta, float irn) {
     float lb, ub;
-    code_bounds(metric, dot, qc, meta, rn, lb, ub);
+    code_bounds(metric, dot, qc, meta, irn, lb, ub);
     return lb;
 }
 

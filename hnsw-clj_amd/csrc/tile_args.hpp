@@ -102,6 +102,11 @@ struct TileArgs {
     // code_group_kernel (code_kernels.hpp): int8 rows of the segments + per-row (scale, bound terms), the batch's query
     // codes and bound scalars; out receives LOWER BOUNDS
     const uint32_t *crows;
+    const uint32_t *ctile;  // the same codes in the MFMA tile layout (code_mfma_kernel), or null
+    // both bounds kernels are launched when both layouts exist; the plan kernel decides on the device which one works:
+    // a kernel whose number is not *sel returns at once (null = always run)
+    const int32_t *sel;
+    int32_t sel_want;
     const float4 *cmeta;
     const uint32_t *qcodes;
     const QueryScal *qscal;

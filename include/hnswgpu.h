@@ -129,8 +129,8 @@ int hnswgpu_hnsw_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, in
  * hnswgpu_ivf_search: search-ivf-flat (ivf_flat.clj:236-294) with explicit nprobe for a batch of
  *   queries: centroid routing (:261-269), brute-force scan of the probed lists with precomputed
  *   norms (:217-234), merge, take k.  out_probes optional (nq x nprobe list ids).
- *   Two summation orders serve this call (cosine / dot): up to 8 (query, list) pairs per list (nq * nprobe <=
- *   8 * nlist) every pair is one GEMV (wave-strided f32 chain + butterfly; from 1.5 pairs per list the pairs of a list
+ *   Two summation orders serve this call (cosine / dot): up to 12 (query, list) pairs per list (nq * nprobe <=
+ *   12 * nlist) every pair is one GEMV (wave-strided f32 chain + butterfly; from 1.5 pairs per list the pairs of a list
  *   share one pass over its rows, and with the int8 copies of hnswgpu_set_rejection_test only the candidates whose
  *   lower bound can still reach the k nearest are evaluated at all -- same chain, same bits); larger batches are grouped by list and
  *   scanned by the f32-MFMA tile kernel (k-ordered f32 chain).  Both are within 1e-6 of the f64 reference, but a
@@ -235,7 +235,7 @@ int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
  * hnswgpu_set_rejection_test: mode 0 = off (no int8 copy is made: saves n * dim bytes; the bounds entry then fails),
  * 1 = launches of at least two queries per CU, where the traversal is bandwidth-bound, and only for dim >= 128 (an int8
  * row of a shorter vector saves no cache line) (default), 2 = every launch, every dim.  The same int8 codes serve the
- * IVF search's bounds pass (batches of 9 queries up to 8 (query, list) pairs per list; every Euclidean batch).
+ * IVF search's bounds pass (batches of 9 queries up to 12 (query, list) pairs per list; every Euclidean batch).
  * HNSWGPU_PREFILTER=<mode> in the environment sets the default of new handles.  Results never depend on the mode. */
 int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out);
 int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode);

@@ -31,9 +31,9 @@ def eng(native_lib):
 
 def _ivf_mode(O, metric, dim, nq, nprobe, nlist):
     """Which arithmetic serves an IVF search (ivf.hip: ivf_search_enqueue, kTilePairs): the MFMA tile path once the batch
-    has more than 8 (query, list) pairs per list (cosine / dot), else the GEMV order (one GEMV per pair, the register-row
+    has more than 12 (query, list) pairs per list (cosine / dot), else the GEMV order (one GEMV per pair, the register-row
     group kernel or the int8 bounds pass + f32 refine: the same bits)."""
-    tiled = metric != O.L2 and dim <= 3072 and nq * min(nprobe, nlist) > 8 * nlist
+    tiled = metric != O.L2 and dim <= 3072 and nq * min(nprobe, nlist) > 12 * nlist
     return O.MODE_MFMA if tiled else O.MODE_DEV
 
 
@@ -619,7 +619,7 @@ def test_ivf_bounds_pass_agrees_and_rejects(eng, oracle, metric):
         cen, off, lids = idx.get_ivf()
         idx.set_profiling(True)
         for nq, nprobe, k in [(16, 4, 10), (9, 5, 30), (16, 2, 1000)]:
-            assert metric == "l2" or nq * nprobe <= 8 * 40
+            assert metric == "l2" or nq * nprobe <= 12 * 40
             got = {}
             for mode in (2, 0):
                 idx.set_rejection_test(mode)
@@ -791,7 +791,7 @@ def test_ivf_group_regime_keeps_gemv_bits(eng, oracle, metric, dim):
         idx.ivf_build(32, 3, 42)
         cen, off, lids = idx.get_ivf()
         for nq, nprobe, k in [(12, 4, 10), (16, 4, 10), (13, 4, 200), (16, 3, 1)]:
-            assert nq * nprobe <= 8 * 32                      # the GEMV-order side of the boundary
+            assert nq * nprobe <= 12 * 32                      # the GEMV-order side of the boundary
             ids, d, pr = idx.ivf_search(Q[:nq], k, nprobe, want_probes=True)
             oi, od, opr = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=metric, mode=O.MODE_DEV)
             np.testing.assert_array_equal(pr, opr)
@@ -837,7 +837,7 @@ def test_ivf_tile_path_several_k_phases(eng, oracle, dim):
     with eng.Index(base) as idx:
         idx.ivf_build(5, 2, 42)
         cen, off, lids = idx.get_ivf()
-        for nq, nprobe, k in [(70, 5, 10), (33, 2, 40), (9, 5, 3)]:
+        for nq, nprobe, k in [(70, 5, 10), (33, 2, 40), (13, 5, 3)]:
             mode = _ivf_mode(O, O.COSINE, dim, nq, nprobe, 5)
             assert mode == O.MODE_MFMA
             ids, d = idx.ivf_search(Q[:nq], k, nprobe)
@@ -1237,7 +1237,7 @@ def test_ivf_search_given_lists_exact(eng, oracle, metric):
                 pick = rs.permutation(nlist)[:nprobe]
                 keep = rs.rand(nprobe) < 0.8
                 probes[q, keep] = pick[keep]
-            tiled = m != O.L2 and nq * nprobe > 8 * nlist
+            tiled = m != O.L2 and nq * nprobe > 12 * nlist
             dense = _dense_oracle(O, base, Q, m, O.MODE_MFMA if tiled else O.MODE_DEV)
             cand_ids = np.full((nq, n), -1, np.int32)
             cand_d = np.full((nq, n), np.inf, np.float32)

@@ -118,8 +118,8 @@ def _ivf_worker(rank, world, port, use_gpu, out):
     assign = np.concatenate([allp[r, :counts[r]] for r in range(world)])
     off, lids = lists_from_assign(assign, nlist)
     mode = O.MODE_DEV
-    if use_gpu:                                       # the kernel the batch selects: 7 * 5 = 35 pairs <= 8 * 12 lists: the GEMV order
-        mode = O.MODE_MFMA if len(Q) * nprobe > 8 * nlist else O.MODE_DEV
+    if use_gpu:                                       # the kernel the batch selects: 7 * 5 = 35 pairs <= 12 * 12 lists: the GEMV order
+        mode = O.MODE_MFMA if len(Q) * nprobe > 12 * nlist else O.MODE_DEV
     oi, od, _ = O.ivf_search(base, idx.centroids, off, lids, Q, k, nprobe, metric=metric, mode=mode)
     out["ids_%d" % rank] = bool(np.array_equal(ids, oi))
     out["d_%d" % rank] = bool(np.array_equal(d.view(np.uint32), od.astype(np.float32).view(np.uint32)))

@@ -27,7 +27,7 @@ def eng(native_lib):
 
 
 def _ivf_mode(O, metric, nq, nprobe, nlist):
-    return O.MODE_MFMA if (metric != O.L2 and nq * min(nprobe, nlist) > 8 * nlist) else O.MODE_DEV
+    return O.MODE_MFMA if (metric != O.L2 and nq * min(nprobe, nlist) > 12 * nlist) else O.MODE_DEV
 
 
 def _search_shards(eng, shards, cen, lens, metric, Qt, k, nprobe):

@@ -16,6 +16,12 @@ metric = os.environ.get("METRIC", "cosine")   # METRIC=l2: no tile path, every b
 idx = engine.Index(x, metric, 0)
 del x
 idx.ivf_build(1024, 10, 42)
+import numpy as np
+_, _off, _ = idx.get_ivf()
+_lens = np.diff(_off)
+_, _, _pr = idx.ivf_search(Qa[:32].cpu().numpy(), 10, 32, want_probes=True)
+print("lists: max %d, mean %.0f; candidates per query at nprobe 32: %.0f; distinct lists probed by 32 queries: %d" % (
+    _lens.max(), _lens.mean(), _lens[_pr.ravel()].sum() / 32.0, len(np.unique(_pr))), flush=True)
 for nq in [int(a) for a in sys.argv[1:]] or [256, 1024, 4096]:
     Q = Qa[:nq].contiguous()
     for _ in range(3):
