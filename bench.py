@@ -506,7 +506,7 @@ def ivf_roofline(engine, dev, args, traffic):
            "achieved_from": "PMC traffic / kernel time" if tr else "requested bytes / kernel time (no PMC pass in this run: "
                             "--no-pmc, N > 1 or rocprofv3 unavailable; a lower bound of the traffic; profiles/ holds a PMC run)",
            "frac_of_copy_ceiling": round(achieved / 6290.0, 4),
-           "kernel": "code_group_kernel<3>",
+           "kernel": "code_bounds_kernel<3> (dot4c body: 1.6 queries per probed list at this batch)",
            "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch: lower bounds of every "
                        "candidate from the int8 list rows (then f32 distances of the %.0f survivors per query: "
                        "ivf_refine_kernel)" % (n, r["survivors_per_query"]),
@@ -566,7 +566,7 @@ def ivf_dataset(dev, n, nlist, nq_all):
     return x, Qa
 
 
-PMC_SCAN_KERNEL = "code_group_kernel<3>"             # the bounds kernel for dim 768 (default path at batch 32)
+PMC_SCAN_KERNEL = "code_bounds_kernel<3>"            # the bounds kernel for dim 768 (default path at batch 32)
 PMC_F32_KERNEL = "scan_kernel<3, 8, false, 0>"       # ROLE_LIST_SCAN instantiation: the f32 scan (bounds pass off)
 
 

@@ -6,7 +6,7 @@
 // quantize_rows_kernel -- the same codes and bounds as the HNSW traversal's rejection test), so for every candidate
 //     lb <= d_f32(q, v) <= ub        from one exact integer dot product (v_dot4c_i32_i8).
 // Pipeline of a batch (ivf.hip: ivf_code_scan):
-//   1. code_group_kernel: lb of every (query, candidate) into the dense candidate array (position = order key);
+//   1. code_bounds_kernel (dot4c body code_group_body, or the matrix cores: code_mfma_body): lb of every (query, candidate) into the dense candidate array (position = order key);
 //   2. select_topk_kernel on the lb values; ivf_tau_kernel: tau_q = the largest ub among the k smallest lb.  At least
 //      k candidates have d <= ub <= tau_q, so the k-th smallest distance D_k <= tau_q;
 //   3. ivf_refine_kernel: a candidate with lb > tau_q has d >= lb > tau_q >= D_k and cannot be among the k nearest --
@@ -48,8 +48,7 @@ __host__ inline size_t code_group_lds_bytes(int nch) {
 // over them; a row is fetched once per group.  Per eight (row, query) pairs: 8 * NCH v_dot4c, one halving reduction
 // (wave_sum8_int), the bound in the eight lanes that own a row, one store.
 template <int NCH>
-__global__ __launch_bounds__(kTileThreads) void code_group_kernel(TileArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void code_group_body(const TileArgs &a, unsigned char *smem) {
     uint32_t *qc_s = reinterpret_cast<uint32_t *>(smem);                                  // [32][NCH][64]
     int64_t *ob_s = reinterpret_cast<int64_t *>(qc_s + kTileQ * NCH * kWave);             // [32] output bases
     int32_t *qi_s = reinterpret_cast<int32_t *>(ob_s + kTileQ);                           // [32] query index (-1 = empty)
@@ -57,7 +56,6 @@ __global__ __launch_bounds__(kTileThreads) void code_group_kernel(TileArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
-    if (a.sel && *a.sel != a.sel_want) return;  // the plan gave this batch to the other bounds kernel
     // ---- work item -> (group, chunk): identical to tile_scan_kernel (XCD-contiguous slices of the work list)
     const int nitems = *a.nitems;
     const int per_xcd = (nitems + 7) >> 3;
@@ -173,12 +171,11 @@ __host__ inline size_t code_mfma_lds_bytes(int nch, int waves) {
            + static_cast<size_t>(waves) * (sizeof(float) * 32 * 33 + sizeof(float4) * 32);  // per wave: result tile + row meta
 }
 
-constexpr int kCodeMfmaWaves = 4;
+constexpr int kCodeMfmaWaves = kTileWaves;  // both bodies run in the same launch shape
 
 template <int NCH>
-__global__ __launch_bounds__(kCodeMfmaWaves * kWave) void code_mfma_kernel(TileArgs a) {
+__device__ __forceinline__ void code_mfma_body(const TileArgs &a, unsigned char *smem) {
     constexpr int S = NCH * 8;  // steps of 32 bytes
-    extern __shared__ __align__(16) unsigned char smem[];
     v4i_t *qb_s = reinterpret_cast<v4i_t *>(smem);                                        // [S][2][32]
     int64_t *ob_s = reinterpret_cast<int64_t *>(qb_s + S * 64);                           // [32] output bases
     int32_t *qi_s = reinterpret_cast<int32_t *>(ob_s + kTileQ);                           // [32] query index (-1 = empty)
@@ -188,8 +185,7 @@ __global__ __launch_bounds__(kCodeMfmaWaves * kWave) void code_mfma_kernel(TileA
     const int wave = tid >> 6;
     float *tile_s = reinterpret_cast<float *>(qs_s + kTileQ) + wave * (32 * 33 + 4 * 32);  // [32 queries][33] bounds
     float4 *meta_s = reinterpret_cast<float4 *>(tile_s + 32 * 33);                        // [32] row meta
-    if (a.sel && *a.sel != a.sel_want) return;  // the plan gave this batch to the other bounds kernel
-    // ---- work item -> (group, chunk): as code_group_kernel
+    // ---- work item -> (group, chunk): as code_group_body
     const int nitems = *a.nitems;
     const int per_xcd = (nitems + 7) >> 3;
     const int slot = blockIdx.x >> 3;
@@ -274,6 +270,16 @@ __global__ __launch_bounds__(kCodeMfmaWaves * kWave) void code_mfma_kernel(TileA
         }
         __builtin_amdgcn_wave_barrier();  // the next block overwrites meta_s / tile_s
     }
+}
+
+// ONE launch for the bounds pass: the plan kernel's choice (*a.sel, made on the device from the actual number of queries
+// per probed list) selects the body -- the matrix cores, or the dot4c path when a.ctile is null or lists are probed by
+// few queries.
+template <int NCH>
+__global__ __launch_bounds__(kTileThreads) void code_bounds_kernel(TileArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (a.ctile != nullptr && a.sel != nullptr && *a.sel != 0) code_mfma_body<NCH>(a, smem);
+    else code_group_body<NCH>(a, smem);
 }
 
 struct TauArgs {

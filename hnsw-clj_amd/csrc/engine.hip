@@ -117,37 +117,18 @@ int ensure_list_codes(hnswgpu_index *idx, hipStream_t st) {
     return ensure_list_tile(idx, st);
 }
 
-int launch_code_mfma(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st) {
+int launch_code_bounds(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st) {
     int64_t blocks = (ngroups_bound * a.nchunks + 7) & ~7LL;
     if (blocks <= 0) return 0;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "code scan grid too large");
-    const size_t lds = code_mfma_lds_bytes(nch, kCodeMfmaWaves);
+    const size_t lds = std::max(code_group_lds_bytes(nch), a.ctile ? code_mfma_lds_bytes(nch, kCodeMfmaWaves) : size_t(0));
 #define CALL(N, R, L)                                                                                                  \
     do {                                                                                                               \
         static bool attr_done[64] = {};                                                                                \
         if (lds > 48 * 1024 && attr_needed(attr_done))                                                                 \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&code_mfma_kernel<N>),                           \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&code_bounds_kernel<N>),                         \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
-        hipLaunchKernelGGL((code_mfma_kernel<N>), dim3(static_cast<unsigned>(blocks)), dim3(kCodeMfmaWaves * kWave), lds, st, a); \
-    } while (0)
-    HG_DISPATCH(nch, false, CALL);
-#undef CALL
-    HG_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_code_group(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st) {
-    int64_t blocks = (ngroups_bound * a.nchunks + 7) & ~7LL;
-    if (blocks <= 0) return 0;
-    HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "code scan grid too large");
-    const size_t lds = code_group_lds_bytes(nch);
-#define CALL(N, R, L)                                                                                                  \
-    do {                                                                                                               \
-        static bool attr_done[64] = {};                                                                                \
-        if (lds > 48 * 1024 && attr_needed(attr_done))                                                                 \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&code_group_kernel<N>),                          \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
-        hipLaunchKernelGGL((code_group_kernel<N>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, a); \
+        hipLaunchKernelGGL((code_bounds_kernel<N>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, a); \
     } while (0)
     HG_DISPATCH(nch, false, CALL);
 #undef CALL

@@ -220,8 +220,7 @@ bool attr_needed(bool (&done)[64]);
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);
 int ensure_qrows(hnswgpu_index *idx, hipStream_t st);
 int ensure_list_codes(hnswgpu_index *idx, hipStream_t st);
-int launch_code_group(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st);
-int launch_code_mfma(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st);
+int launch_code_bounds(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st);
 int launch_scan(int nch, const ScanArgs &a, hipStream_t st);
 int launch_merge(const MergeArgs &a, hipStream_t st);
 // Serve `me` through combiner `c`: queue it, lead one batch at a time while it is not done.  `take(first, r, total)`

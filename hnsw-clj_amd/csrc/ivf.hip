@@ -598,14 +598,9 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
         t.qcodes = idx->s_qp.as<uint32_t>();
         t.qscal = qscal;
         t.ctile = idx->d_lctile;
+        t.sel = ngr + 2;  // the plan's choice of the body: matrix cores from six queries per probed list
         prof_begin(idx, PROF_IVF_SCAN, st, &e0);
-        if (t.ctile) {  // both layouts: both kernels are enqueued, the plan's choice (ngr[2]) runs, the other returns at once
-            t.sel = ngr + 2;
-            t.sel_want = 1;
-            HG_TRY(launch_code_mfma(t, gbound, idx->nch, st));
-            t.sel_want = 0;
-        }
-        HG_TRY(launch_code_group(t, gbound, idx->nch, st));
+        HG_TRY(launch_code_bounds(t, gbound, idx->nch, st));
         prof_end(idx, PROF_IVF_SCAN, st, e0);
         // 2. the k smallest lower bounds -> tau
         HG_TRY(launch_select(s, st));

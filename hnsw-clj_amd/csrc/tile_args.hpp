@@ -99,14 +99,12 @@ struct TileArgs {
     // best make_key(distance, row) is folded in registers and merged with one 64-bit atomicMin per wave
     // (implicit groups only; the caller presets out_key[q] = ~0)
     unsigned long long *out_key;
-    // code_group_kernel (code_kernels.hpp): int8 rows of the segments + per-row (scale, bound terms), the batch's query
+    // code_bounds_kernel (code_kernels.hpp): int8 rows of the segments + per-row (scale, bound terms), the batch's query
     // codes and bound scalars; out receives LOWER BOUNDS
     const uint32_t *crows;
-    const uint32_t *ctile;  // the same codes in the MFMA tile layout (code_mfma_kernel), or null
-    // both bounds kernels are launched when both layouts exist; the plan kernel decides on the device which one works:
-    // a kernel whose number is not *sel returns at once (null = always run)
+    const uint32_t *ctile;  // the same codes in the MFMA tile layout (code_mfma_body), or null
+    // which body of code_bounds_kernel serves the batch: decided by the plan kernel on the device (1 = matrix cores)
     const int32_t *sel;
-    int32_t sel_want;
     const float4 *cmeta;
     const uint32_t *qcodes;
     const QueryScal *qscal;
