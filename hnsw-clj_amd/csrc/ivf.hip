@@ -743,6 +743,10 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         order_buf = idx->s_grp.as<int32_t>() + npairs + nq + 16;
     }
     if (use_tile || use_group) HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
+    static const int route_group_min = []() {
+        const char *e = getenv("HNSWGPU_ROUTE_GROUP");  // queries from which a GEMV-order batch routes through the group kernel
+        return e ? atoi(e) : 1024;  // Euclidean 1M x 768: 512 queries 0.85 vs 0.87 ms (GEMV vs group), 1024: 1.50 vs 1.43, 4096: 5.08 vs 4.70
+    }();
     if (d_given_probes) {  // caller-chosen lists (the :turbo mode's random partitions, :271-272); -1 = none
         hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st,
                            reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff, glistoff,
@@ -766,7 +770,13 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     if (use_tile)  // every query against the centroid table on the tile kernel as well
         HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
                              nprobe, st, -1));
-    else if (static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20))  // dense [nq][nlist] distances + select
+    else if (nq >= route_group_min && idx->dim <= kL2MaxDim && tm != 0) {
+        // a large batch in the GEMV order (Euclidean): the centroid table once per group of 32 queries (register-row group
+        // kernel) instead of once per query, the same bits
+        if (!use_group) HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
+        HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
+                             nprobe, st, -1, true));
+    } else if (static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20))  // dense [nq][nlist] distances + select
         HG_TRY(scan_dense_topk(idx, a, nq, idx->nlist, st));
     else
         HG_TRY(scan_topk(idx, a, nq, 1, idx->nlist, st, -1));
