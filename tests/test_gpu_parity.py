@@ -604,6 +604,22 @@ def test_rejection_test_modes_agree(eng, oracle, metric):
         np.testing.assert_array_equal(res[2][2][sub], ost)
 
 
+def test_ivf_euclidean_large_batch_all_gemv_order(eng, oracle):
+    """A Euclidean batch of more than 1024 queries: routing through the register-row group kernel, bounds on the matrix
+    cores (dozens of queries per probed list), refine in the GEMV order -- every stage keeps the one arithmetic the
+    Euclidean metric has at any batch size: probes, ids and distance bits equal the oracle's."""
+    O = oracle
+    base = _data(O, 3000, 136, "clustered", num_clusters=12, noise_level=0.3, seed=61)
+    Q = _data(O, 1100, 136, "clustered", num_clusters=12, noise_level=0.3, seed=62)
+    with eng.Index(base, "l2") as idx:
+        idx.ivf_build(16, 3, 42)
+        cen, off, lids = idx.get_ivf()
+        ids, d, pr = idx.ivf_search(Q, 10, 4, want_probes=True)
+        oi, od, opr = O.ivf_search(base, cen, off, lids, Q, 10, 4, metric=O.L2, mode=O.MODE_DEV)
+        np.testing.assert_array_equal(pr, opr)
+        assert_exact(ids, d, oi, od, "euclidean batch 1100")
+
+
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
 def test_ivf_bounds_pass_agrees_and_rejects(eng, oracle, metric):
     """The IVF bounds pass (code_kernels.hpp): a batch in the GEMV regime with the int8 bounds pass on (mode 2) and off
