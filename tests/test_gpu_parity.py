@@ -674,6 +674,7 @@ def test_rejection_bounds_never_exceed_the_distance(eng, metric, dim):
     queries = [rs.randn(dim).astype(np.float32), base[5].copy(), (base[7] * 1000).astype(np.float32),
                np.zeros(dim, np.float32), base[201].copy()]
     with eng.Index(base, metric) as idx:
+        idx.set_rejection_test(2)          # int8 rows whatever the default mode and the dim
         for qi, q in enumerate(queries):
             lb = idx.rejection_bounds(q, ids)
             d = idx.batch_distances(q, ids)
