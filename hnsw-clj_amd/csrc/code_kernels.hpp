@@ -282,6 +282,83 @@ __global__ __launch_bounds__(kTileThreads) void code_bounds_kernel(TileArgs a) {
     else code_group_body<NCH>(a, smem);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k-means++ seeding (ivf_flat.clj:43-49) as a bounds pass: a round folds the distances to ONE new centre into every
+// row's running minimum (scan_kernel, MODE_MINUPD: `if (d < min) min = d`).  A row whose lower bound is already >= its
+// minimum keeps it whatever d is, so only the rows the new centre may actually be nearest to -- its own cluster, and
+// early in the seeding the rows that have no centre nearby yet -- fetch their f32 row; the others cost their int8 row.
+// Same arithmetic for the rows that are evaluated, hence the same minima, bit for bit.
+// ------------------------------------------------------------------------------------------------
+struct SeedArgs {
+    const float *rows;
+    const float *row_norms;
+    int64_t ld, n;
+    int32_t dim, metric;
+    int64_t cur;             // the new centre is base row `cur`
+    const uint32_t *qrows;   // codes of the base rows (lane layout) + meta
+    const float4 *qmeta;
+    float *out;              // running minima [n]
+    int32_t rows_per_wg;     // multiple of 32
+};
+
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void seed_update_kernel(SeedArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int nvec = static_cast<int>(a.ld / 4);
+    float4 q[NCH];
+    load_row<NCH>(q, a.rows + a.cur * a.ld, nvec, lane, true);
+    const float qn = a.metric == METRIC_COS ? a.row_norms[a.cur] : 0.0f;  // as the f32 pass: the stored norm
+    QueryCode<NCH> qc;
+    encode_query<NCH>(q, qc);
+    const int own = wave_sum8_row(lane);
+    const int64_t w0 = static_cast<int64_t>(blockIdx.x) * a.rows_per_wg;
+    const int64_t w1 = w0 + a.rows_per_wg < a.n ? w0 + a.rows_per_wg : a.n;
+    for (int64_t base = w0 + wave * 8; base < w1; base += kNWave * 8) {
+        const int64_t myrow = base + own;
+        const bool ok = (lane & 7) == 0 && myrow < w1;
+        const float4 mymeta = ok ? a.qmeta[myrow] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float myold = ok ? a.out[myrow] : 0.0f;
+        int acc[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const int64_t row = base + b < w1 ? base + b : w1 - 1;
+            const uint32_t *rp = a.qrows + (row * kWave + lane) * NCH;
+            uint32_t w[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) w[c] = rp[c];
+            acc[b] = code_dot<NCH>(qc.a, w);
+        }
+        const int tot = wave_sum8_int(acc, lane);
+        const float lb = code_lower_bound(a.metric, tot, qc.sc, mymeta, mymeta.w);
+        const bool need = ok && !(lb >= myold);  // NaN: evaluate
+        uint64_t m = __ballot(need);             // bit 8r = row r of the block
+        while (m) {
+            float4 r[RB][NCH];
+            int64_t rw[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                rw[b] = -1;
+                if (m) {
+                    rw[b] = base + ((__ffsll(static_cast<unsigned long long>(m)) - 1) >> 3);
+                    m &= m - 1;
+                    load_row<NCH>(r[b], a.rows + rw[b] * a.ld, nvec, lane, true);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                if (rw[b] < 0) break;
+                const float s = wave_sum(lane_partial<NCH, L2>(q, r[b]));
+                if (lane == 0) {
+                    const float d = finish_dist(a.metric, s, qn, a.metric == METRIC_COS ? a.row_norms[rw[b]] : 0.0f);
+                    const float o = a.out[rw[b]];
+                    if (d < o) a.out[rw[b]] = d;
+                }
+            }
+        }
+    }
+}
+
 struct TauArgs {
     const uint32_t *ord;   // [nq][k] order keys of the k smallest lower bounds (0xffffffff = none)
     const float *lb;       // [nq][k]
