@@ -1304,20 +1304,12 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                         int pos = __popcll(m & ((1ull << lane) - 1ull));
                         if (fresh) {
                             cand_id[pos] = nb;
-                            if (PF && have) cand_d[pos] = pubd;  // (the gather below skips this candidate)
+                            if (PF) {
+                                cand_P[pos] = have ? 1 : 0;     // (cand_P is the merge's from step 2 on; until then: published?)
+                                if (have) cand_d[pos] = pubd;   // the gather below skips this candidate
+                            }
                         }
                         ncand = __popcll(m);
-                        if (PF) {  // which compacted candidates carry a published distance
-                            uint64_t pm = __ballot(fresh && have), packed = 0;
-                            for (; pm; pm &= pm - 1) {
-                                const int l = __ffsll(static_cast<unsigned long long>(pm)) - 1;
-                                packed |= 1ull << __popcll(m & ((1ull << l) - 1ull));
-                            }
-                            if (lane == 0) {
-                                sc[9] = static_cast<int32_t>(static_cast<uint32_t>(packed));
-                                sc[10] = static_cast<int32_t>(static_cast<uint32_t>(packed >> 32));
-                            }
-                        }
                         if (lane == 0) curA[found].y = node | kExpanded;
                     }
                     if (lane == 0) {
@@ -1350,8 +1342,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                 //      shrinks within a hop) and its distance is never looked at again -- it gets +inf and no f32 fetch
                 uint64_t needmask = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
                 if (PF && a.pf_res != nullptr)  // distances a helper has published (cand_d holds them): nothing to gather
-                    needmask &= ~(static_cast<uint64_t>(static_cast<uint32_t>(sc[9])) |
-                                  (static_cast<uint64_t>(static_cast<uint32_t>(sc[10])) << 32));
+                    needmask &= ~__ballot(lane < nc && cand_P[lane] != 0);
                 if (a.qrows != nullptr && list_full) {
                     // eight code rows per wave step (sixteen in flight cost 220 VGPRs at dim 768: a wave less per SIMD)
                     uint64_t wmask = 0;
