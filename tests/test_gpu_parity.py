@@ -535,20 +535,22 @@ def test_ivf_build_golden(eng, oracle, name):
         assert all(i in members for i in ids.ravel() if i >= 0)
 
 
-def test_helpers_evaluate_small_launches(eng, oracle):
+@pytest.mark.parametrize("metric,dim,M", [("cosine", 136, 16), ("l2", 72, 16), ("dot", 300, 32)])
+def test_helpers_evaluate_small_launches(eng, oracle, metric, dim, M):
     """Launches of a handful of queries: helper workgroups on idle CUs evaluate the neighbours of the candidates the
     traversal will expand next and publish the distances (kernels.hpp: pf_res); the traversal gathers only what has not
     arrived.  Timing decides WHICH distances arrive, never what they are: ids, distance bits and both counters equal the
     oracle's for 1 / 3 / 20 / 64 queries, several times over, and the device counters show that published distances
     were used (the int8 test is switched off here, so every neighbour not gathered locally was published)."""
     O = oracle
-    base = _data(O, 20000, 136, "clustered", seed=51)
+    code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
+    base = _data(O, 20000, dim, "clustered", seed=51)
     base[9000:9100] = base[17]                                  # ties among the candidates
-    Q = np.concatenate([_data(O, 63, 136, "clustered", seed=52), base[17:18]]).astype(np.float32)
-    with eng.Index(base) as idx:
-        idx.hnsw_build(16, 80, 42)
+    Q = np.concatenate([_data(O, 63, dim, "clustered", seed=52), base[17:18]]).astype(np.float32)
+    with eng.Index(base, metric) as idx:
+        idx.hnsw_build(M, 80, 42)                               # M = 32: 64 neighbour slots, 16 per helper
         g = idx.get_graph()
-        oi, od, ost, _ = O.hnsw_search(base, g, Q, 10, ef=96, mode=O.MODE_DEV)
+        oi, od, ost, _ = O.hnsw_search(base, g, Q, 10, ef=96, metric=code, mode=O.MODE_DEV)
         idx.set_rejection_test(0)
         idx.set_profiling(True)
         used = 0
