@@ -15,7 +15,7 @@
 #include "engine.hpp"
 #include "tile_kernels.hpp"
 #include "l2_kernels.hpp"
-#include "code_kernels.hpp"
+#include "stream_kernels.hpp"
 
 namespace hg {
 
@@ -70,67 +70,76 @@ static bool codes_wanted(const hnswgpu_index *idx) {
     return idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128);
 }
 
-// The int8 rows of the traversal's rejection test: once per handle (the base rows never change), on the first graph.
+// The int8 rows of the traversal's rejection test and of the k-means++ bounds pass (base order, lane layout): once per
+// handle (the base rows never change), on the first graph or build.
 int ensure_qrows(hnswgpu_index *idx, hipStream_t st) {
     if (!codes_wanted(idx) || idx->d_qrows || idx->n <= 0) return 0;
-    if (idx->lrows_alias && idx->d_lcrows) {  // the IVF lists are the base rows in place and already coded
-        idx->d_qrows = idx->d_lcrows;
-        idx->d_qmeta = idx->d_lcmeta;
-        return 0;
-    }
-    HG_TRY(quantize_rows(idx, idx->d_base, idx->n, &idx->d_qrows, &idx->d_qmeta, st));
-    if (idx->lrows_alias && idx->nlist > 0 && !idx->d_lcrows) {
-        idx->d_lcrows = idx->d_qrows;
-        idx->d_lcmeta = idx->d_qmeta;
-    }
-    return 0;
+    return quantize_rows(idx, idx->d_base, idx->n, &idx->d_qrows, &idx->d_qmeta, st);
 }
 
-// The list codes once more in the MFMA tile layout: blocks of 32 rows x 32-byte steps (code_mfma_kernel)
-static int ensure_list_tile(hnswgpu_index *idx, hipStream_t st) {
-    static const int on = []() {
-        const char *e = getenv("HNSWGPU_CODE_MFMA");  // 0 = the bounds pass stays on the dot4c kernel (A/B; no tile copy)
-        return e ? atoi(e) : 1;
-    }();
-    if (!on || idx->d_lctile || idx->n <= 0) return 0;
+// The int8 rows of the IVF list scan's bounds pass (stream_kernels.hpp): list order, MFMA tile layout -- blocks of 32
+// rows x 32-byte steps -- plus the per-row bound terms; ONE copy, once per set of lists.
+int ensure_list_codes(hnswgpu_index *idx, hipStream_t st) {
+    if (!codes_wanted(idx) || idx->d_lctile || idx->n <= 0 || idx->nlist <= 0) return 0;
     const int64_t n = idx->n, blocks = (n + 31) / 32;
     const size_t bytes = static_cast<size_t>(blocks) * 32 * idx->nch * 256;
     HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lctile), bytes));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lcmeta), sizeof(float4) * n));
     HG_HIP(hipMemsetAsync(idx->d_lctile, 0, bytes, st));
     unsigned grid = static_cast<unsigned>((n + kNWave - 1) / kNWave);
-#define CALL(N, R, L) \
-    hipLaunchKernelGGL((quantize_rows_tile_kernel<N>), dim3(grid), dim3(kWG), 0, st, idx->d_lrows, idx->ld, n, idx->d_lctile)
+#define CALL(N, R, L)                                                                                                   \
+    hipLaunchKernelGGL((quantize_rows_tile_kernel<N>), dim3(grid), dim3(kWG), 0, st, idx->d_lrows, idx->ld, n, idx->metric, \
+                       idx->d_lctile, idx->d_lcmeta)
     HG_DISPATCH(idx->nch, false, CALL);
 #undef CALL
     HG_HIP(hipGetLastError());
     return 0;
 }
 
-// ... and of the IVF list scan's bounds pass (code_kernels.hpp): once per set of lists.
-int ensure_list_codes(hnswgpu_index *idx, hipStream_t st) {
-    if (!codes_wanted(idx) || idx->d_lcrows || idx->n <= 0 || idx->nlist <= 0) return 0;
-    if (idx->lrows_alias) {
-        HG_TRY(ensure_qrows(idx, st));  // one copy serves both (it sets d_lcrows)
-        return ensure_list_tile(idx, st);
-    }
-    HG_TRY(quantize_rows(idx, idx->d_lrows, idx->n, &idx->d_lcrows, &idx->d_lcmeta, st));
-    return ensure_list_tile(idx, st);
-}
-
-int launch_code_bounds(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st) {
-    int64_t blocks = (ngroups_bound * a.nchunks + 7) & ~7LL;
+int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, hipStream_t st) {
     if (blocks <= 0) return 0;
-    HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "code scan grid too large");
-    const size_t lds = std::max(code_group_lds_bytes(nch), a.ctile ? code_mfma_lds_bytes(nch, kCodeMfmaWaves) : size_t(0));
+    HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "bounds pass grid too large");
+    const size_t lds = stream_lds_bytes(nch);
 #define CALL(N, R, L)                                                                                                  \
     do {                                                                                                               \
         static bool attr_done[64] = {};                                                                                \
         if (lds > 48 * 1024 && attr_needed(attr_done))                                                                 \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&code_bounds_kernel<N>),                         \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_bounds_kernel<N>),                       \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
-        hipLaunchKernelGGL((code_bounds_kernel<N>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, a); \
+        hipLaunchKernelGGL((stream_bounds_kernel<N>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, a); \
     } while (0)
     HG_DISPATCH(nch, false, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_finish(const FinishArgs &a, int nch, hipStream_t st) {
+    const int64_t blocks = static_cast<int64_t>(a.nq) * a.slices;
+    if (blocks <= 0) return 0;
+    HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "finish grid too large");
+    const size_t lds = sizeof(uint64_t) * (kNWave + 2) * a.k;  // W lists + final list + (ord, dist) of the result
+    HG_REQUIRE(lds <= 64 * 1024, HNSWGPU_ELIMIT, "k too large for the finish kernel (k=%d)", a.k);
+    const bool l2 = a.metric == METRIC_L2;
+#define CALL(N, R, L)                                                                                                   \
+    do {                                                                                                                \
+        static bool attr_done[64] = {};                                                                                 \
+        if (lds > 48 * 1024 && attr_needed(attr_done))                                                                  \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_finish_kernel<N, R, L>),                     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));                         \
+        hipLaunchKernelGGL((ivf_finish_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a);   \
+    } while (0)
+    HG_DISPATCH(nch, l2, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_query_prep(const PrepArgs &a, int nch, hipStream_t st) {
+    if (a.nq <= 0) return 0;
+    const bool l2 = a.metric == METRIC_L2;
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_query_prep_kernel<N, R, L>), dim3(a.nq), dim3(kWG), 0, st, a)
+    HG_DISPATCH(nch, l2, CALL);
 #undef CALL
     HG_HIP(hipGetLastError());
     return 0;
@@ -296,7 +305,7 @@ int scan_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_quer
 }
 
 // zero-initialised per-query counters of the fused tails (each tail resets its own counter: zero between calls)
-static int ensure_counters(hnswgpu_index *idx, size_t n, hipStream_t st) {
+int ensure_counters(hnswgpu_index *idx, size_t n, hipStream_t st) {
     const size_t bytes = sizeof(uint32_t) * 2 * n;  // [n] scan tails | [n] route tails
     if (bytes <= idx->s_done.cap) return 0;
     HG_TRY(idx->s_done.ensure(bytes));
@@ -348,6 +357,14 @@ struct RouteArgs {
     Pair *pairs;
     int32_t *probes;  // optional
     int32_t *qcnt;    // optional
+    // optional, for the survivor stream of the list scan (stream_kernels.hpp): the query's int8 codes + bound scalars,
+    // tau = none, an empty survivor list
+    uint32_t *qcodes;
+    QueryScal *qscal;
+    uint32_t *tau, *surv_cnt;
+    int32_t k;               // of the search: the first threshold is the k-th smallest distance of the stream's head
+    const float *rows;       // list rows (f32) + norms
+    const float *row_norms;
 };
 
 template <int NCH, int RB, bool L2>
@@ -359,10 +376,17 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
     const int qi = blockIdx.x / a.blocks_per_query, bx = blockIdx.x % a.blocks_per_query;
     const int64_t r0 = static_cast<int64_t>(bx) * a.rows_per_block;
     const int64_t r1 = r0 + a.rows_per_block < a.nlist ? r0 + a.rows_per_block : a.nlist;
+    float4 q[NCH];
+    load_query<NCH>(q, a.Q + qi * a.qld, a.dim, lane);
+    const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
     if (r0 < r1) {
-        float4 q[NCH];
-        load_query<NCH>(q, a.Q + qi * a.qld, a.dim, lane);
-        const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+        if (a.qcodes && bx == 0 && wave == kNWave - 1) {  // once per query (its last wave has the fewest rows to scan)
+            QueryCode<NCH> qc;
+            encode_query<NCH>(q, qc);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) a.qcodes[(static_cast<int64_t>(qi) * NCH + c) * kWave + lane] = qc.a[c];
+            if (lane == 0) a.qscal[qi] = qc.sc;
+        }
         const int nvec = static_cast<int>(a.ld / 4);
         for (int64_t base = r0 + wave * RB; base < r1; base += kNWave * RB) {
             float4 r[RB][NCH];
@@ -405,7 +429,8 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
     s.out_ord = a.out_ord;
     s.out_dist = a.out_dist;
     select_topk_wg<true>(s, qi, kNWave, smem);
-    if (wave != 0) return;
+    __shared__ int64_t tail_qcnt;
+    if (wave == 0) {
     __threadfence_block();
     // the query's probe table: offsets of the probed lists in its candidate stream (probe_pairs_kernel, one wave)
     uint32_t carry = 0, gcarry = 0;
@@ -441,12 +466,29 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
         gcarry += __shfl(gincl, kWave - 1, kWave);
     }
     if (a.qcnt && lane == 0) a.qcnt[qi] = static_cast<int32_t>(carry);
+    if (lane == 0) tail_qcnt = carry;
+    wait_stores_acked();  // the probe table is read back by the other waves below
+    }
+    if (!a.tau) return;
+    // survivor stream: an empty survivor list and the first threshold, from the head of the query's candidate stream
+    __syncthreads();
+    if (threadIdx.x == 0) a.surv_cnt[qi] = 0;
+    seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, a.pairs + static_cast<int64_t>(qi) * a.nprobe, a.nprobe, tail_qcnt, a.k, a.rows,
+                             a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi);
 }
 
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
-                     int32_t *qcnt, hipStream_t st) {
+                     int32_t *qcnt, hipStream_t st, uint32_t *qcodes, QueryScal *qscal, uint32_t *tau, uint32_t *surv_cnt,
+                     int32_t k) {
     RouteArgs a;
     memset(&a, 0, sizeof(a));
+    a.qcodes = qcodes;
+    a.qscal = qscal;
+    a.tau = tau;
+    a.surv_cnt = surv_cnt;
+    a.k = k;
+    a.rows = idx->d_lrows;
+    a.row_norms = idx->d_lnorms;
     a.cent = idx->d_cent;
     a.cnorms = idx->d_cnorms;
     a.ld = idx->ld;
@@ -478,7 +520,7 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
     a.pairs = pairs;
     a.probes = probes;
     a.qcnt = qcnt;
-    const size_t lds = sizeof(uint64_t) * (kNWave + 1) * nprobe;
+    const size_t lds = std::max<size_t>(sizeof(uint64_t) * (kNWave + 1) * nprobe, sizeof(float) * kSeedMax);
     HG_REQUIRE(lds <= 48 * 1024, HNSWGPU_ELIMIT, "nprobe too large for the fused routing kernel");
     const int64_t blocks = static_cast<int64_t>(nq) * a.blocks_per_query;
     const bool l2 = a.metric == METRIC_L2;
@@ -1186,8 +1228,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows in place: freed once, below
-    if (idx->d_lcrows == idx->d_qrows) idx->d_lcrows = nullptr, idx->d_lcmeta = nullptr;  // one copy serving both
-    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_lcrows, idx->d_lcmeta, idx->d_lctile, idx->d_rej_stats, idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
+    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_lcmeta, idx->d_lctile, idx->d_rej_stats, idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
                     idx->d_cent,  idx->d_cnorms, idx->d_lrows,  idx->d_lnorms,  idx->d_listoff, idx->d_listids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

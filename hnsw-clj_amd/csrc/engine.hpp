@@ -86,11 +86,10 @@ struct hnswgpu_index {
     // quantize_rows_kernel); made when a graph is installed or built, null while rejection_mode is 0
     uint32_t *d_qrows = nullptr;
     float4 *d_qmeta = nullptr;
-    // the same for the IVF list rows (list order; code_kernels.hpp); alias d_qrows / d_qmeta when the lists are the
-    // base rows in place
-    uint32_t *d_lcrows = nullptr;
+    // int8 copy of the IVF list rows (list order) in the MFMA tile layout + per-row bound terms, for the bounds pass of
+    // the list scan (stream_kernels.hpp); made with the lists, null while rejection_mode is 0
+    uint32_t *d_lctile = nullptr;
     float4 *d_lcmeta = nullptr;
-    uint32_t *d_lctile = nullptr;  // the list codes once more, in the MFMA tile layout (code_kernels.hpp: code_mfma_kernel)
     unsigned long long *d_rej_stats = nullptr;  // [2], counted by the traversal while profiling is on
     int rejection_mode = 1;  // 0 = off, 1 = batches that fill the chip (launch_hnsw_idx), 2 = every launch
     int cus = 256;
@@ -220,7 +219,6 @@ bool attr_needed(bool (&done)[64]);
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);
 int ensure_qrows(hnswgpu_index *idx, hipStream_t st);
 int ensure_list_codes(hnswgpu_index *idx, hipStream_t st);
-int launch_code_bounds(const TileArgs &a, int64_t ngroups_bound, int nch, hipStream_t st);
 int launch_scan(int nch, const ScanArgs &a, hipStream_t st);
 int launch_merge(const MergeArgs &a, hipStream_t st);
 // Serve `me` through combiner `c`: queue it, lead one batch at a time while it is not done.  `take(first, r, total)`
@@ -238,7 +236,17 @@ int ensure_pinned(hnswgpu_index *idx, size_t bytes);
 int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st);
 // small IVF batches: routing in one launch, list scan with the merge / decode folded into its last workgroups
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
-                     int32_t *qcnt, hipStream_t st);
+                     int32_t *qcnt, hipStream_t st, uint32_t *qcodes = nullptr, QueryScal *qscal = nullptr,
+                     uint32_t *tau = nullptr, uint32_t *surv_cnt = nullptr, int32_t k = 0);
+// the survivor stream of the IVF list scan (stream_kernels.hpp)
+struct StreamArgs;
+struct FinishArgs;
+struct PrepArgs;
+int launch_query_prep(const PrepArgs &a, int nch, hipStream_t st);
+int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, hipStream_t st);
+int launch_finish(const FinishArgs &a, int nch, hipStream_t st);
+// zero-initialised per-query counters of the fused tails (s_done: [n] scan / finish tails | [n] route tails)
+int ensure_counters(hnswgpu_index *idx, size_t n, hipStream_t st);
 int scan_fused(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_query, int64_t max_rows, int64_t mean_rows,
                hipStream_t st, int prof_slot);
 extern unsigned long long *g_tile_dbg_buf;

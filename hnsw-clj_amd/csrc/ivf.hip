@@ -7,10 +7,16 @@
 #include <algorithm>
 
 #include "engine.hpp"
-#include "code_kernels.hpp"
+#include "stream_kernels.hpp"
 #include "javarandom.hpp"
 
 namespace hg {
+
+// tuning / test switches that are read on EVERY call (the tests flip them inside one process)
+static int64_t env_now(const char *name, int64_t dflt) {
+    const char *e = getenv(name);
+    return e ? atoll(e) : dflt;
+}
 
 // probes[q][p] = p-th nearest centroid; pairs[q*nprobe+p] = that list's row range + the offset of
 // its rows in the query's concatenated candidate stream (ties are broken in that order, which is
@@ -113,7 +119,8 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(int32_t *cnt, int nlist,
                                                         const int64_t *list_off, int64_t chunk_rows, int max_chunks,
                                                         int32_t *wi_group, int32_t *wi_chunk, int32_t *nitems,
                                                         int32_t *work_ctr, const int32_t *probes, int64_t npairs,
-                                                        const Pair *pairs, int64_t stride, GroupMember *members) {
+                                                        const Pair *pairs, int64_t stride, GroupMember *members,
+                                                        WorkDesc *wi_desc) {
     __shared__ int32_t sm[1024], sg[1024], sw[1024];
     __shared__ int32_t carry_m, carry_g, carry_w;
     const int tid = threadIdx.x;
@@ -156,10 +163,23 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(int32_t *cnt, int nlist,
                 grp_mem_cnt[g] = c - b < tq ? c - b : tq;
             }
             // work items chunk-major: the groups of one chunk (same rows) are neighbours -- see tile_scan_kernel
+            const int64_t tiles = (rows + kTileRows - 1) / kTileRows;
+            const int64_t per = nch > 0 ? (tiles + nch - 1) / nch * kTileRows : 0;
             for (int ch = 0; ch < nch; ch++)
-                for (int g = g0; g < g0 + ng; g++, w++) {
+                for (int g = g0, b = 0; g < g0 + ng; g++, w++, b += tq) {
                     wi_group[w] = g;
                     wi_chunk[w] = ch;
+                    if (wi_desc) {  // the bounds pass reads ONE record per work item instead of five dependent tables
+                        WorkDesc d;
+                        d.rb0 = list_off[l];
+                        const int64_t a0 = ch * per, a1 = a0 + per < rows ? a0 + per : rows;
+                        d.r0_off = static_cast<int32_t>(a0);
+                        d.r1_off = static_cast<int32_t>(a1 > a0 ? a1 : a0);
+                        d.mem_begin = mem + b;
+                        d.cnt = c - b < tq ? c - b : tq;
+                        d.pad[0] = d.pad[1] = 0;
+                        wi_desc[w] = d;
+                    }
                 }
         }
         __syncthreads();
@@ -173,10 +193,6 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(int32_t *cnt, int nlist,
     if (tid == 0) {
         *ngroups = carry_g;
         *nitems = carry_w;
-        // which bounds kernel serves the batch (code_kernels.hpp): the matrix cores once a list is probed by six queries
-        // or more on average (a 32 x 32 MFMA tile costs the same for one query as for 32; measured on 1M x 768: 4 per
-        // list 0.20 vs 0.17 ms for the dot4c kernel, 8 per list 0.18 vs 0.23, Euclidean batch 1024: 0.39 vs 1.31)
-        ngroups[2] = carry_m >= 6 * carry_g ? 1 : 0;
     }
     if (probes) {  // ivf_scatter_kernel's job: every pair into a slot of its list's member range
         __syncthreads();
@@ -308,13 +324,11 @@ static int validate_lists(int64_t n, int32_t nlist, const int64_t *off, const in
 
 static void free_ivf(hnswgpu_index *idx) {
     if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows themselves: not ours to free
-    if (idx->d_lcrows == idx->d_qrows) idx->d_lcrows = nullptr, idx->d_lcmeta = nullptr;  // the traversal's copy: stays
     void *ptrs[] = {idx->d_cent, idx->d_cnorms, idx->d_lrows, idx->d_lnorms, idx->d_listoff, idx->d_listids, idx->d_glistoff,
-                    idx->d_lcrows, idx->d_lcmeta, idx->d_lctile};
+                    idx->d_lcmeta, idx->d_lctile};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     idx->d_cent = idx->d_cnorms = idx->d_lrows = idx->d_lnorms = nullptr;
-    idx->d_lcrows = nullptr;
     idx->d_lcmeta = nullptr;
     idx->d_lctile = nullptr;
     idx->d_listoff = idx->d_glistoff = nullptr;
@@ -510,29 +524,91 @@ static int kmeanspp_device(hnswgpu_index *idx, int32_t nlist, int64_t seed, std:
     return 0;
 }
 
-// Large batches: group the (query, list) pairs by list, keep each group of <= 32 queries resident in LDS
-// and stream the list through the MFMA tile kernel once per group; distances land in a dense
-// per-query candidate array (position = the pair's order key), then one select pass per query.
-// scan_mode 0 = that; 1 = the register-row group kernel (GEMV order); 2 = bounds on int8 rows first, f32 distances
-// (GEMV order) for the candidates that can still be among the k nearest (code_kernels.hpp)
-static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
-                         const int32_t *d_probes, const int32_t *d_qcnt, hipStream_t st, int scan_mode = 0) {
-    const bool gemv_order = scan_mode == 1, coded = scan_mode == 2;
+// The (query, probed list) pairs of a batch grouped by list on the device: groups of <= 32 queries, every group cut into
+// chunks of whole tiles -- the dense work list the tile scan, the register-row group kernel and the bounds pass share.
+struct GroupPlan {
+    int64_t stride;      // candidates per query, upper bound (a multiple of 4)
+    int64_t gbound;      // upper bound of the number of groups
+    int64_t cr;          // rows per chunk (whole tiles)
+    int32_t max_chunks;
+    int64_t wbound;      // upper bound of the number of work items
+    int32_t *gseg, *gmb, *gmc, *wig, *wic, *ngr, *nit, *wctr;
+    WorkDesc *desc;      // per work item (bounds pass), or null
+    GroupMember *members;
+};
+
+// ptiles > 0: persistent workgroups pulling items of up to `ptiles` tiles off a queue (tile_scan_kernel); 0 = one
+// workgroup per item, items sized to fill the chip.  member_stride: a member's output base is q * member_stride + the
+// pair's offset in the query's candidate stream (0 = the offset alone: the survivor stream's order keys).
+static int plan_groups(hnswgpu_index *idx, int32_t nq, int32_t nprobe, const int32_t *d_probes, int64_t ptiles,
+                       int64_t member_stride, bool want_desc, hipStream_t st, GroupPlan &g) {
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
     const int nlist = idx->nlist;
-    // candidates per query, upper bound; a multiple of 4 so that every query's array is 16-B aligned (float4 select)
-    const int64_t stride = (static_cast<int64_t>(nprobe) * idx->max_list_len + 3) / 4 * 4;
+    // a multiple of 4 so that every query's array is 16-B aligned (float4 select)
+    g.stride = (static_cast<int64_t>(nprobe) * idx->max_list_len + 3) / 4 * 4;
     const int tq = tile_tq(idx->dim);
-    const int64_t gbound = npairs / tq + nlist;                                // sum_l ceil(cnt_l / tq) <= this
-    HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(nq) * stride));  // queries already padded
-    // rows per workgroup: whole tiles of 128, enough workgroups to fill the chip; the device splits every list
-    int64_t mean = std::max<int64_t>(1, idx->n / std::max(nlist, 1));
-    int64_t est_groups = std::max<int64_t>(1, npairs / tq + nlist / 2);
-    int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows;
+    g.gbound = npairs / tq + nlist;  // sum_l ceil(cnt_l / tq) <= this
+    // rows per workgroup: whole tiles, enough workgroups to fill the chip; the device splits every list
+    const int64_t mean = std::max<int64_t>(1, idx->n / std::max(nlist, 1));
+    const int64_t est_groups = std::max<int64_t>(1, npairs / tq + nlist / 2);
+    const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows;
     static const int64_t tgt = []() {
         const char *e = getenv("HNSWGPU_TILE_WGS");  // tuning override
         return e ? atoll(e) : 2048LL;
     }();
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + est_groups - 1) / est_groups));
+    int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows;
+    if (ptiles > 0) cr = std::max<int64_t>(1, std::min<int64_t>(ptiles, mean_tiles)) * kTileRows;
+    const int64_t max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows, tpc = cr / kTileRows;
+    g.cr = cr;
+    g.max_chunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
+    g.wbound = g.gbound * g.max_chunks;
+    // int32 scratch: cnt | list_mem_begin | fill [nlist each] | grp_seg | grp_mem_begin | grp_mem_cnt [gbound each] |
+    //                wi_group | wi_chunk [wbound each] | ngroups | nitems | work counters; then descriptors [wbound]
+    size_t ints = 3 * static_cast<size_t>(nlist) + 3 * static_cast<size_t>(g.gbound) + 2 * static_cast<size_t>(g.wbound) + 4 + 8 + 8;
+    ints = (ints + 7) & ~static_cast<size_t>(7);  // the descriptors behind them stay 32-B aligned
+    const size_t desc_bytes = want_desc ? sizeof(WorkDesc) * static_cast<size_t>(g.wbound) : 0;
+    HG_TRY(idx->s_misc.ensure(sizeof(int32_t) * ints + desc_bytes));
+    HG_TRY(idx->s_misc2.ensure(sizeof(GroupMember) * static_cast<size_t>(npairs)));
+    int32_t *cnt = idx->s_misc.as<int32_t>();
+    int32_t *lmb = cnt + nlist, *fill = lmb + nlist;
+    g.gseg = fill + nlist;
+    g.gmb = g.gseg + g.gbound;
+    g.gmc = g.gmb + g.gbound;
+    g.wig = g.gmc + g.gbound;
+    g.wic = g.wig + g.wbound;
+    g.ngr = g.wic + g.wbound;
+    g.nit = g.ngr + 1;
+    g.wctr = g.ngr + 4;
+    g.desc = want_desc ? reinterpret_cast<WorkDesc *>(cnt + ints) : nullptr;
+    g.members = idx->s_misc2.as<GroupMember>();
+    if (npairs <= 8192) {  // small batches are launch-bound: histogram, plan and scatter in the one-workgroup kernel
+        hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, g.gseg, g.gmb, g.gmc, g.ngr, tq,
+                           idx->d_listoff, cr, g.max_chunks, g.wig, g.wic, g.nit, ptiles > 0 ? g.wctr : nullptr, d_probes,
+                           npairs, idx->s_pairs.as<Pair>(), member_stride, g.members, g.desc);
+    } else {
+        HG_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nlist, st));
+        hipLaunchKernelGGL(ivf_hist_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st, d_probes,
+                           npairs, cnt);
+        hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, g.gseg, g.gmb, g.gmc, g.ngr, tq,
+                           idx->d_listoff, cr, g.max_chunks, g.wig, g.wic, g.nit, ptiles > 0 ? g.wctr : nullptr,
+                           static_cast<const int32_t *>(nullptr), static_cast<int64_t>(0), static_cast<const Pair *>(nullptr),
+                           static_cast<int64_t>(0), static_cast<GroupMember *>(nullptr), g.desc);
+        hipLaunchKernelGGL(ivf_scatter_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st,
+                           idx->s_pairs.as<Pair>(), d_probes, npairs, member_stride, lmb, fill, g.members);
+    }
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+// Large batches: group the (query, list) pairs by list, keep each group of <= 32 queries resident in LDS
+// and stream the list through the MFMA tile kernel once per group; distances land in a dense
+// per-query candidate array (position = the pair's order key), then one select pass per query.
+// gemv_order: the register-row group kernel (GEMV summation order) instead of the MFMA tiles.
+static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
+                         const int32_t *d_probes, const int32_t *d_qcnt, hipStream_t st, bool gemv_order) {
+    const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
+    const int tq = tile_tq(idx->dim);
     // persistent workgroups pulling items off a queue (tile_scan_kernel): items of up to `ptiles` tiles, however many
     // there are -- the queue balances them.  0 = one workgroup per item, items sized to fill the chip (round 1)
     static const int64_t ptiles_env = []() {
@@ -540,38 +616,13 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
         return e ? atoll(e) : 4LL;
     }();
     // the L2 group kernel takes one item per workgroup; few groups: shorter items, so that every CU has several
-    const int64_t ptiles =
-        idx->metric == METRIC_L2 || gemv_order || coded ? 0 : (ptiles_env == 4 && est_groups < 1200 ? 2 : ptiles_env);
-    int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + est_groups - 1) / est_groups));
-    int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows;
-    if (ptiles > 0) cr = std::max<int64_t>(1, std::min<int64_t>(ptiles, mean_tiles)) * kTileRows;
-    const int64_t max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows, tpc = cr / kTileRows;
-    const int32_t max_chunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
-    const int64_t wbound = gbound * max_chunks;
-    // int32 scratch: cnt | list_mem_begin | fill [nlist each] | grp_seg | grp_mem_begin | grp_mem_cnt [gbound each] |
-    //                wi_group | wi_chunk [wbound each] | ngroups | nitems
-    size_t ints = 3 * static_cast<size_t>(nlist) + 3 * static_cast<size_t>(gbound) + 2 * static_cast<size_t>(wbound) + 4 + 8;
-    HG_TRY(idx->s_misc.ensure(sizeof(int32_t) * ints));
-    HG_TRY(idx->s_misc2.ensure(sizeof(GroupMember) * static_cast<size_t>(npairs)));
-    int32_t *cnt = idx->s_misc.as<int32_t>();
-    int32_t *lmb = cnt + nlist, *fill = lmb + nlist, *gseg = fill + nlist, *gmb = gseg + gbound, *gmc = gmb + gbound,
-            *wig = gmc + gbound, *wic = wig + wbound, *ngr = wic + wbound, *nit = ngr + 1, *wctr = ngr + 4;
-    if (npairs <= 8192) {  // small batches are launch-bound: histogram, plan and scatter in the one-workgroup kernel
-        hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr, tq,
-                           idx->d_listoff, cr, max_chunks, wig, wic, nit, ptiles > 0 ? wctr : nullptr, d_probes, npairs,
-                           idx->s_pairs.as<Pair>(), stride, idx->s_misc2.as<GroupMember>());
-    } else {
-        HG_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nlist, st));
-        hipLaunchKernelGGL(ivf_hist_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st, d_probes,
-                           npairs, cnt);
-        hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, gseg, gmb, gmc, ngr, tq,
-                           idx->d_listoff, cr, max_chunks, wig, wic, nit, ptiles > 0 ? wctr : nullptr,
-                           static_cast<const int32_t *>(nullptr), static_cast<int64_t>(0), static_cast<const Pair *>(nullptr),
-                           static_cast<int64_t>(0), static_cast<GroupMember *>(nullptr));
-        hipLaunchKernelGGL(ivf_scatter_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st,
-                           idx->s_pairs.as<Pair>(), d_probes, npairs, stride, lmb, fill, idx->s_misc2.as<GroupMember>());
-    }
-    HG_HIP(hipGetLastError());
+    const int64_t est_groups = std::max<int64_t>(1, npairs / tq + idx->nlist / 2);
+    const int64_t ptiles = idx->metric == METRIC_L2 || gemv_order ? 0 : (ptiles_env == 4 && est_groups < 1200 ? 2 : ptiles_env);
+    GroupPlan g;
+    const int64_t stride0 = (static_cast<int64_t>(nprobe) * idx->max_list_len + 3) / 4 * 4;
+    HG_TRY(plan_groups(idx, nq, nprobe, d_probes, ptiles, stride0, false, st, g));
+    const int64_t stride = g.stride;
+    HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(nq) * stride));  // queries already padded
     TileArgs t;
     memset(&t, 0, sizeof(t));
     t.rows = idx->d_lrows;
@@ -582,19 +633,19 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     t.gemv_order = gemv_order ? 1 : 0;
     t.Qp = idx->s_qp.as<float>();
     t.q_norms = idx->s_qn.as<float>();
-    t.grp_seg = gseg;
-    t.grp_mem_begin = gmb;
-    t.grp_mem_cnt = gmc;
-    t.ngroups = ngr;
-    t.members = idx->s_misc2.as<GroupMember>();
+    t.grp_seg = g.gseg;
+    t.grp_mem_begin = g.gmb;
+    t.grp_mem_cnt = g.gmc;
+    t.ngroups = g.ngr;
+    t.members = g.members;
     t.seg_off = idx->d_listoff;
     t.nq = nq;
-    t.wi_group = wig;
-    t.wi_chunk = wic;
-    t.nitems = nit;
-    t.work_ctr = ptiles > 0 ? wctr : nullptr;
-    t.chunk_rows = static_cast<int32_t>(cr);
-    t.nchunks = max_chunks;
+    t.wi_group = g.wig;
+    t.wi_chunk = g.wic;
+    t.nitems = g.nit;
+    t.work_ctr = ptiles > 0 ? g.wctr : nullptr;
+    t.chunk_rows = static_cast<int32_t>(g.cr);
+    t.nchunks = g.max_chunks;
     t.out = idx->s_tile.as<float>();
     hipEvent_t e0;
     HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * k));
@@ -608,85 +659,113 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     s.k = k;
     s.out_ord = idx->s_ord.as<uint32_t>();
     s.out_dist = idx->s_dist.as<float>();
-    if (coded) {
-        // 1. query codes, then the lower bound of every candidate
-        const size_t cw = sizeof(uint32_t) * kWave * idx->nch;
-        HG_TRY(idx->s_qp.ensure(cw * static_cast<size_t>(nq)));
-        HG_TRY(idx->s_qn.ensure(sizeof(QueryScal) * static_cast<size_t>(nq) + sizeof(float) * static_cast<size_t>(nq)));
-        QueryScal *qscal = idx->s_qn.as<QueryScal>();
-        float *tau = reinterpret_cast<float *>(qscal + nq);
-#define CALL(N, R, L)                                                                                                  \
-    hipLaunchKernelGGL((quantize_queries_kernel<N>), dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st, d_Q,         \
-                       static_cast<int64_t>(idx->dim), idx->dim, nq, idx->s_qp.as<uint32_t>(), qscal)
-        HG_DISPATCH(idx->nch, false, CALL);
-#undef CALL
-        HG_HIP(hipGetLastError());
-        t.crows = idx->d_lcrows;
-        t.cmeta = idx->d_lcmeta;
-        t.qcodes = idx->s_qp.as<uint32_t>();
-        t.qscal = qscal;
-        t.ctile = idx->d_lctile;
-        t.sel = ngr + 2;  // the plan's choice of the body: matrix cores from six queries per probed list
-        prof_begin(idx, PROF_IVF_SCAN, st, &e0);
-        HG_TRY(launch_code_bounds(t, gbound, idx->nch, st));
-        prof_end(idx, PROF_IVF_SCAN, st, e0);
-        // 2. the k smallest lower bounds -> tau
-        HG_TRY(launch_select(s, st));
-        TauArgs ta;
-        memset(&ta, 0, sizeof(ta));
-        ta.ord = s.out_ord;
-        ta.lb = s.out_dist;
-        ta.pairs = idx->s_pairs.as<Pair>();
-        ta.nq = nq;
-        ta.k = k;
-        ta.nprobe = nprobe;
-        ta.metric = idx->metric;
-        ta.crows = idx->d_lcrows;
-        ta.cmeta = idx->d_lcmeta;
-        ta.qcodes = t.qcodes;
-        ta.qscal = qscal;
-        ta.tau = tau;
-#define CALL(N, R, L) hipLaunchKernelGGL((ivf_tau_kernel<N>), dim3(nq), dim3(kWave), 0, st, ta)
-        HG_DISPATCH(idx->nch, false, CALL);
-#undef CALL
-        HG_HIP(hipGetLastError());
-        // 3. f32 distances of the survivors, +inf for the rest
-        RefineArgs ra;
-        memset(&ra, 0, sizeof(ra));
-        ra.dist = t.out;
-        ra.q_cnt = d_qcnt;
-        ra.stride = stride;
-        ra.tau = tau;
-        ra.pairs = ta.pairs;
-        ra.nq = nq;
-        ra.nprobe = nprobe;
-        // the survivors of a query are a few dense runs (its nearest lists): a small batch spreads them over four times
-        // as many waves (16 candidates per wave: two trips of eight rows for a full window)
-        ra.span = nq <= 32 ? 16 : 64;
-        ra.chunk = 4 * ra.span;
-        ra.nchunks = static_cast<int32_t>((stride + ra.chunk - 1) / ra.chunk);
-        ra.rows = idx->d_lrows;
-        ra.row_norms = idx->d_lnorms;
-        ra.ld = idx->ld;
-        ra.Q = d_Q;
-        ra.qld = idx->dim;
-        ra.dim = idx->dim;
-        ra.metric = idx->metric;
-        ra.stats = idx->prof ? idx->d_rej_stats : nullptr;
-        const int64_t rblocks = static_cast<int64_t>(nq) * ra.nchunks;
-        HG_REQUIRE(rblocks < 2147483647LL, HNSWGPU_ELIMIT, "refine grid too large");
-#define CALL(N, R, L) \
-    hipLaunchKernelGGL((ivf_refine_kernel<N, (N <= 3 ? 8 : (N <= 6 ? 4 : 2)), L>), dim3(static_cast<unsigned>(rblocks)), dim3(kWG), 0, st, ra)
-        HG_DISPATCH(idx->nch, idx->metric == METRIC_L2, CALL);
-#undef CALL
-        HG_HIP(hipGetLastError());
-        // 4. the k nearest of what is left
-        return launch_select(s, st);
-    }
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);
-    HG_TRY(launch_tile(t, gbound, idx->dim, st));
+    HG_TRY(launch_tile(t, g.gbound, idx->dim, st));
     prof_end(idx, PROF_IVF_SCAN, st, e0);
     return launch_select(s, st);
+}
+
+// scratch of the survivor stream, carved out of s_qn: [QueryScal x nq | tau x nq | survivor count x nq]
+struct StreamScratch {
+    uint32_t *qcodes;
+    QueryScal *qscal;
+    uint32_t *tau, *surv_cnt;
+};
+static int stream_scratch(hnswgpu_index *idx, int32_t nq, StreamScratch &s) {
+    HG_TRY(idx->s_qp.ensure(sizeof(uint32_t) * kWave * idx->nch * static_cast<size_t>(nq)));
+    HG_TRY(idx->s_qn.ensure((sizeof(QueryScal) + 2 * sizeof(uint32_t)) * static_cast<size_t>(nq)));
+    s.qcodes = idx->s_qp.as<uint32_t>();
+    s.qscal = idx->s_qn.as<QueryScal>();
+    s.tau = reinterpret_cast<uint32_t *>(s.qscal + nq);
+    s.surv_cnt = s.tau + nq;
+    return 0;
+}
+
+// The list scan as a survivor stream (stream_kernels.hpp): int8 bounds with a running threshold -> compact survivor
+// lists -> f32 distances (GEMV order), top-k, ids and distances written by the finish kernel.  The query codes, tau = none
+// and empty survivor lists are set up by the routing step.
+static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
+                           const int32_t *d_probes, const int32_t *d_qcnt, int32_t *d_out_ids, float *d_out_dist,
+                           uint32_t *d_out_gord, bool grouped, hipStream_t st) {
+    const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
+    StreamScratch sc;
+    HG_TRY(stream_scratch(idx, nq, sc));
+    StreamArgs b;
+    memset(&b, 0, sizeof(b));
+    int64_t blocks;
+    const int64_t stride = (static_cast<int64_t>(nprobe) * idx->max_list_len + 3) / 4 * 4;
+    if (grouped) {
+        GroupPlan g;
+        HG_TRY(plan_groups(idx, nq, nprobe, d_probes, 0, 0, true, st, g));
+        b.wi_desc = g.desc;
+        b.nitems = g.nit;
+        b.members = g.members;
+        b.chunk_rows = static_cast<int32_t>(g.cr);
+        b.nchunks = g.max_chunks;
+        blocks = (g.wbound + 7) & ~7LL;
+    } else {  // a handful of queries: every (query, list) pair is its own group, no plan launch
+        const int64_t mean = std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1));
+        const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows, max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows;
+        const int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (1024 + npairs - 1) / npairs));
+        const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows, tpc = cr / kTileRows;
+        b.pairs = idx->s_pairs.as<Pair>();
+        b.npairs = static_cast<int32_t>(npairs);
+        b.chunk_rows = static_cast<int32_t>(cr);
+        b.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
+        blocks = npairs * b.nchunks;
+    }
+    // survivors per query that fit; a query with more takes the finish kernel's fallback (the plain f32 scan)
+    const int64_t cap_env = env_now("HNSWGPU_STREAM_CAP", 0);  // tests: a tiny list forces the fallback
+    int64_t cap = std::min<int64_t>(stride, std::max<int64_t>(4096, 4 * idx->max_list_len));
+    if (cap_env > 0) cap = cap_env;
+    cap = std::max<int64_t>(cap, 1);
+    HG_TRY(idx->s_tile.ensure(sizeof(uint2) * static_cast<size_t>(nq) * cap));
+    b.metric = idx->metric;
+    b.k = k;
+    b.ctile = idx->d_lctile;
+    b.cmeta = idx->d_lcmeta;
+    b.qcodes = sc.qcodes;
+    b.qscal = sc.qscal;
+    b.tau = sc.tau;
+    b.surv_cnt = sc.surv_cnt;
+    b.surv = idx->s_tile.as<uint2>();
+    b.cap = cap;
+    hipEvent_t e0;
+    prof_begin(idx, PROF_IVF_SCAN, st, &e0);
+    HG_TRY(launch_stream_bounds(b, blocks, idx->nch, st));
+    prof_end(idx, PROF_IVF_SCAN, st, e0);
+    FinishArgs f;
+    memset(&f, 0, sizeof(f));
+    f.surv = b.surv;
+    f.surv_cnt = b.surv_cnt;
+    f.tau = b.tau;
+    f.cap = cap;
+    f.q_cnt = d_qcnt;
+    f.pairs = idx->s_pairs.as<Pair>();
+    f.nq = nq;
+    f.nprobe = nprobe;
+    f.k = k;
+    // workgroups per query: the chip filled a few times over for small batches; one or two for large ones
+    f.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(64, 2048 / nq)));
+    f.span = nq <= 32 ? 16 : 64;
+    f.rows = idx->d_lrows;
+    f.row_norms = idx->d_lnorms;
+    f.ld = idx->ld;
+    f.Q = d_Q;
+    f.qld = idx->dim;
+    f.dim = idx->dim;
+    f.metric = idx->metric;
+    const size_t keys = static_cast<size_t>(nq) * f.slices * (k <= kWave ? 1 : kNWave) * k;
+    HG_TRY(idx->s_partial.ensure(sizeof(uint64_t) * keys));
+    HG_TRY(ensure_counters(idx, nq, st));
+    f.partial = idx->s_partial.as<uint64_t>();
+    f.done = idx->s_done.as<uint32_t>();
+    f.listids = idx->d_listids;
+    f.out_ids = d_out_ids;
+    f.out_dist = d_out_dist;
+    f.out_gord = d_out_gord;
+    f.stats = idx->prof ? idx->d_rej_stats : nullptr;
+    return launch_finish(f, idx->nch, st);
 }
 
 // (query, list) pairs per list from which the MFMA tile scan serves a cosine / dot batch -- and with it the k-ordered
@@ -696,6 +775,7 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
 // 0.80; 768: 1.04 vs 0.89 -- the tile scan reads every probed list in f32 whatever the batch, the bounds pipeline a quarter
 // of that (on the matrix cores from six queries per list) plus the survivors.
 constexpr int64_t kTilePairs = 12;
+constexpr int32_t kStreamMaxK = 256;  // largest k the bounds pass serves (larger k: the f32 scans)
 
 static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
                               int32_t *d_out_ids, float *d_out_dist, int32_t *d_out_probes, hipStream_t st,
@@ -713,12 +793,10 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     // GEMV vs tiled, end to end): batch 32: 0.42 vs 0.56 ms; 48: 0.54 vs 0.61; 64: 0.64 vs 0.64; 80: 0.72 vs 0.65;
     // 96: 0.82 vs 0.71; 128: 1.03 vs 0.71.
     const int tm = tile_mode();
-    static const int code_env = []() {
-        const char *e = getenv("HNSWGPU_IVF_CODES");  // 0 = never (A/B), N > 0 = from N queries per batch
-        return e ? atoi(e) : 9;
-    }();
-    const bool codes_ok = idx->d_lcrows != nullptr && (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128)) &&
-                          code_env > 0 && nq >= code_env && tm != 0;
+    const int code_env = static_cast<int>(env_now("HNSWGPU_IVF_CODES", 9));  // 0 = never (A/B), N > 0 = from N queries per batch
+    // the survivor stream (stream_kernels.hpp): k up to a tile chunk's rows can get a threshold from one chunk
+    const bool codes_ok = idx->d_lctile != nullptr && (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128)) &&
+                          code_env > 0 && nq >= code_env && tm != 0 && k <= kStreamMaxK;
     // (Euclidean has one arithmetic at every batch size -- its "tile" path is the register-row group kernel -- so the
     // bounds pipeline below serves all its batches: batch 1024 at 1M x 768: 4.8 -> 2.8 ms)
     static const int64_t tile_pairs = []() {
@@ -771,6 +849,13 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         order_buf = idx->s_grp.as<int32_t>() + npairs + nq + 16;
     }
     if (use_tile || use_group) HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
+    // survivor stream: query codes, thresholds and survivor counters live in s_qp / s_qn (sized here: the routing below may
+    // still use both for padded queries and norms, and must not move s_qn afterwards)
+    StreamScratch sc = {nullptr, nullptr, nullptr, nullptr};
+    if (use_code) HG_TRY(stream_scratch(idx, nq, sc));
+    const int stream_route_max = static_cast<int>(env_now("HNSWGPU_STREAM_ROUTE", 256));  // largest batch routed by the one-launch routing kernel
+    const int stream_group_min = static_cast<int>(env_now("HNSWGPU_STREAM_GROUP", 5));    // queries from which the bounds pass groups the pairs by list
+    bool codes_done = false;
     static const int route_group_min = []() {
         const char *e = getenv("HNSWGPU_ROUTE_GROUP");  // queries from which a GEMV-order batch routes through the group kernel
         return e ? atoi(e) : 1024;  // Euclidean 1M x 768: 512 queries 0.85 vs 0.87 ms (GEMV vs group), 1024: 1.50 vs 1.43, 4096: 5.08 vs 4.70
@@ -791,9 +876,12 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     a.metric = idx->metric;
     a.k = nprobe;
     a.role = ROLE_ROUTE;
-    if (!use_tile && fused_mode && static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20)) {
+    if (!use_tile && (fused_mode || (use_code && nq <= stream_route_max)) && static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20)) {
         // small batches: distances to the centroids, the choice of the nprobe nearest and the probe table in ONE launch
-        HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st));
+        // (for the survivor stream also the query codes, tau = none and the empty survivor lists)
+        HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, sc.qcodes, sc.qscal,
+                                sc.tau, sc.surv_cnt, k));
+        codes_done = use_code;
     } else {
     if (use_tile)  // every query against the centroid table on the tile kernel as well
         HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
@@ -813,6 +901,34 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     HG_HIP(hipGetLastError());
     }
     }
+    if (use_code) {
+        // bounds on the int8 list rows with a running threshold, f32 distances -- the GEMV order, so the bits of this regime
+        // are unchanged -- only for the survivors; the finish kernel writes ids and distances
+        if (!codes_done) {  // what the fused routing kernel does in its tail: codes, empty survivor lists, first thresholds
+            HG_TRY(stream_scratch(idx, nq, sc));  // (s_qp may have moved under the padded queries of the routing)
+            PrepArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            pa.Q = d_Q;
+            pa.qld = idx->dim;
+            pa.dim = idx->dim;
+            pa.metric = idx->metric;
+            pa.nq = nq;
+            pa.nprobe = nprobe;
+            pa.k = k;
+            pa.pairs = idx->s_pairs.as<Pair>();
+            pa.qcnt = qcnt_buf;
+            pa.rows = idx->d_lrows;
+            pa.row_norms = idx->d_lnorms;
+            pa.ld = idx->ld;
+            pa.qcodes = sc.qcodes;
+            pa.qscal = sc.qscal;
+            pa.tau = sc.tau;
+            pa.surv_cnt = sc.surv_cnt;
+            HG_TRY(launch_query_prep(pa, idx->nch, st));
+        }
+        return ivf_stream_scan(idx, d_Q, nq, k, nprobe, probes_buf, qcnt_buf, d_out_ids, d_out_dist, d_out_gord,
+                               nq >= stream_group_min, st);
+    }
     // 2. scan the probed lists (:217-234) and merge (:291-294)
     memset(&a, 0, sizeof(a));
     a.rows = idx->d_lrows;
@@ -825,8 +941,8 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     a.pairs = idx->s_pairs.as<Pair>();
     a.k = k;
     a.role = ROLE_LIST_SCAN;
-    if (use_tile || use_group || use_code) {
-        HG_TRY(ivf_tile_scan(idx, d_Q, nq, k, nprobe, probes_buf, qcnt_buf, st, use_code ? 2 : (use_group ? 1 : 0)));
+    if (use_tile || use_group) {
+        HG_TRY(ivf_tile_scan(idx, d_Q, nq, k, nprobe, probes_buf, qcnt_buf, st, use_group));
     } else {
         if (use_order) {
             const size_t olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);

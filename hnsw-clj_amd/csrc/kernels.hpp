@@ -755,6 +755,23 @@ __device__ __forceinline__ int wave_sum_int(int x) {
     return x;
 }
 
+// per-row bound terms (s_v, E, Z, 1 / |v|) from the row's residual, code norm and norm (both code layouts use it);
+// .w = 1 / |v|: no second random read for the norm, no division in the bound
+__device__ __forceinline__ float4 code_row_meta(int metric, float mx, float res, int c2, float nv, bool bad) {
+    float E, Z = 0.0f;
+    if (metric == METRIC_COS) {
+        E = 1.01f * res / nv + 1.0e-4f;  // nv == 0: NaN or infinity -> exact path
+    } else if (metric == METRIC_DOT) {
+        E = 1.01f * res + 2.0e-5f * nv;  // times |q| at the point of use
+        Z = 1.01f * (nv + res);          // times r_q
+    } else {
+        E = 1.01f * res + 4.0e-6f * nv;
+        Z = static_cast<float>(c2);
+    }
+    if (bad || !(E >= 0.0f)) E = __uint_as_float(0x7fc00000u);  // NaN: the comparison fails, exact path
+    return make_float4(mx / 127.0f, E, Z, 1.0f / nv);
+}
+
 template <int NCH>
 __global__ __launch_bounds__(kWG) void quantize_rows_kernel(const float *rows, int64_t ld, int64_t n, int metric,
                                                             uint32_t *qrows, float4 *qmeta) {
@@ -775,20 +792,7 @@ __global__ __launch_bounds__(kWG) void quantize_rows_kernel(const float *rows, i
     uint32_t *dst = qrows + (row * kWave + lane) * NCH;
 #pragma unroll
     for (int c = 0; c < NCH; c++) dst[c] = w[c];
-    if (lane == 0) {
-        float E, Z = 0.0f;
-        if (metric == METRIC_COS) {
-            E = 1.01f * res / nv + 1.0e-4f;  // nv == 0: NaN or infinity -> exact path
-        } else if (metric == METRIC_DOT) {
-            E = 1.01f * res + 2.0e-5f * nv;  // times |q| at the point of use
-            Z = 1.01f * (nv + res);          // times r_q
-        } else {
-            E = 1.01f * res + 4.0e-6f * nv;
-            Z = static_cast<float>(c2);
-        }
-        if (bad || !(E >= 0.0f)) E = __uint_as_float(0x7fc00000u);  // NaN: the comparison fails, exact path
-        qmeta[row] = make_float4(mx / 127.0f, E, Z, 1.0f / nv);  // .w = 1 / |v|: no second random read for the norm, no division in the bound
-    }
+    if (lane == 0) qmeta[row] = code_row_meta(metric, mx, res, c2, nv, bad);
 }
 
 // The query's side of the test, once per search and wave: codes in the row layout + the scalars of the bounds.

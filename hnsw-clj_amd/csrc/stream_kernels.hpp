@@ -1,0 +1,699 @@
+// stream_kernels.hpp -- the IVF list scan as a SURVIVOR STREAM: int8 bounds with a running per-query threshold, then
+// ONE launch that evaluates the survivors in f32, keeps the k nearest and writes the results.
+//
+// search-partition scores every row of every probed list (ivf_flat.clj:217-234) and search-ivf-flat keeps the k smallest
+// (:281-294).  Every list row also exists as int8 codes with its exact residual (kernels.hpp: quantize_rows_kernel), so
+//     lb <= d_f32(q, v) <= ub        from one exact integer dot product
+// for every (query, candidate).  Round 2 wrote every lb into a dense [query][candidate] array, selected the k smallest,
+// derived a threshold, rewrote the array with f32 distances and selected again: eleven launches, the array touched four
+// times.  Here:
+//   1. stream_bounds_kernel (matrix cores, v_mfma_i32_32x32x32_i8: a group of <= 32 queries against 32 list rows per
+//      wave step, each probed list read ONCE per group in int8).  tau[q] is a running upper bound of the query's k-th
+//      nearest distance D_k: whenever a wave has seen m >= k candidates of a query, the largest of their ub is >= D_k
+//      (k candidates are at least that near) and is folded into tau[q] with an agent-scope atomic min on the orderable
+//      bits.  A candidate with lb > tau[q] has d >= lb > tau >= D_k: it can neither be among the k nearest nor tie with
+//      the k-th, and is dropped on the spot; every other candidate is appended -- (order key, lb), 8 bytes -- to the
+//      query's survivor list (one atomic add per query and wave step reserves the slots).
+//   2. ivf_finish_kernel: filters the list once more against the FINAL tau (and against the k-th distance found so
+//      far), computes the f32 distance of what is left by the GEMV scan's own arithmetic (lane_partial + wave butterfly +
+//      finish_dist: the same bits), keeps the k smallest (distance, order key) per wave in registers, and the last
+//      workgroup of a query merges the partial lists, maps the winners to row ids and writes ids / distances.
+// tau only ever decides what is NOT computed; every candidate with d <= D_k survives any valid tau, so the result is
+// exactly the full f32 scan's whatever order the workgroups run in.  A query whose survivors do not fit its list (data
+// on which int8 bounds separate nothing) is flagged by its counter and served by the same finish kernel from the
+// candidate stream itself -- the plain f32 scan -- so memory stays bounded and the answer exact.
+#pragma once
+#include "kernels.hpp"
+#include "tile_args.hpp"
+
+namespace hg {
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+// dword address of natural code dword g4 (elements 4 g4 .. 4 g4 + 3) of list row R in the tile layout; S = steps per row.
+// Layout: [block of 32 rows][step s of 32 bytes][half h][row r][16 B] -- every MFMA A operand is one contiguous 1 KB
+// wave load straight into registers.
+__host__ __device__ inline int64_t tile_code_dword(int64_t R, int g4, int S) {
+    const int s = g4 >> 3, h = (g4 >> 2) & 1, w = g4 & 3;
+    return ((((R >> 5) * S + s) * 2 + h) * 32 + (R & 31)) * 4 + w;
+}
+
+// codes of `n` list rows into the tile layout + the per-row bound terms: one wave per row
+template <int NCH>
+__global__ __launch_bounds__(kWG) void quantize_rows_tile_kernel(const float *rows, int64_t ld, int64_t n, int metric,
+                                                                 uint32_t *tile, float4 *meta) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kNWave + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float4 r[NCH];
+    load_row<NCH>(r, rows + row * ld, static_cast<int>(ld / 4), lane, true);
+    bool bad;
+    const float mx = wave_absmax<NCH>(r, bad);
+    uint32_t w[NCH];
+    float res;
+    int c2;
+    encode_lane<NCH>(r, mx, bad, w, res, c2);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) tile[tile_code_dword(row, c * kWave + lane, NCH * 8)] = w[c];
+    if (meta) {
+        res = __builtin_sqrtf(wave_sum(res));
+        c2 = wave_sum_int(c2);
+        const float nv = __builtin_sqrtf(wave_sum(lane_partial<NCH, false>(r, r)));
+        if (lane == 0) meta[row] = code_row_meta(metric, mx, res, c2, nv, bad);
+    }
+}
+
+// ---- the running threshold: orderable bits of a float (make_key's order), 0xffffffff = no bound yet -----------------
+__device__ __forceinline__ uint32_t tau_encode(float t) {
+    t = t + 0.0f;
+    const uint32_t u = __float_as_uint(t);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float tau_decode(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    const float f = __uint_as_float(u);
+    return f == f ? f : __builtin_inff();  // the initial all-ones (a NaN pattern): nothing is excluded
+}
+
+// ---- the first threshold of a query -----------------------------------------------------------------------------
+// The bounds pass drops a candidate against the threshold it knows at that moment, and its workgroups run in list
+// order, not in the query's probe order: without a first threshold every list visited before the query's nearest one
+// would be appended whole.  So before the pass the query's workgroup evaluates the HEAD of its candidate stream -- the
+// first m = max(k, 64) rows of its nearest non-empty lists -- in f32 (the GEMV arithmetic) and takes the k-th smallest of
+// those distances: k candidates are at most that far, hence D_k <= tau0.  All threads of a 256-thread workgroup call it.
+constexpr int kSeedMax = 256;  // rows evaluated at most (>= the largest k the bounds pass serves)
+
+template <int NCH, int RB, bool L2>
+__device__ __forceinline__ void seed_tau_wg(const float4 (&q)[NCH], float qn, int metric, const Pair *pp, int nprobe,
+                                            int64_t qcnt, int k, const float *rows, const float *row_norms, int64_t ld,
+                                            float *dist_s /* [kSeedMax] LDS */, uint32_t *tau_out) {
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    int m = k > 64 ? k : 64;
+    m = (m + 31) & ~31;
+    if (m > kSeedMax) m = kSeedMax;
+    if (m > qcnt) m = static_cast<int>(qcnt);
+    if (m < k) {  // fewer candidates than k: every one of them is a result, nothing can be excluded
+        if (tid == 0) *tau_out = 0xffffffffu;
+        return;
+    }
+    const int nvec = static_cast<int>(ld / 4);
+    for (int j0 = wave * RB; j0 < m; j0 += kNWave * RB) {
+        // lane b < RB resolves candidate j0 + b of the stream to its list row (as ivf_finish_kernel does)
+        int64_t myrow = 0;
+        float myrn = 0.0f;
+        if (lane < RB && j0 + lane < m) {
+            const uint32_t o = static_cast<uint32_t>(j0 + lane);
+            int lo = 0, hi = nprobe - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pp[mid].ord_base <= o) lo = mid;
+                else hi = mid - 1;
+            }
+            myrow = pp[lo].row_begin + (o - pp[lo].ord_base);
+            myrn = metric == METRIC_COS ? row_norms[myrow] : 0.0f;
+        }
+        const int rlo = static_cast<int>(myrow), rhi = static_cast<int>(myrow >> 32);
+        float4 r[RB][NCH];
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            const int64_t row = (static_cast<int64_t>(__builtin_amdgcn_readlane(rhi, b)) << 32) |
+                                static_cast<uint32_t>(__builtin_amdgcn_readlane(rlo, b));
+            load_row<NCH>(r[b], rows + row * ld, nvec, lane, j0 + b < m);
+        }
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            const float sum = wave_sum(lane_partial<NCH, L2>(q, r[b]));
+            const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), b));
+            const float d = finish_dist(metric, sum, qn, rn);
+            if (lane == 0 && j0 + b < m) dist_s[j0 + b] = d == d ? d : __builtin_inff();
+        }
+    }
+    __syncthreads();
+    if (tid < m) {
+        const float v = dist_s[tid];
+        int rank = 0;
+        for (int j = 0; j < m; j++) {
+            const float o = dist_s[j];  // uniform address: an LDS broadcast
+            rank += (o < v || (o == v && j < tid)) ? 1 : 0;
+        }
+        if (rank == k - 1) *tau_out = tau_encode(v);  // ranks are a permutation of 0..m-1: exactly one thread
+    }
+}
+
+// What the survivor stream needs of every query before the bounds pass, when the routing was not done by the fused routing
+// kernel (which does the same in its tail): int8 codes + bound scalars, an empty survivor list, the first threshold.
+// One workgroup per query.
+struct PrepArgs {
+    const float *Q;
+    int64_t qld;
+    int32_t dim, metric, nq, nprobe, k;
+    const Pair *pairs;
+    const int32_t *qcnt;
+    const float *rows;
+    const float *row_norms;
+    int64_t ld;
+    uint32_t *qcodes;
+    QueryScal *qscal;
+    uint32_t *tau, *surv_cnt;
+};
+
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void ivf_query_prep_kernel(PrepArgs a) {
+    __shared__ float dist_s[kSeedMax];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x;
+    float4 q[NCH];
+    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+    const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+    if (wave == kNWave - 1) {
+        QueryCode<NCH> qc;
+        encode_query<NCH>(q, qc);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) a.qcodes[(static_cast<int64_t>(qi) * NCH + c) * kWave + lane] = qc.a[c];
+        if (lane == 0) {
+            a.qscal[qi] = qc.sc;
+            a.surv_cnt[qi] = 0;
+        }
+    }
+    seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, a.pairs + static_cast<int64_t>(qi) * a.nprobe, a.nprobe, a.qcnt[qi], a.k, a.rows,
+                             a.row_norms, a.ld, dist_s, a.tau + qi);
+}
+
+// One work item of the bounds pass, written by the plan kernel: rows [rb0 + r0_off, rb0 + r1_off) of the list that starts
+// at rb0, against the cnt (<= 32) group members members[mem_begin ..).
+struct WorkDesc {
+    int64_t rb0;
+    int32_t r0_off, r1_off;
+    int32_t mem_begin, cnt;
+    int32_t pad[2];
+};
+
+struct StreamArgs {
+    // grouped mode: dense work list built on the device (ivf_plan_kernel); workgroup b serves item
+    // (b & 7) * ceil(nitems / 8) + (b >> 3): one contiguous eighth of the list per XCD
+    const WorkDesc *wi_desc;
+    const int32_t *nitems;
+    const GroupMember *members;  // out_base = the pair's offset in the query's candidate stream (Pair::ord_base)
+    // ungrouped mode (a handful of queries: no plan launch): item = (pair, chunk), chunk-major, one query per item
+    const Pair *pairs;
+    int32_t npairs;
+    int32_t chunk_rows, nchunks;
+    int32_t metric, k;
+    const uint32_t *ctile;  // list codes, tile layout
+    const float4 *cmeta;    // per list row: (scale, E, Z, 1 / |v|)
+    const uint32_t *qcodes; // [nq][NCH * 64] natural order
+    const QueryScal *qscal;
+    uint32_t *tau;       // [nq] running threshold (orderable bits), all-ones at the start
+    uint32_t *surv_cnt;  // [nq] survivors appended so far (may exceed cap: the query then takes the fallback)
+    uint2 *surv;         // [nq][cap] (order key, lb bits)
+    int64_t cap;
+};
+
+__host__ inline size_t stream_lds_bytes(int nch) {
+    return static_cast<size_t>(nch) * 256 * kTileQ                       // query codes [step][half][query][16 B]
+           + sizeof(QueryScal) * kTileQ + sizeof(float4) * 32 * kTileWaves  // query scalars, per-wave row meta
+           + (sizeof(float) + sizeof(int32_t)) * 32 * kTileWaves            // per-wave chunk maxima / counts
+           + (sizeof(uint32_t) + sizeof(int32_t)) * kTileQ;                 // order bases, query indices
+}
+
+template <int NCH>
+__global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs a) {
+    constexpr int S = NCH * 8;  // steps of 32 bytes
+    extern __shared__ __align__(16) unsigned char smem[];
+    v4i_t *qb_s = reinterpret_cast<v4i_t *>(smem);                               // [S][2][32]
+    QueryScal *qs_s = reinterpret_cast<QueryScal *>(qb_s + S * 64);              // [32]
+    float4 *meta_all = reinterpret_cast<float4 *>(qs_s + kTileQ);                // [waves][32]
+    float *wmax_s = reinterpret_cast<float *>(meta_all + 32 * kTileWaves);       // [waves][32]
+    int32_t *wcnt_s = reinterpret_cast<int32_t *>(wmax_s + 32 * kTileWaves);     // [waves][32]
+    uint32_t *ob_s = reinterpret_cast<uint32_t *>(wcnt_s + 32 * kTileWaves);     // [32]
+    int32_t *qi_s = reinterpret_cast<int32_t *>(ob_s + kTileQ);                  // [32]
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+    float4 *meta_s = meta_all + wave * 32;
+
+    // ---- work item
+    int64_t rb0, r0, r1;
+    int cnt, mem_begin = 0, one_q = -1;
+    uint32_t one_ob = 0;
+    if (a.pairs) {
+        const int pair = static_cast<int>(blockIdx.x % a.npairs), chunk = static_cast<int>(blockIdx.x / a.npairs);
+        const Pair p = a.pairs[pair];
+        rb0 = p.row_begin;
+        const int64_t rows = p.row_end - p.row_begin;
+        if (rows <= 0) return;
+        const int64_t tiles = (rows + kTileRows - 1) / kTileRows;
+        const int64_t nch = tile_nchunks(rows, a.chunk_rows, a.nchunks);
+        if (chunk >= nch) return;
+        const int64_t per = (tiles + nch - 1) / nch * kTileRows;
+        r0 = rb0 + static_cast<int64_t>(chunk) * per;
+        r1 = r0 + per < p.row_end ? r0 + per : p.row_end;
+        cnt = 1;
+        one_q = p.q;
+        one_ob = p.ord_base;
+    } else {
+        const int nitems = *a.nitems;
+        const int per_xcd = (nitems + 7) >> 3;
+        const int slot = blockIdx.x >> 3;
+        if (slot >= per_xcd) return;
+        const int item = (blockIdx.x & 7) * per_xcd + slot;
+        if (item >= nitems) return;
+        const WorkDesc d = a.wi_desc[item];
+        rb0 = d.rb0;
+        r0 = rb0 + d.r0_off;
+        r1 = rb0 + d.r1_off;
+        cnt = d.cnt;
+        mem_begin = d.mem_begin;
+    }
+    if (r0 >= r1 || cnt <= 0) return;
+
+    if (tid < kTileQ) {
+        int qi = -1;
+        uint32_t ob = 0;
+        if (tid < cnt) {
+            if (a.pairs) {
+                qi = one_q;
+                ob = one_ob;
+            } else {
+                const GroupMember m = a.members[mem_begin + tid];
+                qi = m.q;
+                ob = static_cast<uint32_t>(m.out_base);
+            }
+            qs_s[tid] = a.qscal[qi];
+        }
+        qi_s[tid] = qi;
+        ob_s[tid] = ob;
+    }
+    __syncthreads();
+    // query codes: natural order in global memory (16-B chunk t of query q = step t / 2, half t & 1); empty slots are zero
+    for (int f = tid; f < kTileQ * S * 2; f += kTileThreads) {
+        const int q = f / (S * 2), t = f - q * (S * 2);
+        v4i_t v = {0, 0, 0, 0};
+        if (q < cnt) v = reinterpret_cast<const v4i_t *>(a.qcodes + static_cast<int64_t>(qi_s[q]) * NCH * kWave)[t];
+        qb_s[t * 32 + q] = v;
+    }
+    __syncthreads();
+
+    const int col = lane & 31, half = lane >> 5;
+    const bool live = col < cnt;
+    const QueryScal myqs = live ? qs_s[col] : QueryScal{};
+    const int myq = live ? qi_s[col] : 0;
+    const uint32_t myob = live ? ob_s[col] : 0;
+    const float kInf = __builtin_inff();
+    float my_tau = kInf;
+    float run_max = -kInf, all_max = -kInf;
+    int run_cnt = 0, all_cnt = 0;
+    uint2 *dst = a.surv + static_cast<int64_t>(myq) * a.cap;
+    // blocks of 32 rows of the tile layout that overlap [r0, r1): the layout's blocks are aligned to the WHOLE list array,
+    // not to a list, so the first and the last block of a chunk may hold rows of the neighbours -- computed, not used
+    const int64_t b0 = r0 >> 5, b1 = (r1 + 31) >> 5;
+    for (int64_t b = b0 + wave; b < b1; b += kTileWaves) {
+        const v4i_t *ap = reinterpret_cast<const v4i_t *>(a.ctile) + (b * S) * 64 + lane;
+        if (lane < 32) {
+            const int64_t row = b * 32 + lane;
+            meta_s[lane] = (row >= r0 && row < r1) ? a.cmeta[row] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        // what the other workgroups have found meanwhile (in flight under the MFMAs)
+        const uint32_t tnow = live ? coherent_load(a.tau + myq) : 0xffffffffu;
+        v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        v4i_t av[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) av[u] = ap[(u < S ? u : S - 1) * 64];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const v4i_t cur = av[s & 7];
+            if (s + 8 < S) av[s & 7] = ap[(s + 8) * 64];  // eight operands (8 KB per wave) in flight
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur, qb_s[(s * 2 + half) * 32 + col], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // meta_s written by lanes 0-31 above is read by every lane below
+        // C/D: lane holds column `col` (the query); register g is row (g & 3) + 8 (g >> 2) + 4 half of the block
+        float lbv[16];
+        uint32_t vmask = 0;
+        float bmax = -kInf;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int i = (g & 3) + 8 * (g >> 2) + 4 * half;
+            const int64_t row = b * 32 + i;
+            const float4 mt = meta_s[i];
+            float lb, ub;
+            code_bounds(a.metric, acc[g], myqs, mt, mt.w, lb, ub);
+            lbv[g] = lb;
+            if (row >= r0 && row < r1) {
+                vmask |= 1u << g;
+                ub = ub == ub ? ub : kInf;
+                bmax = ub > bmax ? ub : bmax;
+            }
+        }
+        int bcnt = __popc(vmask);
+        {  // the other half of the block's rows of this query
+            const float om = __shfl_xor(bmax, 32, kWave);
+            bcnt += __shfl_xor(bcnt, 32, kWave);
+            bmax = om > bmax ? om : bmax;
+        }
+        run_max = bmax > run_max ? bmax : run_max;
+        run_cnt += bcnt;
+        all_max = bmax > all_max ? bmax : all_max;
+        all_cnt += bcnt;
+        const float tg = tau_decode(tnow);
+        my_tau = tg < my_tau ? tg : my_tau;
+        if (run_cnt >= a.k) {  // k candidates of this query are at most run_max away: D_k <= run_max
+            if (run_max < my_tau) {
+                my_tau = run_max;
+                if (live && half == 0)
+                    (void)__hip_atomic_fetch_min(a.tau + myq, tau_encode(run_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            run_max = -kInf;
+            run_cnt = 0;
+        }
+        uint32_t pmask = 0;
+#pragma unroll
+        for (int g = 0; g < 16; g++)
+            if (((vmask >> g) & 1u) && !(lbv[g] > my_tau)) pmask |= 1u << g;  // NaN (no bound) survives
+        if (!live) pmask = 0;
+        const int n = __popc(pmask);
+        const int on = __shfl_xor(n, 32, kWave);
+        uint32_t base = 0;
+        if (half == 0 && n + on > 0)
+            base = __hip_atomic_fetch_add(a.surv_cnt + myq, static_cast<uint32_t>(n + on), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = __shfl(base, col, kWave);
+        if (half) base += on;  // half 1 writes behind half 0's `on` entries
+        if (pmask) {
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                if ((pmask >> g) & 1u) {
+                    const int i = (g & 3) + 8 * (g >> 2) + 4 * half;
+                    if (base < a.cap)
+                        dst[base] = make_uint2(myob + static_cast<uint32_t>(b * 32 + i - rb0), __float_as_uint(lbv[g]));
+                    base++;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the next block overwrites meta_s
+    }
+    // the whole chunk as one block of candidates: for a k no single wave reaches
+    if (half == 0) {
+        wmax_s[wave * 32 + col] = all_max;
+        wcnt_s[wave * 32 + col] = all_cnt;
+    }
+    __syncthreads();
+    if (wave == 0 && half == 0 && live) {
+        float m = -kInf;
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < kTileWaves; w++) {
+            const float x = wmax_s[w * 32 + col];
+            m = x > m ? x : m;
+            c += wcnt_s[w * 32 + col];
+        }
+        if (c >= a.k && m < my_tau)
+            (void)__hip_atomic_fetch_min(a.tau + myq, tau_encode(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Step 2: survivors -> f32 distances -> the k nearest -> results.
+// ------------------------------------------------------------------------------------------------
+struct FinishArgs {
+    const uint2 *surv;
+    const uint32_t *surv_cnt;
+    uint32_t *tau;         // keeps falling while the survivors are evaluated
+    int64_t cap;
+    const int32_t *q_cnt;  // candidates per query (the fallback walks them all)
+    const Pair *pairs;     // [nq][nprobe]
+    int32_t nq, nprobe, k;
+    int32_t slices;        // workgroups per query
+    int32_t span;          // entries a wave looks at per step: 64, or 16 for a handful of queries
+    const float *rows;     // list rows, f32
+    const float *row_norms;
+    int64_t ld;
+    const float *Q;
+    int64_t qld;
+    int32_t dim, metric;
+    uint64_t *partial;     // [nq][slices][k] (k <= 64) or [nq][slices][4][k]
+    uint32_t *done;        // [nq], zero between calls
+    const int32_t *listids;
+    int32_t *out_ids;      // [nq][k]
+    float *out_dist;       // [nq][k]
+    uint32_t *out_gord;    // optional [nq][k]
+    unsigned long long *stats;  // optional: [0] += f32 rows evaluated, [1] += candidates
+};
+
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int tail_last;
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);  // [kNWave][k] (+ the tail's final list and results)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    // slice-major: a query's survivors sit in the first slices of its list when it is short, and query-major order would
+    // put the busy workgroups of all queries on the same XCDs
+    const int qi = blockIdx.x % a.nq, sl = blockIdx.x / a.nq;
+    const uint32_t nsv = a.surv_cnt[qi];
+    const bool over = nsv > a.cap;  // survivors did not fit: walk the candidate stream itself (the plain f32 scan)
+    const int64_t total = over ? a.q_cnt[qi] : nsv;
+    const int span = a.span, gran = kNWave * span;
+    int64_t per = (total + a.slices - 1) / a.slices;
+    per = (per + gran - 1) / gran * gran;
+    const int64_t i0 = static_cast<int64_t>(sl) * per;
+    const int64_t i1 = i0 + per < total ? i0 + per : total;
+    // the threshold keeps falling in this kernel too: a wave that holds k exact distances folds its k-th into tau[qi]
+    // (k candidates are at most that far), every wave re-reads it once per step
+    float tau = tau_decode(a.tau[qi]);
+    const uint2 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
+    const Pair *pp = a.pairs + static_cast<int64_t>(qi) * a.nprobe;
+    const bool regk = a.k <= kWave;
+    uint64_t *mylist = lists + wave * a.k;
+    int cnt = 0;
+    uint64_t thr = ~0ull, mine = ~0ull;
+    const int nvec = static_cast<int>(a.ld / 4);
+    float4 q[NCH];
+    float qn = 0.0f;
+    bool have_q = false;  // the query is fetched by the first step that has a survivor
+    unsigned long long nsurv = 0;
+    for (int64_t base = i0 + wave * span; base < i1; base += gran) {
+        const int64_t i = base + lane;
+        const bool in = lane < span && i < i1;
+        uint32_t o = 0;
+        float l = -__builtin_inff();
+        if (in) {
+            if (over) {
+                o = static_cast<uint32_t>(i);
+            } else {
+                const uint2 e = sv[i];
+                o = e.x;
+                l = __uint_as_float(e.y);
+            }
+        }
+        const uint32_t tnext = coherent_load(a.tau + qi);  // used by the NEXT step: in flight under this one's rows
+        const bool s = in && !(l > tau);  // NaN (no bound) survives
+        uint64_t m = __ballot(s);
+        if (!m) {
+            const float tg = tau_decode(tnext);
+            tau = tg < tau ? tg : tau;
+            continue;
+        }
+        nsurv += __popcll(m);
+        if (!have_q) {
+            load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+            qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+            have_q = true;
+        }
+        // every lane resolves ITS candidate to a list row (the last pair whose ord_base <= ord: lists of length 0 share
+        // an ord_base with their successor, as in ivf_decode_kernel) and fetches that row's norm
+        int lo = 0, hi = a.nprobe - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pp[mid].ord_base <= o) lo = mid;
+            else hi = mid - 1;
+        }
+        const int64_t myrow = s ? pp[lo].row_begin + (o - pp[lo].ord_base) : 0;
+        const float myrn = (s && a.metric == METRIC_COS) ? a.row_norms[myrow] : 0.0f;
+        const int rlo = static_cast<int>(myrow), rhi = static_cast<int>(myrow >> 32);
+        while (m) {
+            float4 r[RB][NCH];
+            int js[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                js[b] = -1;
+                if (m) {
+                    js[b] = __ffsll(static_cast<unsigned long long>(m)) - 1;
+                    m &= m - 1;
+                    const int64_t row = (static_cast<int64_t>(__builtin_amdgcn_readlane(rhi, js[b])) << 32) |
+                                        static_cast<uint32_t>(__builtin_amdgcn_readlane(rlo, js[b]));
+                    load_row<NCH>(r[b], a.rows + row * a.ld, nvec, lane, true);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                if (js[b] < 0) break;
+                const float sum = wave_sum(lane_partial<NCH, L2>(q, r[b]));
+                const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), js[b]));
+                const float dv = finish_dist(a.metric, sum, qn, rn);
+                const uint32_t ob = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(o), js[b]));
+                const uint64_t key = make_key(dv, ob);
+                if (key < thr) {
+                    if (regk) {
+                        wave_insert_reg(mine, cnt, a.k, key, lane);
+                        thr = wave_kth_reg(mine, a.k);  // ~0 until the list is full
+                    } else {
+                        wave_insert(mylist, cnt, a.k, key, lane);
+                        thr = cnt == a.k ? mylist[a.k - 1] : ~0ull;
+                    }
+                }
+            }
+        }
+        {
+            const float tg = tau_decode(tnext);
+            tau = tg < tau ? tg : tau;
+            const float kd = thr == ~0ull ? __builtin_inff() : key_dist(thr);  // k exact distances at or below kd: D_k <= kd
+            if (kd < tau) {
+                tau = kd;
+                if (lane == 0) (void)__hip_atomic_fetch_min(a.tau + qi, tau_encode(kd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // profiling only; few atomics on purpose (one per wave WITH survivors, one per query)
+    if (a.stats && lane == 0) {
+        if (nsurv) atomicAdd(a.stats, nsurv);
+        if (wave == 0 && sl == 0) atomicAdd(a.stats + 1, static_cast<unsigned long long>(a.q_cnt[qi]));
+    }
+    // ---- this workgroup's partial list (k <= 64: its four lists merged into one first)
+    if (regk) {
+        if (wave != 0 && lane < a.k) lists[wave * a.k + lane] = mine;
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 1; w < kNWave; w++)
+                for (int j = 0; j < a.k; j++) {
+                    const uint64_t key = lists[w * a.k + j];  // uniform address: an LDS broadcast
+                    if (!(key < thr)) break;
+                    wave_insert_reg(mine, cnt, a.k, key, lane);
+                    thr = wave_kth_reg(mine, a.k);
+                }
+            uint64_t *dstp = a.partial + (static_cast<int64_t>(qi) * a.slices + sl) * a.k;
+            if (lane < a.k) coherent_store(dstp + lane, mine);
+        }
+    } else {
+        uint64_t *dstp = a.partial + ((static_cast<int64_t>(qi) * a.slices + sl) * kNWave + wave) * a.k;
+        for (int i = lane; i < a.k; i += kWave) coherent_store(dstp + i, i < cnt ? mylist[i] : static_cast<uint64_t>(~0ull));
+    }
+    // ---- tail: the last workgroup of query qi merges the partial lists, maps the winners to row ids
+    // (ivf_flat.clj:291-294) and writes the results (the hand-over protocol of scan_kernel's fused tail)
+    wait_stores_acked();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(a.done + qi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tail_last = prev == static_cast<uint32_t>(a.slices) - 1 ? 1 : 0;
+        if (tail_last) __hip_atomic_store(a.done + qi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!tail_last) return;
+    MergeArgs mg;
+    mg.partial = a.partial;
+    mg.keys_per_query = static_cast<int64_t>(a.slices) * (regk ? 1 : kNWave) * a.k;
+    mg.nq = 0;
+    mg.k = a.k;
+    mg.out_ord = nullptr;
+    mg.out_dist = nullptr;
+    uint32_t *ord_s = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (kNWave + 1) * a.k);  // [k]
+    float *dist_s = reinterpret_cast<float *>(ord_s + a.k);                                         // [k]
+    merge_topk_wg<true>(mg, qi, kNWave, smem, ord_s, dist_s);  // waves 1..3 return from it after its barrier
+    if (wave != 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < a.k; i += kWave) {
+        const uint32_t o = ord_s[i];
+        uint32_t go = 0xffffffffu;
+        int32_t id = -1;
+        if (o != 0xffffffffu) {
+            int p = 0;
+            while (p + 1 < a.nprobe && pp[p + 1].ord_base <= o) p++;  // as ivf_decode_kernel
+            id = a.listids[pp[p].row_begin + (o - pp[p].ord_base)];
+            go = pp[p].gord_base + (o - pp[p].ord_base);
+        }
+        a.out_ids[static_cast<int64_t>(qi) * a.k + i] = id;
+        a.out_dist[static_cast<int64_t>(qi) * a.k + i] = dist_s[i];
+        if (a.out_gord) a.out_gord[static_cast<int64_t>(qi) * a.k + i] = go;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-means++ seeding (ivf_flat.clj:43-49) as a bounds pass: a round folds the distances to ONE new centre into every
+// row's running minimum (scan_kernel, MODE_MINUPD: `if (d < min) min = d`).  A row whose lower bound is already >= its
+// minimum keeps it whatever d is, so only the rows the new centre may actually be nearest to -- its own cluster, and
+// early in the seeding the rows that have no centre nearby yet -- fetch their f32 row; the others cost their int8 row.
+// Same arithmetic for the rows that are evaluated, hence the same minima, bit for bit.  (Base-order codes in the lane
+// layout: the traversal's copy, kernels.hpp.)
+// ------------------------------------------------------------------------------------------------
+struct SeedArgs {
+    const float *rows;
+    const float *row_norms;
+    int64_t ld, n;
+    int32_t dim, metric;
+    int64_t cur;             // the new centre is base row `cur`
+    const uint32_t *qrows;   // codes of the base rows (lane layout) + meta
+    const float4 *qmeta;
+    float *out;              // running minima [n]
+    int32_t rows_per_wg;     // multiple of 32
+};
+
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void seed_update_kernel(SeedArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int nvec = static_cast<int>(a.ld / 4);
+    float4 q[NCH];
+    load_row<NCH>(q, a.rows + a.cur * a.ld, nvec, lane, true);
+    const float qn = a.metric == METRIC_COS ? a.row_norms[a.cur] : 0.0f;  // as the f32 pass: the stored norm
+    QueryCode<NCH> qc;
+    encode_query<NCH>(q, qc);
+    const int own = wave_sum8_row(lane);
+    const int64_t w0 = static_cast<int64_t>(blockIdx.x) * a.rows_per_wg;
+    const int64_t w1 = w0 + a.rows_per_wg < a.n ? w0 + a.rows_per_wg : a.n;
+    for (int64_t base = w0 + wave * 8; base < w1; base += kNWave * 8) {
+        const int64_t myrow = base + own;
+        const bool ok = (lane & 7) == 0 && myrow < w1;
+        const float4 mymeta = ok ? a.qmeta[myrow] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float myold = ok ? a.out[myrow] : 0.0f;
+        int acc[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const int64_t row = base + b < w1 ? base + b : w1 - 1;
+            const uint32_t *rp = a.qrows + (row * kWave + lane) * NCH;
+            uint32_t w[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) w[c] = rp[c];
+            acc[b] = code_dot<NCH>(qc.a, w);
+        }
+        const int tot = wave_sum8_int(acc, lane);
+        const float lb = code_lower_bound(a.metric, tot, qc.sc, mymeta, mymeta.w);
+        const bool need = ok && !(lb >= myold);  // NaN: evaluate
+        uint64_t m = __ballot(need);             // bit 8r = row r of the block
+        while (m) {
+            float4 r[RB][NCH];
+            int64_t rw[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                rw[b] = -1;
+                if (m) {
+                    rw[b] = base + ((__ffsll(static_cast<unsigned long long>(m)) - 1) >> 3);
+                    m &= m - 1;
+                    load_row<NCH>(r[b], a.rows + rw[b] * a.ld, nvec, lane, true);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                if (rw[b] < 0) break;
+                const float s = wave_sum(lane_partial<NCH, L2>(q, r[b]));
+                if (lane == 0) {
+                    const float d = finish_dist(a.metric, s, qn, a.metric == METRIC_COS ? a.row_norms[rw[b]] : 0.0f);
+                    const float o = a.out[rw[b]];
+                    if (d < o) a.out[rw[b]] = d;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace hg
