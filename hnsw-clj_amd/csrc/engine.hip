@@ -125,9 +125,10 @@ int launch_finish(const FinishArgs &a, int nch, hipStream_t st) {
     do {                                                                                                                \
         static bool attr_done[64] = {};                                                                                 \
         if (lds > 48 * 1024 && attr_needed(attr_done))                                                                  \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_finish_kernel<N, R, L>),                     \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_finish_kernel<N, (R > 2 ? R / 2 : R), L>),   \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));                         \
-        hipLaunchKernelGGL((ivf_finish_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a);   \
+        /* half the rows in flight of the streaming kernels: a gathered row costs this kernel 24 registers */          \
+        hipLaunchKernelGGL((ivf_finish_kernel<N, (R > 2 ? R / 2 : R), L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a); \
     } while (0)
     HG_DISPATCH(nch, l2, CALL);
 #undef CALL

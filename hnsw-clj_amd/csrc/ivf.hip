@@ -719,7 +719,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     int64_t cap = std::min<int64_t>(stride, std::max<int64_t>(4096, 4 * idx->max_list_len));
     if (cap_env > 0) cap = cap_env;
     cap = std::max<int64_t>(cap, 1);
-    HG_TRY(idx->s_tile.ensure(sizeof(uint2) * static_cast<size_t>(nq) * cap));
+    HG_TRY(idx->s_tile.ensure(sizeof(uint4) * static_cast<size_t>(nq) * cap));
     b.metric = idx->metric;
     b.k = k;
     b.ctile = idx->d_lctile;
@@ -728,7 +728,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     b.qscal = sc.qscal;
     b.tau = sc.tau;
     b.surv_cnt = sc.surv_cnt;
-    b.surv = idx->s_tile.as<uint2>();
+    b.surv = idx->s_tile.as<uint4>();
     b.cap = cap;
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);

@@ -206,7 +206,7 @@ struct StreamArgs {
     const QueryScal *qscal;
     uint32_t *tau;       // [nq] running threshold (orderable bits), all-ones at the start
     uint32_t *surv_cnt;  // [nq] survivors appended so far (may exceed cap: the query then takes the fallback)
-    uint2 *surv;         // [nq][cap] (order key, lb bits)
+    uint4 *surv;         // [nq][cap] (order key, list row, lb bits, 0)
     int64_t cap;
 };
 
@@ -217,9 +217,14 @@ __host__ inline size_t stream_lds_bytes(int nch) {
            + (sizeof(uint32_t) + sizeof(int32_t)) * kTileQ;                 // order bases, query indices
 }
 
+// Latency, not arithmetic, is what this kernel has to manage (a 32-row block is 24 KB of codes: ~1.2 us of a CU's share
+// of HBM, against 0.7 us of matrix-core time): every wave keeps eight 1 KB operand loads in flight and issues the first
+// loads of its NEXT block before the epilogue of the current one -- and of its first block before the group is set up,
+// since the rows to read depend on the work item alone.
 template <int NCH>
 __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs a) {
     constexpr int S = NCH * 8;  // steps of 32 bytes
+    constexpr int PF = 8;       // operand loads in flight per wave
     extern __shared__ __align__(16) unsigned char smem[];
     v4i_t *qb_s = reinterpret_cast<v4i_t *>(smem);                               // [S][2][32]
     QueryScal *qs_s = reinterpret_cast<QueryScal *>(qb_s + S * 64);              // [32]
@@ -268,6 +273,21 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
     }
     if (r0 >= r1 || cnt <= 0) return;
 
+    // blocks of 32 rows of the tile layout that overlap [r0, r1): the layout's blocks are aligned to the WHOLE list array,
+    // not to a list, so the first and the last block of a chunk may hold rows of the neighbours -- computed, not used
+    const int64_t b0 = r0 >> 5, b1 = (r1 + 31) >> 5;
+    int64_t b = b0 + wave;
+    const v4i_t *tile = reinterpret_cast<const v4i_t *>(a.ctile);
+    v4i_t av[PF];
+    float4 metar = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (b < b1) {  // the first block's operands are on their way while the group is set up
+        const v4i_t *ap = tile + (b * S) * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < PF; u++) av[u] = ap[u * 64];
+        const int64_t row = b * 32 + (lane & 31);
+        if (row >= r0 && row < r1) metar = a.cmeta[row];
+    }
+
     if (tid < kTileQ) {
         int qi = -1;
         uint32_t ob = 0;
@@ -280,13 +300,13 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
                 qi = m.q;
                 ob = static_cast<uint32_t>(m.out_base);
             }
-            qs_s[tid] = a.qscal[qi];
         }
         qi_s[tid] = qi;
         ob_s[tid] = ob;
     }
     __syncthreads();
     // query codes: natural order in global memory (16-B chunk t of query q = step t / 2, half t & 1); empty slots are zero
+    if (tid < cnt) qs_s[tid] = a.qscal[qi_s[tid]];
     for (int f = tid; f < kTileQ * S * 2; f += kTileThreads) {
         const int q = f / (S * 2), t = f - q * (S * 2);
         v4i_t v = {0, 0, 0, 0};
@@ -304,48 +324,75 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
     float my_tau = kInf;
     float run_max = -kInf, all_max = -kInf;
     int run_cnt = 0, all_cnt = 0;
-    uint2 *dst = a.surv + static_cast<int64_t>(myq) * a.cap;
-    // blocks of 32 rows of the tile layout that overlap [r0, r1): the layout's blocks are aligned to the WHOLE list array,
-    // not to a list, so the first and the last block of a chunk may hold rows of the neighbours -- computed, not used
-    const int64_t b0 = r0 >> 5, b1 = (r1 + 31) >> 5;
-    for (int64_t b = b0 + wave; b < b1; b += kTileWaves) {
-        const v4i_t *ap = reinterpret_cast<const v4i_t *>(a.ctile) + (b * S) * 64 + lane;
-        if (lane < 32) {
-            const int64_t row = b * 32 + lane;
-            meta_s[lane] = (row >= r0 && row < r1) ? a.cmeta[row] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
+    uint4 *dst = a.surv + static_cast<int64_t>(myq) * a.cap;
+    const v4i_t *ap = tile + (b * S) * 64 + lane;  // this wave's current block
+    const v4i_t *qb_mine = qb_s + half * 32 + col;   // B operand of step s: qb_mine[s * 64]
+    for (; b < b1; b += kTileWaves, ap += static_cast<int64_t>(kTileWaves) * S * 64) {
+        if (lane < 32) meta_s[lane] = metar;
         // what the other workgroups have found meanwhile (in flight under the MFMAs)
         const uint32_t tnow = live ? coherent_load(a.tau + myq) : 0xffffffffu;
         v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        v4i_t av[8];
+        {
+            const v4i_t *p = ap;
+            const v4i_t *qp = qb_mine;
+#pragma unroll 1
+            for (int s0 = 0; s0 + PF < S; s0 += PF) {  // a real loop: unrolled, all S query operands leave LDS at once
 #pragma unroll
-        for (int u = 0; u < 8; u++) av[u] = ap[(u < S ? u : S - 1) * 64];
+                for (int u = 0; u < PF; u++) {
+                    const v4i_t cur = av[u];
+                    av[u] = p[(PF + u) * 64];
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur, qp[u * 64], acc, 0, 0, 0);
+                }
+                p += PF * 64;
+                qp += PF * 64;
+            }
 #pragma unroll
-        for (int s = 0; s < S; s++) {
-            const v4i_t cur = av[s & 7];
-            if (s + 8 < S) av[s & 7] = ap[(s + 8) * 64];  // eight operands (8 KB per wave) in flight
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur, qb_s[(s * 2 + half) * 32 + col], acc, 0, 0, 0);
+            for (int u = 0; u < PF; u++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[u], qp[u * 64], acc, 0, 0, 0);
+        }
+        metar = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (b + kTileWaves < b1) {  // the next block's first operands and row terms, before this block's epilogue
+            const v4i_t *np = ap + static_cast<int64_t>(kTileWaves) * S * 64;
+#pragma unroll
+            for (int u = 0; u < PF; u++) av[u] = np[u * 64];
+            const int64_t row = (b + kTileWaves) * 32 + (lane & 31);
+            if (row >= r0 && row < r1) metar = a.cmeta[row];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // meta_s written by lanes 0-31 above is read by every lane below
-        // C/D: lane holds column `col` (the query); register g is row (g & 3) + 8 (g >> 2) + 4 half of the block
-        float lbv[16];
-        uint32_t vmask = 0;
+        {
+            const float tg = tau_decode(tnow);
+            my_tau = tg < my_tau ? tg : my_tau;
+        }
+        // C/D: lane holds column `col` (the query); register g is row (g & 3) + 8 (g >> 2) + 4 half of the block.  Four
+        // registers at a time in a real loop (unrolled, the sixteen bounds with their row terms cost 180 registers and the
+        // kernel half its occupancy)
+        const int rel = static_cast<int>(b * 32 - rb0) + 4 * half;  // row (relative to the list) of register 0
+        const int rel0 = static_cast<int>(r0 - rb0), rel1 = static_cast<int>(r1 - rb0);
+        uint32_t vmask = 0, pmask = 0;
         float bmax = -kInf;
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) {
+            const int a0 = j == 0 ? acc[0] : (j == 1 ? acc[4] : (j == 2 ? acc[8] : acc[12]));
+            const int a1 = j == 0 ? acc[1] : (j == 1 ? acc[5] : (j == 2 ? acc[9] : acc[13]));
+            const int a2 = j == 0 ? acc[2] : (j == 1 ? acc[6] : (j == 2 ? acc[10] : acc[14]));
+            const int a3 = j == 0 ? acc[3] : (j == 1 ? acc[7] : (j == 2 ? acc[11] : acc[15]));
+            const int av4[4] = {a0, a1, a2, a3};
 #pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int i = (g & 3) + 8 * (g >> 2) + 4 * half;
-            const int64_t row = b * 32 + i;
-            const float4 mt = meta_s[i];
-            float lb, ub;
-            code_bounds(a.metric, acc[g], myqs, mt, mt.w, lb, ub);
-            lbv[g] = lb;
-            if (row >= r0 && row < r1) {
-                vmask |= 1u << g;
-                ub = ub == ub ? ub : kInf;
-                bmax = ub > bmax ? ub : bmax;
+            for (int t = 0; t < 4; t++) {
+                const int i = 8 * j + 4 * half + t;
+                const int r = rel + 8 * j + t;
+                const float4 mt = meta_s[i];
+                float lb, ub;
+                code_bounds(a.metric, av4[t], myqs, mt, mt.w, lb, ub);
+                if (r >= rel0 && r < rel1) {
+                    vmask |= 1u << (4 * j + t);
+                    ub = ub == ub ? ub : kInf;
+                    bmax = ub > bmax ? ub : bmax;
+                    if (!(lb > my_tau)) pmask |= 1u << (4 * j + t);  // NaN (no bound) survives
+                }
             }
         }
+        if (!live) pmask = 0;
         int bcnt = __popc(vmask);
         {  // the other half of the block's rows of this query
             const float om = __shfl_xor(bmax, 32, kWave);
@@ -356,8 +403,6 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
         run_cnt += bcnt;
         all_max = bmax > all_max ? bmax : all_max;
         all_cnt += bcnt;
-        const float tg = tau_decode(tnow);
-        my_tau = tg < my_tau ? tg : my_tau;
         if (run_cnt >= a.k) {  // k candidates of this query are at most run_max away: D_k <= run_max
             if (run_max < my_tau) {
                 my_tau = run_max;
@@ -367,26 +412,32 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
             run_max = -kInf;
             run_cnt = 0;
         }
-        uint32_t pmask = 0;
-#pragma unroll
-        for (int g = 0; g < 16; g++)
-            if (((vmask >> g) & 1u) && !(lbv[g] > my_tau)) pmask |= 1u << g;  // NaN (no bound) survives
-        if (!live) pmask = 0;
         const int n = __popc(pmask);
         const int on = __shfl_xor(n, 32, kWave);
-        uint32_t base = 0;
-        if (half == 0 && n + on > 0)
-            base = __hip_atomic_fetch_add(a.surv_cnt + myq, static_cast<uint32_t>(n + on), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        base = __shfl(base, col, kWave);
-        if (half) base += on;  // half 1 writes behind half 0's `on` entries
-        if (pmask) {
+        if (__ballot(n > 0)) {  // (most blocks of most lists append nothing)
+            uint32_t base = 0;
+            if (half == 0 && n + on > 0)
+                base = __hip_atomic_fetch_add(a.surv_cnt + myq, static_cast<uint32_t>(n + on), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base = __shfl(base, col, kWave);
+            if (half) base += on;  // half 1 writes behind half 0's `on` entries
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                if (((pmask >> (4 * j)) & 15u) == 0) continue;
+                const int a0 = j == 0 ? acc[0] : (j == 1 ? acc[4] : (j == 2 ? acc[8] : acc[12]));
+                const int a1 = j == 0 ? acc[1] : (j == 1 ? acc[5] : (j == 2 ? acc[9] : acc[13]));
+                const int a2 = j == 0 ? acc[2] : (j == 1 ? acc[6] : (j == 2 ? acc[10] : acc[14]));
+                const int a3 = j == 0 ? acc[3] : (j == 1 ? acc[7] : (j == 2 ? acc[11] : acc[15]));
+                const int av4[4] = {a0, a1, a2, a3};
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-                if ((pmask >> g) & 1u) {
-                    const int i = (g & 3) + 8 * (g >> 2) + 4 * half;
-                    if (base < a.cap)
-                        dst[base] = make_uint2(myob + static_cast<uint32_t>(b * 32 + i - rb0), __float_as_uint(lbv[g]));
-                    base++;
+                for (int t = 0; t < 4; t++) {
+                    if ((pmask >> (4 * j + t)) & 1u) {
+                        const float4 mt = meta_s[8 * j + 4 * half + t];
+                        const float lb = code_lower_bound(a.metric, av4[t], myqs, mt, mt.w);
+                        const uint32_t r = static_cast<uint32_t>(rel + 8 * j + t);
+                        if (base < a.cap)
+                            dst[base] = make_uint4(myob + r, static_cast<uint32_t>(rb0) + r, __float_as_uint(lb), 0u);
+                        base++;
+                    }
                 }
             }
         }
@@ -416,7 +467,7 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
 // Step 2: survivors -> f32 distances -> the k nearest -> results.
 // ------------------------------------------------------------------------------------------------
 struct FinishArgs {
-    const uint2 *surv;
+    const uint4 *surv;     // (order key, list row, lb bits, 0)
     const uint32_t *surv_cnt;
     uint32_t *tau;         // keeps falling while the survivors are evaluated
     int64_t cap;
@@ -461,7 +512,7 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     // the threshold keeps falling in this kernel too: a wave that holds k exact distances folds its k-th into tau[qi]
     // (k candidates are at most that far), every wave re-reads it once per step
     float tau = tau_decode(a.tau[qi]);
-    const uint2 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
+    const uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
     const Pair *pp = a.pairs + static_cast<int64_t>(qi) * a.nprobe;
     const bool regk = a.k <= kWave;
     uint64_t *mylist = lists + wave * a.k;
@@ -469,21 +520,22 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     uint64_t thr = ~0ull, mine = ~0ull;
     const int nvec = static_cast<int>(a.ld / 4);
     float4 q[NCH];
-    float qn = 0.0f;
-    bool have_q = false;  // the query is fetched by the first step that has a survivor
+    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+    const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
     unsigned long long nsurv = 0;
     for (int64_t base = i0 + wave * span; base < i1; base += gran) {
         const int64_t i = base + lane;
         const bool in = lane < span && i < i1;
-        uint32_t o = 0;
+        uint32_t o = 0, erow = 0;
         float l = -__builtin_inff();
         if (in) {
             if (over) {
                 o = static_cast<uint32_t>(i);
             } else {
-                const uint2 e = sv[i];
+                const uint4 e = sv[i];
                 o = e.x;
-                l = __uint_as_float(e.y);
+                erow = e.y;
+                l = __uint_as_float(e.z);
             }
         }
         const uint32_t tnext = coherent_load(a.tau + qi);  // used by the NEXT step: in flight under this one's rows
@@ -495,22 +547,21 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
             continue;
         }
         nsurv += __popcll(m);
-        if (!have_q) {
-            load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
-            qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
-            have_q = true;
+        // a survivor carries its list row; the fallback resolves the candidate's position in the stream to one (the last
+        // pair whose ord_base <= ord: lists of length 0 share an ord_base with their successor, as in ivf_decode_kernel)
+        int64_t myrow = erow;
+        if (over) {
+            int lo = 0, hi = a.nprobe - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pp[mid].ord_base <= o) lo = mid;
+                else hi = mid - 1;
+            }
+            myrow = s ? pp[lo].row_begin + (o - pp[lo].ord_base) : 0;
         }
-        // every lane resolves ITS candidate to a list row (the last pair whose ord_base <= ord: lists of length 0 share
-        // an ord_base with their successor, as in ivf_decode_kernel) and fetches that row's norm
-        int lo = 0, hi = a.nprobe - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (pp[mid].ord_base <= o) lo = mid;
-            else hi = mid - 1;
-        }
-        const int64_t myrow = s ? pp[lo].row_begin + (o - pp[lo].ord_base) : 0;
         const float myrn = (s && a.metric == METRIC_COS) ? a.row_norms[myrow] : 0.0f;
         const int rlo = static_cast<int>(myrow), rhi = static_cast<int>(myrow >> 32);
+        float dmine = 0.0f;  // a surviving lane ends up with ITS candidate's distance
         while (m) {
             float4 r[RB][NCH];
             int js[RB];
@@ -531,16 +582,23 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
                 const float sum = wave_sum(lane_partial<NCH, L2>(q, r[b]));
                 const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), js[b]));
                 const float dv = finish_dist(a.metric, sum, qn, rn);
-                const uint32_t ob = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(o), js[b]));
-                const uint64_t key = make_key(dv, ob);
-                if (key < thr) {
-                    if (regk) {
-                        wave_insert_reg(mine, cnt, a.k, key, lane);
-                        thr = wave_kth_reg(mine, a.k);  // ~0 until the list is full
-                    } else {
-                        wave_insert(mylist, cnt, a.k, key, lane);
-                        thr = cnt == a.k ? mylist[a.k - 1] : ~0ull;
-                    }
+                dmine = lane == js[b] ? dv : dmine;
+            }
+        }
+        // the step's keys into this wave's top-k, one at a time (the insertion code exists once, not once per row in flight)
+        const uint64_t key = s ? make_key(dmine, o) : ~0ull;
+        uint64_t mask = __ballot(key < thr);
+        while (mask) {
+            const int bl = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+            mask &= mask - 1;
+            const uint64_t kb = lane_bcast(key, bl);
+            if (kb < thr) {
+                if (regk) {
+                    wave_insert_reg(mine, cnt, a.k, kb, lane);
+                    thr = wave_kth_reg(mine, a.k);  // ~0 until the list is full
+                } else {
+                    wave_insert(mylist, cnt, a.k, kb, lane);
+                    thr = cnt == a.k ? mylist[a.k - 1] : ~0ull;
                 }
             }
         }
@@ -607,8 +665,12 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
         uint32_t go = 0xffffffffu;
         int32_t id = -1;
         if (o != 0xffffffffu) {
-            int p = 0;
-            while (p + 1 < a.nprobe && pp[p + 1].ord_base <= o) p++;  // as ivf_decode_kernel
+            int p = 0, hi = a.nprobe - 1;  // the last pair whose ord_base <= o (as ivf_decode_kernel), by bisection
+            while (p < hi) {
+                const int mid = (p + hi + 1) >> 1;
+                if (pp[mid].ord_base <= o) p = mid;
+                else hi = mid - 1;
+            }
             id = a.listids[pp[p].row_begin + (o - pp[p].ord_base)];
             go = pp[p].gord_base + (o - pp[p].ord_base);
         }
