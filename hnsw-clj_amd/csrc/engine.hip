@@ -96,20 +96,26 @@ int ensure_list_codes(hnswgpu_index *idx, hipStream_t st) {
     return 0;
 }
 
-int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, hipStream_t st) {
+int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narrow, hipStream_t st) {
     if (blocks <= 0) return 0;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "bounds pass grid too large");
     const size_t lds = stream_lds_bytes(nch);
-#define CALL(N, R, L)                                                                                                  \
+#define CALLV(N, NARROW)                                                                                               \
     do {                                                                                                               \
         static bool attr_done[64] = {};                                                                                \
         if (lds > 48 * 1024 && attr_needed(attr_done))                                                                 \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_bounds_kernel<N>),                       \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_bounds_kernel<N, NARROW>),               \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
-        hipLaunchKernelGGL((stream_bounds_kernel<N>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, a); \
+        hipLaunchKernelGGL((stream_bounds_kernel<N, NARROW>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, a); \
+    } while (0)
+#define CALL(N, R, L)             \
+    do {                          \
+        if (narrow) CALLV(N, true); \
+        else CALLV(N, false);     \
     } while (0)
     HG_DISPATCH(nch, false, CALL);
 #undef CALL
+#undef CALLV
     HG_HIP(hipGetLastError());
     return 0;
 }
@@ -427,17 +433,24 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
     s.k = a.nprobe;
     s.wpq = kNWave;
     s.vec4 = 0;
-    s.out_ord = a.out_ord;
-    s.out_dist = a.out_dist;
-    select_topk_wg<true>(s, qi, kNWave, smem);
+    s.out_ord = nullptr;  // the probed lists stay in LDS: the probe table below is all that leaves
+    s.out_dist = nullptr;
+    const uint64_t *keys = nullptr;
+    select_topk_wg<true>(s, qi, kNWave, smem, &keys);
     __shared__ int64_t tail_qcnt;
+    __shared__ uint32_t tail_cover;
+    constexpr int kHead = 16;
+    __shared__ Pair head_s[kHead];  // the first probes' table entries, for the threshold seed below
     if (wave == 0) {
-    __threadfence_block();
     // the query's probe table: offsets of the probed lists in its candidate stream (probe_pairs_kernel, one wave)
     uint32_t carry = 0, gcarry = 0;
     for (int p0 = 0; p0 < a.nprobe; p0 += kWave) {
         const int p = p0 + lane;
-        const uint32_t l = p < a.nprobe ? a.out_ord[static_cast<int64_t>(qi) * a.nprobe + p] : 0xffffffffu;
+        uint32_t l = 0xffffffffu;
+        if (p < a.nprobe) {
+            const uint64_t key = keys[p];
+            if (key != ~0ull) l = static_cast<uint32_t>(key);
+        }
         Pair pr;
         pr.q = qi;
         pr.pad = 0;
@@ -462,20 +475,25 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
         if (p < a.nprobe) {
             a.pairs[static_cast<int64_t>(qi) * a.nprobe + p] = pr;
             if (a.probes) a.probes[static_cast<int64_t>(qi) * a.nprobe + p] = l == 0xffffffffu ? -1 : static_cast<int32_t>(l);
+            if (p < kHead) head_s[p] = pr;
+            if (p == kHead - 1 || (p < kHead && p == a.nprobe - 1)) tail_cover = carry + incl;  // candidates the head covers
         }
         carry += __shfl(incl, kWave - 1, kWave);
         gcarry += __shfl(gincl, kWave - 1, kWave);
     }
     if (a.qcnt && lane == 0) a.qcnt[qi] = static_cast<int32_t>(carry);
     if (lane == 0) tail_qcnt = carry;
-    wait_stores_acked();  // the probe table is read back by the other waves below
+    wait_stores_acked();  // the probe table may be read back by the other waves below
     }
     if (!a.tau) return;
     // survivor stream: an empty survivor list and the first threshold, from the head of the query's candidate stream
     __syncthreads();
     if (threadIdx.x == 0) a.surv_cnt[qi] = 0;
-    seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, a.pairs + static_cast<int64_t>(qi) * a.nprobe, a.nprobe, tail_qcnt, a.k, a.rows,
-                             a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi);
+    // the head's table entries are in LDS (no dependent global reads) when they cover the rows the seed looks at
+    const bool head_ok = a.nprobe <= kHead || tail_cover >= static_cast<uint32_t>(kSeedMax);
+    const Pair *pp = head_ok ? head_s : a.pairs + static_cast<int64_t>(qi) * a.nprobe;
+    seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, pp, head_ok ? (a.nprobe < kHead ? a.nprobe : kHead) : a.nprobe, tail_qcnt, a.k,
+                             a.rows, a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi);
 }
 
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,

@@ -243,7 +243,8 @@ struct StreamArgs;
 struct FinishArgs;
 struct PrepArgs;
 int launch_query_prep(const PrepArgs &a, int nch, hipStream_t st);
-int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, hipStream_t st);
+// narrow: the epilogue for few queries per probed list (lane = row); otherwise lane = query
+int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narrow, hipStream_t st);
 int launch_finish(const FinishArgs &a, int nch, hipStream_t st);
 // zero-initialised per-query counters of the fused tails (s_done: [n] scan / finish tails | [n] route tails)
 int ensure_counters(hnswgpu_index *idx, size_t n, hipStream_t st);

@@ -730,9 +730,13 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     b.surv_cnt = sc.surv_cnt;
     b.surv = idx->s_tile.as<uint4>();
     b.cap = cap;
+    b.dbg = static_cast<int32_t>(env_now("HNSWGPU_STREAM_DBG", 0));
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);
-    HG_TRY(launch_stream_bounds(b, blocks, idx->nch, st));
+    // which epilogue: few queries per probed list -> lane = row (a list probed by more takes several passes); many -> lane = query
+    const int64_t narrow_env = env_now("HNSWGPU_STREAM_NARROW", -1);  // A/B: 0 / 1 force
+    const bool narrow = narrow_env >= 0 ? narrow_env != 0 : npairs < 6LL * idx->nlist;
+    HG_TRY(launch_stream_bounds(b, blocks, idx->nch, narrow, st));
     prof_end(idx, PROF_IVF_SCAN, st, e0);
     FinishArgs f;
     memset(&f, 0, sizeof(f));

@@ -208,20 +208,41 @@ struct StreamArgs {
     uint32_t *surv_cnt;  // [nq] survivors appended so far (may exceed cap: the query then takes the fallback)
     uint4 *surv;         // [nq][cap] (order key, list row, lb bits, 0)
     int64_t cap;
+    int32_t dbg;         // developer ablation switches (HNSWGPU_STREAM_DBG); 0 in production
 };
 
-__host__ inline size_t stream_lds_bytes(int nch) {
-    return static_cast<size_t>(nch) * 256 * kTileQ                       // query codes [step][half][query][16 B]
-           + sizeof(QueryScal) * kTileQ + sizeof(float4) * 32 * kTileWaves  // query scalars, per-wave row meta
-           + (sizeof(float) + sizeof(int32_t)) * 32 * kTileWaves            // per-wave chunk maxima / counts
-           + (sizeof(uint32_t) + sizeof(int32_t)) * kTileQ;                 // order bases, query indices
-}
 
 // Latency, not arithmetic, is what this kernel has to manage (a 32-row block is 24 KB of codes: ~1.2 us of a CU's share
 // of HBM, against 0.7 us of matrix-core time): every wave keeps eight 1 KB operand loads in flight and issues the first
 // loads of its NEXT block before the epilogue of the current one -- and of its first block before the group is set up,
 // since the rows to read depend on the work item alone.
-template <int NCH>
+//
+// Two epilogues turn the 32 x 32 integer tile into bounds.  A group of up to kNarrow queries (small batches: one or two
+// queries per probed list) parks its few live columns in LDS and lets every LANE take a ROW -- one pass over 32 rows per
+// pair of queries, survivors written side by side -- instead of sixteen passes in which one or two lanes work.  Wider
+// groups keep the MFMA's own distribution (lane = query, sixteen rows each); the Euclidean test is done on the squared
+// bound there, so that a block costs one square root per lane, not thirty-two.
+constexpr int kNarrow = 8;
+
+__host__ inline size_t stream_lds_bytes(int nch) {
+    return static_cast<size_t>(nch) * 256 * kTileQ                          // query codes [step][half][query][16 B]
+           + sizeof(QueryScal) * kTileQ + sizeof(float4) * 32 * kTileWaves  // query scalars, per-wave row terms
+           + (sizeof(float) + sizeof(int32_t)) * 32 * kTileWaves            // per-wave chunk maxima / counts
+           + (sizeof(uint32_t) + sizeof(int32_t)) * kTileQ                  // order bases, query indices
+           + sizeof(int32_t) * (kNarrow * 33 + 3 * kTileQ) * kTileWaves;    // narrow epilogue: per-wave tile + running state
+}
+
+// Euclidean bound terms of one (query, row): lb = sqrt(max(lo, 0)) - W, ub = sqrt(hi) (1 + 1e-6) + W (code_bounds)
+__device__ __forceinline__ void l2_bound_terms(int dot, const QueryScal &qc, float4 meta, float &lo, float &hi, float &W) {
+    const float dh = static_cast<float>(dot) * (qc.s * meta.x);
+    const float v2 = meta.x * meta.x * meta.z;
+    const float d2 = qc.a2 - 2.0f * dh + v2, dl = 2.0e-6f * (qc.a2 + v2);
+    lo = d2 - dl;
+    hi = d2 + dl;
+    W = (qc.rq + 4.0e-6f * qc.qn) + meta.y;
+}
+
+template <int NCH, bool NARROW>
 __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs a) {
     constexpr int S = NCH * 8;  // steps of 32 bytes
     constexpr int PF = 8;       // operand loads in flight per wave
@@ -233,10 +254,15 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
     int32_t *wcnt_s = reinterpret_cast<int32_t *>(wmax_s + 32 * kTileWaves);     // [waves][32]
     uint32_t *ob_s = reinterpret_cast<uint32_t *>(wcnt_s + 32 * kTileWaves);     // [32]
     int32_t *qi_s = reinterpret_cast<int32_t *>(ob_s + kTileQ);                  // [32]
+    int32_t *narrow_all = qi_s + kTileQ;                                          // [waves][kNarrow * 33 + 3 * 32]
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
     float4 *meta_s = meta_all + wave * 32;
+    int32_t *tile_w = narrow_all + wave * (kNarrow * 33 + 3 * kTileQ);            // [kNarrow][33] dot products
+    float *tauw = reinterpret_cast<float *>(tile_w + kNarrow * 33);               // [32] thresholds
+    float *runm = tauw + kTileQ;                                                  // [32] running maxima
+    int32_t *runc = reinterpret_cast<int32_t *>(runm + kTileQ);                   // [32] ... of how many candidates
 
     // ---- work item
     int64_t rb0, r0, r1;
@@ -313,6 +339,15 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
         if (q < cnt) v = reinterpret_cast<const v4i_t *>(a.qcodes + static_cast<int64_t>(qi_s[q]) * NCH * kWave)[t];
         qb_s[t * 32 + q] = v;
     }
+    const float kInf = __builtin_inff();
+    constexpr bool narrow = NARROW;
+    if (lane < 32) {  // this wave's chunk maxima / counts; narrow epilogue: thresholds and running maxima
+        wmax_s[wave * 32 + lane] = -kInf;
+        wcnt_s[wave * 32 + lane] = 0;
+        tauw[lane] = kInf;
+        runm[lane] = -kInf;
+        runc[lane] = 0;
+    }
     __syncthreads();
 
     const int col = lane & 31, half = lane >> 5;
@@ -320,16 +355,17 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
     const QueryScal myqs = live ? qs_s[col] : QueryScal{};
     const int myq = live ? qi_s[col] : 0;
     const uint32_t myob = live ? ob_s[col] : 0;
-    const float kInf = __builtin_inff();
     float my_tau = kInf;
     float run_max = -kInf, all_max = -kInf;
     int run_cnt = 0, all_cnt = 0;
     uint4 *dst = a.surv + static_cast<int64_t>(myq) * a.cap;
     const v4i_t *ap = tile + (b * S) * 64 + lane;  // this wave's current block
     const v4i_t *qb_mine = qb_s + half * 32 + col;   // B operand of step s: qb_mine[s * 64]
+    const int rel0 = static_cast<int>(r0 - rb0), rel1 = static_cast<int>(r1 - rb0);
     for (; b < b1; b += kTileWaves, ap += static_cast<int64_t>(kTileWaves) * S * 64) {
-        if (lane < 32) meta_s[lane] = metar;
-        // what the other workgroups have found meanwhile (in flight under the MFMAs)
+        const float4 mcur = metar;  // narrow groups: lane & 31 is the row whose terms these are
+        if (!narrow && lane < 32) meta_s[lane] = metar;
+        // what the other workgroups have found meanwhile (in flight under the MFMAs): lane = query in both epilogues
         const uint32_t tnow = live ? coherent_load(a.tau + myq) : 0xffffffffu;
         v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         {
@@ -357,19 +393,98 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
             const int64_t row = (b + kTileWaves) * 32 + (lane & 31);
             if (row >= r0 && row < r1) metar = a.cmeta[row];
         }
+        if (a.dbg & 1) {  // ablation: no epilogue (results are wrong)
+            if (acc[0] == 0x7fffffff) dst[0] = make_uint4(tnow, 0, 0, 0);
+            continue;
+        }
+        // C/D: lane holds column `col` (the query); register g is row (g & 3) + 8 (g >> 2) + 4 half of the block
+        const int rel = static_cast<int>(b * 32 - rb0);  // row 0 of the block, relative to the list
+        if (narrow) {
+            // ---- eight live columns at a time into LDS; then lane = row, one half of the wave per query
+            if (live && half == 0) {
+                const float tg = tau_decode(tnow), to = tauw[col];
+                tauw[col] = tg < to ? tg : to;
+            }
+            const int r = rel + col;
+            const bool valid = r >= rel0 && r < rel1;
+            for (int c0 = 0; c0 < cnt; c0 += kNarrow) {
+            if (col >= c0 && col < c0 + kNarrow && live) {
+#pragma unroll
+                for (int g = 0; g < 16; g++) tile_w[(col - c0) * 33 + (g & 3) + 8 * (g >> 2) + 4 * half] = acc[g];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int cend = c0 + kNarrow < cnt ? c0 + kNarrow : cnt;
+            for (int q0 = c0; q0 < cend; q0 += 2) {
+                const int qx = q0 + half;
+                const bool act = qx < cend;
+                const int qxc = act ? qx : q0;
+                const QueryScal qs = qs_s[qxc];
+                float lb, ub;
+                code_bounds(a.metric, tile_w[(qxc - c0) * 33 + col], qs, mcur, mcur.w, lb, ub);
+                const float tq = tauw[qxc];
+                const bool va = valid && act;
+                float um = va ? (ub == ub ? ub : kInf) : -kInf;
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) {  // the largest ub of this query's rows (the half's 32 lanes)
+                    const float o = __shfl_xor(um, off, kWave);
+                    um = o > um ? o : um;
+                }
+                const uint64_t vb = __ballot(va);
+                const bool pass = va && !(lb > tq);  // NaN (no bound) survives
+                const uint64_t pb = __ballot(pass);
+                const uint32_t pm = half ? static_cast<uint32_t>(pb >> 32) : static_cast<uint32_t>(pb);
+                const int n = __popc(pm);
+                if (col == 0 && act) {  // the half's leader: running maxima, the threshold
+                    const int bc = __popc(half ? static_cast<uint32_t>(vb >> 32) : static_cast<uint32_t>(vb));
+                    const float wm = wmax_s[wave * 32 + qx];
+                    wmax_s[wave * 32 + qx] = um > wm ? um : wm;
+                    wcnt_s[wave * 32 + qx] += bc;
+                    float rm = runm[qx];
+                    int rc = runc[qx] + bc;
+                    rm = um > rm ? um : rm;
+                    if (rc >= a.k) {  // k candidates of this query are at most rm away: D_k <= rm
+                        if (rm < tq) {
+                            tauw[qx] = rm;
+                            (void)__hip_atomic_fetch_min(a.tau + qi_s[qx], tau_encode(rm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        rm = -kInf;
+                        rc = 0;
+                    }
+                    runm[qx] = rm;
+                    runc[qx] = rc;
+                }
+                if (pb) {  // (most blocks of most lists append nothing)
+                    uint32_t base = 0;
+                    if (col == 0 && n > 0)
+                        base = __hip_atomic_fetch_add(a.surv_cnt + qi_s[qxc], static_cast<uint32_t>(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    base = __shfl(base, half * 32, kWave);
+                    if (pass) {
+                        const uint32_t slot = base + __popc(pm & ((1u << col) - 1u));
+                        if (slot < a.cap)
+                            a.surv[static_cast<int64_t>(qi_s[qxc]) * a.cap + slot] =
+                                make_uint4(ob_s[qxc] + static_cast<uint32_t>(r), static_cast<uint32_t>(rb0) + static_cast<uint32_t>(r),
+                                           __float_as_uint(lb), 0u);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the next columns overwrite tile_w
+            }
+            continue;
+        }
+        // ---- wide groups: lane = query, sixteen rows each.  Four registers at a time in a real loop (unrolled, the
+        // sixteen bounds with their row terms cost 180 registers and the kernel half its occupancy)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // meta_s written by lanes 0-31 above is read by every lane below
         {
             const float tg = tau_decode(tnow);
             my_tau = tg < my_tau ? tg : my_tau;
         }
-        // C/D: lane holds column `col` (the query); register g is row (g & 3) + 8 (g >> 2) + 4 half of the block.  Four
-        // registers at a time in a real loop (unrolled, the sixteen bounds with their row terms cost 180 registers and the
-        // kernel half its occupancy)
-        const int rel = static_cast<int>(b * 32 - rb0) + 4 * half;  // row (relative to the list) of register 0
-        const int rel0 = static_cast<int>(r0 - rb0), rel1 = static_cast<int>(r1 - rb0);
+        const bool l2 = a.metric == METRIC_L2;
         uint32_t vmask = 0, pmask = 0;
-        float bmax = -kInf;
+        float bmax = -kInf, wmax = -kInf;  // Euclidean: bmax = the largest squared upper term, wmax = the largest W
+        // Euclidean: lb > tau  <=>  lo > (tau + W)^2 (tau, W >= 0), tested with a margin above the rounding of the square
 #pragma unroll 1
         for (int j = 0; j < 4; j++) {
             const int a0 = j == 0 ? acc[0] : (j == 1 ? acc[4] : (j == 2 ? acc[8] : acc[12]));
@@ -380,20 +495,36 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int i = 8 * j + 4 * half + t;
-                const int r = rel + 8 * j + t;
+                const int r = rel + i;
                 const float4 mt = meta_s[i];
-                float lb, ub;
-                code_bounds(a.metric, av4[t], myqs, mt, mt.w, lb, ub);
-                if (r >= rel0 && r < rel1) {
-                    vmask |= 1u << (4 * j + t);
-                    ub = ub == ub ? ub : kInf;
-                    bmax = ub > bmax ? ub : bmax;
-                    if (!(lb > my_tau)) pmask |= 1u << (4 * j + t);  // NaN (no bound) survives
+                const bool valid = r >= rel0 && r < rel1;
+                if (l2) {
+                    float lo, hi, W;
+                    l2_bound_terms(av4[t], myqs, mt, lo, hi, W);
+                    if (valid) {
+                        vmask |= 1u << (4 * j + t);
+                        hi = hi == hi ? hi : kInf;
+                        const float Wn = W == W ? W : kInf;
+                        bmax = hi > bmax ? hi : bmax;
+                        wmax = Wn > wmax ? Wn : wmax;
+                        const float tw = my_tau + W;
+                        if (!(lo > tw * tw * (1.0f + 1.0e-6f))) pmask |= 1u << (4 * j + t);  // NaN survives
+                    }
+                } else {
+                    float lb, ub;
+                    code_bounds(a.metric, av4[t], myqs, mt, mt.w, lb, ub);
+                    if (valid) {
+                        vmask |= 1u << (4 * j + t);
+                        ub = ub == ub ? ub : kInf;
+                        bmax = ub > bmax ? ub : bmax;
+                        if (!(lb > my_tau)) pmask |= 1u << (4 * j + t);  // NaN (no bound) survives
+                    }
                 }
             }
         }
         if (!live) pmask = 0;
         int bcnt = __popc(vmask);
+        if (l2) bmax = bcnt > 0 ? __builtin_sqrtf(bmax) * (1.0f + 1.0e-6f) + wmax : -kInf;  // >= every row's ub
         {  // the other half of the block's rows of this query
             const float om = __shfl_xor(bmax, 32, kWave);
             bcnt += __shfl_xor(bcnt, 32, kWave);
@@ -431,9 +562,10 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     if ((pmask >> (4 * j + t)) & 1u) {
-                        const float4 mt = meta_s[8 * j + 4 * half + t];
+                        const int i = 8 * j + 4 * half + t;
+                        const float4 mt = meta_s[i];
                         const float lb = code_lower_bound(a.metric, av4[t], myqs, mt, mt.w);
-                        const uint32_t r = static_cast<uint32_t>(rel + 8 * j + t);
+                        const uint32_t r = static_cast<uint32_t>(rel + i);
                         if (base < a.cap)
                             dst[base] = make_uint4(myob + r, static_cast<uint32_t>(rb0) + r, __float_as_uint(lb), 0u);
                         base++;
@@ -444,7 +576,7 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
         __builtin_amdgcn_wave_barrier();  // the next block overwrites meta_s
     }
     // the whole chunk as one block of candidates: for a k no single wave reaches
-    if (half == 0) {
+    if (!narrow && half == 0) {
         wmax_s[wave * 32 + col] = all_max;
         wcnt_s[wave * 32 + col] = all_cnt;
     }
@@ -458,7 +590,10 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
             m = x > m ? x : m;
             c += wcnt_s[w * 32 + col];
         }
-        if (c >= a.k && m < my_tau)
+        // (only when it improves on what this wave knows: an agent-scope atomic on ONE address costs ~1 us and they queue --
+        // issued by every workgroup, this line alone doubled the kernel's time)
+        const float known = narrow ? tauw[col] : my_tau;
+        if (c >= a.k && m < known)
             (void)__hip_atomic_fetch_min(a.tau + myq, tau_encode(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -512,6 +647,7 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     // the threshold keeps falling in this kernel too: a wave that holds k exact distances folds its k-th into tau[qi]
     // (k candidates are at most that far), every wave re-reads it once per step
     float tau = tau_decode(a.tau[qi]);
+    const bool share = a.slices <= 8;
     const uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
     const Pair *pp = a.pairs + static_cast<int64_t>(qi) * a.nprobe;
     const bool regk = a.k <= kWave;
@@ -538,7 +674,9 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
                 l = __uint_as_float(e.z);
             }
         }
-        const uint32_t tnext = coherent_load(a.tau + qi);  // used by the NEXT step: in flight under this one's rows
+        // (shared across waves only where a wave has many steps: with dozens of slices per query every wave takes one or
+        // two steps, and hundreds of agent-scope atomics on one address queue up, ~1 us each)
+        const uint32_t tnext = share ? coherent_load(a.tau + qi) : 0xffffffffu;  // used by the NEXT step: in flight under this one's rows
         const bool s = in && !(l > tau);  // NaN (no bound) survives
         uint64_t m = __ballot(s);
         if (!m) {
@@ -608,7 +746,7 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
             const float kd = thr == ~0ull ? __builtin_inff() : key_dist(thr);  // k exact distances at or below kd: D_k <= kd
             if (kd < tau) {
                 tau = kd;
-                if (lane == 0) (void)__hip_atomic_fetch_min(a.tau + qi, tau_encode(kd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0 && share) (void)__hip_atomic_fetch_min(a.tau + qi, tau_encode(kd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

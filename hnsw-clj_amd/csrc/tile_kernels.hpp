@@ -461,7 +461,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(TileArgs a) {
 // The body of select_topk_kernel for query q served by W waves of this workgroup (W = 1: this wave alone).  Also the
 // tail of ivf_route_kernel (ivf.hip), whose last workgroup per query picks the probed lists in the same launch.
 template <bool COH = false>
-__device__ __forceinline__ void select_topk_wg(const SelectArgs &a, int q, int W, unsigned char *smem) {
+__device__ __forceinline__ void select_topk_wg(const SelectArgs &a, int q, int W, unsigned char *smem,
+                                               const uint64_t **final_keys = nullptr) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
@@ -586,6 +587,8 @@ __device__ __forceinline__ void select_topk_wg(const SelectArgs &a, int q, int W
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (final_keys) *final_keys = list;  // (the wave that finishes the job: k ascending keys in LDS, all-ones padded)
+    if (!a.out_ord) return;
     for (int i = lane; i < a.k; i += kWave) {
         const uint64_t key = list[i];
         const bool ok = key != ~0ull;
