@@ -342,10 +342,12 @@ int scan_fused(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_que
 }
 
 // ---- centroid routing of a small batch in ONE launch (search-ivf-flat's centroid ranking, ivf_flat.clj:261-269) ----
-// Every workgroup computes the distances of its query to a slice of the centroid table (the GEMV order of scan_kernel:
-// same bits), the last workgroup of a query picks the nprobe nearest (select_topk_wg: keys (distance, centroid), the
-// stable sort of :266-268) and writes the query's probe table -- what used to be three launches (scan, select,
-// probe_pairs).
+// Every workgroup computes the distances of a GROUP of up to `qgroup` queries to a slice of the centroid table (the GEMV
+// order of scan_kernel: same bits; a wave fetches its eight centroid rows once and walks the group's queries over them),
+// the last workgroup of a query picks the nprobe nearest (select_topk_wg: keys (distance, centroid), the stable sort of
+// :266-268) and writes the query's probe table -- what used to be three launches (scan, select, probe_pairs).  For the
+// survivor stream of the list scan (stream_kernels.hpp) the same tail also files the query's (query, list) pairs into
+// the per-list buckets the bounds pass reads, and seeds the query's threshold.
 struct RouteArgs {
     const float *cent;
     const float *cnorms;
@@ -357,22 +359,128 @@ struct RouteArgs {
     int32_t rows_per_block, blocks_per_query;
     float *dense;     // [nq][nlist]
     uint32_t *done;   // [nq], zero between calls
-    uint32_t *out_ord;
-    float *out_dist;  // [nq][nprobe]
     const int64_t *listoff;
     const int64_t *glistoff;
     Pair *pairs;
     int32_t *probes;  // optional
     int32_t *qcnt;    // optional
     // optional, for the survivor stream of the list scan (stream_kernels.hpp): the query's int8 codes + bound scalars,
-    // tau = none, an empty survivor list
+    // tau seeded from the head of the candidate stream, an empty survivor list, the pairs filed by list
     uint32_t *qcodes;
     QueryScal *qscal;
     uint32_t *tau, *surv_cnt;
     int32_t k;               // of the search: the first threshold is the k-th smallest distance of the stream's head
     const float *rows;       // list rows (f32) + norms
     const float *row_norms;
+    uint32_t *bk_cnt;        // [nlist] members filed per list (zeroed before the launch), or null
+    uint2 *bk_mem;           // [nlist][bk_cap] (query, offset of the list in the query's candidate stream)
+    int32_t bk_cap;
 };
+
+// The tail of the routing of query qi, run by one whole workgroup once all of the query's centroid distances are in
+// a.dense: pick the nprobe nearest, write the probe table, file the pairs by list, seed the threshold.  COH: the
+// distances were written by other workgroups of THIS launch (agent-scope loads), not by an earlier one.
+template <int NCH, int RB, bool L2, bool COH>
+__device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsigned char *smem) {
+    __shared__ int64_t tail_qcnt;
+    __shared__ uint32_t tail_cover;
+    constexpr int kHead = 16;
+    __shared__ Pair head_s[kHead];  // the first probes' table entries, for the threshold seed below
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    SelectArgs s;
+    s.dist = a.dense;
+    s.q_cnt = nullptr;
+    s.stride = a.nlist;
+    s.cnt_all = a.nlist;
+    s.nq = a.nq;
+    s.k = a.nprobe;
+    s.wpq = kNWave;
+    s.vec4 = 0;
+    s.out_ord = nullptr;  // the probed lists stay in LDS: the probe table below is all that leaves
+    s.out_dist = nullptr;
+    const uint64_t *keys = nullptr;
+    select_topk_wg<COH>(s, qi, kNWave, smem, &keys);
+    if (wave == 0) {
+        // the query's probe table: offsets of the probed lists in its candidate stream (probe_pairs_kernel, one wave)
+        uint32_t carry = 0, gcarry = 0;
+        bool over = false;
+        for (int p0 = 0; p0 < a.nprobe; p0 += kWave) {
+            const int p = p0 + lane;
+            uint32_t l = 0xffffffffu;
+            if (p < a.nprobe) {
+                const uint64_t key = keys[p];
+                if (key != ~0ull) l = static_cast<uint32_t>(key);
+            }
+            Pair pr;
+            pr.q = qi;
+            pr.pad = 0;
+            pr.row_begin = pr.row_end = 0;
+            uint32_t glen = 0;
+            if (l != 0xffffffffu) {
+                pr.row_begin = a.listoff[l];
+                pr.row_end = a.listoff[l + 1];
+                glen = static_cast<uint32_t>(a.glistoff[l + 1] - a.glistoff[l]);
+            }
+            const uint32_t len = static_cast<uint32_t>(pr.row_end - pr.row_begin);
+            uint32_t incl = len, gincl = glen;
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off, kWave), go = __shfl_up(gincl, off, kWave);
+                if (lane >= off) {
+                    incl += o;
+                    gincl += go;
+                }
+            }
+            pr.ord_base = carry + incl - len;
+            pr.gord_base = gcarry + gincl - glen;
+            if (p < a.nprobe) {
+                a.pairs[static_cast<int64_t>(qi) * a.nprobe + p] = pr;
+                if (a.probes) a.probes[static_cast<int64_t>(qi) * a.nprobe + p] = l == 0xffffffffu ? -1 : static_cast<int32_t>(l);
+                if (p < kHead) head_s[p] = pr;
+                if (p == kHead - 1 || (p < kHead && p == a.nprobe - 1)) tail_cover = carry + incl;  // candidates the head covers
+                if (a.bk_cnt && len > 0) {  // file the pair under its list: the bounds pass serves a list's members together
+                    const uint32_t slot = __hip_atomic_fetch_add(a.bk_cnt + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (slot < static_cast<uint32_t>(a.bk_cap))
+                        a.bk_mem[static_cast<int64_t>(l) * a.bk_cap + slot] = make_uint2(static_cast<uint32_t>(qi), pr.ord_base);
+                    else
+                        over = true;
+                }
+            }
+            carry += __shfl(incl, kWave - 1, kWave);
+            gcarry += __shfl(gincl, kWave - 1, kWave);
+        }
+        if (a.qcnt && lane == 0) a.qcnt[qi] = static_cast<int32_t>(carry);
+        const bool any_over = __ballot(over) != 0;
+        if (lane == 0) {
+            tail_qcnt = carry;
+            // an empty survivor list -- or, when a bucket was full, the mark that sends the query through the finish
+            // kernel's fallback (the plain f32 scan of all its candidates)
+            if (a.surv_cnt) a.surv_cnt[qi] = any_over ? 0x80000000u : 0u;
+        }
+        wait_stores_acked();  // the probe table may be read back by the other waves below
+    }
+    if (!a.tau) return;
+    // survivor stream: the first threshold, from the head of the query's candidate stream
+    __syncthreads();
+    float4 q[NCH];
+    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+    const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+    // the head's table entries are in LDS (no dependent global reads) when they cover the rows the seed looks at
+    const bool head_ok = a.nprobe <= kHead || tail_cover >= static_cast<uint32_t>(kSeedMax);
+    const Pair *pp = head_ok ? head_s : a.pairs + static_cast<int64_t>(qi) * a.nprobe;
+    seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, pp, head_ok ? (a.nprobe < kHead ? a.nprobe : kHead) : a.nprobe, tail_qcnt, a.k,
+                             a.rows, a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi);
+}
+
+// int8 codes + bound scalars of query qi (the survivor stream's bounds pass): one wave
+template <int NCH>
+__device__ __forceinline__ void route_encode(const RouteArgs &a, int qi, const float4 (&q)[NCH], int lane) {
+    QueryCode<NCH> qc;
+    encode_query<NCH>(q, qc);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) a.qcodes[(static_cast<int64_t>(qi) * NCH + c) * kWave + lane] = qc.a[c];
+    if (lane == 0) a.qscal[qi] = qc.sc;
+}
 
 template <int NCH, int RB, bool L2>
 __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
@@ -383,34 +491,28 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
     const int qi = blockIdx.x / a.blocks_per_query, bx = blockIdx.x % a.blocks_per_query;
     const int64_t r0 = static_cast<int64_t>(bx) * a.rows_per_block;
     const int64_t r1 = r0 + a.rows_per_block < a.nlist ? r0 + a.rows_per_block : a.nlist;
-    float4 q[NCH];
-    load_query<NCH>(q, a.Q + qi * a.qld, a.dim, lane);
-    const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
     if (r0 < r1) {
-        if (a.qcodes && bx == 0 && wave == kNWave - 1) {  // once per query (its last wave has the fewest rows to scan)
-            QueryCode<NCH> qc;
-            encode_query<NCH>(q, qc);
-#pragma unroll
-            for (int c = 0; c < NCH; c++) a.qcodes[(static_cast<int64_t>(qi) * NCH + c) * kWave + lane] = qc.a[c];
-            if (lane == 0) a.qscal[qi] = qc.sc;
-        }
+        float4 q[NCH];
+        load_query<NCH>(q, a.Q + qi * a.qld, a.dim, lane);
+        const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+        if (a.qcodes && bx == 0 && wave == kNWave - 1) route_encode<NCH>(a, qi, q, lane);  // once per query
         const int nvec = static_cast<int>(a.ld / 4);
         for (int64_t base = r0 + wave * RB; base < r1; base += kNWave * RB) {
             float4 r[RB][NCH];
             const float myrn = (a.metric == METRIC_COS && lane < RB && base + lane < r1) ? a.cnorms[base + lane] : 0.0f;
 #pragma unroll
             for (int b = 0; b < RB; b++) load_row<NCH>(r[b], a.cent + (base + b) * a.ld, nvec, lane, base + b < r1);
-            float s[RB];
+            float sm[RB];
 #pragma unroll
-            for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2>(q, r[b]);
+            for (int b = 0; b < RB; b++) sm[b] = lane_partial<NCH, L2>(q, r[b]);
 #pragma unroll
-            for (int b = 0; b < RB; b++) s[b] = wave_sum(s[b]);
+            for (int b = 0; b < RB; b++) sm[b] = wave_sum(sm[b]);
 #pragma unroll
             for (int b = 0; b < RB; b++) {
                 const int64_t row = base + b;
                 if (row < r1 && lane == 0) {
                     const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), b));
-                    coherent_store(a.dense + static_cast<int64_t>(qi) * a.nlist + row, finish_dist(a.metric, s[b], qn, rn));
+                    coherent_store(a.dense + static_cast<int64_t>(qi) * a.nlist + row, finish_dist(a.metric, sm[b], qn, rn));
                 }
             }
         }
@@ -424,88 +526,39 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
     }
     __syncthreads();
     if (!tail_last) return;
-    SelectArgs s;
-    s.dist = a.dense;
-    s.q_cnt = nullptr;
-    s.stride = a.nlist;
-    s.cnt_all = a.nlist;
-    s.nq = a.nq;
-    s.k = a.nprobe;
-    s.wpq = kNWave;
-    s.vec4 = 0;
-    s.out_ord = nullptr;  // the probed lists stay in LDS: the probe table below is all that leaves
-    s.out_dist = nullptr;
-    const uint64_t *keys = nullptr;
-    select_topk_wg<true>(s, qi, kNWave, smem, &keys);
-    __shared__ int64_t tail_qcnt;
-    __shared__ uint32_t tail_cover;
-    constexpr int kHead = 16;
-    __shared__ Pair head_s[kHead];  // the first probes' table entries, for the threshold seed below
-    if (wave == 0) {
-    // the query's probe table: offsets of the probed lists in its candidate stream (probe_pairs_kernel, one wave)
-    uint32_t carry = 0, gcarry = 0;
-    for (int p0 = 0; p0 < a.nprobe; p0 += kWave) {
-        const int p = p0 + lane;
-        uint32_t l = 0xffffffffu;
-        if (p < a.nprobe) {
-            const uint64_t key = keys[p];
-            if (key != ~0ull) l = static_cast<uint32_t>(key);
-        }
-        Pair pr;
-        pr.q = qi;
-        pr.pad = 0;
-        pr.row_begin = pr.row_end = 0;
-        uint32_t glen = 0;
-        if (l != 0xffffffffu) {
-            pr.row_begin = a.listoff[l];
-            pr.row_end = a.listoff[l + 1];
-            glen = static_cast<uint32_t>(a.glistoff[l + 1] - a.glistoff[l]);
-        }
-        const uint32_t len = static_cast<uint32_t>(pr.row_end - pr.row_begin);
-        uint32_t incl = len, gincl = glen;
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, kWave), go = __shfl_up(gincl, off, kWave);
-            if (lane >= off) {
-                incl += o;
-                gincl += go;
-            }
-        }
-        pr.ord_base = carry + incl - len;
-        pr.gord_base = gcarry + gincl - glen;
-        if (p < a.nprobe) {
-            a.pairs[static_cast<int64_t>(qi) * a.nprobe + p] = pr;
-            if (a.probes) a.probes[static_cast<int64_t>(qi) * a.nprobe + p] = l == 0xffffffffu ? -1 : static_cast<int32_t>(l);
-            if (p < kHead) head_s[p] = pr;
-            if (p == kHead - 1 || (p < kHead && p == a.nprobe - 1)) tail_cover = carry + incl;  // candidates the head covers
-        }
-        carry += __shfl(incl, kWave - 1, kWave);
-        gcarry += __shfl(gincl, kWave - 1, kWave);
+    route_tail_wg<NCH, RB, L2, true>(a, qi, smem);
+}
+
+// The same tail as a launch of its own, one workgroup per query, behind a distance pass that serves many queries per
+// centroid row (large batches): select, probe table, pairs filed by list, query codes, first threshold.
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void ivf_route_tail_kernel(RouteArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x;
+    if (a.qcodes && wave == kNWave - 1) {
+        float4 q[NCH];
+        load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+        route_encode<NCH>(a, qi, q, lane);
     }
-    if (a.qcnt && lane == 0) a.qcnt[qi] = static_cast<int32_t>(carry);
-    if (lane == 0) tail_qcnt = carry;
-    wait_stores_acked();  // the probe table may be read back by the other waves below
-    }
-    if (!a.tau) return;
-    // survivor stream: an empty survivor list and the first threshold, from the head of the query's candidate stream
-    __syncthreads();
-    if (threadIdx.x == 0) a.surv_cnt[qi] = 0;
-    // the head's table entries are in LDS (no dependent global reads) when they cover the rows the seed looks at
-    const bool head_ok = a.nprobe <= kHead || tail_cover >= static_cast<uint32_t>(kSeedMax);
-    const Pair *pp = head_ok ? head_s : a.pairs + static_cast<int64_t>(qi) * a.nprobe;
-    seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, pp, head_ok ? (a.nprobe < kHead ? a.nprobe : kHead) : a.nprobe, tail_qcnt, a.k,
-                             a.rows, a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi);
+    route_tail_wg<NCH, RB, L2, false>(a, qi, smem);
 }
 
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
-                     int32_t *qcnt, hipStream_t st, uint32_t *qcodes, QueryScal *qscal, uint32_t *tau, uint32_t *surv_cnt,
-                     int32_t k) {
+                     int32_t *qcnt, hipStream_t st, const RouteStream *rs, const float *dense_done) {
     RouteArgs a;
     memset(&a, 0, sizeof(a));
-    a.qcodes = qcodes;
-    a.qscal = qscal;
-    a.tau = tau;
-    a.surv_cnt = surv_cnt;
-    a.k = k;
+    if (rs) {
+        a.qcodes = rs->qcodes;
+        a.qscal = rs->qscal;
+        a.tau = rs->tau;
+        a.surv_cnt = rs->surv_cnt;
+        a.k = rs->k;
+        a.bk_cnt = rs->bk_cnt;
+        a.bk_mem = rs->bk_mem;
+        a.bk_cap = rs->bk_cap;
+    }
     a.rows = idx->d_lrows;
     a.row_norms = idx->d_lnorms;
     a.cent = idx->d_cent;
@@ -527,13 +580,9 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
     a.rows_per_block = static_cast<int32_t>(rpb);
     a.blocks_per_query = static_cast<int32_t>((idx->nlist + rpb - 1) / rpb);
     HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(nq) * idx->nlist));
-    HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * nprobe));
-    HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * nprobe));
     HG_TRY(ensure_counters(idx, nq, st));
     a.dense = idx->s_tile.as<float>();
     a.done = idx->s_done.as<uint32_t>() + idx->s_done_n;
-    a.out_ord = idx->s_ord.as<uint32_t>();
-    a.out_dist = idx->s_dist.as<float>();
     a.listoff = idx->d_listoff;
     a.glistoff = idx->d_glistoff ? idx->d_glistoff : idx->d_listoff;
     a.pairs = pairs;
@@ -541,8 +590,16 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
     a.qcnt = qcnt;
     const size_t lds = std::max<size_t>(sizeof(uint64_t) * (kNWave + 1) * nprobe, sizeof(float) * kSeedMax);
     HG_REQUIRE(lds <= 48 * 1024, HNSWGPU_ELIMIT, "nprobe too large for the fused routing kernel");
-    const int64_t blocks = static_cast<int64_t>(nq) * a.blocks_per_query;
     const bool l2 = a.metric == METRIC_L2;
+    if (dense_done) {  // the distances are in s_tile already ([nq][nlist], an earlier launch): the tail alone
+        a.dense = const_cast<float *>(dense_done);
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_tail_kernel<N, R, L>), dim3(static_cast<unsigned>(nq)), dim3(kWG), lds, st, a)
+        HG_DISPATCH(idx->nch, l2, CALL);
+#undef CALL
+        HG_HIP(hipGetLastError());
+        return 0;
+    }
+    const int64_t blocks = static_cast<int64_t>(nq) * a.blocks_per_query;
 #define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a)
     HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
@@ -554,7 +611,7 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
 // ([nq][nrows] floats) and select_topk_kernel picks the k smallest (key = (distance, row), the same keys the
 // partial-list path builds).  For a short table and a large k -- centroid routing: 1024 centroids, k = nprobe = 32 --
 // the partial-list path emitted a k-slot list per wave for ~8 rows each and spent 31-38 us merging them.
-int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st) {
+int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st, bool dense_only) {
     a.mode = MODE_STORE;
     a.npairs = nq;
     a.nchunks = plan_chunks(idx->nch, nrows, nrows, nq, &a.chunk_rows);
@@ -565,6 +622,7 @@ int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, h
     a.out_stride = nrows;
     const int k = a.k;
     HG_TRY(launch_scan(idx->nch, a, st));
+    if (dense_only) return 0;  // [nq][nrows] distances in s_tile
     SelectArgs s;
     memset(&s, 0, sizeof(s));
     s.dist = a.out;
@@ -978,14 +1036,16 @@ static int tile_argmin_all(hnswgpu_index *idx, const float *Qp, const float *q_n
 }
 
 int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int32_t nq, const float *rows,
-                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot, bool gemv_order) {
+                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot, bool gemv_order,
+                  bool dense_only) {
     HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * k));
     HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * k));
-    if (k == 1 && !gemv_order) return tile_argmin_all(idx, Qp, q_norms, nq, rows, row_norms, nrows, st, prof_slot);
-    // distance scratch [qb][nrows]; bound it to ~2 GiB by batching the queries
+    if (k == 1 && !gemv_order && !dense_only) return tile_argmin_all(idx, Qp, q_norms, nq, rows, row_norms, nrows, st, prof_slot);
+    // distance scratch [qb][nrows]; bound it to ~2 GiB by batching the queries (dense_only: the caller made sure all fit)
     const int tq = tile_tq(idx->dim);
     int64_t qb = std::max<int64_t>(tq, ((2LL << 30) / (4 * std::max<int64_t>(nrows, 1))) / tq * tq);
     qb = std::min<int64_t>(qb, (nq + tq - 1) / tq * tq);
+    HG_REQUIRE(!dense_only || qb >= nq, HNSWGPU_ELIMIT, "dense distance pass too large");
     HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(qb) * nrows));
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         int32_t nb = static_cast<int32_t>(std::min<int64_t>(qb, nq - q0));
@@ -1013,6 +1073,7 @@ int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int
         prof_begin(idx, prof_slot, st, &e0);
         HG_TRY(launch_tile(t, groups, idx->dim, st));
         prof_end(idx, prof_slot, st, e0);
+        if (dense_only) return 0;  // [nq][nrows] distances in s_tile
         SelectArgs s;
         memset(&s, 0, sizeof(s));
         s.dist = t.out;

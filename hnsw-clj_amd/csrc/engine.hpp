@@ -233,11 +233,20 @@ int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
                    const std::function<int(const std::vector<hnswgpu_index::SearchReq *> &, int32_t)> &run);
 // pinned staging block of a combined batch (grown on demand)
 int ensure_pinned(hnswgpu_index *idx, size_t bytes);
-int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st);
+int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st, bool dense_only = false);
 // small IVF batches: routing in one launch, list scan with the merge / decode folded into its last workgroups
+// what the routing step prepares for the survivor stream of the list scan (stream_kernels.hpp), or null
+struct RouteStream {
+    uint32_t *qcodes;
+    QueryScal *qscal;
+    uint32_t *tau, *surv_cnt;
+    int32_t k;
+    uint32_t *bk_cnt;  // per-list buckets of (query, list) pairs, or null (ungrouped bounds pass)
+    uint2 *bk_mem;
+    int32_t bk_cap;
+};
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
-                     int32_t *qcnt, hipStream_t st, uint32_t *qcodes = nullptr, QueryScal *qscal = nullptr,
-                     uint32_t *tau = nullptr, uint32_t *surv_cnt = nullptr, int32_t k = 0);
+                     int32_t *qcnt, hipStream_t st, const RouteStream *rs = nullptr, const float *dense_done = nullptr);
 // the survivor stream of the IVF list scan (stream_kernels.hpp)
 struct StreamArgs;
 struct FinishArgs;
@@ -276,7 +285,8 @@ int launch_select(const SelectArgs &a, hipStream_t st);
 int pad_queries(hnswgpu_index *idx, const float *d_Q, int64_t qld, int32_t nq, hipStream_t st);
 // every query against rows [0, nrows): per-query ascending top-k into s_ord / s_dist
 int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int32_t nq, const float *rows,
-                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot, bool gemv_order = false);
+                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot, bool gemv_order = false,
+                  bool dense_only = false);
 
 // Every entry point brackets its device work with these: a call on stream B waits for the previous
 // call's work on stream A before it may reuse the index's scratch buffers.

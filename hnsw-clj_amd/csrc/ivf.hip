@@ -23,13 +23,15 @@ static int64_t env_now(const char *name, int64_t dflt) {
 // the order search-ivf-flat concatenates partitions in, ivf_flat.clj:281-294)
 __global__ __launch_bounds__(kWG) void probe_pairs_kernel(const uint32_t *ord, int nq, int nprobe, const int64_t *listoff,
                                                           const int64_t *glistoff, Pair *pairs, int32_t *probes,
-                                                          int32_t *qcnt) {
+                                                          int32_t *qcnt, uint32_t *bk_cnt, uint2 *bk_mem, int32_t bk_cap,
+                                                          uint32_t *surv_cnt) {
     // one wave per query: lane p owns probe p (+64, +128, ...); the offsets of the probes in the query's
     // concatenated candidate stream are an exclusive prefix sum over the list lengths (wave scan)
     const int lane = threadIdx.x & (kWave - 1);
     const int q = blockIdx.x * kNWave + (threadIdx.x >> 6);
     if (q >= nq) return;
     uint32_t carry = 0, gcarry = 0;
+    bool over = false;
     for (int p0 = 0; p0 < nprobe; p0 += kWave) {
         const int p = p0 + lane;
         uint32_t l = p < nprobe ? ord[static_cast<int64_t>(q) * nprobe + p] : 0xffffffffu;
@@ -57,11 +59,19 @@ __global__ __launch_bounds__(kWG) void probe_pairs_kernel(const uint32_t *ord, i
         if (p < nprobe) {
             pairs[static_cast<int64_t>(q) * nprobe + p] = pr;
             if (probes) probes[static_cast<int64_t>(q) * nprobe + p] = l == 0xffffffffu ? -1 : static_cast<int32_t>(l);
+            if (bk_cnt && len > 0) {  // survivor stream: the pair filed under its list (stream_kernels.hpp)
+                const uint32_t slot = __hip_atomic_fetch_add(bk_cnt + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < static_cast<uint32_t>(bk_cap)) bk_mem[static_cast<int64_t>(l) * bk_cap + slot] = make_uint2(static_cast<uint32_t>(q), pr.ord_base);
+                else over = true;
+            }
         }
         carry += __shfl(incl, kWave - 1, kWave);
         gcarry += __shfl(gincl, kWave - 1, kWave);
     }
     if (qcnt && lane == 0) qcnt[q] = static_cast<int32_t>(carry);
+    // an empty survivor list -- or, when a bucket was full, the mark that sends the query through the finish kernel's fallback
+    const bool any_over = __ballot(over) != 0;
+    if (surv_cnt && lane == 0) surv_cnt[q] = any_over ? 0x80000000u : 0u;
 }
 
 // ---- execution order of the GEMV list scan: pairs sorted by the list they probe (counting sort in one workgroup;
@@ -103,6 +113,81 @@ __global__ __launch_bounds__(1024) void pair_order_kernel(const int32_t *probes,
     }
 }
 
+// ---- work list of the grouped bounds pass (stream_kernels.hpp) --------------------------------------------------
+// The routing step has filed every (query, list) pair under its list (bk_cnt / bk_mem); this turns the per-list counts
+// into the dense list of work items (list, group of <= 32 members, chunk of rows), chunk-major inside a list so that the
+// groups reading the same rows are neighbours.  One workgroup: a scan over the lists' item counts, then every thread
+// fills items by bisection into the scanned offsets (a hot list's hundreds of items are not one thread's job).
+__global__ __launch_bounds__(1024) void ivf_worklist_kernel(const uint32_t *bk_cnt, int32_t bk_cap, int nlist,
+                                                            const int64_t *list_off, int64_t chunk_rows, int max_chunks,
+                                                            WorkDesc *desc, int32_t *nitems) {
+    __shared__ int32_t off_s[1025];  // exclusive offsets of this pass's lists
+    __shared__ int32_t part[16];
+    __shared__ int32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int l0 = 0; l0 < nlist; l0 += 1024) {
+        const int l = l0 + tid;
+        int c = 0, nch = 0;
+        int64_t rows = 0;
+        if (l < nlist) {
+            const uint32_t filed = bk_cnt[l];
+            c = filed < static_cast<uint32_t>(bk_cap) ? static_cast<int>(filed) : bk_cap;
+            rows = list_off[l + 1] - list_off[l];
+            nch = (c > 0 && rows > 0) ? static_cast<int>(tile_nchunks(rows, chunk_rows, max_chunks)) : 0;
+        }
+        const int ng = (c + kTileQ - 1) / kTileQ;
+        const int nw = ng * nch;
+        // inclusive scan: within the wave, then across the 16 waves
+        int incl = nw;
+        for (int o = 1; o < kWave; o <<= 1) {
+            const int v = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += v;
+        }
+        if (lane == kWave - 1) part[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += part[w];
+        const int base = carry_s;
+        off_s[tid] = before + incl - nw;
+        if (tid == 1023) off_s[1024] = before + incl;
+        __syncthreads();
+        const int total = off_s[1024];
+        for (int w = tid; w < total; w += 1024) {
+            int lo = 0, hi = 1023;  // the last list of this pass whose offset <= w
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (off_s[mid] <= w) lo = mid;
+                else hi = mid - 1;
+            }
+            const int ll = l0 + lo, k = w - off_s[lo];
+            const uint32_t filed = bk_cnt[ll];
+            const int cc = filed < static_cast<uint32_t>(bk_cap) ? static_cast<int>(filed) : bk_cap;
+            const int ngl = (cc + kTileQ - 1) / kTileQ;
+            const int ch = k / ngl, g = k - ch * ngl;  // chunk-major
+            const int64_t rb0 = list_off[ll], rws = list_off[ll + 1] - rb0;
+            const int64_t tiles = (rws + kTileRows - 1) / kTileRows;
+            const int64_t nchl = tile_nchunks(rws, chunk_rows, max_chunks);
+            const int64_t per = (tiles + nchl - 1) / nchl * kTileRows;
+            const int64_t a0 = ch * per, a1 = a0 + per < rws ? a0 + per : rws;
+            WorkDesc d;
+            d.rb0 = rb0;
+            d.r0_off = static_cast<int32_t>(a0);
+            d.r1_off = static_cast<int32_t>(a1 > a0 ? a1 : a0);
+            d.list = ll;
+            d.mem0 = g * kTileQ;
+            d.cnt = cc - g * kTileQ < kTileQ ? cc - g * kTileQ : kTileQ;
+            d.pad = 0;
+            desc[base + w] = d;
+        }
+        __syncthreads();
+        if (tid == 0) carry_s = base + total;
+        __syncthreads();
+    }
+    if (tid == 0) *nitems = carry_s;
+}
+
 // ---- grouping of (query, probed list) pairs by list, for the tiled scan --------------------------------
 __global__ void ivf_hist_kernel(const int32_t *probes, int64_t npairs, int32_t *cnt) {
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -119,8 +204,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(int32_t *cnt, int nlist,
                                                         const int64_t *list_off, int64_t chunk_rows, int max_chunks,
                                                         int32_t *wi_group, int32_t *wi_chunk, int32_t *nitems,
                                                         int32_t *work_ctr, const int32_t *probes, int64_t npairs,
-                                                        const Pair *pairs, int64_t stride, GroupMember *members,
-                                                        WorkDesc *wi_desc) {
+                                                        const Pair *pairs, int64_t stride, GroupMember *members) {
     __shared__ int32_t sm[1024], sg[1024], sw[1024];
     __shared__ int32_t carry_m, carry_g, carry_w;
     const int tid = threadIdx.x;
@@ -163,23 +247,10 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(int32_t *cnt, int nlist,
                 grp_mem_cnt[g] = c - b < tq ? c - b : tq;
             }
             // work items chunk-major: the groups of one chunk (same rows) are neighbours -- see tile_scan_kernel
-            const int64_t tiles = (rows + kTileRows - 1) / kTileRows;
-            const int64_t per = nch > 0 ? (tiles + nch - 1) / nch * kTileRows : 0;
             for (int ch = 0; ch < nch; ch++)
-                for (int g = g0, b = 0; g < g0 + ng; g++, w++, b += tq) {
+                for (int g = g0; g < g0 + ng; g++, w++) {
                     wi_group[w] = g;
                     wi_chunk[w] = ch;
-                    if (wi_desc) {  // the bounds pass reads ONE record per work item instead of five dependent tables
-                        WorkDesc d;
-                        d.rb0 = list_off[l];
-                        const int64_t a0 = ch * per, a1 = a0 + per < rows ? a0 + per : rows;
-                        d.r0_off = static_cast<int32_t>(a0);
-                        d.r1_off = static_cast<int32_t>(a1 > a0 ? a1 : a0);
-                        d.mem_begin = mem + b;
-                        d.cnt = c - b < tq ? c - b : tq;
-                        d.pad[0] = d.pad[1] = 0;
-                        wi_desc[w] = d;
-                    }
                 }
         }
         __syncthreads();
@@ -533,7 +604,6 @@ struct GroupPlan {
     int32_t max_chunks;
     int64_t wbound;      // upper bound of the number of work items
     int32_t *gseg, *gmb, *gmc, *wig, *wic, *ngr, *nit, *wctr;
-    WorkDesc *desc;      // per work item (bounds pass), or null
     GroupMember *members;
 };
 
@@ -541,7 +611,7 @@ struct GroupPlan {
 // workgroup per item, items sized to fill the chip.  member_stride: a member's output base is q * member_stride + the
 // pair's offset in the query's candidate stream (0 = the offset alone: the survivor stream's order keys).
 static int plan_groups(hnswgpu_index *idx, int32_t nq, int32_t nprobe, const int32_t *d_probes, int64_t ptiles,
-                       int64_t member_stride, bool want_desc, hipStream_t st, GroupPlan &g) {
+                       int64_t member_stride, hipStream_t st, GroupPlan &g) {
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
     const int nlist = idx->nlist;
     // a multiple of 4 so that every query's array is 16-B aligned (float4 select)
@@ -564,11 +634,9 @@ static int plan_groups(hnswgpu_index *idx, int32_t nq, int32_t nprobe, const int
     g.max_chunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
     g.wbound = g.gbound * g.max_chunks;
     // int32 scratch: cnt | list_mem_begin | fill [nlist each] | grp_seg | grp_mem_begin | grp_mem_cnt [gbound each] |
-    //                wi_group | wi_chunk [wbound each] | ngroups | nitems | work counters; then descriptors [wbound]
-    size_t ints = 3 * static_cast<size_t>(nlist) + 3 * static_cast<size_t>(g.gbound) + 2 * static_cast<size_t>(g.wbound) + 4 + 8 + 8;
-    ints = (ints + 7) & ~static_cast<size_t>(7);  // the descriptors behind them stay 32-B aligned
-    const size_t desc_bytes = want_desc ? sizeof(WorkDesc) * static_cast<size_t>(g.wbound) : 0;
-    HG_TRY(idx->s_misc.ensure(sizeof(int32_t) * ints + desc_bytes));
+    //                wi_group | wi_chunk [wbound each] | ngroups | nitems | work counters
+    const size_t ints = 3 * static_cast<size_t>(nlist) + 3 * static_cast<size_t>(g.gbound) + 2 * static_cast<size_t>(g.wbound) + 4 + 8 + 8;
+    HG_TRY(idx->s_misc.ensure(sizeof(int32_t) * ints));
     HG_TRY(idx->s_misc2.ensure(sizeof(GroupMember) * static_cast<size_t>(npairs)));
     int32_t *cnt = idx->s_misc.as<int32_t>();
     int32_t *lmb = cnt + nlist, *fill = lmb + nlist;
@@ -580,12 +648,11 @@ static int plan_groups(hnswgpu_index *idx, int32_t nq, int32_t nprobe, const int
     g.ngr = g.wic + g.wbound;
     g.nit = g.ngr + 1;
     g.wctr = g.ngr + 4;
-    g.desc = want_desc ? reinterpret_cast<WorkDesc *>(cnt + ints) : nullptr;
     g.members = idx->s_misc2.as<GroupMember>();
     if (npairs <= 8192) {  // small batches are launch-bound: histogram, plan and scatter in the one-workgroup kernel
         hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, g.gseg, g.gmb, g.gmc, g.ngr, tq,
                            idx->d_listoff, cr, g.max_chunks, g.wig, g.wic, g.nit, ptiles > 0 ? g.wctr : nullptr, d_probes,
-                           npairs, idx->s_pairs.as<Pair>(), member_stride, g.members, g.desc);
+                           npairs, idx->s_pairs.as<Pair>(), member_stride, g.members);
     } else {
         HG_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nlist, st));
         hipLaunchKernelGGL(ivf_hist_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st, d_probes,
@@ -593,7 +660,7 @@ static int plan_groups(hnswgpu_index *idx, int32_t nq, int32_t nprobe, const int
         hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, lmb, fill, g.gseg, g.gmb, g.gmc, g.ngr, tq,
                            idx->d_listoff, cr, g.max_chunks, g.wig, g.wic, g.nit, ptiles > 0 ? g.wctr : nullptr,
                            static_cast<const int32_t *>(nullptr), static_cast<int64_t>(0), static_cast<const Pair *>(nullptr),
-                           static_cast<int64_t>(0), static_cast<GroupMember *>(nullptr), g.desc);
+                           static_cast<int64_t>(0), static_cast<GroupMember *>(nullptr));
         hipLaunchKernelGGL(ivf_scatter_kernel, dim3(static_cast<unsigned>((npairs + 255) / 256)), dim3(256), 0, st,
                            idx->s_pairs.as<Pair>(), d_probes, npairs, member_stride, lmb, fill, g.members);
     }
@@ -620,7 +687,7 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     const int64_t ptiles = idx->metric == METRIC_L2 || gemv_order ? 0 : (ptiles_env == 4 && est_groups < 1200 ? 2 : ptiles_env);
     GroupPlan g;
     const int64_t stride0 = (static_cast<int64_t>(nprobe) * idx->max_list_len + 3) / 4 * 4;
-    HG_TRY(plan_groups(idx, nq, nprobe, d_probes, ptiles, stride0, false, st, g));
+    HG_TRY(plan_groups(idx, nq, nprobe, d_probes, ptiles, stride0, st, g));
     const int64_t stride = g.stride;
     HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(nq) * stride));  // queries already padded
     TileArgs t;
@@ -670,7 +737,30 @@ struct StreamScratch {
     uint32_t *qcodes;
     QueryScal *qscal;
     uint32_t *tau, *surv_cnt;
+    // the (query, list) pairs filed by list for the grouped bounds pass (s_misc): counters [nlist], members [nlist][bk_cap]
+    uint32_t *bk_cnt;
+    uint2 *bk_mem;
+    int32_t bk_cap;
 };
+
+// Buckets for the pairs of a batch: room for the whole batch under every list (a list may be probed by every query) as
+// long as that stays under 256 MB -- 32M / nlist members per list otherwise.  A hotter list files what fits; the queries
+// beyond take the finish kernel's fallback (exact, just slower).
+static int stream_buckets(hnswgpu_index *idx, int32_t nq, int32_t nprobe, StreamScratch &s, hipStream_t st) {
+    const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
+    (void)npairs;
+    int64_t cap = std::max<int64_t>(64, (32LL << 20) / std::max(idx->nlist, 1) / 32 * 32);  // <= 256 MB of members
+    cap = std::min<int64_t>(cap, (static_cast<int64_t>(nq) + 31) / 32 * 32);
+    const int64_t cap_env = env_now("HNSWGPU_STREAM_BUCKET", 0);  // tests: tiny buckets force the fallback
+    if (cap_env > 0) cap = cap_env;
+    const size_t cnt_bytes = (sizeof(uint32_t) * static_cast<size_t>(idx->nlist) + 15) & ~static_cast<size_t>(15);
+    HG_TRY(idx->s_misc.ensure(cnt_bytes + sizeof(uint2) * static_cast<size_t>(idx->nlist) * cap));
+    s.bk_cnt = idx->s_misc.as<uint32_t>();
+    s.bk_mem = reinterpret_cast<uint2 *>(static_cast<char *>(idx->s_misc.p) + cnt_bytes);
+    s.bk_cap = static_cast<int32_t>(cap);
+    HG_HIP(hipMemsetAsync(s.bk_cnt, 0, sizeof(uint32_t) * static_cast<size_t>(idx->nlist), st));
+    return 0;
+}
 static int stream_scratch(hnswgpu_index *idx, int32_t nq, StreamScratch &s) {
     HG_TRY(idx->s_qp.ensure(sizeof(uint32_t) * kWave * idx->nch * static_cast<size_t>(nq)));
     HG_TRY(idx->s_qn.ensure((sizeof(QueryScal) + 2 * sizeof(uint32_t)) * static_cast<size_t>(nq)));
@@ -684,34 +774,44 @@ static int stream_scratch(hnswgpu_index *idx, int32_t nq, StreamScratch &s) {
 // The list scan as a survivor stream (stream_kernels.hpp): int8 bounds with a running threshold -> compact survivor
 // lists -> f32 distances (GEMV order), top-k, ids and distances written by the finish kernel.  The query codes, tau = none
 // and empty survivor lists are set up by the routing step.
-static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
-                           const int32_t *d_probes, const int32_t *d_qcnt, int32_t *d_out_ids, float *d_out_dist,
-                           uint32_t *d_out_gord, bool grouped, hipStream_t st) {
+static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe, const int32_t *d_qcnt,
+                           int32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_gord, const StreamScratch &sc, hipStream_t st) {
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
-    StreamScratch sc;
-    HG_TRY(stream_scratch(idx, nq, sc));
     StreamArgs b;
     memset(&b, 0, sizeof(b));
     int64_t blocks;
     const int64_t stride = (static_cast<int64_t>(nprobe) * idx->max_list_len + 3) / 4 * 4;
+    // rows per workgroup: whole tiles; enough working workgroups to fill the chip a few times over
+    const int64_t mean = std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1));
+    const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows, max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows;
+    static const int64_t tgt = []() {
+        const char *e = getenv("HNSWGPU_STREAM_WGS");  // tuning override
+        return e ? atoll(e) : 2048LL;
+    }();
+    const bool grouped = sc.bk_cnt != nullptr;
+    const int64_t units = grouped ? std::min<int64_t>(npairs, idx->nlist) : npairs;  // lists (or pairs) that have work
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + units - 1) / std::max<int64_t>(units, 1)));
+    const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows, tpc = cr / kTileRows;
+    b.chunk_rows = static_cast<int32_t>(cr);
+    b.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
     if (grouped) {
-        GroupPlan g;
-        HG_TRY(plan_groups(idx, nq, nprobe, d_probes, 0, 0, true, st, g));
-        b.wi_desc = g.desc;
-        b.nitems = g.nit;
-        b.members = g.members;
-        b.chunk_rows = static_cast<int32_t>(g.cr);
-        b.nchunks = g.max_chunks;
-        blocks = (g.wbound + 7) & ~7LL;
-    } else {  // a handful of queries: every (query, list) pair is its own group, no plan launch
-        const int64_t mean = std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1));
-        const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows, max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows;
-        const int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (1024 + npairs - 1) / npairs));
-        const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows, tpc = cr / kTileRows;
+        // the work list: items <= sum over lists of ceil(members / 32) * chunks <= (npairs / 32 + nlist) * nchunks
+        const int64_t wbound = (npairs / kTileQ + idx->nlist) * b.nchunks;
+        HG_REQUIRE(wbound < 2147483647LL, HNSWGPU_ELIMIT, "bounds pass work list too large");
+        HG_TRY(idx->s_misc2.ensure(sizeof(WorkDesc) * static_cast<size_t>(wbound) + 64));
+        WorkDesc *desc = idx->s_misc2.as<WorkDesc>();
+        int32_t *nit = reinterpret_cast<int32_t *>(desc + wbound);
+        hipLaunchKernelGGL(ivf_worklist_kernel, dim3(1), dim3(1024), 0, st, sc.bk_cnt, sc.bk_cap, idx->nlist, idx->d_listoff, cr,
+                           b.nchunks, desc, nit);
+        HG_HIP(hipGetLastError());
+        b.wi_desc = desc;
+        b.nitems = nit;
+        b.bk_mem = sc.bk_mem;
+        b.bk_cap = sc.bk_cap;
+        blocks = (wbound + 7) & ~7LL;
+    } else {  // a handful of queries: every (query, list) pair is its own item
         b.pairs = idx->s_pairs.as<Pair>();
         b.npairs = static_cast<int32_t>(npairs);
-        b.chunk_rows = static_cast<int32_t>(cr);
-        b.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
         blocks = npairs * b.nchunks;
     }
     // survivors per query that fit; a query with more takes the finish kernel's fallback (the plain f32 scan)
@@ -855,10 +955,14 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     if (use_tile || use_group) HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
     // survivor stream: query codes, thresholds and survivor counters live in s_qp / s_qn (sized here: the routing below may
     // still use both for padded queries and norms, and must not move s_qn afterwards)
-    StreamScratch sc = {nullptr, nullptr, nullptr, nullptr};
-    if (use_code) HG_TRY(stream_scratch(idx, nq, sc));
-    const int stream_route_max = static_cast<int>(env_now("HNSWGPU_STREAM_ROUTE", 256));  // largest batch routed by the one-launch routing kernel
+    StreamScratch sc;
+    memset(&sc, 0, sizeof(sc));
+    const int stream_route_max = static_cast<int>(env_now("HNSWGPU_STREAM_ROUTE", 64));  // largest batch routed by the one-launch routing kernel
     const int stream_group_min = static_cast<int>(env_now("HNSWGPU_STREAM_GROUP", 5));    // queries from which the bounds pass groups the pairs by list
+    if (use_code) {
+        HG_TRY(stream_scratch(idx, nq, sc));
+        if (nq >= stream_group_min) HG_TRY(stream_buckets(idx, nq, nprobe, sc, st));  // (zeroes the per-list counters)
+    }
     bool codes_done = false;
     static const int route_group_min = []() {
         const char *e = getenv("HNSWGPU_ROUTE_GROUP");  // queries from which a GEMV-order batch routes through the group kernel
@@ -867,7 +971,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     if (d_given_probes) {  // caller-chosen lists (the :turbo mode's random partitions, :271-272); -1 = none
         hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st,
                            reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff, glistoff,
-                           idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf);
+                           idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, sc.bk_cnt, sc.bk_mem, sc.bk_cap, sc.surv_cnt);
         HG_HIP(hipGetLastError());
     } else {
     a.rows = idx->d_cent;
@@ -883,9 +987,24 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     if (!use_tile && (fused_mode || (use_code && nq <= stream_route_max)) && static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20)) {
         // small batches: distances to the centroids, the choice of the nprobe nearest and the probe table in ONE launch
         // (for the survivor stream also the query codes, tau = none and the empty survivor lists)
-        HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, sc.qcodes, sc.qscal,
-                                sc.tau, sc.surv_cnt, k));
+        RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap};
+        HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, use_code ? &rs : nullptr));
         codes_done = use_code;
+    } else if (use_code && static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20)) {
+        // survivor stream, larger batches: the centroid distances by a pass that serves many queries per centroid row (the
+        // GEMV order: register-row group kernel, or one GEMV per query for long rows), then ONE launch for everything else
+        // of the routing -- select, probe table, pairs filed by list, query codes, first thresholds
+        if (idx->dim <= kL2MaxDim && tm != 0) {
+            HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
+            HG_TRY(stream_scratch(idx, nq, sc));  // (s_qp may have moved under the padded queries)
+            HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
+                                 nprobe, st, -1, true, true));
+        } else {
+            HG_TRY(scan_dense_topk(idx, a, nq, idx->nlist, st, true));
+        }
+        RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap};
+        HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, &rs, idx->s_tile.as<float>()));
+        codes_done = true;
     } else {
     if (use_tile)  // every query against the centroid table on the tile kernel as well
         HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
@@ -901,7 +1020,8 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     else
         HG_TRY(scan_topk(idx, a, nq, 1, idx->nlist, st, -1));
     hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st, idx->s_ord.as<uint32_t>(), nq,
-                       nprobe, idx->d_listoff, glistoff, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf);
+                       nprobe, idx->d_listoff, glistoff, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, sc.bk_cnt, sc.bk_mem, sc.bk_cap,
+                       sc.surv_cnt);
     HG_HIP(hipGetLastError());
     }
     }
@@ -927,11 +1047,9 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
             pa.qcodes = sc.qcodes;
             pa.qscal = sc.qscal;
             pa.tau = sc.tau;
-            pa.surv_cnt = sc.surv_cnt;
             HG_TRY(launch_query_prep(pa, idx->nch, st));
         }
-        return ivf_stream_scan(idx, d_Q, nq, k, nprobe, probes_buf, qcnt_buf, d_out_ids, d_out_dist, d_out_gord,
-                               nq >= stream_group_min, st);
+        return ivf_stream_scan(idx, d_Q, nq, k, nprobe, qcnt_buf, d_out_ids, d_out_dist, d_out_gord, sc, st);
     }
     // 2. scan the probed lists (:217-234) and merge (:291-294)
     memset(&a, 0, sizeof(a));

@@ -155,7 +155,7 @@ struct PrepArgs {
     int64_t ld;
     uint32_t *qcodes;
     QueryScal *qscal;
-    uint32_t *tau, *surv_cnt;
+    uint32_t *tau;
 };
 
 template <int NCH, int RB, bool L2>
@@ -171,31 +171,28 @@ __global__ __launch_bounds__(kWG) void ivf_query_prep_kernel(PrepArgs a) {
         encode_query<NCH>(q, qc);
 #pragma unroll
         for (int c = 0; c < NCH; c++) a.qcodes[(static_cast<int64_t>(qi) * NCH + c) * kWave + lane] = qc.a[c];
-        if (lane == 0) {
-            a.qscal[qi] = qc.sc;
-            a.surv_cnt[qi] = 0;
-        }
+        if (lane == 0) a.qscal[qi] = qc.sc;
     }
     seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, a.pairs + static_cast<int64_t>(qi) * a.nprobe, a.nprobe, a.qcnt[qi], a.k, a.rows,
                              a.row_norms, a.ld, dist_s, a.tau + qi);
 }
 
-// One work item of the bounds pass, written by the plan kernel: rows [rb0 + r0_off, rb0 + r1_off) of the list that starts
-// at rb0, against the cnt (<= 32) group members members[mem_begin ..).
+// One work item of the grouped bounds pass: rows [rb0 + r0_off, rb0 + r1_off) of inverted list `list` (which starts at row
+// rb0) against its members [mem0, mem0 + cnt) (cnt <= 32).  Written by ivf_worklist_kernel from the per-list buckets.
 struct WorkDesc {
     int64_t rb0;
     int32_t r0_off, r1_off;
-    int32_t mem_begin, cnt;
-    int32_t pad[2];
+    int32_t list, mem0, cnt, pad;
 };
 
 struct StreamArgs {
-    // grouped mode: dense work list built on the device (ivf_plan_kernel); workgroup b serves item
-    // (b & 7) * ceil(nitems / 8) + (b >> 3): one contiguous eighth of the list per XCD
-    const WorkDesc *wi_desc;
-    const int32_t *nitems;
-    const GroupMember *members;  // out_base = the pair's offset in the query's candidate stream (Pair::ord_base)
-    // ungrouped mode (a handful of queries: no plan launch): item = (pair, chunk), chunk-major, one query per item
+    // grouped mode: the (query, list) pairs were filed under their list by the routing step (bk_mem); one workgroup per
+    // (list, group of <= 32 members, chunk of the list's rows)
+    const WorkDesc *wi_desc;  // dense work list built on the device (ivf_worklist_kernel); workgroup b serves item
+    const int32_t *nitems;    // (b & 7) * ceil(nitems / 8) + (b >> 3): one contiguous eighth of the list per XCD
+    const uint2 *bk_mem;      // [nlist][bk_cap] (query, offset of the list in the query's candidate stream)
+    int32_t bk_cap;
+    // ungrouped mode (a handful of queries): item = (pair, chunk), chunk-major, one query per item
     const Pair *pairs;
     int32_t npairs;
     int32_t chunk_rows, nchunks;
@@ -264,10 +261,15 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
     float *runm = tauw + kTileQ;                                                  // [32] running maxima
     int32_t *runc = reinterpret_cast<int32_t *>(runm + kTileQ);                   // [32] ... of how many candidates
 
+    const int col = lane & 31, half = lane >> 5;
+    const float kInf = __builtin_inff();
+    constexpr bool narrow = NARROW;
+    const v4i_t *tile = reinterpret_cast<const v4i_t *>(a.ctile);
     // ---- work item
     int64_t rb0, r0, r1;
-    int cnt, mem_begin = 0, one_q = -1;
+    int cnt, one_q = -1;
     uint32_t one_ob = 0;
+    const uint2 *mem = nullptr;
     if (a.pairs) {
         const int pair = static_cast<int>(blockIdx.x % a.npairs), chunk = static_cast<int>(blockIdx.x / a.npairs);
         const Pair p = a.pairs[pair];
@@ -295,15 +297,15 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
         r0 = rb0 + d.r0_off;
         r1 = rb0 + d.r1_off;
         cnt = d.cnt;
-        mem_begin = d.mem_begin;
+        mem = a.bk_mem + static_cast<int64_t>(d.list) * a.bk_cap + d.mem0;
     }
     if (r0 >= r1 || cnt <= 0) return;
+    const int rel0 = static_cast<int>(r0 - rb0), rel1 = static_cast<int>(r1 - rb0);
 
     // blocks of 32 rows of the tile layout that overlap [r0, r1): the layout's blocks are aligned to the WHOLE list array,
     // not to a list, so the first and the last block of a chunk may hold rows of the neighbours -- computed, not used
     const int64_t b0 = r0 >> 5, b1 = (r1 + 31) >> 5;
     int64_t b = b0 + wave;
-    const v4i_t *tile = reinterpret_cast<const v4i_t *>(a.ctile);
     v4i_t av[PF];
     float4 metar = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (b < b1) {  // the first block's operands are on their way while the group is set up
@@ -322,9 +324,9 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
                 qi = one_q;
                 ob = one_ob;
             } else {
-                const GroupMember m = a.members[mem_begin + tid];
-                qi = m.q;
-                ob = static_cast<uint32_t>(m.out_base);
+                const uint2 m = mem[tid];
+                qi = static_cast<int>(m.x);
+                ob = m.y;
             }
         }
         qi_s[tid] = qi;
@@ -339,8 +341,6 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
         if (q < cnt) v = reinterpret_cast<const v4i_t *>(a.qcodes + static_cast<int64_t>(qi_s[q]) * NCH * kWave)[t];
         qb_s[t * 32 + q] = v;
     }
-    const float kInf = __builtin_inff();
-    constexpr bool narrow = NARROW;
     if (lane < 32) {  // this wave's chunk maxima / counts; narrow epilogue: thresholds and running maxima
         wmax_s[wave * 32 + lane] = -kInf;
         wcnt_s[wave * 32 + lane] = 0;
@@ -350,7 +350,6 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
     }
     __syncthreads();
 
-    const int col = lane & 31, half = lane >> 5;
     const bool live = col < cnt;
     const QueryScal myqs = live ? qs_s[col] : QueryScal{};
     const int myq = live ? qi_s[col] : 0;
@@ -361,7 +360,6 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
     uint4 *dst = a.surv + static_cast<int64_t>(myq) * a.cap;
     const v4i_t *ap = tile + (b * S) * 64 + lane;  // this wave's current block
     const v4i_t *qb_mine = qb_s + half * 32 + col;   // B operand of step s: qb_mine[s * 64]
-    const int rel0 = static_cast<int>(r0 - rb0), rel1 = static_cast<int>(r1 - rb0);
     for (; b < b1; b += kTileWaves, ap += static_cast<int64_t>(kTileWaves) * S * 64) {
         const float4 mcur = metar;  // narrow groups: lane & 31 is the row whose terms these are
         if (!narrow && lane < 32) meta_s[lane] = metar;

@@ -661,7 +661,8 @@ def test_ivf_survivor_stream_regimes(eng, oracle, metric, monkeypatch):
     """The survivor stream of the IVF list scan (stream_kernels.hpp) in each of its regimes, all bit-equal to the oracle:
     a handful of queries (every pair its own work item, no plan launch), grouped batches, survivor lists too small for
     what the bounds let through (HNSWGPU_STREAM_CAP: the finish kernel falls back to the candidate stream itself, i.e. the
-    plain f32 scan), and routing through the separate launches instead of the fused routing kernel."""
+    plain f32 scan), per-list buckets too small for the pairs of a hot list (the queries that do not fit take the same
+    fallback), and routing through the separate launches instead of the fused routing kernel."""
     O = oracle
     code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
     base = _data(O, 9000, 200, "clustered", num_clusters=40, noise_level=0.25, seed=71)
@@ -693,6 +694,12 @@ def test_ivf_survivor_stream_regimes(eng, oracle, metric, monkeypatch):
         monkeypatch.setenv("HNSWGPU_STREAM_CAP", "300")      # some queries fit, some do not
         check(12, 10, 12, "mixed fallback")
         monkeypatch.delenv("HNSWGPU_STREAM_CAP")
+        monkeypatch.setenv("HNSWGPU_STREAM_BUCKET", "3")     # three pairs fit a list's bucket: most queries take the fallback
+        check(12, 10, 12, "full buckets")
+        check(41, 10, 5, "full buckets")
+        monkeypatch.setenv("HNSWGPU_STREAM_ROUTE", "0")      # ... filed by the separate routing launches
+        check(41, 33, 12 if metric == "l2" else 5, "full buckets, separate routing")
+        monkeypatch.delenv("HNSWGPU_STREAM_BUCKET")
         monkeypatch.setenv("HNSWGPU_STREAM_ROUTE", "0")      # routing by the separate launches
         check(12, 10, 12, "separate routing")
         monkeypatch.setenv("HNSWGPU_STREAM_GROUP", "1000")   # ungrouped work items for a mid-size batch as well
