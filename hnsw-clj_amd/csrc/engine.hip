@@ -124,7 +124,8 @@ int launch_finish(const FinishArgs &a, int nch, hipStream_t st) {
     const int64_t blocks = static_cast<int64_t>(a.nq) * a.slices;
     if (blocks <= 0) return 0;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "finish grid too large");
-    const size_t lds = sizeof(uint64_t) * (kNWave + 2) * a.k;  // W lists + final list + (ord, dist) of the result
+    // W lists + final list + (ord, dist) of the result + the probed lists' stream offsets
+    const size_t lds = sizeof(uint64_t) * (kNWave + 2) * a.k + sizeof(uint32_t) * a.nprobe;
     HG_REQUIRE(lds <= 64 * 1024, HNSWGPU_ELIMIT, "k too large for the finish kernel (k=%d)", a.k);
     const bool l2 = a.metric == METRIC_L2;
 #define CALL(N, R, L)                                                                                                   \
@@ -357,6 +358,7 @@ struct RouteArgs {
     int64_t qld;
     int32_t dim, metric, nq, nprobe;
     int32_t rows_per_block, blocks_per_query;
+    int32_t qgroup;   // ivf_route_dist_kernel: queries per workgroup
     float *dense;     // [nq][nlist]
     uint32_t *done;   // [nq], zero between calls
     const int64_t *listoff;
@@ -529,6 +531,49 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
     route_tail_wg<NCH, RB, L2, true>(a, qi, smem);
 }
 
+// Centroid distances of a batch, [nq][nlist] in the GEMV order (same bits as above), for the tail launch below: a
+// workgroup takes a slice of the centroid table and a group of `qgroup` queries; every wave fetches its eight centroid
+// rows ONCE and walks the group's queries over them, the next query on its way while the current one is scored.  (One
+// GEMV per query reads the whole table per query: 805 MB out of L2 for 256 queries x 1024 centroids x 768.)
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void ivf_route_dist_kernel(RouteArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int grp = blockIdx.x / a.blocks_per_query, bx = blockIdx.x % a.blocks_per_query;
+    const int q0 = grp * a.qgroup;
+    const int qn_here = a.nq - q0 < a.qgroup ? a.nq - q0 : a.qgroup;
+    const int64_t r0 = static_cast<int64_t>(bx) * a.rows_per_block;
+    const int64_t r1 = r0 + a.rows_per_block < a.nlist ? r0 + a.rows_per_block : a.nlist;
+    const int nvec = static_cast<int>(a.ld / 4);
+    for (int64_t base = r0 + wave * RB; base < r1; base += kNWave * RB) {
+        float4 r[RB][NCH];
+        const float myrn = (a.metric == METRIC_COS && lane < RB && base + lane < r1) ? a.cnorms[base + lane] : 0.0f;
+#pragma unroll
+        for (int b = 0; b < RB; b++) load_row<NCH>(r[b], a.cent + (base + b) * a.ld, nvec, lane, base + b < r1);
+        float4 q[NCH];
+        load_query<NCH>(q, a.Q + static_cast<int64_t>(q0) * a.qld, a.dim, lane);
+        for (int g = 0; g < qn_here; g++) {
+            const int qi = q0 + g;
+            float4 qnext[NCH];
+            load_query<NCH>(qnext, a.Q + static_cast<int64_t>(g + 1 < qn_here ? qi + 1 : qi) * a.qld, a.dim, lane);
+            const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+            float sm[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++) sm[b] = lane_partial<NCH, L2>(q, r[b]);
+#pragma unroll
+            for (int b = 0; b < RB; b++) sm[b] = wave_sum(sm[b]);
+            // lane b takes row b's distance: RB consecutive floats of the query's row of the matrix
+            float mine = 0.0f;
+#pragma unroll
+            for (int b = 0; b < RB; b++) mine = lane == b ? sm[b] : mine;
+            if (lane < RB && base + lane < r1)
+                a.dense[static_cast<int64_t>(qi) * a.nlist + base + lane] = finish_dist(a.metric, mine, qn, myrn);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) q[c] = qnext[c];
+        }
+    }
+}
+
 // The same tail as a launch of its own, one workgroup per query, behind a distance pass that serves many queries per
 // centroid row (large batches): select, probe table, pairs filed by list, query codes, first threshold.
 template <int NCH, int RB, bool L2>
@@ -546,7 +591,7 @@ __global__ __launch_bounds__(kWG) void ivf_route_tail_kernel(RouteArgs a) {
 }
 
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
-                     int32_t *qcnt, hipStream_t st, const RouteStream *rs, const float *dense_done) {
+                     int32_t *qcnt, hipStream_t st, const RouteStream *rs, const float *dense_done, bool two_launches) {
     RouteArgs a;
     memset(&a, 0, sizeof(a));
     if (rs) {
@@ -591,6 +636,22 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
     const size_t lds = std::max<size_t>(sizeof(uint64_t) * (kNWave + 1) * nprobe, sizeof(float) * kSeedMax);
     HG_REQUIRE(lds <= 48 * 1024, HNSWGPU_ELIMIT, "nprobe too large for the fused routing kernel");
     const bool l2 = a.metric == METRIC_L2;
+    if (two_launches && !dense_done) {
+        // larger batches: the distances by workgroups that share their centroid rows among a group of queries, then the tail
+        a.qgroup = static_cast<int32_t>(std::max(2, std::min(16, nq / 16)));
+        const int64_t ngroups = (nq + a.qgroup - 1) / a.qgroup;
+        int64_t wb = std::max<int64_t>(1, 2048 / ngroups);
+        int64_t rp = (idx->nlist + wb - 1) / wb;
+        rp = std::max<int64_t>(per_iter, (rp + per_iter - 1) / per_iter * per_iter);
+        a.rows_per_block = static_cast<int32_t>(rp);
+        a.blocks_per_query = static_cast<int32_t>((idx->nlist + rp - 1) / rp);
+        const int64_t dblocks = ngroups * a.blocks_per_query;
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_dist_kernel<N, R, L>), dim3(static_cast<unsigned>(dblocks)), dim3(kWG), 0, st, a)
+        HG_DISPATCH(idx->nch, l2, CALL);
+#undef CALL
+        HG_HIP(hipGetLastError());
+        dense_done = a.dense;
+    }
     if (dense_done) {  // the distances are in s_tile already ([nq][nlist], an earlier launch): the tail alone
         a.dense = const_cast<float *>(dense_done);
 #define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_tail_kernel<N, R, L>), dim3(static_cast<unsigned>(nq)), dim3(kWG), lds, st, a)

@@ -246,7 +246,8 @@ struct RouteStream {
     int32_t bk_cap;
 };
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
-                     int32_t *qcnt, hipStream_t st, const RouteStream *rs = nullptr, const float *dense_done = nullptr);
+                     int32_t *qcnt, hipStream_t st, const RouteStream *rs = nullptr, const float *dense_done = nullptr,
+                     bool two_launches = false);
 // the survivor stream of the IVF list scan (stream_kernels.hpp)
 struct StreamArgs;
 struct FinishArgs;

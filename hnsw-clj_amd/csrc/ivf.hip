@@ -852,6 +852,8 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     // workgroups per query: the chip filled a few times over for small batches; one or two for large ones
     f.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(64, 2048 / nq)));
     f.span = nq <= 32 ? 16 : 64;
+    if (const int64_t sl = env_now("HNSWGPU_FINISH_SLICES", 0)) f.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(sl, 256)));  // tuning
+    if (const int64_t sp = env_now("HNSWGPU_FINISH_SPAN", 0)) f.span = sp >= 64 ? 64 : (sp >= 32 ? 32 : 16);
     f.rows = idx->d_lrows;
     f.row_norms = idx->d_lnorms;
     f.ld = idx->ld;
@@ -897,7 +899,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     // GEMV vs tiled, end to end): batch 32: 0.42 vs 0.56 ms; 48: 0.54 vs 0.61; 64: 0.64 vs 0.64; 80: 0.72 vs 0.65;
     // 96: 0.82 vs 0.71; 128: 1.03 vs 0.71.
     const int tm = tile_mode();
-    const int code_env = static_cast<int>(env_now("HNSWGPU_IVF_CODES", 9));  // 0 = never (A/B), N > 0 = from N queries per batch
+    const int code_env = static_cast<int>(env_now("HNSWGPU_IVF_CODES", 1));  // 0 = never (A/B), N > 0 = from N queries per batch
     // the survivor stream (stream_kernels.hpp): k up to a tile chunk's rows can get a threshold from one chunk
     const bool codes_ok = idx->d_lctile != nullptr && (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128)) &&
                           code_env > 0 && nq >= code_env && tm != 0 && k <= kStreamMaxK;
@@ -957,7 +959,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     // still use both for padded queries and norms, and must not move s_qn afterwards)
     StreamScratch sc;
     memset(&sc, 0, sizeof(sc));
-    const int stream_route_max = static_cast<int>(env_now("HNSWGPU_STREAM_ROUTE", 64));  // largest batch routed by the one-launch routing kernel
+    const int stream_route_max = static_cast<int>(env_now("HNSWGPU_STREAM_ROUTE", 12));  // largest batch routed by the one-launch routing kernel
     const int stream_group_min = static_cast<int>(env_now("HNSWGPU_STREAM_GROUP", 5));    // queries from which the bounds pass groups the pairs by list
     if (use_code) {
         HG_TRY(stream_scratch(idx, nq, sc));
@@ -991,19 +993,11 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, use_code ? &rs : nullptr));
         codes_done = use_code;
     } else if (use_code && static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20)) {
-        // survivor stream, larger batches: the centroid distances by a pass that serves many queries per centroid row (the
-        // GEMV order: register-row group kernel, or one GEMV per query for long rows), then ONE launch for everything else
-        // of the routing -- select, probe table, pairs filed by list, query codes, first thresholds
-        if (idx->dim <= kL2MaxDim && tm != 0) {
-            HG_TRY(pad_queries(idx, d_Q, idx->dim, nq, st));
-            HG_TRY(stream_scratch(idx, nq, sc));  // (s_qp may have moved under the padded queries)
-            HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,
-                                 nprobe, st, -1, true, true));
-        } else {
-            HG_TRY(scan_dense_topk(idx, a, nq, idx->nlist, st, true));
-        }
+        // survivor stream, larger batches: the centroid distances by a pass that serves a group of queries per fetch of a
+        // centroid row (the GEMV order, same bits), then ONE launch for everything else of the routing -- select, probe
+        // table, pairs filed by list, query codes, first thresholds
         RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap};
-        HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, &rs, idx->s_tile.as<float>()));
+        HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, &rs, nullptr, true));
         codes_done = true;
     } else {
     if (use_tile)  // every query against the centroid table on the tile kernel as well

@@ -792,6 +792,11 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     mg.out_dist = nullptr;
     uint32_t *ord_s = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (kNWave + 1) * a.k);  // [k]
     float *dist_s = reinterpret_cast<float *>(ord_s + a.k);                                         // [k]
+    // (the offsets of the probed lists in the candidate stream, fetched side by side while the lists are merged: the
+    // winners are then resolved against LDS instead of a chain of dependent global reads)
+    uint32_t *pob_s = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (kNWave + 2) * a.k);  // [nprobe]
+    if (wave == kNWave - 1)
+        for (int p = lane; p < a.nprobe; p += kWave) pob_s[p] = pp[p].ord_base;
     merge_topk_wg<true>(mg, qi, kNWave, smem, ord_s, dist_s);  // waves 1..3 return from it after its barrier
     if (wave != 0) return;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -804,11 +809,12 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
             int p = 0, hi = a.nprobe - 1;  // the last pair whose ord_base <= o (as ivf_decode_kernel), by bisection
             while (p < hi) {
                 const int mid = (p + hi + 1) >> 1;
-                if (pp[mid].ord_base <= o) p = mid;
+                if (pob_s[mid] <= o) p = mid;
                 else hi = mid - 1;
             }
-            id = a.listids[pp[p].row_begin + (o - pp[p].ord_base)];
-            go = pp[p].gord_base + (o - pp[p].ord_base);
+            const Pair pr = pp[p];
+            id = a.listids[pr.row_begin + (o - pr.ord_base)];
+            go = pr.gord_base + (o - pr.ord_base);
         }
         a.out_ids[static_cast<int64_t>(qi) * a.k + i] = id;
         a.out_dist[static_cast<int64_t>(qi) * a.k + i] = dist_s[i];
