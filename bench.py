@@ -72,6 +72,12 @@ def make_31k(distribution, seed, n):
                                      dtype=np.float64)
         x /= np.linalg.norm(x, axis=1, keepdims=True)
         return x.astype(np.float32)
+    if distribution == "uniform01":
+        # what the published run and the hnswlib script used: (rand) / np.random.rand, i.i.d. uniform on [0, 1)
+        # (wip/ultra_optimized.clj:293-296, scripts/benchmark_python_hnswlib.py:31) -- here java.util.Random.nextDouble
+        return datagen.JavaRandom(seed).next_doubles(n * DIM).reshape(n, DIM).astype(np.float32)
+    if distribution == "uniform_pm1":      # the generator's own :uniform, 2 (rand) - 1 on [-1, 1) (test/data_generator.clj:71)
+        distribution = "uniform"
     return datagen.generate_dataset(n, DIM, distribution, seed=seed)
 
 
@@ -120,7 +126,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nq", type=int, default=10000, help="queries per step per GPU")
     ap.add_argument("--ef", type=int, default=0, help="0 = first ef of the sweep with recall@10 >= 0.98")
-    ap.add_argument("--dist", default="manifold", choices=["manifold", "clustered", "gaussian", "uniform"])
+    ap.add_argument("--dist", default="manifold", choices=["manifold", "clustered", "gaussian", "uniform01", "uniform_pm1"])
     ap.add_argument("--no-ivf", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--ivf-n", type=int, default=1_000_000)
@@ -323,7 +329,7 @@ def main():
     }
     result["config"]["qps_host_buffers"] = host_buffer_qps(idx, queries, ef, args.steps)
     if rank == 0 and world == 1 and not args.no_dists:
-        result["config"]["by_distribution"] = by_distribution(engine, dev, args)
+        result["config"]["by_distribution"] = by_distribution(engine, dev, args, not args.no_cpu)
 
     # ------------------------------------------------------------------ IVF-FLAT scan roofline (configs[2])
     if not args.no_ivf and rank == 0:
@@ -354,6 +360,7 @@ def main():
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if not args.no_cpu and rank == 0 and world == 1:
         result["cpu_baseline"] = cpu_baseline(idx, base, queries, ef)
+        result["config"]["parity_checked"] = parity_check(idx, base, queries, ef, out_ids, out_d)
     idx.close()
     if dist.is_initialized():
         dist.barrier()
@@ -373,21 +380,31 @@ def host_buffer_qps(idx, queries, ef, steps):
     return round(len(queries) * steps / (time.perf_counter() - t0), 1)
 
 
-def by_distribution(engine, dev, args):
-    """the generator's three distributions beside the headline's manifold set -- gaussian (primary in
-    the survey), uniform[0,1) (what the published run and benchmark_python_hnswlib.py:31 used), clustered-normalised.
-    Each: build on the device, ground truth by GPU brute force over the full base, then the FIRST ef of the sweep whose
-    recall@10 reaches 0.98 -- or the last point of the sweep if none does (ef <= 4096 is the kernel's limit)."""
+def by_distribution(engine, dev, args, want_cpu):
+    """the generator's distributions beside the headline's manifold set -- gaussian (primary in the
+    survey), uniform01 = i.i.d. uniform on [0, 1) (what the published run and benchmark_python_hnswlib.py:31 used),
+    uniform_pm1 = the generator's own :uniform on [-1, 1), clustered-normalised.  Each: build on the device, ground truth by
+    GPU brute force over the full base, then the FIRST ef of the sweep whose recall@10 reaches 0.98 -- or the last point of
+    the sweep if none does (ef <= 4096 is the kernel's limit).  Beside every operating point the two numbers that say what
+    it is worth (bench.clj:72-92 defines both sides): exact_knn_qps = the same queries answered at recall 1.0 by the GPU's
+    exact scan (hnswgpu_exact_knn_dev), cpu_qps = the CPU oracle (f64 reference order) on the same graph at the same ef."""
     out = {}
     sweep = [50, 100, 200, 400, 800, 1600, 3200, 4096]
     nq = min(args.nq, 4096)
-    for name in ("gaussian", "uniform", "clustered"):
+    for name in ("gaussian", "uniform01", "uniform_pm1", "clustered"):
         t0 = time.time()
         base = make_31k(name, 42, N31K)
-        Q = torch.from_numpy(make_31k(name, 43, nq)).to(dev)
+        qh = make_31k(name, 43, nq)
+        Q = torch.from_numpy(qh).to(dev)
         with engine.Index(base, "cosine", dev.index) as idx:
             idx.hnsw_build(M, EFC, 42)
             truth, _ = idx.exact_knn_dev(Q, K)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                idx.exact_knn_dev(Q, K)
+            torch.cuda.synchronize()
+            exact_qps = 3 * nq / (time.perf_counter() - t1)
             pts, hit = [], None
             for e in sweep:
                 ids, _ = idx.hnsw_search_dev(Q, K, e)
@@ -404,12 +421,39 @@ def by_distribution(engine, dev, args):
                     break
             first = hit or pts[-1]
             out[name] = {"ef": first[0], "recall_at_10": first[1], "qps": first[2], "reached_0.98": hit is not None,
-                         "sweep_ef_recall_qps": pts, "queries": nq}
+                         "exact_knn_qps": round(exact_qps, 1), "sweep_ef_recall_qps": pts, "queries": nq}
+            if want_cpu:
+                out[name].update(cpu_point(idx, base, qh, first[0]))
+            o = out[name]
+            o["better_at_0.98"] = "exact scan" if (not o["reached_0.98"] or o["exact_knn_qps"] > o["qps"]) else "hnsw"
         log("by_distribution %s: %s (%.1fs)" % (name, out[name], time.time() - t0))
-    out["note"] = ("i.i.d. gaussian / uniform 768-d have no neighbourhood structure (recall needs ef in the thousands: near "
-                   "brute force); clustered leaves the reference-style graph (closest-m pruning, no diversity heuristic, "
-                   "ultra_fast.clj:279-299) disconnected between clusters.  DESIGN.md section 6.")
+    out["note"] = ("i.i.d. gaussian / uniform 768-d have no neighbourhood structure: recall 0.98 needs ef in the thousands, where "
+                   "the traversal evaluates most of the base per query -- on those sets the GPU's exact scan (recall 1.0) is the "
+                   "better answer by two orders of magnitude, and better_at_0.98 says so; clustered leaves the reference-style "
+                   "graph (closest-m pruning, no diversity heuristic, ultra_fast.clj:279-299) disconnected between clusters.  "
+                   "DESIGN.md section 6.")
     return out
+
+
+def cpu_point(idx, base, queries, ef, seconds=4.0):
+    """The CPU oracle (f64, reference order) on THIS index's graph at `ef`, one task per query on the best thread count of
+    a short pilot; a bounded sample of the same queries (about `seconds` of wall time)."""
+    from oracle import oracle as O
+
+    g = idx.get_graph()
+    og = O.Graph(g.levels, g.l0_adj, g.up_off, g.up_adj, g.M, g.entry, g.max_level)
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    t = max(1, min(32, ncpu))
+    npilot = min(len(queries), 2 * t)
+    _, _, _, ms = O.hnsw_search(base, og, queries[:npilot], K, ef=ef, nthreads=t)
+    rate = npilot / max(ms, 1e-3) * 1e3
+    nqc = int(max(npilot, min(len(queries), rate * seconds)))
+    _, _, _, ms = O.hnsw_search(base, og, queries[:nqc], K, ef=ef, nthreads=t)
+    return {"cpu_qps": round(nqc / (ms * 1e-3), 1), "cpu_threads": t, "cpu_sample_queries": nqc}
 
 
 def ivf_roofline(engine, dev, args, traffic):
@@ -432,7 +476,7 @@ def ivf_roofline(engine, dev, args, traffic):
     _, off, _ = idx.get_ivf()
     lens = np.diff(off)
     out = {}
-    for nq in (1, 32, 1024, "32_f32"):
+    for nq in (1, 32, 256, 1024, "32_f32"):
         f32_only = nq == "32_f32"                      # the same batch of 32 with the int8 bounds pass switched off
         key, nq = nq, 32 if f32_only else nq
         idx.set_rejection_test(0 if f32_only else 1)
@@ -443,7 +487,7 @@ def ivf_roofline(engine, dev, args, traffic):
         alg_bytes = rows * (4 * DIM + 4)
         for _ in range(3):
             idx.ivf_search_dev(Q, K, nprobe)
-        steps = 5 if nq == 1024 else 20
+        steps = 5 if nq >= 1024 else 20
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -491,25 +535,32 @@ def ivf_roofline(engine, dev, args, traffic):
     f = out["32_f32"]
     b = out[1024]
     o = out[1]
+    m = out[256]
     flops = 2.0 * b["algorithmic_GB"] * 1e9 / (4 * DIM + 4) * DIM      # 2 * rows scanned * D
     tf = flops / (b["avg_scan_ms"] * 1e-3) / 1e12
-    code_row = 256 * ((DIM + 255) // 256) + 16                         # int8 row + (scale, bound terms, norm)
+    code_row = 256 * ((DIM + 255) // 256) + 16                         # int8 row + (scale, bound terms, 1 / norm)
     # what the bounds kernel has to move per launch: every probed list once (all the pairs of a list are one group at
-    # this batch size) in int8, and one lower bound per candidate written
-    req_bytes = r["unique_rows"] * code_row + 4 * r["candidates_per_query"] * r["nq"]
+    # this batch size) in int8, and 16 bytes per survivor appended
+    req_bytes = r["unique_rows"] * code_row + 16 * r["survivors_per_query"] * r["nq"]
     tr = traffic["traffic"] if traffic else None
     achieved = (tr if tr else req_bytes) / 1e9 / (r["avg_scan_ms"] * 1e-3)
     tr_f = traffic["traffic_f32_scan"] if traffic else None
     ach_f = (tr_f / 1e9 if tr_f else f["unique_GB"]) / (f["avg_scan_ms"] * 1e-3)
+    # the whole search: every byte its launches moved (PMC, all kernels of one search) -- or, without a PMC pass, the bytes
+    # it has to move: the probed lists once in int8, the survivors' f32 rows, the centroid table once per query group
+    need_search = req_bytes + r["survivors_per_query"] * r["nq"] * (4 * DIM + 4) + nlist * (4 * DIM + 4) * max(1, r["nq"] // 2)
+    tr_s = traffic["traffic_search"] if traffic else None
+    ach_s = (tr_s if tr_s else need_search) / 1e9 / (r["search_wall_ms"] * 1e-3)
     res = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr,
            "achieved_from": "PMC traffic / kernel time" if tr else "requested bytes / kernel time (no PMC pass in this run: "
                             "--no-pmc, N > 1 or rocprofv3 unavailable; a lower bound of the traffic; profiles/ holds a PMC run)",
            "frac_of_copy_ceiling": round(achieved / 6290.0, 4),
-           "kernel": "code_bounds_kernel<3> (dot4c body: 1.6 queries per probed list at this batch)",
-           "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch: lower bounds of every "
-                       "candidate from the int8 list rows (then f32 distances of the %.0f survivors per query: "
-                       "ivf_refine_kernel)" % (n, r["survivors_per_query"]),
+           "kernel": "stream_bounds_kernel<3, true> (v_mfma_i32_32x32x32_i8; 1.6 queries per probed list at this batch: the "
+                     "lane = row epilogue)",
+           "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch: bounds of every candidate "
+                       "from the int8 list rows against the query's running threshold, %.0f survivors per query appended "
+                       "(their f32 distances, the top-k and the results: ivf_finish_kernel)" % (n, r["survivors_per_query"]),
            "avg_launch_ms": r["avg_scan_ms"], "requested_bytes_per_launch": int(req_bytes),
            "algorithmic_bytes_per_launch": int(r["algorithmic_GB"] * 1e9),
            "algorithmic_GBs": r["algorithmic_GBs"], "frac_algorithmic": round(r["algorithmic_GBs"] / HBM_PEAK_GBS, 4),
@@ -517,6 +568,12 @@ def ivf_roofline(engine, dev, args, traffic):
                          "pair (SURVEY 8d).  The search reads each probed list once per batch in int8 and f32 rows only for "
                          "the candidates whose lower bound does not exclude them from the k nearest, so algorithmic_GBs is "
                          "a throughput figure far above any memory rate -- frac is the kernel's own traffic over its time",
+           "search": {"what": "ONE batch-32 search end to end (routing distances, routing tail, work list, bounds pass, finish): "
+                              "all the bytes its launches moved / its wall time",
+                      "wall_ms": r["search_wall_ms"], "traffic": tr_s, "bytes_needed": int(need_search),
+                      "achieved": round(ach_s, 1), "unit": "GB/s", "frac": round(ach_s / HBM_PEAK_GBS, 4),
+                      "achieved_from": "PMC traffic of every kernel of the search / wall" if tr_s else "bytes needed / wall (no PMC pass)",
+                      "per_kernel_bytes": traffic["per_kernel"] if traffic else None, "qps": r["qps"]},
            "f32_scan": {"kernel": "scan_kernel<3,8,false,ROLE_LIST_SCAN>", "avg_launch_ms": f["avg_scan_ms"],
                         "search_wall_ms": f["search_wall_ms"], "qps": f["qps"], "traffic": tr_f,
                         "achieved": round(ach_f, 1), "unit": "GB/s", "frac": round(ach_f / HBM_PEAK_GBS, 4),
@@ -525,13 +582,17 @@ def ivf_roofline(engine, dev, args, traffic):
                         "note": "the same batch with the bounds pass switched off (hnswgpu_set_rejection_test 0): one f32 GEMV "
                                 "per (query, probed list) pair -- round 1 / 2's roofline kernel, same results bit for bit"},
            "batch_32": r,
+           "batch_256": m,
            "batch_1": {"kernel_ms": o["avg_scan_ms"], "algorithmic_bytes": int(o["algorithmic_GB"] * 1e9),
-                       "achieved": o["algorithmic_GBs"], "unit": "GB/s", "frac": round(o["algorithmic_GBs"] / HBM_PEAK_GBS, 4),
+                       "int8_bytes": int(o["unique_rows"] * code_row), "survivors": o["survivors_per_query"],
+                       "achieved": round(o["unique_rows"] * code_row / 1e9 / (o["avg_scan_ms"] * 1e-3), 1), "unit": "GB/s",
+                       "frac": round(o["unique_rows"] * code_row / 1e9 / (o["avg_scan_ms"] * 1e-3) / HBM_PEAK_GBS, 4),
                        "end_to_end_us": {"p50": round(lat[len(lat) // 2], 1), "min": round(lat[0], 1),
                                          "p95": round(lat[int(len(lat) * 0.95)], 1)},
-                       "end_to_end_frac": round(o["algorithmic_GB"] * 1e9 / (lat[len(lat) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                       "note": "one query, 32 lists, every byte read once (algorithmic = unique); end to end = route, "
-                               "probe table, scan, merge, decode in one call + sync"},
+                       "end_to_end_frac_of_reference_bytes": round(o["algorithmic_GB"] * 1e9 / (lat[len(lat) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                       "note": "one query, 32 lists: the bounds pass reads them once in int8 (achieved / frac: those bytes over "
+                               "the bounds kernel's time); end to end = routing, bounds, finish in one call + sync, priced at "
+                               "the reference algorithm's f32 bytes"},
            "batched_mfma": {"bound": "mfma", "kernel": "tile_scan_kernel (v_mfma_f32_32x32x2_f32)",
                             "workload": "same index, batch of 1024 queries per launch, pairs grouped by list",
                             "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
@@ -541,7 +602,7 @@ def ivf_roofline(engine, dev, args, traffic):
                             "note": "a group of <= 32 queries shares one fetch of a row: 2 * 32 * 768 flop per 3 KB = 16 flop/B, "
                                     "below the machine balance (157 TFLOP/s / 6.3 TB/s = 25 flop/B) -- at this batch the kernel is "
                                     "HBM-bound as well: every list is read at least once (unique_GBs is that lower bound of the "
-                                    "traffic; the PMC pass in profiles/ has the measured bytes: 4.3 GB per launch = 5.2 TB/s)"},
+                                    "traffic; the PMC pass in profiles/ has the measured bytes)"},
            "ivf_recall_at_10": round(rec, 4), "ivf_build_s": round(build_s, 1),
            "mean_list_len": float(lens.mean()), "max_list_len": int(lens.max())}
     if traffic:
@@ -566,8 +627,12 @@ def ivf_dataset(dev, n, nlist, nq_all):
     return x, Qa
 
 
-PMC_SCAN_KERNEL = "code_bounds_kernel<3>"            # the bounds kernel for dim 768 (default path at batch 32)
+PMC_SCAN_KERNEL = "stream_bounds_kernel<3, true>"    # the bounds kernel for dim 768 (batch 32: the lane = row epilogue)
 PMC_F32_KERNEL = "scan_kernel<3, 8, false, 0>"       # ROLE_LIST_SCAN instantiation: the f32 scan (bounds pass off)
+# every kernel of one batch-32 search through the survivor stream (roofline.search)
+PMC_SEARCH_KERNELS = ("ivf_route_kernel", "ivf_route_dist_kernel", "ivf_route_tail_kernel", "ivf_worklist_kernel",
+                      "stream_bounds_kernel", "ivf_finish_kernel")
+PMC_CHILD_SEARCHES = 6
 
 
 def pmc_child(args):
@@ -585,7 +650,7 @@ def pmc_child(args):
     Q = Qa[:32].contiguous()
     for mode in (1, 0):                                # the bounds pipeline, then the f32 scan of the same batch
         idx.set_rejection_test(mode)
-        for _ in range(6):
+        for _ in range(PMC_CHILD_SEARCHES):
             idx.ivf_search_dev(Q, K, 32)
         torch.cuda.synchronize()
     idx.close()
@@ -607,7 +672,7 @@ def pmc_traffic(args):
     if exe is None:
         log("pmc: rocprofv3 not found, roofline.traffic stays null")
         return None
-    got = {}
+    got, search = {}, {}
     env = dict(os.environ, TMPDIR="/tmp")
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="hnswgpu_pmc_", dir="/tmp")
@@ -617,6 +682,7 @@ def pmc_traffic(args):
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
             vals, vals_f = [], []
+            per_k = {}
             for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f)):
                     if row["Counter_Name"] != ctr:
@@ -625,6 +691,10 @@ def pmc_traffic(args):
                         vals.append(float(row["Counter_Value"]))
                     elif PMC_F32_KERNEL in row["Kernel_Name"]:
                         vals_f.append(float(row["Counter_Value"]))
+                    for kn in PMC_SEARCH_KERNELS:      # every launch of the six searches through the survivor stream
+                        if ("hg::" + kn + "<") in row["Kernel_Name"] or ("hg::" + kn + "(") in row["Kernel_Name"]:
+                            per_k[kn] = per_k.get(kn, 0.0) + float(row["Counter_Value"]) * 1024.0 / PMC_CHILD_SEARCHES
+            search[ctr] = per_k
             if r.returncode != 0 or not vals or not vals_f:
                 log("pmc: %s pass failed (rc %d, %d + %d rows): %s" % (ctr, r.returncode, len(vals), len(vals_f), r.stderr.decode()[-300:]))
                 return None
@@ -637,11 +707,14 @@ def pmc_traffic(args):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     # gfx950: FETCH_SIZE tallies a 128-B request of a wide coalesced read at 64 B (MI355X_MICROARCH.md, HBM section:
-    # calibrated there for 16 B per lane; the bounds kernel reads 12 B per lane, calibrated in profiles/README.md
-    # against its known byte count -- every probed list exactly once at this batch size); WRITE_SIZE is exact
+    # calibrated there for 16 B per lane -- exactly what the bounds kernel's operand loads, the finish kernel's row
+    # gathers and the routing kernels' centroid reads are); WRITE_SIZE is exact
     rd, wr = 2.0 * got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
     rd_f, wr_f = 2.0 * got["FETCH_SIZE"][2], got["WRITE_SIZE"][2]
+    per_kernel = {kn: int(2.0 * search["FETCH_SIZE"].get(kn, 0.0) + search["WRITE_SIZE"].get(kn, 0.0))
+                  for kn in PMC_SEARCH_KERNELS if kn in search["FETCH_SIZE"] or kn in search["WRITE_SIZE"]}
     return {"traffic": int(rd + wr), "traffic_f32_scan": int(rd_f + wr_f),
+            "traffic_search": int(sum(per_kernel.values())), "per_kernel": per_kernel,
             "raw_fetch_size_bytes": int(got["FETCH_SIZE"][0]), "raw_fetch_size_bytes_f32_scan": int(got["FETCH_SIZE"][2]),
             "traffic_note": "HBM bytes per launch at batch 32: 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE, each "
                             "from its own rocprofv3 --pmc pass over %d launches of the same index and batch in a child "
@@ -814,6 +887,32 @@ def reference_protocol(ef):
                 "qps_by_threads": qps, "published_reference": "4,719-5,376 QPS at 20 JVM threads, Apple M4 -- other hardware"}
     except Exception as e:  # noqa: BLE001 -- a side measurement never takes the bench down
         return {"note": "%s: %s" % (type(e).__name__, e)}
+
+
+def parity_check(idx, base, queries, ef, out_ids, out_d, n=32):
+    """The timed launches against the oracle, outside the timed region: the first `n` queries of the timed batch -- ids,
+    distance bits and both traversal counters of the launch configuration that was timed (same batch size, same ef, so
+    the same kernel instantiation) against the oracle's device-order mode, and ids / distances against its f64
+    reference-order mode within the north_star's tolerance (1e-4 relative)."""
+    from oracle import oracle as O
+
+    g = idx.get_graph()
+    og = O.Graph(g.levels, g.l0_adj, g.up_off, g.up_adj, g.M, g.entry, g.max_level)
+    Q = torch.from_numpy(queries).to(out_ids.device)
+    stats = torch.zeros((len(queries), 2), dtype=torch.int64, device=out_ids.device)
+    idx.hnsw_search_dev(Q, K, ef, out=(out_ids, out_d), stats=stats)          # the timed launch once more, with counters
+    torch.cuda.synchronize()
+    gi, gd, gs = out_ids[:n].cpu().numpy(), out_d[:n].cpu().numpy(), stats[:n].cpu().numpy()
+    oi, od, ost, _ = O.hnsw_search(base, og, queries[:n], K, ef=ef, mode=O.MODE_DEV)
+    fi, fd, _, _ = O.hnsw_search(base, og, queries[:n], K, ef=ef)
+    od32 = np.asarray(od, np.float64).astype(np.float32)
+    close = np.abs(gd.astype(np.float64) - fd) <= 1e-4 * np.abs(fd) + 1e-6
+    return {"queries": n, "launch": "%d queries, ef %d (the timed configuration)" % (len(queries), ef),
+            "ids_equal_oracle": bool(np.array_equal(gi, oi)),
+            "distance_bits_equal_oracle": bool(np.array_equal(gd.view(np.uint32), od32.view(np.uint32))),
+            "counters_equal_oracle": bool(np.array_equal(gs, ost)),
+            "within_1e-4_of_f64_reference_order": bool(close.all()),
+            "id_sets_equal_f64_reference_order": bool(all(set(a.tolist()) == set(b.tolist()) for a, b in zip(gi, fi)))}
 
 
 def cpu_baseline(idx, base, queries, ef):
