@@ -1770,6 +1770,11 @@ int hnswgpu_dense_distances(hnswgpu_index *idx, const float *Q, int32_t nq, floa
 // Measurement / test entry: the lower bounds the HNSW traversal's rejection test (kernels.hpp: quantize_rows_kernel)
 // computes for query q against rows ids[0..m), by the traversal's own device functions.  NaN = "no bound".
 int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out) {
+    return hnswgpu_distance_bounds(idx, q, ids, m, out, nullptr);
+}
+
+int hnswgpu_distance_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out,
+                            float *out_ub) {
     HG_REQUIRE(idx && q && ids && out && m >= 1, HNSWGPU_EINVAL, "null argument");
     for (int32_t i = 0; i < m; i++) HG_REQUIRE(ids[i] >= 0 && ids[i] < idx->n, HNSWGPU_EINVAL, "id out of range");
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -1781,15 +1786,17 @@ int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *
                "this handle has no int8 rows (hnswgpu_set_rejection_test: mode 0, or mode 1 with dim < 128)");
     HG_TRY(upload_queries(idx, q, 1, st));
     HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * m));
-    HG_TRY(idx->s_outd.ensure(sizeof(float) * m));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * 2 * static_cast<size_t>(m)));
     HG_HIP(hipMemcpyAsync(idx->s_ids.p, ids, sizeof(int32_t) * m, hipMemcpyHostToDevice, st));
+    float *d_ub = out_ub ? idx->s_outd.as<float>() + m : nullptr;
 #define CALL(N, R, L)                                                                                                \
     hipLaunchKernelGGL((code_bound_kernel<N>), dim3((m + 7) / 8), dim3(kWave), 0, st, idx->s_q.as<float>(), idx->dim, \
-                       idx->metric, idx->d_qrows, idx->d_qmeta, idx->s_ids.as<int32_t>(), m, idx->s_outd.as<float>())
+                       idx->metric, idx->d_qrows, idx->d_qmeta, idx->s_ids.as<int32_t>(), m, idx->s_outd.as<float>(), d_ub)
     HG_DISPATCH(idx->nch, false, CALL);
 #undef CALL
     HG_HIP(hipGetLastError());
     HG_HIP(hipMemcpyAsync(out, idx->s_outd.p, sizeof(float) * m, hipMemcpyDeviceToHost, st));
+    if (out_ub) HG_HIP(hipMemcpyAsync(out_ub, d_ub, sizeof(float) * m, hipMemcpyDeviceToHost, st));
     HG_TRY(end_call(idx, st));
     HG_HIP(hipStreamSynchronize(st));
     return 0;

@@ -896,7 +896,8 @@ __device__ __forceinline__ float code_lower_bound(int metric, int dot, const Que
 // functions the traversal uses.  One wave per eight rows.
 template <int NCH>
 __global__ __launch_bounds__(kWave) void code_bound_kernel(const float *Q, int dim, int metric, const uint32_t *qrows,
-                                                           const float4 *qmeta, const int32_t *ids, int m, float *out) {
+                                                           const float4 *qmeta, const int32_t *ids, int m, float *out,
+                                                           float *out_ub) {
     const int lane = threadIdx.x;
     float4 q[NCH];
     load_query<NCH>(q, Q, dim, lane);
@@ -918,7 +919,10 @@ __global__ __launch_bounds__(kWave) void code_bound_kernel(const float *Q, int d
     if ((lane & 7) == 0 && j < m) {
         const int32_t rid = ids[j];
         const float4 mt = qmeta[rid];
-        out[j] = code_lower_bound(metric, tot, qc.sc, mt, mt.w);
+        float lb, ub;
+        code_bounds(metric, tot, qc.sc, mt, mt.w, lb, ub);
+        out[j] = lb;
+        if (out_ub) out_ub[j] = ub;  // (the IVF bounds pass derives its thresholds from upper bounds)
     }
 }
 

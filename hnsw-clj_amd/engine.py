@@ -146,6 +146,16 @@ class Index:
         check(lib().hnswgpu_rejection_bounds(self._h, _p(q), _p(ids), len(ids), _p(out)))
         return out
 
+    def distance_bounds(self, q, ids):
+        """(lower, upper) bounds of d(q, row) from the int8 rows: lower <= distance <= upper, NaN = no bound."""
+        q = _f32(q).reshape(-1)
+        if len(q) != self.dim:
+            raise ValueError("query has %d elements, index dim is %d" % (len(q), self.dim))
+        ids = np.ascontiguousarray(ids, np.int32)
+        lb, ub = np.empty(len(ids), np.float32), np.empty(len(ids), np.float32)
+        check(lib().hnswgpu_distance_bounds(self._h, _p(q), _p(ids), len(ids), _p(lb), _p(ub)))
+        return lb, ub
+
     def norms(self):
         out = np.empty(self.n, np.float32)
         check(lib().hnswgpu_norms(self._h, _p(out)))

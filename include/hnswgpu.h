@@ -234,10 +234,17 @@ int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
  * reports for the same pair, NaN where the test abstains -- so the property can be checked from outside.
  * hnswgpu_set_rejection_test: mode 0 = off (no int8 copy is made: saves n * dim bytes; the bounds entry then fails),
  * 1 = launches of at least two queries per CU, where the traversal is bandwidth-bound, and only for dim >= 128 (an int8
- * row of a shorter vector saves no cache line) (default), 2 = every launch, every dim.  The same int8 codes serve the
- * IVF search's bounds pass (batches of 9 queries up to 12 (query, list) pairs per list; every Euclidean batch).
+ * row of a shorter vector saves no cache line) (default), 2 = every launch, every dim.  The same setting decides whether
+ * the IVF lists get their int8 copy for the bounds pass of the list scan (every batch up to 12 (query, list) pairs per
+ * list; every Euclidean batch; k <= 256).
  * HNSWGPU_PREFILTER=<mode> in the environment sets the default of new handles.  Results never depend on the mode. */
 int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out);
+/* The same with the UPPER bounds beside them (out_ub, may be NULL): out_lb[i] <= distance <= out_ub[i].  The IVF search's
+ * bounds pass (hnsw-clj_amd/csrc/stream_kernels.hpp) derives a query's threshold from upper bounds -- k candidates whose
+ * upper bound is at most tau put the k-th nearest distance at or below tau -- and drops candidates whose lower bound is
+ * above it: both sides have to hold for its result to be the full f32 scan's. */
+int hnswgpu_distance_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out_lb,
+                            float *out_ub);
 int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode);
 /* While profiling is on the traversal counts the neighbours it evaluated and the f32 rows it had to fetch for them
  * (everything with the test off): the bytes a search really moved = neighbours * (int8 row + 16 B) + f32_rows * 4 * dim. */

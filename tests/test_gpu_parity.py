@@ -729,17 +729,26 @@ def test_rejection_bounds_never_exceed_the_distance(eng, metric, dim):
     with eng.Index(base, metric) as idx:
         idx.set_rejection_test(2)          # int8 rows whatever the default mode and the dim
         for qi, q in enumerate(queries):
-            lb = idx.rejection_bounds(q, ids)
+            lb, ub = idx.distance_bounds(q, ids)
+            np.testing.assert_array_equal(lb.view(np.uint32), idx.rejection_bounds(q, ids).view(np.uint32))
             d = idx.batch_distances(q, ids)
             ok = ~np.isnan(lb)
             assert np.all(lb[ok] <= d[ok]), "metric %s dim %d query %d: bound above the distance at rows %s" % (
                 metric, dim, qi, np.nonzero(ok & ~(lb <= d))[0][:8])
+            # the UPPER bound sets the IVF bounds pass's threshold (k candidates with ub <= tau put D_k at or below tau):
+            # it may never be below the distance the exact path computes
+            oku = ~np.isnan(ub) & ~np.isnan(d)
+            assert np.all(d[oku] <= ub[oku]), "metric %s dim %d query %d: upper bound below the distance at rows %s" % (
+                metric, dim, qi, np.nonzero(oku & ~(d <= ub))[0][:8])
             assert np.isnan(lb[203]) and np.isnan(lb[204])            # non-finite rows abstain
+            assert not (ub[203] < np.inf) and not (ub[204] < np.inf)  # ... on both sides (NaN or +inf: no threshold from them)
             if qi == 0:                                               # tightness on the well-behaved block
                 qn, vn = np.linalg.norm(q), np.linalg.norm(base[:200], axis=1)
                 scale = {"cosine": 1.0, "dot": qn * vn, "l2": qn + vn}[metric]
                 gap = (d[:200] - lb[:200]) / scale
                 assert ok[:200].all() and gap.max() < 0.04, gap.max()
+                gap_u = (ub[:200] - d[:200]) / scale
+                assert gap_u.max() < 0.04, gap_u.max()
 
 
 @pytest.mark.parametrize("n,dim,nlist,metric", [(6000, 48, 40, 0), (3000, 100, 17, 2), (2500, 32, 12, 1)])
@@ -1018,6 +1027,37 @@ def test_full_size_31k_properties(eng, oracle):
         ii, dd = idx.ivf_search(Q, 10, 24)
         # the list scan (GEMV order) and the brute force (MFMA tile order) sum in different orders
         assert_topk_parity(ii, dd, ei, ed, "ivf(all lists) vs exact")
+
+
+@pytest.mark.parametrize("dist,ef,nsub", [("manifold", 100, 64), ("gaussian", 3200, 24)])
+def test_timed_launch_configurations_against_oracle(eng, oracle, dist, ef, nsub):
+    """The launches bench.py times, under the oracle: bench.make_31k's 31,173 x 768 sets, the graph built on the
+    device, 4,096 held-out queries in ONE launch with the DEFAULT rejection mode -- one wave per query, two f32 rows in
+    flight, the int8 rejection test on (hnsw_search_kernel<3, 2, false, 1, false, false>, the instantiation of the
+    headline) -- at the headline's ef (manifold, 100) and at the ef the gaussian set needs (3200: the large-ef merge).
+    A subsample of the batch: ids, distance bits and both traversal counters equal the oracle's device-order mode; ids and
+    distances agree with its f64 reference-order mode within the north_star's tolerance (ultra_fast.clj:151-212, 346-374)."""
+    import bench
+
+    O = oracle
+    base = bench.make_31k(dist, 42, bench.N31K)
+    Q = bench.make_31k(dist, 43, 4096)
+    with eng.Index(base, "cosine") as idx:
+        idx.set_rejection_test(1)                 # the default of a new handle outside the test processes
+        idx.hnsw_build(bench.M, bench.EFC, 42)
+        g = idx.get_graph()
+        idx.set_profiling(True)
+        idx.rejection_stats(reset=True)
+        ids, d, st = idx.hnsw_search(Q, 10, ef, want_stats=True)
+        f32_rows, neighbours = idx.rejection_stats(reset=True)
+        idx.set_profiling(False)
+        assert 0 < f32_rows < 0.6 * neighbours, "the rejection test did not run on the timed configuration"
+        sub = np.linspace(0, len(Q) - 1, nsub).astype(np.int64)
+        oi, od, ost, _ = O.hnsw_search(base, g, Q[sub], 10, ef=ef, mode=O.MODE_DEV, nthreads=8)
+        assert_exact(ids[sub], d[sub], oi, od, "%s ef %d vs oracle (device order)" % (dist, ef))
+        np.testing.assert_array_equal(st[sub], ost)
+        fi, fd, _, _ = O.hnsw_search(base, g, Q[sub[:16]], 10, ef=ef, nthreads=8)
+        assert_topk_parity(ids[sub[:16]], d[sub[:16]], fi, fd, "%s ef %d vs oracle (f64 reference order)" % (dist, ef))
 
 
 def test_persistence_and_lightning(eng, oracle, tmp_path):
