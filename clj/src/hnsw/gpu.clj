@@ -196,7 +196,15 @@
         idx (create (mapv (fn [nd] [(.id nd) (.vector nd)]) nodes) metric :hnsw)
         levels (mapv #(int (.level %)) nodes)
         up-off (vec (reductions + 0 levels))
-        pad (fn [ids width] (take width (concat (map row-of ids) (repeat -1))))
+        ;; a neighbour id the node map does not hold, or a set larger than the layer's width, is a broken graph: say so
+        ;; here instead of an NPE inside ints-of / a silently truncated HashSet
+        pad (fn [ids width]
+              (let [rows (mapv (fn [id] (or (row-of id)
+                                            (throw (ex-info "neighbour id is not a node of the graph" {:id id}))))
+                               ids)]
+                (when (> (count rows) width)
+                  (throw (ex-info "neighbour set larger than the layer's width (M0 / M)" {:size (count rows) :width width})))
+                (take width (concat rows (repeat -1)))))
         nbrs (fn [nd lv] (seq ^java.util.Set (aget ^objects (.neighbors nd) (int lv))))
         l0 (mapcat #(pad (nbrs % 0) M0) nodes)
         up (mapcat (fn [nd] (mapcat #(pad (nbrs nd %) M) (range 1 (inc (.level nd))))) nodes)

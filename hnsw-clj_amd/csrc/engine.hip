@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <chrono>
 
+#include <thread>
+
 #include "engine.hpp"
 #include "tile_kernels.hpp"
 #include "l2_kernels.hpp"
@@ -700,6 +702,13 @@ int begin_call(hnswgpu_index *idx, hipStream_t st) {
     if (idx->ev_valid && idx->ev_stream != st) HG_HIP(hipStreamWaitEvent(st, idx->ev_last, 0));
     return 0;
 }
+int quiesce(hnswgpu_index *idx, hipStream_t st) {
+    HG_TRY(begin_call(idx, st));
+    HG_HIP(hipStreamSynchronize(st));
+    for (auto &sl : idx->slots)
+        if (sl.st) HG_HIP(hipStreamSynchronize(sl.st));
+    return 0;
+}
 int end_call(hnswgpu_index *idx, hipStream_t st) {
     if (!idx->ev_last) HG_HIP(hipEventCreateWithFlags(&idx->ev_last, hipEventDisableTiming));
     HG_HIP(hipEventRecord(idx->ev_last, st));
@@ -718,20 +727,37 @@ int ensure_pinned(hnswgpu_index *idx, size_t bytes) {
     return 0;
 }
 
-// ---- waiting on one 32-bit word: a short spin, then the kernel's futex (Linux) ------------------------------------
+// ---- waiting on one 32-bit word: a short spin, then the kernel's futex (Linux; elsewhere the spin yields) ----------
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
 static void word_wake(std::atomic<uint32_t> *w) {
+#if defined(__linux__)
     syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+#else
+    (void)w;  // the waiter polls
+#endif
 }
 static uint32_t word_wait_nonzero(std::atomic<uint32_t> *w) {
     for (int i = 0; i < 256; i++) {  // a batch usually answers in a few hundred microseconds: brief spin, then sleep
         const uint32_t v = w->load(std::memory_order_acquire);
         if (v) return v;
-        __builtin_ia32_pause();
+        cpu_relax();
     }
     for (;;) {
         const uint32_t v = w->load(std::memory_order_acquire);
         if (v) return v;
+#if defined(__linux__)
         syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, 0u, nullptr, nullptr, 0);
+#else
+        std::this_thread::yield();
+#endif
     }
 }
 static double now_us() {
@@ -769,7 +795,7 @@ int slot_wait(hnswgpu_index::Slot &s, volatile uint32_t *flag, uint32_t seq) {
     const double t0 = now_us();
     for (uint64_t spins = 0;; spins++) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((spins & 0x3fff) == 0x3fff && now_us() - t0 > 2e6) break;  // 2 s: something is wrong, ask the runtime
     }
     HG_HIP(hipStreamSynchronize(s.st));  // surfaces a kernel fault; a healthy launch has set the flag by now
@@ -820,14 +846,15 @@ int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
             c.slot_waiter = nullptr;
         }
         // ---- linger for the callers on their way back
-        if (c.last > 1) {
-            const double limit = std::min(100.0, std::max(10.0, c.last_run_us * 0.25)), t0 = now_us();
+        const int last_batch = c.last.load(std::memory_order_relaxed);
+        if (last_batch > 1) {
+            const double limit = std::min(100.0, std::max(10.0, c.last_run_us.load(std::memory_order_relaxed) * 0.25)), t0 = now_us();
             int seen = c.npending.load(std::memory_order_acquire);
             double t_change = t0;
-            while (seen < c.last) {
+            while (seen < last_batch) {
                 const double t = now_us();
                 if (t - t0 > limit || (seen > 1 && t - t_change > 10.0)) break;
-                __builtin_ia32_pause();
+                cpu_relax();
                 const int n = c.npending.load(std::memory_order_acquire);
                 if (n != seen) {
                     seen = n;
@@ -864,7 +891,7 @@ int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
             }
             c.npending.store(static_cast<int>(c.pending.size()), std::memory_order_release);
             if (!split_failed) {
-                c.last = static_cast<int>(batch.size());
+                c.last.store(static_cast<int>(batch.size()), std::memory_order_relaxed);
                 c.inflight++;
             }
             // hand the collector role on before running: the next batch forms while this one is on the device
@@ -902,7 +929,7 @@ int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
         {
             std::lock_guard<std::mutex> cl(c.mu);
             c.inflight--;
-            c.last_run_us = now_us() - t_run;
+            c.last_run_us.store(now_us() - t_run, std::memory_order_relaxed);
             waiter = c.slot_waiter;
             c.slot_waiter = nullptr;
         }
@@ -1368,6 +1395,8 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     if (!idx) return 0;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    for (auto &sl : idx->slots)  // before anything a traversal in flight may read is freed
+        if (sl.st) (void)hipStreamSynchronize(sl.st);
     if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows in place: freed once, below
     void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_lcmeta, idx->d_lctile, idx->d_rej_stats, idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
                     idx->d_cent,  idx->d_cnorms, idx->d_lrows,  idx->d_lnorms,  idx->d_listoff, idx->d_listids};
@@ -1582,6 +1611,7 @@ int hnswgpu_merge_keyed_dev(int32_t device, const int32_t *d_ids, const float *d
                             int32_t nshard, int32_t nq, int32_t k, int32_t *d_out_ids, float *d_out_dist, void *stream) {
     HG_REQUIRE(nshard >= 1 && nq >= 0 && k >= 1, HNSWGPU_EINVAL, "bad sizes");
     HG_REQUIRE(k <= 1024, HNSWGPU_ELIMIT, "k > 1024 is not supported");
+    HG_REQUIRE(static_cast<int64_t>(nshard) * k < 2147483647LL, HNSWGPU_ELIMIT, "nshard * k must be below 2^31");
     if (nq == 0) return 0;
     HG_REQUIRE(d_ids && d_dist && d_order && d_out_ids && d_out_dist, HNSWGPU_EINVAL, "null argument");
     HG_HIP(hipSetDevice(device));

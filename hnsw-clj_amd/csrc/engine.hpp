@@ -120,8 +120,9 @@ struct hnswgpu_index {
         int inflight = 0;              // batches launched and not yet answered
         int max_inflight = 1;          // batches that may overlap on the device (own stream + staging each)
         SearchReq *slot_waiter = nullptr;  // the collector, parked until a batch in flight completes
-        int last = 0;                  // requests in the batch launched last
-        double last_run_us = 0.0;      // how long that batch took from launch to results (its callers return after that)
+        // (atomics: a lingering collector reads both while a finishing batch of the other slot writes them)
+        std::atomic<int> last{0};              // requests in the batch launched last
+        std::atomic<double> last_run_us{0.0};  // how long that batch took from launch to results (its callers return after that)
     };
     Combiner cmb_hnsw, cmb_ivf;
     // One batch in flight of the small synchronous searches: its own stream, one block of MAPPED pinned host memory
@@ -147,6 +148,8 @@ struct hnswgpu_index {
 
     // HNSW graph (device + host mirror for export)
     bool has_graph = false;
+    uint64_t graph_gen = 0;  // bumped whenever the graph is replaced: a search in flight on a slot stream notices
+
     int M = 0, M0 = 0, entry = -1, max_level = 0;
     int64_t up_blocks = 0;
     int32_t *d_levels = nullptr, *d_l0 = nullptr, *d_upadj = nullptr;
@@ -293,5 +296,9 @@ int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int
 // call's work on stream A before it may reuse the index's scratch buffers.
 int begin_call(hnswgpu_index *idx, hipStream_t st);
 int end_call(hnswgpu_index *idx, hipStream_t st);
+// Before device memory that searches read is freed (graph, lists, the handle itself): wait, under idx->mu, for the
+// main stream AND for the two slot streams -- the small synchronous searches launch on those without begin_call /
+// end_call and release idx->mu before their kernel has finished.
+int quiesce(hnswgpu_index *idx, hipStream_t st);
 
 }  // namespace hg

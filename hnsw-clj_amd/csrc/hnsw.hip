@@ -89,13 +89,20 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
         const size_t mail_bytes = sizeof(uint32_t) * kPfMailWords * kPfMaxQueries;
         const size_t res_bytes = sizeof(unsigned long long) * kPfMaxQueries * kPfRing * kMaxDeg;
         const size_t region = mail_bytes + res_bytes;
+        // (both zero fills are waited for: the other slot's launch runs on ITS stream and would otherwise see the old bytes
+        // -- harmless for results, the words are tagged, but its helpers would poll until their timeout; once per handle
+        // and once per 2^24 launches)
         if (idx->s_pf.cap < 4 * region) {
             HG_TRY(idx->s_pf.ensure(4 * region));
             HG_HIP(hipMemsetAsync(idx->s_pf.p, 0, idx->s_pf.cap, st));
+            HG_HIP(hipStreamSynchronize(st));
         }
         idx->pf_seq = (idx->pf_seq + 1) & 0xffffff;
         if (idx->pf_seq == 0) {  // the launch numbers start over: no tag of the previous cycle may survive
+            for (auto &sl : idx->slots)
+                if (sl.st) HG_HIP(hipStreamSynchronize(sl.st));
             HG_HIP(hipMemsetAsync(idx->s_pf.p, 0, idx->s_pf.cap, st));
+            HG_HIP(hipStreamSynchronize(st));
             idx->pf_seq = 1;
         }
         a.pf_seq = idx->pf_seq;
@@ -201,6 +208,7 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
 }
 
 static void free_graph(hnswgpu_index *idx) {
+    idx->graph_gen++;  // searches in flight on a slot stream compare it before their repeat pass
     void *ptrs[] = {idx->d_levels, idx->d_l0, idx->d_upadj, idx->d_upoff};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -598,10 +606,10 @@ int hnswgpu_set_graph(hnswgpu_index *idx, const int32_t *levels, const int32_t *
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
-    // every earlier call on this handle is ordered before `st` by begin_call: once `st` is idle nothing can still be
-    // traversing the graph that is about to be freed (and no other handle on this GPU is stalled)
-    HG_TRY(begin_call(idx, st));
-    HG_HIP(hipStreamSynchronize(st));
+    // every earlier call on this handle is ordered before `st` by begin_call, except the small synchronous searches on
+    // the slot streams: once `st` and both slot streams are idle nothing can still be traversing the graph that is about
+    // to be freed (and no other handle on this GPU is stalled)
+    HG_TRY(quiesce(idx, st));
     free_graph(idx);
     HG_TRY(alloc_graph(idx, M, M0, blocks));
     HG_TRY(ensure_qrows(idx, st));
@@ -709,16 +717,22 @@ static int hnsw_search_batch_slot(hnswgpu_index *idx, const std::vector<hnswgpu_
     sig.host_again = reinterpret_cast<int32_t *>(dp + 4);
     sig.flag_val = ++slot->seq;
     volatile uint32_t *h_flag = reinterpret_cast<volatile uint32_t *>(hp);
+    uint64_t gen;
     {
         std::lock_guard<std::mutex> lk(idx->mu);  // the index state is read (and the launch enqueued) under its lock
         HG_REQUIRE(idx->has_graph && idx->n > 0, HNSWGPU_ESTATE, "index has no graph (call hnswgpu_hnsw_build / hnswgpu_set_graph)");
+        gen = idx->graph_gen;
         HG_TRY(search_enqueue(idx, reinterpret_cast<const float *>(dp + o_q), total, k, ef, reinterpret_cast<int32_t *>(dp + o_i),
                               reinterpret_cast<float *>(dp + o_d), reinterpret_cast<int64_t *>(dp + o_s), slot->st, &sig));
     }
     HG_TRY(slot_wait(*slot, h_flag, sig.flag_val));
     if (*reinterpret_cast<volatile int32_t *>(hp + 4) != 0) {
-        // some query met more tied candidates than the ghost slots hold (hundreds of duplicated rows): the repeat pass
+        // some query met more tied candidates than the ghost slots hold (hundreds of duplicated rows): the repeat pass --
+        // against the graph the first pass ran on, or not at all (set_graph / hnsw_build wait for this slot's stream
+        // before they free the old graph, but may have installed a new one since the first pass finished)
         std::lock_guard<std::mutex> lk(idx->mu);
+        HG_REQUIRE(idx->has_graph && idx->graph_gen == gen, HNSWGPU_ESTATE,
+                   "the graph was replaced while a search on it was in flight");
         HG_TRY(search_enqueue(idx, reinterpret_cast<const float *>(dp + o_q), total, k, ef, reinterpret_cast<int32_t *>(dp + o_i),
                               reinterpret_cast<float *>(dp + o_d), reinterpret_cast<int64_t *>(dp + o_s), slot->st, &sig, true));
         HG_HIP(hipStreamSynchronize(slot->st));
@@ -869,8 +883,7 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
         }
     }
     const int64_t blocks = n > 0 ? g.up_off[n] : 0;
-    HG_TRY(begin_call(idx, st));
-    HG_HIP(hipStreamSynchronize(st));  // as in hnswgpu_set_graph
+    HG_TRY(quiesce(idx, st));  // as in hnswgpu_set_graph
     free_graph(idx);
     HG_TRY(alloc_graph(idx, M, M0, blocks));
     HG_TRY(ensure_qrows(idx, st));

@@ -1124,10 +1124,10 @@ static int set_ivf_impl(hnswgpu_index *idx, const float *centroids, int32_t nlis
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
-    // every earlier call on this handle is ordered before `st` by begin_call: waiting for `st` alone retires all work
-    // that may still read the lists about to be freed (no device-wide synchronisation: other handles keep running)
-    HG_TRY(begin_call(idx, st));
-    HG_HIP(hipStreamSynchronize(st));
+    // every earlier call on this handle is ordered before `st` by begin_call (the small HNSW searches on the slot streams
+    // are waited for as well: lists that alias the base rows share them with the traversal): nothing can still read the
+    // lists about to be freed (no device-wide synchronisation: other handles keep running)
+    HG_TRY(quiesce(idx, st));
     free_ivf(idx);
     HG_TRY(alloc_centroids(idx, nlist));
     HG_HIP(hipMemsetAsync(idx->d_cent, 0, sizeof(float) * nlist * idx->ld, st));
@@ -1258,8 +1258,7 @@ int hnswgpu_ivf_build(hnswgpu_index *idx, int32_t nlist, int32_t max_iter, int64
     HG_HIP(hipSetDevice(idx->device));
     hipStream_t st = idx->stream;
     const int64_t n = idx->n;
-    HG_TRY(begin_call(idx, st));
-    HG_HIP(hipStreamSynchronize(st));  // see set_ivf_impl: retires every earlier call on this handle, and only those
+    HG_TRY(quiesce(idx, st));  // see set_ivf_impl: retires every earlier call on this handle, and only those
     free_ivf(idx);
     std::vector<int32_t> chosen;
     HG_TRY(kmeanspp_device(idx, nlist, seed, chosen, st));

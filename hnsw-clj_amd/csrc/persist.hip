@@ -7,12 +7,15 @@
 //   ivf       centroids[nlist * dim] float32, list_off[nlist + 1] int64, list_ids[n] int32
 // The String-id table stays with the caller (the Python mirror writes it next to this file).
 #include <stdio.h>
+#include <unistd.h>
 #include <string.h>
 
 #include <exception>
 #include <memory>
 #include <new>
 #include <string>
+
+#include <atomic>
 
 #include "engine.hpp"
 
@@ -112,12 +115,19 @@ extern "C" {
 int hnswgpu_save(hnswgpu_index *idx, const char *path) {
     HG_REQUIRE(idx && path, HNSWGPU_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
+    // a shard of a larger IVF index (hnswgpu_set_ivf_shard) numbers its candidates by the WHOLE index's list lengths, which
+    // the file format does not carry: loaded back it would silently be an ordinary index with another tie order
+    HG_REQUIRE(idx->h_glistlen.empty(), HNSWGPU_ESTATE,
+               "this handle holds a shard of a larger IVF index (hnswgpu_set_ivf_shard): save the whole index instead");
     HG_HIP(hipSetDevice(idx->device));
-    // written beside the target and renamed over it once complete and closed: a reader never sees half a file, and a
-    // failed save leaves the previous index file untouched
+    // written beside the target -- under a name of this process's and this call's own: two savers of one path never share
+    // a temporary -- flushed to the disk, and renamed over the target once complete and closed: a reader never sees half a
+    // file, a crash never leaves a renamed file with missing contents, a failed save leaves the previous file untouched
+    static std::atomic<unsigned> save_ctr{0};
     std::string tmp;
     try {
-        tmp = std::string(path) + ".tmp";
+        tmp = std::string(path) + "." + std::to_string(static_cast<long long>(getpid())) + "." +
+              std::to_string(save_ctr.fetch_add(1)) + ".tmp";
     } catch (...) {
         set_error("host allocation failed");
         return HNSWGPU_ENOMEM;
@@ -130,6 +140,10 @@ int hnswgpu_save(hnswgpu_index *idx, const char *path) {
     } catch (const std::bad_alloc &) {
         set_error("host allocation failed while saving the index");
         rc = HNSWGPU_ENOMEM;
+    }
+    if (rc == 0 && (fflush(f) != 0 || fsync(fileno(f)) != 0)) {
+        set_error("flushing %s to the disk failed", tmp.c_str());
+        rc = HNSWGPU_EINVAL;
     }
     if (fclose(f) != 0 && rc == 0) {
         set_error("closing %s failed (disk full?)", tmp.c_str());

@@ -123,7 +123,7 @@ def test_sharded_ivf_class_single_rank_equals_ivf_build(eng, oracle):
     sh.close()
 
 
-def test_set_ivf_shard_rejects_bad_lengths(eng, oracle):
+def test_set_ivf_shard_rejects_bad_lengths(eng, oracle, tmp_path):
     base = oracle.generate_dataset(100, 8).astype(np.float32)
     cen = base[:4].copy()
     off = np.array([0, 25, 50, 75, 100], np.int64)
@@ -133,6 +133,9 @@ def test_set_ivf_shard_rejects_bad_lengths(eng, oracle):
         idx.set_ivf_shard(cen, off, np.arange(100, dtype=np.int32), np.array([25, 30, 25, 1000], np.int64))
         ids, d = idx.ivf_search(base[:3], 5, 4)
         assert (ids[:, 0] == np.arange(3)).all()
+        # the file format does not carry the whole index's list lengths: a shard refuses to be saved as if it were one
+        with pytest.raises(Exception, match="shard"):
+            idx.save(str(tmp_path / "shard.bin"))
 
 
 @pytest.mark.parametrize("metric", ["cosine", "l2"])
