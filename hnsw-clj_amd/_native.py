@@ -81,10 +81,17 @@ _SIGS = {
     "hnswgpu_distance_bounds": ["p", "p", "p", "i32", "p", "p"],
     "hnswgpu_set_rejection_test": ["p", "i32"],
     "hnswgpu_get_rejection_stats": ["p", "p", "p", "i32"],
+    "hnswgpu_group_create": ["p", "i32", "i32", "i32", "p"],
+    "hnswgpu_group_destroy": ["p"],
+    "hnswgpu_group_info": ["p", "p", "p", "p", "p"],
+    "hnswgpu_group_set_ivf": ["p", "p", "i64", "p", "i32", "p", "p"],
+    "hnswgpu_group_ivf_search": ["p", "p", "i32", "i32", "i32", "p", "p"],
+    "hnswgpu_group_hnsw_build": ["p", "p", "i64", "i32", "i32", "i64"],
+    "hnswgpu_group_hnsw_search": ["p", "p", "i32", "i32", "i32", "p", "p"],
 }
 _T = {"p": C.c_void_p, "i32": C.c_int32, "i64": C.c_int64}
 
-EXPORTS = sorted(list(_SIGS) + ["hnswgpu_last_error"])
+EXPORTS = sorted(list(_SIGS) + ["hnswgpu_last_error", "hnswgpu_group_member"])
 
 
 def lib():
@@ -108,6 +115,8 @@ def lib():
         fn.argtypes = [_T[a] for a in args]
     L.hnswgpu_last_error.restype = C.c_char_p
     L.hnswgpu_last_error.argtypes = []
+    L.hnswgpu_group_member.restype = C.c_void_p
+    L.hnswgpu_group_member.argtypes = [C.c_void_p, C.c_int32]
     _lib = L
     return L
 

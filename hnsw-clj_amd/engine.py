@@ -421,3 +421,79 @@ def merge_lists_dev(ids, dist, k, out=None):
 
 
 device_count = _native.device_count
+
+
+class Group:
+    """ONE index over several GPUs behind the C ABI (include/hnswgpu.h: hnswgpu_group_*): whole inverted lists of an
+    IVF-FLAT index dealt to the devices, or one HNSW sub-graph per device -- the reference's search-partitioned
+    (partitioned_hnsw.clj:149-196) as one call.  `devices` may name a GPU several times."""
+
+    def __init__(self, devices, dim, metric="cosine"):
+        self.devices = np.ascontiguousarray(devices, np.int32)
+        self.dim = int(dim)
+        self.metric = METRICS[metric]
+        self._h = C.c_void_p(None)
+        check(lib().hnswgpu_group_create(_p(self.devices), len(self.devices), self.dim, self.metric, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            check(lib().hnswgpu_group_destroy(self._h))
+            self._h = C.c_void_p(None)
+
+    __enter__ = lambda self: self  # noqa: E731
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def info(self):
+        nd, n, kind = C.c_int32(0), C.c_int64(0), C.c_int32(0)
+        rows = np.zeros(len(self.devices), np.int64)
+        check(lib().hnswgpu_group_info(self._h, C.byref(nd), C.byref(n), C.byref(kind), _p(rows)))
+        return {"devices": nd.value, "n": n.value, "kind": {0: None, 1: "ivf", 2: "hnsw"}[kind.value], "rows_per_device": rows}
+
+    def set_ivf(self, base, centroids, list_off, list_ids):
+        base = _queries(base, self.dim)
+        centroids = _queries(centroids, self.dim)
+        list_off = np.ascontiguousarray(list_off, np.int64)
+        list_ids = np.ascontiguousarray(list_ids, np.int32)
+        if len(list_off) != len(centroids) + 1 or len(list_ids) != len(base):
+            raise ValueError("list_off must have nlist + 1 entries and list_ids one per base row")
+        check(lib().hnswgpu_group_set_ivf(self._h, _p(base), len(base), _p(centroids), len(centroids), _p(list_off), _p(list_ids)))
+
+    def hnsw_build(self, base, M=16, ef_construction=200, seed=42):
+        base = _queries(base, self.dim)
+        check(lib().hnswgpu_group_hnsw_build(self._h, _p(base), len(base), int(M), int(ef_construction), int(seed)))
+
+    def _search(self, fn, Q, k, param):
+        Q = _queries(Q, self.dim)
+        ids = np.empty((len(Q), k), np.int32)
+        d = np.empty((len(Q), k), np.float32)
+        check(fn(self._h, _p(Q), len(Q), int(k), int(param), _p(ids), _p(d)))
+        return ids, d
+
+    def ivf_search(self, Q, k, nprobe):
+        return self._search(lib().hnswgpu_group_ivf_search, Q, k, nprobe)
+
+    def hnsw_search(self, Q, k, ef):
+        return self._search(lib().hnswgpu_group_hnsw_search, Q, k, ef)
+
+    def member_graph(self, i):
+        """The sub-graph device i holds (export: get_graph of that sub-index)."""
+        h = lib().hnswgpu_group_member(self._h, int(i))
+        if not h:
+            raise IndexError(i)
+        ix = Index.__new__(Index)
+        ix._h = C.c_void_p(h)
+        ix._borrowed = True
+        nn, dim, metric, hg, nl = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(lib().hnswgpu_info(ix._h, C.byref(nn), C.byref(dim), C.byref(metric), C.byref(hg), C.byref(nl)))
+        ix.n, ix.dim, ix.metric, ix.device = nn.value, dim.value, metric.value, int(self.devices[i])
+        g = ix.get_graph()
+        ix._h = C.c_void_p(None)   # borrowed: never destroyed from here
+        return g

@@ -251,6 +251,36 @@ int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode);
 int hnswgpu_get_rejection_stats(hnswgpu_index *idx, int64_t *f32_rows, int64_t *neighbours, int32_t reset);
 int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int64_t *launches, int32_t reset);
 
+/* ---- ONE index over several GPUs (hnsw-clj_amd/csrc/group.hip) ---------------------------------------------------
+ * The reference shards inside one process: search-partitioned scatters a query to its partitions, takes a top-k per
+ * partition, concatenates, sorts and takes k (src/hnsw/ann/partition/partitioned_hnsw.clj:149-196).  A group gives the
+ * JVM host the same from one call: it owns one engine handle per device and every device works on its own stream.
+ *   hnswgpu_group_create: `devices` = the GPUs of the group (one GPU may be named several times: several handles on it).
+ *   hnswgpu_group_set_ivf: ONE IVF-FLAT index (base rows, centroids, lists as for hnswgpu_set_ivf) -- centroids
+ *     replicated, whole inverted lists dealt to the devices balanced by row count (longest list first onto the least
+ *     loaded device), every device routes a batch identically and scans the probed lists it holds.
+ *   hnswgpu_group_ivf_search: the per-device top-k lists are moved to devices[0] by peer copies (nq * k * 12 bytes per
+ *     device, xGMI between GPUs) and merged by (distance, position in the candidate stream of the WHOLE index): ids,
+ *     distances and tie order are bit for bit those of hnswgpu_ivf_search on the unsharded index (ivf_flat.clj:291-294).
+ *   hnswgpu_group_hnsw_build / _hnsw_search: contiguous row ranges, one independent sub-graph per device
+ *     (= PartitionedHNSWIndex, partitioned_hnsw.clj:23-27), each searched with the full k; merge by distance, ties to the
+ *     lower device (the reference's stable sort of the concatenation).
+ *   hnswgpu_group_member: the sub-index device i holds (info / export; do not destroy it).
+ * Row ids in and out are rows of the caller's base matrix.  Calls on one group are serialised. */
+typedef struct hnswgpu_group hnswgpu_group;
+int hnswgpu_group_create(const int32_t *devices, int32_t ndev, int32_t dim, int32_t metric, hnswgpu_group **out);
+int hnswgpu_group_destroy(hnswgpu_group *g);
+int hnswgpu_group_info(const hnswgpu_group *g, int32_t *ndev, int64_t *n, int32_t *kind, int64_t *rows_per_device);
+int hnswgpu_group_set_ivf(hnswgpu_group *g, const float *base, int64_t n, const float *centroids, int32_t nlist,
+                          const int64_t *list_off, const int32_t *list_ids);
+int hnswgpu_group_ivf_search(hnswgpu_group *g, const float *Q, int32_t nq, int32_t k, int32_t nprobe, int32_t *out_ids,
+                             float *out_dist);
+int hnswgpu_group_hnsw_build(hnswgpu_group *g, const float *base, int64_t n, int32_t M, int32_t ef_construction,
+                             int64_t seed);
+int hnswgpu_group_hnsw_search(hnswgpu_group *g, const float *Q, int32_t nq, int32_t k, int32_t ef, int32_t *out_ids,
+                              float *out_dist);
+hnswgpu_index *hnswgpu_group_member(hnswgpu_group *g, int32_t i);
+
 #ifdef __cplusplus
 }
 #endif

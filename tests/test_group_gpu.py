@@ -1,0 +1,103 @@
+"""GPU tests of the multi-GPU group behind the C ABI (include/hnswgpu.h: hnswgpu_group_*) on ONE GPU: `devices` names
+GPU 0 several times, so the group holds several engine handles on the card -- the per-device searches on their own
+streams, the peer copies of the partial lists and the merge on the first device are the product's code as it runs on
+an 8-GPU node.  The bar: group == unsharded == oracle, ids and distance bits, tie order included.
+
+Reference: scatter / per-partition top-k / gather / sort / take k, src/hnsw/ann/partition/partitioned_hnsw.clj:149-196;
+probed-list scan and merge, src/hnsw/ann/partition/ivf_flat.clj:261-294."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from util import assert_exact  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(native_lib):
+    from hnsw_clj_amd import engine
+
+    assert engine.device_count() >= 1, "no GPU visible"
+    return engine
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
+@pytest.mark.parametrize("ndev", [1, 3, 8])
+def test_group_ivf_equals_unsharded_and_oracle(eng, oracle, metric, ndev):
+    """ONE IVF-FLAT index over `ndev` handles: lists dealt by row count, every handle scans the probed lists it holds,
+    partial top-k lists merged on the first device by (distance, position in the whole index's candidate stream)."""
+    O = oracle
+    m = O.METRICS[metric]
+    n, dim, nlist, nprobe, k = 30_000, 96, 64, 6, 10
+    base = O.generate_dataset(n, dim, "clustered", num_clusters=20, noise_level=0.5).astype(np.float32)
+    base[5000:5040] = base[3]                 # exact ties that land in different lists' neighbourhoods
+    base[20000:20020, 1:] = base[3, 1:]
+    Q = np.concatenate([O.generate_dataset(70, dim, "clustered", num_clusters=20, noise_level=0.5, seed=43), base[3:4]]).astype(np.float32)
+    with eng.Index(base, metric) as full:
+        full.ivf_build(nlist, 4, 42)
+        cen, off, lids = full.get_ivf()
+        with eng.Group([0] * ndev, dim, metric) as g:
+            g.set_ivf(base, cen, off, lids)
+            info = g.info()
+            assert info["kind"] == "ivf" and info["n"] == n and info["rows_per_device"].sum() == n
+            if ndev > 1:
+                assert info["rows_per_device"].max() - info["rows_per_device"].min() <= np.diff(off).max()   # balanced by rows
+            for nq in (1, 9, len(Q)):
+                gi, gd = g.ivf_search(Q[:nq], k, nprobe)
+                ui, ud = full.ivf_search(Q[:nq], k, nprobe)
+                np.testing.assert_array_equal(gi, ui)
+                np.testing.assert_array_equal(gd.view(np.uint32), ud.view(np.uint32))
+                mode = O.MODE_MFMA if (m != O.L2 and nq * nprobe > 12 * nlist) else O.MODE_DEV
+                oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=m, mode=mode)
+                assert_exact(gi, gd, oi, od, "group ivf %s ndev=%d nq=%d" % (metric, ndev, nq))
+            with pytest.raises(Exception, match="HNSW"):
+                g.hnsw_search(Q[:2], k, 50)
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_group_hnsw_equals_oracle_merge(eng, oracle, metric):
+    """One HNSW sub-graph per handle over contiguous row ranges, each searched with the full k, merged by distance with
+    ties to the lower handle: equal to the oracle searching every exported sub-graph and stable-sorting the
+    concatenation (partitioned_hnsw.clj:171-196)."""
+    O = oracle
+    m = O.METRICS[metric]
+    n, dim, ndev, k, ef = 9000, 64, 3, 10, 80
+    base = O.generate_dataset(n, dim).astype(np.float32)
+    base[7000:7010] = base[11]                # ties across sub-graphs
+    Q = np.concatenate([O.generate_dataset(40, dim, seed=43), base[11:12]]).astype(np.float32)
+    with eng.Group([0] * ndev, dim, metric) as g:
+        g.hnsw_build(base, 16, 100, 42)
+        info = g.info()
+        assert info["kind"] == "hnsw" and list(info["rows_per_device"]) == [3000, 3000, 3000]
+        gi, gd = g.hnsw_search(Q, k, ef)
+        parts_i, parts_d = [], []
+        for r in range(ndev):
+            r0 = n * r // ndev
+            r1 = n * (r + 1) // ndev
+            gr = g.member_graph(r)
+            oi, od, _, _ = O.hnsw_search(base[r0:r1], gr, Q, k, ef=ef, metric=m, mode=O.MODE_DEV)
+            parts_i.append(np.where(oi >= 0, oi + r0, oi))
+            parts_d.append(od.astype(np.float32))
+        ci, cd = np.concatenate(parts_i, axis=1), np.concatenate(parts_d, axis=1)
+        cd = np.where(ci >= 0, cd, np.inf)
+        order = np.argsort(cd, axis=1, kind="stable")[:, :k]
+        wi, wd = np.take_along_axis(ci, order, 1), np.take_along_axis(cd, order, 1)
+        np.testing.assert_array_equal(gi, wi)
+        np.testing.assert_array_equal(gd.view(np.uint32), wd.view(np.uint32))
+
+
+def test_group_from_plain_c(native_lib, tmp_path):
+    """examples/group_demo.c: the group API used the way a JNI / Panama binding uses it -- from C, without Python in
+    the process: an IVF index built on one handle, served by a group of four, the two answers compared bit for bit."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "group_demo")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "group_demo.c"),
+                           "-L" + native_lib.PKG, "-lhnswgpu", "-Wl,-rpath," + native_lib.PKG, "-lm", "-o", exe])
+    out = subprocess.run([exe, "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "group_demo ok" in out.stdout
