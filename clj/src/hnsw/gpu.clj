@@ -264,6 +264,71 @@
 (defn close! [idx]
   (check (.invokeWithArguments ^MethodHandle @h-destroy [(:handle idx)])))
 
+;; ===== ONE index over several GPUs (include/hnswgpu.h: hnswgpu_group_*) =====
+;; search-partitioned's scatter / per-partition top-k / gather / sort / take k (src/hnsw/ann/partition/
+;; partitioned_hnsw.clj:149-196) as one native call: the group owns one engine handle per GPU.
+
+(def ^:private h-gcreate  (delay (fn-handle "hnswgpu_group_create" (FunctionDescriptor/of I (into-array [P I I I P])))))
+(def ^:private h-gdestroy (delay (fn-handle "hnswgpu_group_destroy" (FunctionDescriptor/of I (into-array [P])))))
+(def ^:private h-gsetivf  (delay (fn-handle "hnswgpu_group_set_ivf" (FunctionDescriptor/of I (into-array [P P L P I P P])))))
+(def ^:private h-givf     (delay (fn-handle "hnswgpu_group_ivf_search" (FunctionDescriptor/of I (into-array [P P I I I P P])))))
+(def ^:private h-gbuild   (delay (fn-handle "hnswgpu_group_hnsw_build" (FunctionDescriptor/of I (into-array [P P L I I L])))))
+(def ^:private h-ghnsw    (delay (fn-handle "hnswgpu_group_hnsw_search" (FunctionDescriptor/of I (into-array [P P I I I P P])))))
+
+(defrecord GpuGroup [handle ids dim kind devices])
+
+(defn- group-create [devices dim metric]
+  (with-open [arena (Arena/ofConfined)]
+    (let [out (.allocate arena 8 8)]
+      (check (.invokeWithArguments ^MethodHandle @h-gcreate
+                                   [(ints-of arena devices) (int (count devices)) (int dim) (int (metric-of metric 0)) out]))
+      (.get out P 0))))
+
+(defn build-partitioned-index
+  "hnsw.ann.partition.partitioned-hnsw/build-partitioned-hnsw (partitioned_hnsw.clj:46-143) across GPUs: contiguous row
+   ranges, one HNSW sub-graph per device of `devices` (e.g. (range 8)), built on the devices."
+  [data devices & {:keys [M ef-construction metric seed] :or {M 16 ef-construction 200 metric :cosine seed 42}}]
+  (with-open [arena (Arena/ofConfined)]
+    (let [ids (mapv first data)
+          vecs (mapv second data)
+          dim (alength ^doubles (first vecs))
+          h (group-create (vec devices) dim metric)]
+      (check (.invokeWithArguments ^MethodHandle @h-gbuild
+                                   [h (floats-of arena vecs dim) (long (count ids)) (int M) (int ef-construction) (long seed)]))
+      (->GpuGroup h ids dim :hnsw (vec devices)))))
+
+(defn group-from-ivf-flat-index
+  "An IVFFlatIndex (the reference's own k-means, ivf_flat.clj:137-211) served by several GPUs: centroids replicated, whole
+   inverted lists dealt to the devices by row count.  Answers equal the one-GPU index's bit for bit."
+  [ivf devices & {:keys [metric] :or {metric :cosine}}]
+  (with-open [arena (Arena/ofConfined)]
+    (let [parts (:partitions ivf)
+          rows (vec (mapcat identity parts))
+          dim (alength ^doubles (second (first rows)))
+          off (vec (reductions + 0 (map count parts)))
+          h (group-create (vec devices) dim metric)]
+      (check (.invokeWithArguments ^MethodHandle @h-gsetivf
+                                   [h (floats-of arena (mapv second rows) dim) (long (count rows))
+                                    (floats-of arena (vec (:centroids ivf)) dim) (int (count parts))
+                                    (longs-of arena off) (ints-of arena (range (count rows)))]))
+      (->GpuGroup h (mapv first rows) dim :ivf (vec devices)))))
+
+(defn search-group-batch
+  "All queries in one call over all devices -> vector of result vectors.  :ivf groups take :num-probes, :hnsw groups :ef."
+  [grp queries k & {:keys [num-probes ef] :or {num-probes 4 ef 50}}]
+  (with-open [arena (Arena/ofConfined)]
+    (let [nq (count queries)
+          q (floats-of arena (vec queries) (:dim grp))
+          ids (.allocate arena (* 4 nq k) 4)
+          ds (.allocate arena (* 4 nq k) 4)
+          ivf? (= :ivf (:kind grp))]
+      (check (.invokeWithArguments ^MethodHandle (if ivf? @h-givf @h-ghnsw)
+                                   [(:handle grp) q (int nq) (int k) (int (if ivf? num-probes (max ef k))) ids ds]))
+      (mapv #(results grp ids ds % k) (range nq)))))
+
+(defn close-group! [grp]
+  (check (.invokeWithArguments ^MethodHandle @h-gdestroy [(:handle grp)])))
+
 ;; ===== first-class index next to the reference's own records (src/hnsw/api/unified.clj:30-95) =====
 
 (def ^:private mode->probes {:turbo 1 :fast 2 :balanced 4 :accurate 8 :precise 12})   ; ivf_flat.clj:243-247
