@@ -16,6 +16,7 @@
      (search-ivf-batch index queries k & {:keys [num-probes]})
      (batch-distances index query-vec)                               ; simd-optimized/batch-cosine-distances
      (top-k-distances index query-vec k)                             ; simd-optimized/top-k-distances
+     (add-vector! index new-data)                                    ; hnsw.api/add-vector!, insert-single on a live index
      (from-ultra-graph graph)                                        ; a graph built by the reference's own insert-single
      (from-ivf-flat-index ivf)                                       ; an IVFFlatIndex built by the reference's own k-means
      (save idx path) / (load-index path ids)                         ; helper/index-io save-index / load-index
@@ -88,6 +89,19 @@
   (let [idx (create data metric :hnsw)]
     (check (.invokeWithArguments ^MethodHandle @h-build [(:handle idx) (int M) (int ef-construction) (long seed)]))
     idx))
+
+(def ^:private h-add (delay (fn-handle "hnswgpu_hnsw_add" (FunctionDescriptor/of I (into-array [P P L I L])))))
+
+(defn add-vector!
+  "hnsw.api/add-vector! (src/hnsw/api.clj:30-33) / ultra-fast insert-single (src/hnsw/ultra_fast.clj:216-275) on a live
+   GpuIndex: the new [id ^doubles vector] pairs join the base matrix and the graph; returns the index with their ids
+   appended (a GpuIndex is a value: keep the returned one).  One call per batch of new vectors is the efficient shape."
+  [idx new-data & {:keys [ef-construction seed] :or {ef-construction 200 seed 42}}]
+  (with-open [arena (Arena/ofConfined)]
+    (check (.invokeWithArguments ^MethodHandle @h-add
+                                 [(:handle idx) (floats-of arena (mapv second new-data) (:dim idx)) (long (count new-data))
+                                  (int ef-construction) (long seed)])))
+  (update idx :ids into (map first new-data)))
 
 (defn- results [idx ^MemorySegment ids ^MemorySegment ds q k]
   (vec (for [i (range k)

@@ -847,69 +847,69 @@ int hnswgpu_hnsw_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t 
         });
 }
 
-// build-index / insert-batch (ultra_fast.clj:303-344) as batched insertion: every node of a batch
-// runs the reference's per-level search (search-layer-ultra with ef-construction at layer 0 and 1
-// above, :250-251) on the GPU against the graph as it stood when the batch started, then the
-// host links the batch in row order (:255-266) and prunes over-full lists (:279-299).
-// Level draw: floor(ml * -ln U), ml = 1/ln 2 (:133,:143-147), U from java.util.Random(seed).
-// Differences from the reference's sequential insert-single, stated in DESIGN.md: nodes of one
-// batch do not see each other (batches grow from 1 to at most 1/8 of the graph, capped); the walk
-// starts at the top layer with ef = 1 instead of at min(level, entry-level) (:247-248); each node
-// links to its m CLOSEST candidates (the reference's `(take m candidates)` takes PriorityQueue
-// array order, which is unspecified).
-int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, int64_t seed) {
-    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
-    HG_REQUIRE(M >= 1 && 2 * M <= kMaxDeg, HNSWGPU_ELIMIT, "need 1 <= M <= %d", kMaxDeg / 2);
-    HG_REQUIRE(ef_construction >= 1 && ef_construction <= 4096, HNSWGPU_ELIMIT, "need 1 <= ef_construction <= 4096");
-    std::lock_guard<std::mutex> lk(idx->mu);
-    HG_HIP(hipSetDevice(idx->device));
-    hipStream_t st = idx->stream;
-    const int64_t n = idx->n;
-    const int M0 = 2 * M;
-    HostGraph g;
-    g.n = n;
-    g.M = M;
-    g.M0 = M0;
-    g.levels.resize(n);
-    g.up_off.assign(n + 1, 0);
-    {
-        JavaRandom rng(seed);
-        const double ml = 1.0 / log(2.0);
-        for (int64_t i = 0; i < n; i++) {
-            double u = rng.next_double();
-            int lv = u > 0.0 ? static_cast<int>(ml * (-log(u))) : 30;
-            g.levels[i] = std::min(lv, 30);
-            g.up_off[i + 1] = g.up_off[i] + g.levels[i];
+}  // extern "C"
+
+namespace hg {
+
+// Distances of the edges of `nlists` adjacency lists (list t belongs to node owner[t], `width` slots, -1 padded), by the
+// traversal's own arithmetic: d(node, neighbour) carries the bits the build-mode search reported for that edge (the lane
+// sums are symmetric in their two operands).  One wave per list.  insert-single prunes an over-full list by the stored
+// edge distances (ultra_fast.clj:279-299); a graph that arrives through hnswgpu_set_graph / hnswgpu_load has none.
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void edge_dist_kernel(const float *rows, const float *norms, int64_t ld, int dim, int metric,
+                                                        const int32_t *owner, const int32_t *adj, int width, int64_t nlists,
+                                                        float *out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * kNWave + (threadIdx.x >> 6);
+    if (t >= nlists) return;
+    const int64_t node = owner ? owner[t] : t;
+    const int nvec = static_cast<int>(ld / 4);
+    float4 q[NCH];
+    load_row<NCH>(q, rows + node * ld, nvec, lane, true);
+    const float qn = metric == METRIC_COS ? norms[node] : 0.0f;
+    for (int j0 = 0; j0 < width; j0 += RB) {
+        float4 r[RB][NCH];
+        int32_t nb[RB];
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            nb[b] = j0 + b < width ? adj[t * width + j0 + b] : -1;
+            load_row<NCH>(r[b], rows + static_cast<int64_t>(nb[b] >= 0 ? nb[b] : 0) * ld, nvec, lane, nb[b] >= 0);
+        }
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            const float sum = wave_sum(lane_partial<NCH, L2>(q, r[b]));
+            if (lane == 0 && j0 + b < width)
+                out[t * width + j0 + b] = nb[b] >= 0 ? finish_dist(metric, sum, qn, metric == METRIC_COS ? norms[nb[b]] : 0.0f) : 0.0f;
         }
     }
-    const int64_t blocks = n > 0 ? g.up_off[n] : 0;
-    HG_TRY(quiesce(idx, st));  // as in hnswgpu_set_graph
-    free_graph(idx);
-    HG_TRY(alloc_graph(idx, M, M0, blocks));
-    HG_TRY(ensure_qrows(idx, st));
-    if (n == 0) {
-        idx->h_levels.clear();
-        idx->h_l0.clear();
-        idx->h_upoff.assign(1, 0);
-        idx->h_upadj.clear();
-        idx->entry = -1;
-        idx->max_level = 0;
-        idx->has_graph = true;
-        return 0;
-    }
-    g.l0.assign(static_cast<size_t>(n) * (M0 + 1), -1);
-    g.l0_d.assign(static_cast<size_t>(n) * (M0 + 1), 0.f);
-    g.l0_cnt.assign(n, 0);
-    g.up.assign(static_cast<size_t>(std::max<int64_t>(blocks, 1)) * (M + 1), -1);
-    g.up_d.assign(static_cast<size_t>(std::max<int64_t>(blocks, 1)) * (M + 1), 0.f);
-    g.up_cnt.assign(std::max<int64_t>(blocks, 1), 0);
-    int maxlv = 1;
-    for (int64_t i = 0; i < n; i++) maxlv = std::max(maxlv, g.levels[i]);
-    HG_HIP(hipMemcpyAsync(idx->d_levels, g.levels.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
-    HG_HIP(hipMemcpyAsync(idx->d_upoff, g.up_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
+}
 
+static int launch_edge_dist(hnswgpu_index *idx, const int32_t *d_owner, const int32_t *d_adj, int width, int64_t nlists,
+                            float *d_out, hipStream_t st) {
+    if (nlists <= 0) return 0;
+    const unsigned grid = static_cast<unsigned>((nlists + kNWave - 1) / kNWave);
+    const bool l2 = idx->metric == METRIC_L2;
+#define CALL(N, R, L)                                                                                                  \
+    hipLaunchKernelGGL((edge_dist_kernel<N, R, L>), dim3(grid), dim3(kWG), 0, st, idx->d_base, idx->d_norms, idx->ld, idx->dim, \
+                       idx->metric, d_owner, d_adj, width, nlists, d_out)
+    HG_DISPATCH(idx->nch, l2, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+// insert-batch (ultra_fast.clj:303-344) over rows [done, g.n): every node of a batch runs the reference's per-level
+// search (search-layer-ultra with ef-construction at layer 0 and 1 above, :250-251) on the GPU against the graph as it
+// stood when the batch started, then the host links the batch in row order (:255-266) and prunes over-full lists
+// (:279-299).  The device adjacency (idx->d_l0 / d_upadj, sized for g.n) holds the graph of rows [0, done) on entry and
+// of all rows on return; g.entry / g.top are updated (:271-273).
+static int insert_batches(hnswgpu_index *idx, HostGraph &g, int64_t done, int ef, hipStream_t st) {
+    const int64_t n = g.n;
+    const int M0 = g.M0;
+    const int64_t blocks = g.up_off[n];
+    int maxlv = 1;
+    for (int64_t i = done; i < n; i++) maxlv = std::max(maxlv, g.levels[i]);
     const int64_t maxB = 16384;  // scratch sizing; the batch actually used grows with the graph (see below)
-    const int ef = ef_construction;
     HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * maxB * M0));
     HG_TRY(idx->s_outd.ensure(sizeof(float) * maxB * M0));
     HG_TRY(idx->s_misc.ensure(sizeof(int32_t) * maxB * (2 + maxlv)));   // q_rows, q_levels, up_out_ids
@@ -917,24 +917,17 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
     int32_t *d_qrows = idx->s_misc.as<int32_t>();
     int32_t *d_qlev = d_qrows + maxB;
     int32_t *d_upids = d_qlev + maxB;
-    std::vector<int32_t> h_ids(maxB * M0), h_up(maxB * maxlv), h_qrows(maxB), h_qlev(maxB), tmp0, tmpu;
+    std::vector<int32_t> h_ids(maxB * M0), h_up(maxB * maxlv), h_qrows(maxB), h_qlev(maxB);
     std::vector<float> h_d(maxB * M0), h_upd(maxB * maxlv);
-
     g.flag0.assign(n, 0);
     g.flagu.assign(std::max<int64_t>(blocks, 1), 0);
-    g.sorted0.assign(n, 0);
-    g.sortedu.assign(std::max<int64_t>(blocks, 1), 0);
     // linker threads: at most 16 (a GPU box's CPU share per GPU), HNSWGPU_BUILD_THREADS overrides (1 = sequential)
     int nthreads = static_cast<int>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
     if (const char *e = getenv("HNSWGPU_BUILD_THREADS")) nthreads = std::max(1, std::min(64, atoi(e)));
+    if (n - done < 256) nthreads = 1;  // a handful of rows: no pool to start
     LinkPool pool(nthreads);
     std::vector<HostGraph::Dirty> dirties(pool.size());
     PinnedBuf pin;
-    HG_HIP(hipMemsetAsync(idx->d_l0, 0xff, sizeof(int32_t) * n * M0, st));
-    HG_HIP(hipMemsetAsync(idx->d_upadj, 0xff, sizeof(int32_t) * std::max<int64_t>(blocks, 1) * M, st));
-    g.entry = 0;  // first element becomes the entry point (:229-231)
-    g.top = g.levels[0];
-    int64_t done = 1;
     const bool timing = getenv("HNSWGPU_BUILD_TIMING") != nullptr;  // developer switch: where a build spends its time
     double t_gpu = 0.0, t_link = 0.0, t_up = 0.0;
     int64_t nbatch = 0;
@@ -1047,16 +1040,236 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
         fprintf(stderr, "hnsw build: %lld batches, %.2f s upload + search + download (%.2f s of it packing and uploading "
                         "changed adjacency rows), %.2f s host linking\n",
                 static_cast<long long>(nbatch), t_gpu, t_up, t_link);
+    return 0;
+}
+
+// the finished host graph -> device adjacency + the host mirrors of the handle
+static int publish_graph(hnswgpu_index *idx, HostGraph &g, hipStream_t st) {
+    std::vector<int32_t> tmp0, tmpu;
+    const int64_t blocks = g.up_off[g.n];
     HG_TRY(upload_graph(idx, g, st, tmp0, tmpu));
     idx->h_levels = g.levels;
     idx->h_upoff = g.up_off;
     idx->h_l0.swap(tmp0);
-    tmpu.resize(static_cast<size_t>(blocks) * M);
+    tmpu.resize(static_cast<size_t>(blocks) * g.M);
     idx->h_upadj.swap(tmpu);
     idx->entry = g.entry;
     idx->max_level = std::max(g.top, 0);
     idx->has_graph = true;
     return 0;
+}
+
+// levels of rows [from, to): floor(ml * -ln U), ml = 1/ln 2 (ultra_fast.clj:133,143-147), U the row's draw of
+// java.util.Random(seed) -- row i takes the i-th nextDouble, so rows added later continue the build's sequence
+static void draw_levels(int64_t seed, int64_t from, int64_t to, std::vector<int32_t> &levels, std::vector<int64_t> &up_off) {
+    JavaRandom rng(seed);
+    const double ml = 1.0 / log(2.0);
+    for (int64_t i = 0; i < to; i++) {
+        const double u = rng.next_double();
+        if (i < from) continue;
+        const int lv = u > 0.0 ? static_cast<int>(ml * (-log(u))) : 30;
+        levels[i] = std::min(lv, 30);
+        up_off[i + 1] = up_off[i] + levels[i];
+    }
+}
+
+}  // namespace hg
+
+extern "C" {
+
+// build-index / insert-batch (ultra_fast.clj:303-344) as batched insertion (insert_batches above).
+// Level draw: floor(ml * -ln U), ml = 1/ln 2 (:133,:143-147), U from java.util.Random(seed).
+// Differences from the reference's sequential insert-single, stated in DESIGN.md: nodes of one
+// batch do not see each other (batches grow from 1 to at most 1/8 of the graph, capped); the walk
+// starts at the top layer with ef = 1 instead of at min(level, entry-level) (:247-248); each node
+// links to its m CLOSEST candidates (the reference's `(take m candidates)` takes PriorityQueue
+// array order, which is unspecified).
+int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, int64_t seed) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(M >= 1 && 2 * M <= kMaxDeg, HNSWGPU_ELIMIT, "need 1 <= M <= %d", kMaxDeg / 2);
+    HG_REQUIRE(ef_construction >= 1 && ef_construction <= 4096, HNSWGPU_ELIMIT, "need 1 <= ef_construction <= 4096");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    const int64_t n = idx->n;
+    const int M0 = 2 * M;
+    HostGraph g;
+    g.n = n;
+    g.M = M;
+    g.M0 = M0;
+    g.levels.resize(n);
+    g.up_off.assign(n + 1, 0);
+    draw_levels(seed, 0, n, g.levels, g.up_off);
+    const int64_t blocks = n > 0 ? g.up_off[n] : 0;
+    HG_TRY(quiesce(idx, st));  // as in hnswgpu_set_graph
+    free_graph(idx);
+    HG_TRY(alloc_graph(idx, M, M0, blocks));
+    HG_TRY(ensure_qrows(idx, st));
+    if (n == 0) {
+        idx->h_levels.clear();
+        idx->h_l0.clear();
+        idx->h_upoff.assign(1, 0);
+        idx->h_upadj.clear();
+        idx->entry = -1;
+        idx->max_level = 0;
+        idx->has_graph = true;
+        return 0;
+    }
+    g.l0.assign(static_cast<size_t>(n) * (M0 + 1), -1);
+    g.l0_d.assign(static_cast<size_t>(n) * (M0 + 1), 0.f);
+    g.l0_cnt.assign(n, 0);
+    g.up.assign(static_cast<size_t>(std::max<int64_t>(blocks, 1)) * (M + 1), -1);
+    g.up_d.assign(static_cast<size_t>(std::max<int64_t>(blocks, 1)) * (M + 1), 0.f);
+    g.up_cnt.assign(std::max<int64_t>(blocks, 1), 0);
+    g.sorted0.assign(n, 0);
+    g.sortedu.assign(std::max<int64_t>(blocks, 1), 0);
+    HG_HIP(hipMemcpyAsync(idx->d_levels, g.levels.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    HG_HIP(hipMemcpyAsync(idx->d_upoff, g.up_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
+    HG_HIP(hipMemsetAsync(idx->d_l0, 0xff, sizeof(int32_t) * n * M0, st));
+    HG_HIP(hipMemsetAsync(idx->d_upadj, 0xff, sizeof(int32_t) * std::max<int64_t>(blocks, 1) * M, st));
+    g.entry = 0;  // first element becomes the entry point (:229-231)
+    g.top = g.levels[0];
+    HG_TRY(insert_batches(idx, g, 1, ef_construction, st));
+    return publish_graph(idx, g, st);
+}
+
+// insert-single on a LIVE index (ultra_fast.clj:216-275, reached by add-vector! src/hnsw/api.clj:30-33 and add!
+// src/hnsw/api/simple.clj:31-42): `m` more rows join the base matrix and the graph that is installed.  The new rows'
+// levels continue the seeded java.util.Random sequence (row i takes its i-th draw), they are inserted in batches by the
+// kernels and the linker of hnswgpu_hnsw_build against the CURRENT graph -- whose edge distances, which the reference's
+// pruning sorts by (:279-299), are recomputed on the device by the traversal's own arithmetic -- and the device
+// adjacency, the int8 rows and the host mirrors grow with them.  Row ids of the new rows: n, n + 1, ...
+int hnswgpu_hnsw_add(hnswgpu_index *idx, const float *rows, int64_t m, int32_t ef_construction, int64_t seed) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE(m >= 0, HNSWGPU_EINVAL, "m must be >= 0");
+    if (m == 0) return 0;
+    HG_REQUIRE(rows, HNSWGPU_EINVAL, "rows is null");
+    HG_REQUIRE(ef_construction >= 1 && ef_construction <= 4096, HNSWGPU_ELIMIT, "need 1 <= ef_construction <= 4096");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_REQUIRE(idx->has_graph, HNSWGPU_ESTATE, "index has no graph (call hnswgpu_hnsw_build / hnswgpu_set_graph first)");
+    HG_REQUIRE(idx->nlist == 0, HNSWGPU_ESTATE,
+               "the index holds IVF lists over its present rows: add rows first, then build / install the lists");
+    HG_REQUIRE(idx->M0 == 2 * idx->M, HNSWGPU_ESTATE, "hnswgpu_hnsw_add needs a graph with M0 = 2 M (as hnswgpu_hnsw_build makes)");
+    const int64_t n0 = idx->n, n1 = n0 + m;
+    HG_REQUIRE(n1 < 2147483647LL, HNSWGPU_ELIMIT, "the index must hold fewer than 2^31 rows");
+    HG_HIP(hipSetDevice(idx->device));
+    hipStream_t st = idx->stream;
+    HG_TRY(quiesce(idx, st));
+    const int M = idx->M, M0 = idx->M0;
+    const int64_t ld = idx->ld;
+    // ---- 1. the base matrix, its norms and int8 rows grow
+    {
+        float *nb = nullptr, *nn = nullptr;
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nb), sizeof(float) * static_cast<size_t>(n1) * ld));
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nn), sizeof(float) * static_cast<size_t>(n1)));
+        if (n0 > 0) {
+            HG_HIP(hipMemcpyAsync(nb, idx->d_base, sizeof(float) * static_cast<size_t>(n0) * ld, hipMemcpyDeviceToDevice, st));
+            HG_HIP(hipMemcpyAsync(nn, idx->d_norms, sizeof(float) * static_cast<size_t>(n0), hipMemcpyDeviceToDevice, st));
+        }
+        if (ld != idx->dim) HG_HIP(hipMemsetAsync(nb + n0 * ld, 0, sizeof(float) * static_cast<size_t>(m) * ld, st));
+        HG_HIP(hipMemcpy2DAsync(nb + n0 * ld, sizeof(float) * ld, rows, sizeof(float) * idx->dim, sizeof(float) * idx->dim,
+                                static_cast<size_t>(m), hipMemcpyHostToDevice, st));
+        HG_TRY(launch_norms(idx->nch, nb + n0 * ld, ld, m, nn + n0, st));
+        HG_HIP(hipStreamSynchronize(st));
+        if (idx->d_base) (void)hipFree(idx->d_base);
+        if (idx->d_norms) (void)hipFree(idx->d_norms);
+        idx->d_base = nb;
+        idx->d_norms = nn;
+        if (idx->d_qrows) (void)hipFree(idx->d_qrows);
+        if (idx->d_qmeta) (void)hipFree(idx->d_qmeta);
+        idx->d_qrows = nullptr;
+        idx->d_qmeta = nullptr;
+        idx->n = n1;
+        HG_TRY(ensure_qrows(idx, st));  // (all rows again: one pass over the base, 0.7 ms per million 768-d rows)
+    }
+    // ---- 2. the host graph: the installed adjacency + its edge distances, then room for the new rows
+    HostGraph g;
+    g.n = n1;
+    g.M = M;
+    g.M0 = M0;
+    g.levels = idx->h_levels;
+    g.levels.resize(n1, 0);
+    g.up_off = idx->h_upoff;
+    g.up_off.resize(n1 + 1, 0);
+    draw_levels(seed, n0, n1, g.levels, g.up_off);
+    const int64_t blocks0 = idx->h_upoff[n0], blocks1 = g.up_off[n1];
+    g.l0.assign(static_cast<size_t>(n1) * (M0 + 1), -1);
+    g.l0_d.assign(static_cast<size_t>(n1) * (M0 + 1), 0.f);
+    g.l0_cnt.assign(n1, 0);
+    g.up.assign(static_cast<size_t>(std::max<int64_t>(blocks1, 1)) * (M + 1), -1);
+    g.up_d.assign(static_cast<size_t>(std::max<int64_t>(blocks1, 1)) * (M + 1), 0.f);
+    g.up_cnt.assign(std::max<int64_t>(blocks1, 1), 0);
+    g.sorted0.assign(n1, 0);
+    g.sortedu.assign(std::max<int64_t>(blocks1, 1), 0);
+    {
+        // edge distances of the installed graph, by the traversal's arithmetic (the old device adjacency is still in place)
+        std::vector<float> d0(static_cast<size_t>(n0) * M0), du(static_cast<size_t>(std::max<int64_t>(blocks0, 1)) * M);
+        std::vector<int32_t> owner(static_cast<size_t>(std::max<int64_t>(blocks0, 1)));
+        for (int64_t i = 0; i < n0; i++)
+            for (int64_t b = idx->h_upoff[i]; b < idx->h_upoff[i + 1]; b++) owner[b] = static_cast<int32_t>(i);
+        HG_TRY(idx->s_outd.ensure(sizeof(float) * (d0.size() + du.size())));
+        HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * owner.size()));
+        float *dd0 = idx->s_outd.as<float>(), *ddu = dd0 + d0.size();
+        HG_HIP(hipMemcpyAsync(idx->s_ids.p, owner.data(), sizeof(int32_t) * owner.size(), hipMemcpyHostToDevice, st));
+        HG_TRY(launch_edge_dist(idx, nullptr, idx->d_l0, M0, n0, dd0, st));
+        HG_TRY(launch_edge_dist(idx, idx->s_ids.as<int32_t>(), idx->d_upadj, M, blocks0, ddu, st));
+        HG_HIP(hipMemcpyAsync(d0.data(), dd0, sizeof(float) * d0.size(), hipMemcpyDeviceToHost, st));
+        if (blocks0 > 0) HG_HIP(hipMemcpyAsync(du.data(), ddu, sizeof(float) * static_cast<size_t>(blocks0) * M, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipStreamSynchronize(st));
+        // a full list whose distances ascend IS the pruned order (prune-connections-ultra's stable sort is the identity on
+        // it); any other list is still in insertion order and gets its first sort when it overflows
+        auto adopt = [](const int32_t *src, const float *dsrc, int width, int32_t *dst, float *ddst, int32_t &cnt, uint8_t &srt) {
+            int c = 0;
+            while (c < width && src[c] >= 0) c++;
+            bool asc = true;
+            for (int j = 0; j < c; j++) {
+                dst[j] = src[j];
+                ddst[j] = dsrc[j];
+                if (j > 0 && dsrc[j] < dsrc[j - 1]) asc = false;
+            }
+            cnt = c;
+            srt = (c == width && asc) ? 1 : 0;
+        };
+        for (int64_t i = 0; i < n0; i++)
+            adopt(&idx->h_l0[static_cast<size_t>(i) * M0], &d0[static_cast<size_t>(i) * M0], M0, &g.l0[static_cast<size_t>(i) * (M0 + 1)],
+                  &g.l0_d[static_cast<size_t>(i) * (M0 + 1)], g.l0_cnt[i], g.sorted0[i]);
+        for (int64_t b = 0; b < blocks0; b++)
+            adopt(&idx->h_upadj[static_cast<size_t>(b) * M], &du[static_cast<size_t>(b) * M], M, &g.up[static_cast<size_t>(b) * (M + 1)],
+                  &g.up_d[static_cast<size_t>(b) * (M + 1)], g.up_cnt[b], g.sortedu[b]);
+    }
+    g.entry = idx->entry;
+    g.top = idx->max_level;
+    // ---- 3. the device graph grows: old rows copied, new rows empty
+    {
+        int32_t *nl = nullptr, *n0adj = nullptr, *nu = nullptr;
+        int64_t *no = nullptr;
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nl), sizeof(int32_t) * n1));
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&n0adj), sizeof(int32_t) * n1 * M0));
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&no), sizeof(int64_t) * (n1 + 1)));
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nu), sizeof(int32_t) * std::max<int64_t>(blocks1, 1) * M));
+        HG_HIP(hipMemcpyAsync(nl, g.levels.data(), sizeof(int32_t) * n1, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(no, g.up_off.data(), sizeof(int64_t) * (n1 + 1), hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemsetAsync(n0adj, 0xff, sizeof(int32_t) * n1 * M0, st));
+        HG_HIP(hipMemsetAsync(nu, 0xff, sizeof(int32_t) * std::max<int64_t>(blocks1, 1) * M, st));
+        if (n0 > 0) HG_HIP(hipMemcpyAsync(n0adj, idx->d_l0, sizeof(int32_t) * n0 * M0, hipMemcpyDeviceToDevice, st));
+        if (blocks0 > 0) HG_HIP(hipMemcpyAsync(nu, idx->d_upadj, sizeof(int32_t) * blocks0 * M, hipMemcpyDeviceToDevice, st));
+        HG_HIP(hipStreamSynchronize(st));
+        free_graph(idx);
+        idx->d_levels = nl;
+        idx->d_l0 = n0adj;
+        idx->d_upoff = no;
+        idx->d_upadj = nu;
+        idx->up_blocks = blocks1;
+        idx->has_graph = true;  // (the searches of insert_batches run against it; no caller can: idx->mu is held)
+    }
+    if (n0 == 0) {  // an empty index with an (empty) graph: the first new row becomes the entry point (:229-231)
+        g.entry = 0;
+        g.top = g.levels[0];
+        HG_TRY(insert_batches(idx, g, 1, ef_construction, st));
+    } else {
+        HG_TRY(insert_batches(idx, g, n0, ef_construction, st));
+    }
+    return publish_graph(idx, g, st);
 }
 
 }  // extern "C"

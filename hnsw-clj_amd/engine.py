@@ -194,6 +194,15 @@ class Index:
     def hnsw_build(self, M=16, ef_construction=200, seed=42):
         check(lib().hnswgpu_hnsw_build(self._h, M, ef_construction, seed))
 
+    def hnsw_add(self, rows, ef_construction=200, seed=42):
+        """insert-single on the live index (ultra_fast.clj:216-275): `rows` join the base and the installed graph; returns
+        the row ids they got."""
+        rows = _queries(rows, self.dim)
+        first = self.n
+        check(lib().hnswgpu_hnsw_add(self._h, _p(rows), len(rows), ef_construction, seed))
+        self.n += len(rows)
+        return np.arange(first, self.n, dtype=np.int32)
+
     def get_graph(self):
         M, M0, ent, mx = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         blocks = C.c_int64()

@@ -109,6 +109,15 @@ int hnswgpu_exact_knn_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int3
 int hnswgpu_set_graph(hnswgpu_index *idx, const int32_t *levels, const int32_t *l0_adj, int32_t M0,
                       const int64_t *up_off, const int32_t *up_adj, int32_t M, int32_t entry, int32_t max_level);
 int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, int64_t seed);
+/* insert-single on a LIVE index (src/hnsw/ultra_fast.clj:216-275, reached by add-vector! src/hnsw/api.clj:30-33 and add!
+ * src/hnsw/api/simple.clj:31-42): `m` more rows (m x dim floats) join the base matrix and the installed graph.  Their row
+ * ids are n, n + 1, ...; their levels continue the seeded java.util.Random sequence (row i takes its i-th draw: the same
+ * `seed` as the build gives the levels a from-scratch build of all rows would draw); they are inserted in batches, by
+ * the search kernel and the linker of hnswgpu_hnsw_build, against the CURRENT graph (any graph with M0 = 2 M:
+ * hnswgpu_hnsw_build's, or one installed by hnswgpu_set_graph / hnswgpu_load -- its edge distances, which the reference's
+ * pruning sorts by (:279-299), are recomputed on the device).  Not concurrent with searches on the same handle (they
+ * wait); IVF lists must be built / installed AFTER the rows they cover have been added. */
+int hnswgpu_hnsw_add(hnswgpu_index *idx, const float *rows, int64_t m, int32_t ef_construction, int64_t seed);
 int hnswgpu_graph_sizes(const hnswgpu_index *idx, int32_t *M, int32_t *M0, int64_t *up_blocks, int32_t *entry,
                         int32_t *max_level);
 int hnswgpu_get_graph(const hnswgpu_index *idx, int32_t *levels, int32_t *l0_adj, int64_t *up_off,

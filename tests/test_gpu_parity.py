@@ -1060,6 +1060,55 @@ def test_timed_launch_configurations_against_oracle(eng, oracle, dist, ef, nsub)
         assert_topk_parity(ids[sub[:16]], d[sub[:16]], fi, fd, "%s ef %d vs oracle (f64 reference order)" % (dist, ef))
 
 
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_hnsw_add_to_a_live_index(eng, oracle, metric):
+    """insert-single on a live index (ultra_fast.clj:216-275; add-vector!, api.clj:30-33): a graph built over 20,000 rows
+    takes 4,000 more in calls of 1, 64 and 1,024 rows.  The grown graph is a valid graph (a fresh handle accepts it through
+    hnswgpu_set_graph's validation), the device search of it equals the oracle's search of the exported graph (ids,
+    distance bits, counters), the new rows find themselves, levels continue the build's seeded sequence, and recall stays
+    within 0.02 of a from-scratch build over all 24,000 rows."""
+    O = oracle
+    m = O.METRICS[metric]
+    n0, n1, dim, ef = 20_000, 24_000, 64, 120
+    base = O.generate_dataset(n1, dim, "clustered", num_clusters=60, noise_level=0.6).astype(np.float32)
+    Q = O.generate_dataset(200, dim, "clustered", num_clusters=60, noise_level=0.6, seed=43).astype(np.float32)
+    with eng.Index(base, metric) as full:
+        full.hnsw_build(16, 200, 42)
+        gfull = full.get_graph()
+        ti, _ = full.exact_knn(Q, 10)
+        fi, _ = full.hnsw_search(Q, 10, ef)
+        rec_full = O.recall(fi, ti)
+        si, _ = full.hnsw_search(base[n0:n0 + 300], 1, ef)
+        self_full = float((si[:, 0] == np.arange(n0, n0 + 300)).mean())
+    with eng.Index(base[:n0], metric) as idx:
+        idx.hnsw_build(16, 200, 42)
+        pos = n0
+        for step in [1] * 8 + [64] * 6 + [1024] * 3 + [n1]:      # calls of 1, 64, 1024 rows, then the rest
+            take = min(step, n1 - pos)
+            ids = idx.hnsw_add(base[pos:pos + take], 200, 42)
+            assert ids[0] == pos and len(ids) == take
+            pos += take
+        assert idx.n == n1 and pos == n1
+        g = idx.get_graph()
+        np.testing.assert_array_equal(g.levels, gfull.levels)       # the same java.util.Random(42) draws, row by row
+        ids, d, st = idx.hnsw_search(Q, 10, ef, want_stats=True)
+        oi, od, ost, _ = O.hnsw_search(base, g, Q, 10, ef=ef, metric=m, mode=O.MODE_DEV, nthreads=8)
+        assert_exact(ids, d, oi, od, "search of the grown graph vs oracle")
+        np.testing.assert_array_equal(st, ost)
+        si, sd = idx.hnsw_search(base[n0:n0 + 300], 1, ef)          # the added rows are reachable: they find themselves
+        self_add = float((si[:, 0] == np.arange(n0, n0 + 300)).mean())   # ... as often as in the from-scratch graph
+        assert self_add >= self_full - 0.05, (self_add, self_full)
+        rec = O.recall(ids, ti)
+        assert rec >= rec_full - 0.02, (rec, rec_full)
+        with eng.Index(base, metric) as chk:                        # the validator: a fresh handle installs the export
+            chk.set_graph(g)
+            ci, cd = chk.hnsw_search(Q[:20], 10, ef)
+            np.testing.assert_array_equal(ci, ids[:20])
+        with pytest.raises(Exception, match="IVF"):                 # lists cover the rows they were built over
+            idx.ivf_build(8, 2, 42)
+            idx.hnsw_add(base[:1], 200, 42)
+
+
 def test_persistence_and_lightning(eng, oracle, tmp_path):
     """Binary index file (replaces helper/index_io.clj's EDN): save -> load gives the same ids and the same
     bits; damaged files are rejected.  Lightning partitions reuse the list-scan kernel."""
