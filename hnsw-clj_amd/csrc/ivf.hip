@@ -875,13 +875,27 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
 }
 
 // (query, list) pairs per list from which the MFMA tile scan serves a cosine / dot batch -- and with it the k-ordered
-// summation.  Up to here the GEMV order: one GEMV per pair, the register-row group kernel, or bounds on the int8 rows +
-// f32 refine (same bits all three).  Measured on 1M x 768 / 1024 lists / nprobe 32, bounds pipeline vs tile scan, end to
-// end: batch 96: 0.35 vs 0.67 ms; 128: 0.40 vs 0.66; 256: 0.55 vs 0.70; 320: 0.62 vs 0.76; 384: 0.68 vs 0.78; 512: 0.80 vs
-// 0.80; 768: 1.04 vs 0.89 -- the tile scan reads every probed list in f32 whatever the batch, the bounds pipeline a quarter
-// of that (on the matrix cores from six queries per list) plus the survivors.
-constexpr int64_t kTilePairs = 12;
+// summation.  Up to here the GEMV order: the survivor stream (bounds on the int8 rows, f32 distances of the survivors), or
+// on a handle without int8 rows one GEMV per pair / the register-row group kernel (same bits all three).
+//  * With int8 rows (and k <= kStreamMaxK) the boundary is 48: measured on 1M x 768 / 1024 lists / nprobe 32, survivor
+//    stream vs tile scan, end to end: batch 512: 0.55 vs 0.82 ms; 1024: 0.85 vs 0.98; 2048: 1.53 vs 1.53; 4096: 2.92 vs
+//    2.67 -- the tile scan reads every probed list in f32 whatever the batch, the stream a quarter of that plus the
+//    survivors' rows per query.
+//  * Without them it is 12: the f32 GEMV-order scans re-read a list per pair (or per group of queries at the VALU's rate).
+constexpr int64_t kTilePairs = 12, kTilePairsCoded = 48;
 constexpr int32_t kStreamMaxK = 256;  // largest k the bounds pass serves (larger k: the f32 scans)
+
+// can this search go through the survivor stream at all (int8 list rows present and switched on, k within its range)?
+static bool ivf_codes_usable(const hnswgpu_index *idx, int32_t k) {
+    return idx->d_lctile != nullptr && (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128)) &&
+           tile_mode() != 0 && k <= kStreamMaxK && env_now("HNSWGPU_IVF_CODES", 1) > 0;
+}
+// the boundary of the two summation orders for this handle and k (HNSWGPU_TILE_PAIRS overrides: the parity suite pins it
+// at 12 so that its small indexes still reach the tile path)
+static int64_t ivf_tile_pairs(const hnswgpu_index *idx, int32_t k) {
+    const int64_t e = env_now("HNSWGPU_TILE_PAIRS", 0);
+    return e > 0 ? e : (ivf_codes_usable(idx, k) ? kTilePairsCoded : kTilePairs);
+}
 
 static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
                               int32_t *d_out_ids, float *d_out_dist, int32_t *d_out_probes, hipStream_t st,
@@ -905,10 +919,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
                           code_env > 0 && nq >= code_env && tm != 0 && k <= kStreamMaxK;
     // (Euclidean has one arithmetic at every batch size -- its "tile" path is the register-row group kernel -- so the
     // bounds pipeline below serves all its batches: batch 1024 at 1M x 768: 4.8 -> 2.8 ms)
-    static const int64_t tile_pairs = []() {
-        const char *e = getenv("HNSWGPU_TILE_PAIRS");  // measurement only: it moves the boundary between the two summation orders
-        return e ? atoll(e) : kTilePairs;
-    }();
+    const int64_t tile_pairs = ivf_tile_pairs(idx, k);
     const bool use_tile = tile_path_ok(idx) && tm != 0 && (tm == 1 || npairs > tile_pairs * idx->nlist) &&
                           !(idx->metric == METRIC_L2 && codes_ok && tm != 1);
     // Between the fused small-batch path and the tile scan: bounds on the int8 list rows first, f32 distances -- the
@@ -1414,9 +1425,10 @@ int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k
         const bool one_arith = idx->metric == METRIC_L2 || !tile_path_ok(idx) || tile_mode() == 0;
         // the kernel a batch of `total` queries gets: ivf_search_enqueue's own predicate, on the BATCH's nprobe (the
         // leader that evaluates this may have asked for another one)
-        auto tiled = [idx](int64_t total, int32_t nprobe_req) {
+        const int64_t tile_pairs = ivf_tile_pairs(idx, k);  // (requests of one batch share k)
+        auto tiled = [idx, tile_pairs](int64_t total, int32_t nprobe_req) {
             const int64_t nl = idx->nlist;
-            return total * std::min<int64_t>(nprobe_req, nl) > kTilePairs * nl;
+            return total * std::min<int64_t>(nprobe_req, nl) > tile_pairs * nl;
         };
         return combine_search(
             idx->cmb_ivf, me,

@@ -706,6 +706,32 @@ def test_ivf_survivor_stream_regimes(eng, oracle, metric, monkeypatch):
         check(12, 10, 12, "ungrouped")
 
 
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_ivf_production_boundary(eng, oracle, metric, monkeypatch):
+    """The default boundary between the two summation orders of a cosine / dot IVF search: with int8 rows (and k <= 256)
+    the survivor stream -- GEMV order -- serves up to 48 (query, list) pairs per list, the MFMA tile scan beyond; without
+    them (mode 0), or for a k the stream does not serve, the boundary is 12.  (The suite otherwise pins it at 12.)"""
+    O = oracle
+    code = {"cosine": O.COSINE, "dot": O.DOT}[metric]
+    monkeypatch.delenv("HNSWGPU_TILE_PAIRS")
+    nlist, nprobe = 20, 10
+    base = _data(O, 8000, 136, "clustered", num_clusters=20, noise_level=0.3, seed=81)
+    Q = _data(O, 120, 136, "clustered", num_clusters=20, noise_level=0.3, seed=82)
+    with eng.Index(base, metric) as idx:
+        idx.ivf_build(nlist, 4, 42)
+        cen, off, lids = idx.get_ivf()
+        for nq, k, mode_rej, want in [(40, 10, 2, O.MODE_DEV),       # 20 pairs per list, int8 rows: the stream
+                                      (96, 10, 2, O.MODE_DEV),       # 48: still the stream
+                                      (100, 10, 2, O.MODE_MFMA),     # 50: the tile scan
+                                      (40, 300, 2, O.MODE_MFMA),     # a k the stream does not serve: boundary 12
+                                      (40, 10, 0, O.MODE_MFMA),      # no int8 rows: boundary 12
+                                      (20, 10, 0, O.MODE_DEV)]:      # 10 pairs per list without them: the f32 GEMV order
+            idx.set_rejection_test(mode_rej)
+            ids, d = idx.ivf_search(Q[:nq], k, nprobe)
+            oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=code, mode=want)
+            assert_exact(ids, d, oi, od, "production boundary %s nq=%d k=%d rejection mode %d" % (metric, nq, k, mode_rej))
+
+
 @pytest.mark.parametrize("dim", [24, 300, 768, 1024, 1536, 3072])
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
 def test_rejection_bounds_never_exceed_the_distance(eng, metric, dim):
@@ -1107,6 +1133,35 @@ def test_hnsw_add_to_a_live_index(eng, oracle, metric):
         with pytest.raises(Exception, match="IVF"):                 # lists cover the rows they were built over
             idx.ivf_build(8, 2, 42)
             idx.hnsw_add(base[:1], 200, 42)
+
+
+def test_device_build_vs_reference_structure_on_clustered_data(eng, oracle):
+    """The batched device build (nodes of a batch do not see each other) against the oracle's sequential
+    reference-structure build (orc_hnsw_build, ultra_fast.clj:216-299) where it matters most: 31,173 x 128 clustered
+    (256 centres, noise 0.3, normalised), the shape on which closest-m pruning without a diversity heuristic
+    (:279-299) leaves the graph disconnected between clusters.  Both graphs searched by the same device kernel at equal
+    ef: the device-built graph may not be worse by more than 0.03 recall@10 (measured: 0.042 against 0.011 -- both
+    low, the batched build the better of the two; profiles/r03_build_compare_clustered_31k.txt)."""
+    O = oracle
+    n, dim, ncl = 31173, 128, 256
+    base = O.generate_dataset(n, dim, "clustered", num_clusters=ncl, noise_level=0.3).astype(np.float64)
+    base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    Q = O.generate_dataset(400, dim, "clustered", num_clusters=ncl, noise_level=0.3, seed=43).astype(np.float64)
+    Q = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+    gref = O.hnsw_build(base, O.COSINE, 16, 200, seed=42)
+    with eng.Index(base, "cosine") as idx:
+        ti, _ = idx.exact_knn(Q, 10)
+        idx.hnsw_build(16, 200, 42)
+        dev = {ef: O.recall(idx.hnsw_search(Q, 10, ef)[0], ti) for ef in (50, 200)}
+        idx.set_graph(gref)
+        for ef in (50, 200):
+            ids, d, st = idx.hnsw_search(Q, 10, ef, want_stats=True)
+            ref = O.recall(ids, ti)
+            assert dev[ef] >= ref - 0.03, (ef, dev[ef], ref)
+            if ef == 50:      # ... and the device searches the reference-structure graph as the oracle does
+                oi, od, ost, _ = O.hnsw_search(base, gref, Q[:64], 10, ef=ef, mode=O.MODE_DEV, nthreads=8)
+                assert_exact(ids[:64], d[:64], oi, od, "reference-structure graph, clustered")
+                np.testing.assert_array_equal(st[:64], ost)
 
 
 def test_persistence_and_lightning(eng, oracle, tmp_path):
