@@ -123,7 +123,8 @@ int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narr
 }
 
 int launch_finish(const FinishArgs &a, int nch, hipStream_t st) {
-    const int64_t blocks = static_cast<int64_t>(a.nq) * a.slices;
+    int64_t blocks = static_cast<int64_t>(a.nq) * a.slices;
+    if (a.qorder) blocks = (static_cast<int64_t>(a.nq) + 7) / 8 * 8;  // ordered queries: whole rounds over the eight XCDs
     if (blocks <= 0) return 0;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "finish grid too large");
     // W lists + final list + (ord, dist) of the result + the probed lists' stream offsets

@@ -77,14 +77,15 @@ __global__ __launch_bounds__(kWG) void probe_pairs_kernel(const uint32_t *ord, i
 // ---- execution order of the GEMV list scan: pairs sorted by the list they probe (counting sort in one workgroup;
 // the order inside a list is whatever the atomics give -- it only decides WHEN a pair runs, not what it computes)
 constexpr int kOrderMaxLists = 16384;  // LDS histogram: 64 KiB
-__global__ __launch_bounds__(1024) void pair_order_kernel(const int32_t *probes, int npairs, int nlist, int32_t *order) {
+__global__ __launch_bounds__(1024) void pair_order_kernel(const int32_t *probes, int npairs, int nlist, int32_t *order,
+                                                          int stride = 1) {  // item i probes list probes[i * stride]
     extern __shared__ int32_t ocnt[];  // [nlist + 1] (bucket nlist: pairs without a list), then [1024] scan scratch
     int32_t *part = ocnt + nlist + 1;
     const int tid = threadIdx.x, nb = nlist + 1;
     for (int i = tid; i < nb; i += 1024) ocnt[i] = 0;
     __syncthreads();
     for (int i = tid; i < npairs; i += 1024) {
-        const int l = probes[i];
+        const int l = probes[static_cast<int64_t>(i) * stride];
         atomicAdd(&ocnt[l >= 0 && l < nlist ? l : nlist], 1);
     }
     __syncthreads();
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(1024) void pair_order_kernel(const int32_t *probes,
     }
     __syncthreads();
     for (int i = tid; i < npairs; i += 1024) {
-        const int l = probes[i];
+        const int l = probes[static_cast<int64_t>(i) * stride];
         order[atomicAdd(&ocnt[l >= 0 && l < nlist ? l : nlist], 1)] = i;
     }
 }
@@ -775,7 +776,8 @@ static int stream_scratch(hnswgpu_index *idx, int32_t nq, StreamScratch &s) {
 // lists -> f32 distances (GEMV order), top-k, ids and distances written by the finish kernel.  The query codes, tau = none
 // and empty survivor lists are set up by the routing step.
 static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe, const int32_t *d_qcnt,
-                           int32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_gord, const StreamScratch &sc, hipStream_t st) {
+                           const int32_t *d_probes, int32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_gord,
+                           const StreamScratch &sc, hipStream_t st) {
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
     StreamArgs b;
     memset(&b, 0, sizeof(b));
@@ -871,6 +873,23 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     f.out_dist = d_out_dist;
     f.out_gord = d_out_gord;
     f.stats = idx->prof ? idx->d_rej_stats : nullptr;
+    // Large batches: a query's survivors are, above all, its nearest list -- and several queries share one.  The queries are
+    // taken in the order of their nearest list, a contiguous eighth of that order per XCD, so that the queries which read
+    // the same rows run side by side on ONE L2 (each XCD otherwise fetches the list for itself).
+    const int64_t order_min = env_now("HNSWGPU_FINISH_ORDER", 512);  // 0 = never (A/B)
+    if (d_probes && order_min > 0 && nq >= order_min && f.slices == 1 && idx->nlist <= kOrderMaxLists) {
+        HG_TRY(idx->s_stats.ensure(sizeof(int32_t) * static_cast<size_t>(nq)));  // (s_ids / s_outd may be the caller's outputs)
+        const size_t olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);
+        if (olds > 48 * 1024) {
+            static bool attr_done[64] = {};
+            if (attr_needed(attr_done))
+                HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(sizeof(int32_t) * (kOrderMaxLists + 1 + 1024))));
+        }
+        hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), olds, st, d_probes, nq, idx->nlist, idx->s_stats.as<int32_t>(), nprobe);
+        HG_HIP(hipGetLastError());
+        f.qorder = idx->s_stats.as<int32_t>();
+    }
     return launch_finish(f, idx->nch, st);
 }
 
@@ -1054,7 +1073,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
             pa.tau = sc.tau;
             HG_TRY(launch_query_prep(pa, idx->nch, st));
         }
-        return ivf_stream_scan(idx, d_Q, nq, k, nprobe, qcnt_buf, d_out_ids, d_out_dist, d_out_gord, sc, st);
+        return ivf_stream_scan(idx, d_Q, nq, k, nprobe, qcnt_buf, probes_buf, d_out_ids, d_out_dist, d_out_gord, sc, st);
     }
     // 2. scan the probed lists (:217-234) and merge (:291-294)
     memset(&a, 0, sizeof(a));

@@ -608,6 +608,7 @@ struct FinishArgs {
     const Pair *pairs;     // [nq][nprobe]
     int32_t nq, nprobe, k;
     int32_t slices;        // workgroups per query
+    const int32_t *qorder; // optional (slices == 1): the queries in the order of their nearest list
     int32_t span;          // entries a wave looks at per step: 64, or 16 for a handful of queries
     const float *rows;     // list rows, f32
     const float *row_norms;
@@ -633,7 +634,14 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     const int wave = threadIdx.x >> 6;
     // slice-major: a query's survivors sit in the first slices of its list when it is short, and query-major order would
     // put the busy workgroups of all queries on the same XCDs
-    const int qi = blockIdx.x % a.nq, sl = blockIdx.x / a.nq;
+    int qi = blockIdx.x % a.nq;
+    const int sl = a.qorder ? 0 : blockIdx.x / a.nq;  // (ordered queries: one slice, the grid is padded to whole XCD rounds)
+    if (a.qorder) {  // workgroup b runs on XCD b % 8: XCD x takes a contiguous eighth of the ordered queries
+        const int per = (a.nq + 7) >> 3;
+        const int pos = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (pos >= a.nq || (blockIdx.x >> 3) >= per) return;
+        qi = a.qorder[pos];
+    }
     const uint32_t nsv = a.surv_cnt[qi];
     const bool over = nsv > a.cap;  // survivors did not fit: walk the candidate stream itself (the plain f32 scan)
     const int64_t total = over ? a.q_cnt[qi] : nsv;
