@@ -87,9 +87,9 @@ constexpr int kSeedMax = 256;  // rows evaluated at most (>= the largest k the b
 template <int NCH, int RB, bool L2>
 __device__ __forceinline__ void seed_tau_wg(const float4 (&q)[NCH], float qn, int metric, const Pair *pp, int nprobe,
                                             int64_t qcnt, int k, const float *rows, const float *row_norms, int64_t ld,
-                                            float *dist_s /* [kSeedMax] LDS */, uint32_t *tau_out) {
+                                            float *dist_s /* [kSeedMax] LDS */, uint32_t *tau_out, int sample = 64) {
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    int m = k > 64 ? k : 64;
+    int m = k > sample ? k : sample;  // (large batches sample fewer rows: thousands of queries x 64 rows is the index again)
     m = (m + 31) & ~31;
     if (m > kSeedMax) m = kSeedMax;
     if (m > qcnt) m = static_cast<int>(qcnt);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kWG) void ivf_query_prep_kernel(PrepArgs a) {
         if (lane == 0) a.qscal[qi] = qc.sc;
     }
     seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, a.pairs + static_cast<int64_t>(qi) * a.nprobe, a.nprobe, a.qcnt[qi], a.k, a.rows,
-                             a.row_norms, a.ld, dist_s, a.tau + qi);
+                             a.row_norms, a.ld, dist_s, a.tau + qi, a.nq >= 1024 ? 16 : 64);
 }
 
 // One work item of the grouped bounds pass: rows [rb0 + r0_off, rb0 + r1_off) of inverted list `list` (which starts at row
