@@ -646,7 +646,7 @@ def pmc_child(args):
 
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    x, Qa = ivf_dataset(dev, args.ivf_n, 1024, 1024)
+    x, Qa = ivf_dataset(dev, args.ivf_n, 1024, 4096)       # the same query draws as ivf_roofline()
     idx = engine.Index(x, "cosine", 0)
     del x
     idx.ivf_build(1024, 10, 42)
