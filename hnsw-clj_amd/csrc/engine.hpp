@@ -172,7 +172,11 @@ struct hnswgpu_index {
     std::vector<int32_t> h_listids;
 
     // scratch (grown on demand, reused across calls; calls are serialised by `mu`)
-    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2, s_vis, s_qp, s_qn, s_tile, s_grp, s_done, s_pf;
+    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2, s_vis, s_qp, s_qn, s_tile, s_grp, s_done, s_pf, s_bk;
+    // s_bk: the per-list pair counters of the IVF survivor stream -- zero between searches (the work-list kernel clears
+    // them behind its last read); bk_dirty = a search was enqueued past the point that fills them but not past the
+    // work-list kernel (an error in between): the next search clears them itself
+    bool bk_dirty = false;
     uint32_t pf_seq = 0;  // launch number of the last prefetch-helper launch (24 bits, never 0)
     size_t s_done_n = 0;  // counters per half of s_done (scan tails | route tails)
     uint32_t vis_gen = 0;  // last generation number handed to an HBM visited slab

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(1024) void pair_order_kernel(const int32_t *probes,
 // into the dense list of work items (list, group of <= 32 members, chunk of rows), chunk-major inside a list so that the
 // groups reading the same rows are neighbours.  One workgroup: a scan over the lists' item counts, then every thread
 // fills items by bisection into the scanned offsets (a hot list's hundreds of items are not one thread's job).
-__global__ __launch_bounds__(1024) void ivf_worklist_kernel(const uint32_t *bk_cnt, int32_t bk_cap, int nlist,
+__global__ __launch_bounds__(1024) void ivf_worklist_kernel(uint32_t *bk_cnt, int32_t bk_cap, int nlist,
                                                             const int64_t *list_off, int64_t chunk_rows, int max_chunks,
                                                             WorkDesc *desc, int32_t *nitems) {
     __shared__ int32_t off_s[1025];  // exclusive offsets of this pass's lists
@@ -187,6 +187,8 @@ __global__ __launch_bounds__(1024) void ivf_worklist_kernel(const uint32_t *bk_c
         __syncthreads();
     }
     if (tid == 0) *nitems = carry_s;
+    // the counters are zero again for the next search (every read of them is behind the barriers above)
+    for (int l = tid; l < nlist; l += 1024) bk_cnt[l] = 0;
 }
 
 // ---- grouping of (query, probed list) pairs by list, for the tiled scan --------------------------------
@@ -754,12 +756,19 @@ static int stream_buckets(hnswgpu_index *idx, int32_t nq, int32_t nprobe, Stream
     cap = std::min<int64_t>(cap, (static_cast<int64_t>(nq) + 31) / 32 * 32);
     const int64_t cap_env = env_now("HNSWGPU_STREAM_BUCKET", 0);  // tests: tiny buckets force the fallback
     if (cap_env > 0) cap = cap_env;
-    const size_t cnt_bytes = (sizeof(uint32_t) * static_cast<size_t>(idx->nlist) + 15) & ~static_cast<size_t>(15);
-    HG_TRY(idx->s_misc.ensure(cnt_bytes + sizeof(uint2) * static_cast<size_t>(idx->nlist) * cap));
-    s.bk_cnt = idx->s_misc.as<uint32_t>();
-    s.bk_mem = reinterpret_cast<uint2 *>(static_cast<char *>(idx->s_misc.p) + cnt_bytes);
+    // members in s_misc; the counters in a buffer of their own that is zero between searches (a 4 KB memset is a 6 us
+    // launch: a thirtieth of a batch-32 search)
+    HG_TRY(idx->s_misc.ensure(sizeof(uint2) * static_cast<size_t>(idx->nlist) * cap));
+    const size_t cnt_bytes = sizeof(uint32_t) * static_cast<size_t>(idx->nlist);
+    if (idx->s_bk.cap < cnt_bytes) {
+        HG_TRY(idx->s_bk.ensure(cnt_bytes));
+        idx->bk_dirty = true;
+    }
+    if (idx->bk_dirty) HG_HIP(hipMemsetAsync(idx->s_bk.p, 0, idx->s_bk.cap, st));
+    idx->bk_dirty = true;  // until the work-list kernel of this search has been enqueued
+    s.bk_cnt = idx->s_bk.as<uint32_t>();
+    s.bk_mem = idx->s_misc.as<uint2>();
     s.bk_cap = static_cast<int32_t>(cap);
-    HG_HIP(hipMemsetAsync(s.bk_cnt, 0, sizeof(uint32_t) * static_cast<size_t>(idx->nlist), st));
     return 0;
 }
 static int stream_scratch(hnswgpu_index *idx, int32_t nq, StreamScratch &s) {
@@ -806,6 +815,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         hipLaunchKernelGGL(ivf_worklist_kernel, dim3(1), dim3(1024), 0, st, sc.bk_cnt, sc.bk_cap, idx->nlist, idx->d_listoff, cr,
                            b.nchunks, desc, nit);
         HG_HIP(hipGetLastError());
+        idx->bk_dirty = false;  // (the kernel leaves the counters zero)
         b.wi_desc = desc;
         b.nitems = nit;
         b.bk_mem = sc.bk_mem;
