@@ -80,6 +80,7 @@ _SIGS = {
     "hnswgpu_get_profile": ["p", "i32", "p", "p", "i32"],
     "hnswgpu_rejection_bounds": ["p", "p", "p", "i32", "p"],
     "hnswgpu_distance_bounds": ["p", "p", "p", "i32", "p", "p"],
+    "hnswgpu_ivf_half_bounds": ["p", "p", "p", "i32", "p", "p"],
     "hnswgpu_set_rejection_test": ["p", "i32"],
     "hnswgpu_get_rejection_stats": ["p", "p", "p", "i32"],
     "hnswgpu_group_create": ["p", "i32", "i32", "i32", "p"],

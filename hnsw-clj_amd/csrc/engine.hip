@@ -98,10 +98,45 @@ int ensure_list_codes(hnswgpu_index *idx, hipStream_t st) {
     return 0;
 }
 
+// The half-precision copy of the list rows (stream_kernels.hpp, step 1b): list order, row-major, + (scale, E, 0, 1/|v|)
+// per row.  Half the size of the f32 rows again; HNSWGPU_IVF_HALF=0 leaves it out (the searches then go from the int8
+// bounds straight to the f32 rows at every batch size).
+int ensure_list_half(hnswgpu_index *idx, hipStream_t st) {
+    static const bool wanted = []() {
+        const char *e = getenv("HNSWGPU_IVF_HALF");
+        return !e || atoi(e) != 0;
+    }();
+    if (!wanted || !idx->d_lctile || idx->d_lhalf || idx->n <= 0 || idx->nlist <= 0) return 0;
+    const int64_t n = idx->n;
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lhalf), sizeof(uint16_t) * static_cast<size_t>(n) * idx->ld));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lhmeta), sizeof(float4) * n));
+    unsigned grid = static_cast<unsigned>((n + kNWave - 1) / kNWave);
+#define CALL(N, R, L)                                                                                                   \
+    hipLaunchKernelGGL((quantize_rows_half_kernel<N>), dim3(grid), dim3(kWG), 0, st, idx->d_lrows, idx->ld, n, idx->metric, \
+                       idx->d_lhalf, idx->d_lhmeta)
+    HG_DISPATCH(idx->nch, false, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_mid(const MidArgs &a, int nch, hipStream_t st) {
+    int64_t blocks = static_cast<int64_t>(a.nq) * a.slices;
+    if (a.qorder) blocks = (static_cast<int64_t>(a.nq) + 7) / 8 * 8;  // ordered queries: whole rounds over the eight XCDs
+    if (blocks <= 0) return 0;
+    HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "half-precision pass grid too large");
+    const bool l2 = a.metric == METRIC_L2;
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_mid_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), 0, st, a)
+    HG_DISPATCH(nch, l2, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narrow, hipStream_t st) {
     if (blocks <= 0) return 0;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "bounds pass grid too large");
-    const size_t lds = stream_lds_bytes(nch);
+    const size_t lds = stream_lds_bytes(nch, narrow);
 #define CALLV(N, NARROW)                                                                                               \
     do {                                                                                                               \
         static bool attr_done[64] = {};                                                                                \
@@ -594,7 +629,7 @@ __global__ __launch_bounds__(kWG) void ivf_route_tail_kernel(RouteArgs a) {
 }
 
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
-                     int32_t *qcnt, hipStream_t st, const RouteStream *rs, const float *dense_done, bool two_launches) {
+                     int32_t *qcnt, hipStream_t st, const RouteStream *rs, bool two_launches) {
     RouteArgs a;
     memset(&a, 0, sizeof(a));
     if (rs) {
@@ -639,8 +674,9 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
     const size_t lds = std::max<size_t>(sizeof(uint64_t) * (kNWave + 1) * nprobe, sizeof(float) * kSeedMax);
     HG_REQUIRE(lds <= 48 * 1024, HNSWGPU_ELIMIT, "nprobe too large for the fused routing kernel");
     const bool l2 = a.metric == METRIC_L2;
-    if (two_launches && !dense_done) {
+    if (two_launches) {
         // larger batches: the distances by workgroups that share their centroid rows among a group of queries, then the tail
+        // as a launch of its own (plain loads: the distances come from an earlier launch)
         a.qgroup = static_cast<int32_t>(std::max(2, std::min(16, nq / 16)));
         const int64_t ngroups = (nq + a.qgroup - 1) / a.qgroup;
         int64_t wb = std::max<int64_t>(1, 2048 / ngroups);
@@ -653,10 +689,6 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
         HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
         HG_HIP(hipGetLastError());
-        dense_done = a.dense;
-    }
-    if (dense_done) {  // the distances are in s_tile already ([nq][nlist], an earlier launch): the tail alone
-        a.dense = const_cast<float *>(dense_done);
 #define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_tail_kernel<N, R, L>), dim3(static_cast<unsigned>(nq)), dim3(kWG), lds, st, a)
         HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
@@ -675,7 +707,7 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
 // ([nq][nrows] floats) and select_topk_kernel picks the k smallest (key = (distance, row), the same keys the
 // partial-list path builds).  For a short table and a large k -- centroid routing: 1024 centroids, k = nprobe = 32 --
 // the partial-list path emitted a k-slot list per wave for ~8 rows each and spent 31-38 us merging them.
-int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st, bool dense_only) {
+int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st) {
     a.mode = MODE_STORE;
     a.npairs = nq;
     a.nchunks = plan_chunks(idx->nch, nrows, nrows, nq, &a.chunk_rows);
@@ -686,7 +718,6 @@ int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, h
     a.out_stride = nrows;
     const int k = a.k;
     HG_TRY(launch_scan(idx->nch, a, st));
-    if (dense_only) return 0;  // [nq][nrows] distances in s_tile
     SelectArgs s;
     memset(&s, 0, sizeof(s));
     s.dist = a.out;
@@ -1125,16 +1156,14 @@ static int tile_argmin_all(hnswgpu_index *idx, const float *Qp, const float *q_n
 }
 
 int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int32_t nq, const float *rows,
-                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot, bool gemv_order,
-                  bool dense_only) {
+                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot, bool gemv_order) {
     HG_TRY(idx->s_ord.ensure(sizeof(uint32_t) * static_cast<size_t>(nq) * k));
     HG_TRY(idx->s_dist.ensure(sizeof(float) * static_cast<size_t>(nq) * k));
-    if (k == 1 && !gemv_order && !dense_only) return tile_argmin_all(idx, Qp, q_norms, nq, rows, row_norms, nrows, st, prof_slot);
-    // distance scratch [qb][nrows]; bound it to ~2 GiB by batching the queries (dense_only: the caller made sure all fit)
+    if (k == 1 && !gemv_order) return tile_argmin_all(idx, Qp, q_norms, nq, rows, row_norms, nrows, st, prof_slot);
+    // distance scratch [qb][nrows]; bound it to ~2 GiB by batching the queries
     const int tq = tile_tq(idx->dim);
     int64_t qb = std::max<int64_t>(tq, ((2LL << 30) / (4 * std::max<int64_t>(nrows, 1))) / tq * tq);
     qb = std::min<int64_t>(qb, (nq + tq - 1) / tq * tq);
-    HG_REQUIRE(!dense_only || qb >= nq, HNSWGPU_ELIMIT, "dense distance pass too large");
     HG_TRY(idx->s_tile.ensure(sizeof(float) * static_cast<size_t>(qb) * nrows));
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         int32_t nb = static_cast<int32_t>(std::min<int64_t>(qb, nq - q0));
@@ -1162,7 +1191,6 @@ int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int
         prof_begin(idx, prof_slot, st, &e0);
         HG_TRY(launch_tile(t, groups, idx->dim, st));
         prof_end(idx, prof_slot, st, e0);
-        if (dense_only) return 0;  // [nq][nrows] distances in s_tile
         SelectArgs s;
         memset(&s, 0, sizeof(s));
         s.dist = t.out;
@@ -1399,7 +1427,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     for (auto &sl : idx->slots)  // before anything a traversal in flight may read is freed
         if (sl.st) (void)hipStreamSynchronize(sl.st);
     if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows in place: freed once, below
-    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_lcmeta, idx->d_lctile, idx->d_rej_stats, idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
+    void *ptrs[] = {idx->d_base,  idx->d_norms,  idx->d_qrows,  idx->d_qmeta,   idx->d_lcmeta, idx->d_lctile, idx->d_lhalf, idx->d_lhmeta, idx->d_rej_stats, idx->d_levels, idx->d_l0,      idx->d_upadj,  idx->d_upoff,  idx->d_glistoff,
                     idx->d_cent,  idx->d_cnorms, idx->d_lrows,  idx->d_lnorms,  idx->d_listoff, idx->d_listids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1833,6 +1861,51 @@ int hnswgpu_distance_bounds(hnswgpu_index *idx, const float *q, const int32_t *i
     return 0;
 }
 
+// Diagnostic / test entry: the half-precision bounds (stream_kernels.hpp, step 1b) of `m` LIST rows -- positions in list
+// order, as hnswgpu_get_ivf's list_ids numbers them -- against one query, by the kernel the searches run.
+int hnswgpu_ivf_half_bounds(hnswgpu_index *idx, const float *q, const int32_t *list_rows, int32_t m, float *out_lb,
+                            float *out_ub) {
+    HG_REQUIRE(idx && q && list_rows && out_lb && out_ub && m >= 1, HNSWGPU_EINVAL, "null argument");
+    for (int32_t i = 0; i < m; i++) HG_REQUIRE(list_rows[i] >= 0 && list_rows[i] < idx->n, HNSWGPU_EINVAL, "row out of range");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    HG_REQUIRE(idx->d_lhalf, HNSWGPU_EINVAL, "this handle has no half-precision list rows (no lists, no int8 rows, or HNSWGPU_IVF_HALF=0)");
+    hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(upload_queries(idx, q, 1, st));
+    HG_TRY(idx->s_tile.ensure(sizeof(uint4) * static_cast<size_t>(m) + sizeof(uint32_t)));
+    std::vector<uint4> ent(m);
+    for (int32_t i = 0; i < m; i++)  // no bounds yet: NaN on both sides (the kernel keeps the tighter of old and new)
+        ent[i] = make_uint4(static_cast<uint32_t>(i), static_cast<uint32_t>(list_rows[i]), 0x7fc00000u, 0x7fc00000u);
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(idx->s_tile.as<uint4>() + m);
+    const uint32_t cnt = static_cast<uint32_t>(m);
+    HG_HIP(hipMemcpyAsync(idx->s_tile.p, ent.data(), sizeof(uint4) * m, hipMemcpyHostToDevice, st));
+    HG_HIP(hipMemcpyAsync(d_cnt, &cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
+    MidArgs a;
+    memset(&a, 0, sizeof(a));
+    a.surv = idx->s_tile.as<uint4>();
+    a.surv_cnt = d_cnt;
+    a.cap = m;
+    a.nq = 1;
+    a.slices = 1;
+    a.half = idx->d_lhalf;
+    a.hmeta = idx->d_lhmeta;
+    a.ld = idx->ld;
+    a.Q = idx->s_q.as<float>();
+    a.qld = idx->dim;
+    a.dim = idx->dim;
+    a.metric = idx->metric;
+    HG_TRY(launch_mid(a, idx->nch, st));
+    HG_HIP(hipMemcpyAsync(ent.data(), idx->s_tile.p, sizeof(uint4) * m, hipMemcpyDeviceToHost, st));
+    HG_TRY(end_call(idx, st));
+    HG_HIP(hipStreamSynchronize(st));
+    for (int32_t i = 0; i < m; i++) {
+        memcpy(out_lb + i, &ent[i].z, sizeof(float));
+        memcpy(out_ub + i, &ent[i].w, sizeof(float));
+    }
+    return 0;
+}
+
 int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode) {
     HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
     HG_REQUIRE(mode >= 0 && mode <= 2, HNSWGPU_EINVAL, "mode must be 0 (off), 1 (large batches) or 2 (always)");
@@ -1844,6 +1917,7 @@ int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode) {
         HG_TRY(begin_call(idx, st));
         if (idx->has_graph) HG_TRY(ensure_qrows(idx, st));
         HG_TRY(ensure_list_codes(idx, st));
+        HG_TRY(ensure_list_half(idx, st));
         HG_TRY(end_call(idx, st));
         HG_HIP(hipStreamSynchronize(st));
     }

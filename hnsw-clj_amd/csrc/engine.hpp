@@ -90,6 +90,8 @@ struct hnswgpu_index {
     // the list scan (stream_kernels.hpp); made with the lists, null while rejection_mode is 0
     uint32_t *d_lctile = nullptr;
     float4 *d_lcmeta = nullptr;
+    uint2 *d_lhalf = nullptr;    // list rows in fp16, row-major (four halves per element), + per-row (scale, E, 0, 1/|v|)
+    float4 *d_lhmeta = nullptr;
     unsigned long long *d_rej_stats = nullptr;  // [2], counted by the traversal while profiling is on
     int rejection_mode = 1;  // 0 = off, 1 = batches that fill the chip (launch_hnsw_idx), 2 = every launch
     int cus = 256;
@@ -226,6 +228,7 @@ bool attr_needed(bool (&done)[64]);
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);
 int ensure_qrows(hnswgpu_index *idx, hipStream_t st);
 int ensure_list_codes(hnswgpu_index *idx, hipStream_t st);
+int ensure_list_half(hnswgpu_index *idx, hipStream_t st);
 int launch_scan(int nch, const ScanArgs &a, hipStream_t st);
 int launch_merge(const MergeArgs &a, hipStream_t st);
 // Serve `me` through combiner `c`: queue it, lead one batch at a time while it is not done.  `take(first, r, total)`
@@ -240,7 +243,7 @@ int combine_search(hnswgpu_index::Combiner &c, hnswgpu_index::SearchReq &me,
                    const std::function<int(const std::vector<hnswgpu_index::SearchReq *> &, int32_t)> &run);
 // pinned staging block of a combined batch (grown on demand)
 int ensure_pinned(hnswgpu_index *idx, size_t bytes);
-int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st, bool dense_only = false);
+int scan_dense_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int64_t nrows, hipStream_t st);
 // small IVF batches: routing in one launch, list scan with the merge / decode folded into its last workgroups
 // what the routing step prepares for the survivor stream of the list scan (stream_kernels.hpp), or null
 struct RouteStream {
@@ -253,14 +256,15 @@ struct RouteStream {
     int32_t bk_cap;
 };
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
-                     int32_t *qcnt, hipStream_t st, const RouteStream *rs = nullptr, const float *dense_done = nullptr,
-                     bool two_launches = false);
+                     int32_t *qcnt, hipStream_t st, const RouteStream *rs = nullptr, bool two_launches = false);
 // the survivor stream of the IVF list scan (stream_kernels.hpp)
 struct StreamArgs;
 struct FinishArgs;
 struct PrepArgs;
 int launch_query_prep(const PrepArgs &a, int nch, hipStream_t st);
 // narrow: the epilogue for few queries per probed list (lane = row); otherwise lane = query
+struct MidArgs;
+int launch_mid(const MidArgs &a, int nch, hipStream_t st);
 int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narrow, hipStream_t st);
 int launch_finish(const FinishArgs &a, int nch, hipStream_t st);
 // zero-initialised per-query counters of the fused tails (s_done: [n] scan / finish tails | [n] route tails)
@@ -293,8 +297,7 @@ int launch_select(const SelectArgs &a, hipStream_t st);
 int pad_queries(hnswgpu_index *idx, const float *d_Q, int64_t qld, int32_t nq, hipStream_t st);
 // every query against rows [0, nrows): per-query ascending top-k into s_ord / s_dist
 int tile_topk_all(hnswgpu_index *idx, const float *Qp, const float *q_norms, int32_t nq, const float *rows,
-                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot, bool gemv_order = false,
-                  bool dense_only = false);
+                  const float *row_norms, int64_t nrows, int32_t k, hipStream_t st, int prof_slot, bool gemv_order = false);
 
 // Every entry point brackets its device work with these: a call on stream B waits for the previous
 // call's work on stream A before it may reuse the index's scratch buffers.

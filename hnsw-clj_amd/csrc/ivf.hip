@@ -399,12 +399,14 @@ static int validate_lists(int64_t n, int32_t nlist, const int64_t *off, const in
 static void free_ivf(hnswgpu_index *idx) {
     if (idx->lrows_alias) idx->d_lrows = idx->d_lnorms = nullptr;  // the base rows themselves: not ours to free
     void *ptrs[] = {idx->d_cent, idx->d_cnorms, idx->d_lrows, idx->d_lnorms, idx->d_listoff, idx->d_listids, idx->d_glistoff,
-                    idx->d_lcmeta, idx->d_lctile};
+                    idx->d_lcmeta, idx->d_lctile, idx->d_lhalf, idx->d_lhmeta};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     idx->d_cent = idx->d_cnorms = idx->d_lrows = idx->d_lnorms = nullptr;
     idx->d_lcmeta = nullptr;
     idx->d_lctile = nullptr;
+    idx->d_lhalf = nullptr;
+    idx->d_lhmeta = nullptr;
     idx->d_listoff = idx->d_glistoff = nullptr;
     idx->d_listids = nullptr;
     idx->lrows_alias = false;
@@ -443,6 +445,7 @@ static int install_lists(hnswgpu_index *idx, int32_t nlist, const int64_t *off, 
     for (int l = 0; l < nlist; l++) idx->max_list_len = std::max(idx->max_list_len, off[l + 1] - off[l]);
     idx->nlist = nlist;
     HG_TRY(ensure_list_codes(idx, st));
+    HG_TRY(ensure_list_half(idx, st));
     HG_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -850,8 +853,50 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     const bool narrow = narrow_env >= 0 ? narrow_env != 0 : npairs < 6LL * idx->nlist;
     HG_TRY(launch_stream_bounds(b, blocks, idx->nch, narrow, st));
     prof_end(idx, PROF_IVF_SCAN, st, e0);
+    // Large batches: a query's survivors are, above all, its nearest list -- and several queries share one.  The queries are
+    // taken in the order of their nearest list, a contiguous eighth of that order per XCD, so that the queries which read
+    // the same rows run side by side on ONE L2 (each XCD otherwise fetches the list for itself).
+    const int32_t *qorder = nullptr;
+    const int64_t order_min = env_now("HNSWGPU_FINISH_ORDER", 512);  // 0 = never (A/B)
+    if (d_probes && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists) {
+        HG_TRY(idx->s_stats.ensure(sizeof(int32_t) * static_cast<size_t>(nq)));  // (s_ids / s_outd may be the caller's outputs)
+        const size_t olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);
+        if (olds > 48 * 1024) {
+            static bool attr_done[64] = {};
+            if (attr_needed(attr_done))
+                HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(sizeof(int32_t) * (kOrderMaxLists + 1 + 1024))));
+        }
+        hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), olds, st, d_probes, nq, idx->nlist, idx->s_stats.as<int32_t>(), nprobe);
+        HG_HIP(hipGetLastError());
+        qorder = idx->s_stats.as<int32_t>();
+    }
+    // from a few hundred queries up the exact pass is the largest kernel (its rows are 3 KB each and every query fetches its
+    // own): the survivors first meet their half-precision rows.  Below, the extra launch costs more than the rows it saves.
+    const int64_t mid_min = env_now("HNSWGPU_STREAM_MID", 128);  // 0 = never (A/B)
+    const bool mid = idx->d_lhalf != nullptr && mid_min > 0 && nq >= mid_min;
+    if (mid) {
+        MidArgs ma;
+        memset(&ma, 0, sizeof(ma));
+        ma.surv = b.surv;
+        ma.surv_cnt = b.surv_cnt;
+        ma.cap = cap;
+        ma.nq = nq;
+        ma.slices = qorder ? 1 : static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(16, 4096 / nq)));
+        if (const int64_t sl = env_now("HNSWGPU_MID_SLICES", 0)) ma.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(sl, 64)));  // tuning
+        ma.qorder = ma.slices == 1 ? qorder : nullptr;
+        ma.half = idx->d_lhalf;
+        ma.hmeta = idx->d_lhmeta;
+        ma.ld = idx->ld;
+        ma.Q = d_Q;
+        ma.qld = idx->dim;
+        ma.dim = idx->dim;
+        ma.metric = idx->metric;
+        HG_TRY(launch_mid(ma, idx->nch, st));
+    }
     FinishArgs f;
     memset(&f, 0, sizeof(f));
+    f.prepass = mid ? 1 : 0;
     f.surv = b.surv;
     f.surv_cnt = b.surv_cnt;
     f.tau = b.tau;
@@ -862,7 +907,9 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     f.nprobe = nprobe;
     f.k = k;
     // workgroups per query: the chip filled a few times over for small batches; one or two for large ones
-    f.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(64, 2048 / nq)));
+    // (behind the half-precision pass a query has little more than k rows left to fetch: fewer workgroups, each of which
+    // reads the whole survivor list for the threshold)
+    f.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(64, (mid ? 512 : 2048) / nq)));
     f.span = nq <= 32 ? 16 : 64;
     if (const int64_t sl = env_now("HNSWGPU_FINISH_SLICES", 0)) f.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(sl, 256)));  // tuning
     if (const int64_t sp = env_now("HNSWGPU_FINISH_SPAN", 0)) f.span = sp >= 64 ? 64 : (sp >= 32 ? 32 : 16);
@@ -883,23 +930,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     f.out_dist = d_out_dist;
     f.out_gord = d_out_gord;
     f.stats = idx->prof ? idx->d_rej_stats : nullptr;
-    // Large batches: a query's survivors are, above all, its nearest list -- and several queries share one.  The queries are
-    // taken in the order of their nearest list, a contiguous eighth of that order per XCD, so that the queries which read
-    // the same rows run side by side on ONE L2 (each XCD otherwise fetches the list for itself).
-    const int64_t order_min = env_now("HNSWGPU_FINISH_ORDER", 512);  // 0 = never (A/B)
-    if (d_probes && order_min > 0 && nq >= order_min && f.slices == 1 && idx->nlist <= kOrderMaxLists) {
-        HG_TRY(idx->s_stats.ensure(sizeof(int32_t) * static_cast<size_t>(nq)));  // (s_ids / s_outd may be the caller's outputs)
-        const size_t olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);
-        if (olds > 48 * 1024) {
-            static bool attr_done[64] = {};
-            if (attr_needed(attr_done))
-                HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(sizeof(int32_t) * (kOrderMaxLists + 1 + 1024))));
-        }
-        hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), olds, st, d_probes, nq, idx->nlist, idx->s_stats.as<int32_t>(), nprobe);
-        HG_HIP(hipGetLastError());
-        f.qorder = idx->s_stats.as<int32_t>();
-    }
+    f.qorder = f.slices == 1 ? qorder : nullptr;
     return launch_finish(f, idx->nch, st);
 }
 
@@ -1037,7 +1068,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         // centroid row (the GEMV order, same bits), then ONE launch for everything else of the routing -- select, probe
         // table, pairs filed by list, query codes, first thresholds
         RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap};
-        HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, &rs, nullptr, true));
+        HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, &rs, true));
         codes_done = true;
     } else {
     if (use_tile)  // every query against the centroid table on the tile kernel as well

@@ -203,7 +203,7 @@ struct StreamArgs {
     const QueryScal *qscal;
     uint32_t *tau;       // [nq] running threshold (orderable bits), all-ones at the start
     uint32_t *surv_cnt;  // [nq] survivors appended so far (may exceed cap: the query then takes the fallback)
-    uint4 *surv;         // [nq][cap] (order key, list row, lb bits, 0)
+    uint4 *surv;         // [nq][cap] (order key, list row, lb bits, ub bits)
     int64_t cap;
     int32_t dbg;         // developer ablation switches (HNSWGPU_STREAM_DBG); 0 in production
 };
@@ -221,22 +221,51 @@ struct StreamArgs {
 // bound there, so that a block costs one square root per lane, not thirty-two.
 constexpr int kNarrow = 8;
 
-__host__ inline size_t stream_lds_bytes(int nch) {
+__host__ __device__ constexpr int stream_epilogue_words(bool narrow) { return narrow ? kNarrow * 33 : 16 * kWave; }
+__host__ inline size_t stream_lds_bytes(int nch, bool narrow) {
     return static_cast<size_t>(nch) * 256 * kTileQ                          // query codes [step][half][query][16 B]
            + sizeof(QueryScal) * kTileQ + sizeof(float4) * 32 * kTileWaves  // query scalars, per-wave row terms
-           + (sizeof(float) + sizeof(int32_t)) * 32 * kTileWaves            // per-wave chunk maxima / counts
+           + sizeof(float4) * kTileQ                                        // query terms of the test
            + (sizeof(uint32_t) + sizeof(int32_t)) * kTileQ                  // order bases, query indices
-           + sizeof(int32_t) * (kNarrow * 33 + 3 * kTileQ) * kTileWaves;    // narrow epilogue: per-wave tile + running state
+           + sizeof(int32_t) * stream_epilogue_words(narrow) * kTileWaves;  // per-wave tile of the epilogue
 }
 
-// Euclidean bound terms of one (query, row): lb = sqrt(max(lo, 0)) - W, ub = sqrt(hi) (1 + 1e-6) + W (code_bounds)
-__device__ __forceinline__ void l2_bound_terms(int dot, const QueryScal &qc, float4 meta, float &lo, float &hi, float &W) {
-    const float dh = static_cast<float>(dot) * (qc.s * meta.x);
-    const float v2 = meta.x * meta.x * meta.z;
-    const float d2 = qc.a2 - 2.0f * dh + v2, dl = 2.0e-6f * (qc.a2 + v2);
-    lo = d2 - dl;
-    hi = d2 + dl;
-    W = (qc.rq + 4.0e-6f * qc.qn) + meta.y;
+// The rejection test of one (query, row) in its cheapest form.  code_bounds' lower bound exceeds the threshold tau
+//      cosine     1 - dot s_q s_v / (|q||v|) - W > tau,   W = E + e_q (1 + E)
+//      dot       -dot s_q s_v - W > tau,                  W = |q| E + r_q Z
+//      Euclidean  d2 - dl > (tau + W)^2 (tau, W >= 0),    d2 = a2 - 2 dot s_q s_v + v2, dl = 2e-6 (a2 + v2), W = w_q + E
+// exactly when, with everything that belongs to the row on one side and to the query on the other,
+//      float(dot) * r.x  <  P - Q r.y + K r.z
+// where (r.x, r.y, r.z) = stream_row_terms (per row and block, by the lane that holds the row) and (P, Q, K) =
+// stream_query_terms (per query, once per workgroup).  The rearrangement rounds differently from code_bounds in the
+// last bits; P is pulled back by a few 1e-6 of the magnitudes involved (the allowances E carry 1e-4 / 2e-5 / 4e-6 relative,
+// the test stays on the safe side of code_bounds' own).  NaN on either side (a row or a query without a bound, no
+// threshold yet) fails the comparison: the candidate survives.  The bounds STORED with a survivor are code_bounds'.
+__device__ __forceinline__ float4 stream_row_terms(int metric, float4 m) {
+    if (metric == METRIC_COS) return make_float4(m.x * m.w, m.y, 0.0f, 0.0f);
+    if (metric == METRIC_DOT) return make_float4(m.x, m.y, m.z, 0.0f);
+    const float v2 = m.x * m.x * m.z;  // |v'|^2
+    return make_float4(m.x, m.y, v2 - m.y * m.y * (1.0f + 4.0e-6f), 0.0f);
+}
+__device__ __forceinline__ float4 stream_query_terms(int metric, const QueryScal &qc, float tau) {
+    if (metric == METRIC_COS) {
+        const float ik = 1.0f / (qc.s * qc.iqn);  // NaN for a query without a norm
+        return make_float4(((1.0f - qc.eq) - tau - 4.0e-6f * (1.0f + __builtin_fabsf(tau))) * ik, (1.0f + qc.eq) * ik, 0.0f, 0.0f);
+    }
+    if (metric == METRIC_DOT) {
+        const float ik = 1.0f / qc.s, t = -tau * ik;
+        return make_float4(t - 2.0e-6f * __builtin_fabsf(t), qc.qn * ik, -(qc.rq * ik), 0.0f);
+    }
+    // dot x < [(a2 + v2)(1 - 3e-6) - (tw + E)^2 (1 + 1e-6)] / (2 s_q),  tw = tau + w_q:
+    //       = k1 (a2 - tw^2 c) + k1 (v2 - E^2 c) - (2 tw c k1) E,   k1 = (1 - 3e-6) / (2 s_q), c = (1 + 1e-6) / (1 - 3e-6)
+    const float k1 = (1.0f - 3.0e-6f) / (2.0f * qc.s), c = 1.0f + 4.0e-6f;
+    const float tw = tau + (qc.rq + 4.0e-6f * qc.qn);
+    return make_float4(k1 * (qc.a2 - tw * tw * c), 2.0f * tw * c * k1, k1, 0.0f);
+}
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool stream_reject(int dot, float4 r, float4 qt) {
+    return static_cast<float>(dot) * r.x < __builtin_fmaf(-qt.y, r.y, __builtin_fmaf(r.z, qt.z, qt.x));
 }
 
 template <int NCH, bool NARROW>
@@ -246,23 +275,18 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
     extern __shared__ __align__(16) unsigned char smem[];
     v4i_t *qb_s = reinterpret_cast<v4i_t *>(smem);                               // [S][2][32]
     QueryScal *qs_s = reinterpret_cast<QueryScal *>(qb_s + S * 64);              // [32]
-    float4 *meta_all = reinterpret_cast<float4 *>(qs_s + kTileQ);                // [waves][32]
-    float *wmax_s = reinterpret_cast<float *>(meta_all + 32 * kTileWaves);       // [waves][32]
-    int32_t *wcnt_s = reinterpret_cast<int32_t *>(wmax_s + 32 * kTileWaves);     // [waves][32]
-    uint32_t *ob_s = reinterpret_cast<uint32_t *>(wcnt_s + 32 * kTileWaves);     // [32]
+    float4 *meta_all = reinterpret_cast<float4 *>(qs_s + kTileQ);                // [waves][32] row terms
+    float4 *qt_s = meta_all + 32 * kTileWaves;                                    // [32] query terms
+    uint32_t *ob_s = reinterpret_cast<uint32_t *>(qt_s + kTileQ);                 // [32]
     int32_t *qi_s = reinterpret_cast<int32_t *>(ob_s + kTileQ);                  // [32]
-    int32_t *narrow_all = qi_s + kTileQ;                                          // [waves][kNarrow * 33 + 3 * 32]
+    int32_t *narrow_all = qi_s + kTileQ;                                          // [waves][stream_epilogue_words]
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
-    float4 *meta_s = meta_all + wave * 32;
-    int32_t *tile_w = narrow_all + wave * (kNarrow * 33 + 3 * kTileQ);            // [kNarrow][33] dot products
-    float *tauw = reinterpret_cast<float *>(tile_w + kNarrow * 33);               // [32] thresholds
-    float *runm = tauw + kTileQ;                                                  // [32] running maxima
-    int32_t *runc = reinterpret_cast<int32_t *>(runm + kTileQ);                   // [32] ... of how many candidates
+    float *terms_w = reinterpret_cast<float *>(meta_all + wave * 32);
+    int32_t *tile_w = narrow_all + wave * stream_epilogue_words(NARROW);          // narrow: [kNarrow][33] dot products; wide: [16][64]
 
     const int col = lane & 31, half = lane >> 5;
-    const float kInf = __builtin_inff();
     constexpr bool narrow = NARROW;
     const v4i_t *tile = reinterpret_cast<const v4i_t *>(a.ctile);
     // ---- work item
@@ -341,30 +365,31 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
         if (q < cnt) v = reinterpret_cast<const v4i_t *>(a.qcodes + static_cast<int64_t>(qi_s[q]) * NCH * kWave)[t];
         qb_s[t * 32 + q] = v;
     }
-    if (lane < 32) {  // this wave's chunk maxima / counts; narrow epilogue: thresholds and running maxima
-        wmax_s[wave * 32 + lane] = -kInf;
-        wcnt_s[wave * 32 + lane] = 0;
-        tauw[lane] = kInf;
-        runm[lane] = -kInf;
-        runc[lane] = 0;
+    // the query's side of the test (lane = slot of the group): P, Q, K of stream_query_terms, once per workgroup -- the
+    // threshold of a query does not move while this kernel runs (it falls again in the finish kernel)
+    if (tid < kTileQ) {
+        float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (tid < cnt) t = stream_query_terms(a.metric, qs_s[tid], tau_decode(a.tau[qi_s[tid]]));
+        qt_s[tid] = t;
     }
     __syncthreads();
 
     const bool live = col < cnt;
-    const QueryScal myqs = live ? qs_s[col] : QueryScal{};
+    const float4 myqt = qt_s[col];
+    const v2f_t P2 = {myqt.x, myqt.x}, nQ2 = {-myqt.y, -myqt.y}, K2 = {myqt.z, myqt.z};
     const int myq = live ? qi_s[col] : 0;
     const uint32_t myob = live ? ob_s[col] : 0;
-    float my_tau = kInf;
-    float run_max = -kInf, all_max = -kInf;
-    int run_cnt = 0, all_cnt = 0;
     uint4 *dst = a.surv + static_cast<int64_t>(myq) * a.cap;
     const v4i_t *ap = tile + (b * S) * 64 + lane;  // this wave's current block
     const v4i_t *qb_mine = qb_s + half * 32 + col;   // B operand of step s: qb_mine[s * 64]
     for (; b < b1; b += kTileWaves, ap += static_cast<int64_t>(kTileWaves) * S * 64) {
-        const float4 mcur = metar;  // narrow groups: lane & 31 is the row whose terms these are
-        if (!narrow && lane < 32) meta_s[lane] = metar;
-        // what the other workgroups have found meanwhile (in flight under the MFMAs): lane = query in both epilogues
-        const uint32_t tnow = live ? coherent_load(a.tau + myq) : 0xffffffffu;
+        // the row's side of the test: lane & 31 is the row whose terms these are (rows outside the chunk: zeros)
+        const float4 mcur = stream_row_terms(a.metric, metar);
+        if (!narrow && lane < 32) {  // [3][32]: a lane reads the terms of its four adjacent rows as one vector each
+            terms_w[lane] = mcur.x;
+            terms_w[32 + lane] = mcur.y;
+            terms_w[64 + lane] = mcur.z;
+        }
         v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         {
             const v4i_t *p = ap;
@@ -392,207 +417,290 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
             if (row >= r0 && row < r1) metar = a.cmeta[row];
         }
         if (a.dbg & 1) {  // ablation: no epilogue (results are wrong)
-            if (acc[0] == 0x7fffffff) dst[0] = make_uint4(tnow, 0, 0, 0);
+            if (acc[0] == 0x7fffffff) dst[0] = make_uint4(1, 0, 0, 0);
             continue;
         }
         // C/D: lane holds column `col` (the query); register g is row (g & 3) + 8 (g >> 2) + 4 half of the block
         const int rel = static_cast<int>(b * 32 - rb0);  // row 0 of the block, relative to the list
         if (narrow) {
             // ---- eight live columns at a time into LDS; then lane = row, one half of the wave per query
-            if (live && half == 0) {
-                const float tg = tau_decode(tnow), to = tauw[col];
-                tauw[col] = tg < to ? tg : to;
-            }
             const int r = rel + col;
             const bool valid = r >= rel0 && r < rel1;
             for (int c0 = 0; c0 < cnt; c0 += kNarrow) {
-            if (col >= c0 && col < c0 + kNarrow && live) {
+                if (col >= c0 && col < c0 + kNarrow && live) {
 #pragma unroll
-                for (int g = 0; g < 16; g++) tile_w[(col - c0) * 33 + (g & 3) + 8 * (g >> 2) + 4 * half] = acc[g];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int cend = c0 + kNarrow < cnt ? c0 + kNarrow : cnt;
-            for (int q0 = c0; q0 < cend; q0 += 2) {
-                const int qx = q0 + half;
-                const bool act = qx < cend;
-                const int qxc = act ? qx : q0;
-                const QueryScal qs = qs_s[qxc];
-                float lb, ub;
-                code_bounds(a.metric, tile_w[(qxc - c0) * 33 + col], qs, mcur, mcur.w, lb, ub);
-                const float tq = tauw[qxc];
-                const bool va = valid && act;
-                float um = va ? (ub == ub ? ub : kInf) : -kInf;
-#pragma unroll
-                for (int off = 1; off < 32; off <<= 1) {  // the largest ub of this query's rows (the half's 32 lanes)
-                    const float o = __shfl_xor(um, off, kWave);
-                    um = o > um ? o : um;
+                    for (int g = 0; g < 16; g++) tile_w[(col - c0) * 33 + (g & 3) + 8 * (g >> 2) + 4 * half] = acc[g];
                 }
-                const uint64_t vb = __ballot(va);
-                const bool pass = va && !(lb > tq);  // NaN (no bound) survives
-                const uint64_t pb = __ballot(pass);
-                const uint32_t pm = half ? static_cast<uint32_t>(pb >> 32) : static_cast<uint32_t>(pb);
-                const int n = __popc(pm);
-                if (col == 0 && act) {  // the half's leader: running maxima, the threshold
-                    const int bc = __popc(half ? static_cast<uint32_t>(vb >> 32) : static_cast<uint32_t>(vb));
-                    const float wm = wmax_s[wave * 32 + qx];
-                    wmax_s[wave * 32 + qx] = um > wm ? um : wm;
-                    wcnt_s[wave * 32 + qx] += bc;
-                    float rm = runm[qx];
-                    int rc = runc[qx] + bc;
-                    rm = um > rm ? um : rm;
-                    if (rc >= a.k) {  // k candidates of this query are at most rm away: D_k <= rm
-                        if (rm < tq) {
-                            tauw[qx] = rm;
-                            (void)__hip_atomic_fetch_min(a.tau + qi_s[qx], tau_encode(rm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int cend = c0 + kNarrow < cnt ? c0 + kNarrow : cnt;
+                for (int q0 = c0; q0 < cend; q0 += 2) {
+                    const int qx = q0 + half;
+                    const bool act = qx < cend;
+                    const int qxc = act ? qx : q0;
+                    const int dot = tile_w[(qxc - c0) * 33 + col];
+                    const bool pass = valid && act && !stream_reject(dot, mcur, qt_s[qxc]);  // NaN (no bound) survives
+                    const uint64_t pb = __ballot(pass);
+                    if (pb) {  // (most blocks of most lists append nothing)
+                        const uint32_t pm = half ? static_cast<uint32_t>(pb >> 32) : static_cast<uint32_t>(pb);
+                        const int n = __popc(pm);
+                        uint32_t base = 0;
+                        if (col == 0 && n > 0)
+                            base = __hip_atomic_fetch_add(a.surv_cnt + qi_s[qxc], static_cast<uint32_t>(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        base = __shfl(base, half * 32, kWave);
+                        if (pass) {
+                            const uint32_t slot = base + __popc(pm & ((1u << col) - 1u));
+                            if (slot < a.cap) {
+                                const float4 mt = a.cmeta[rb0 + r];
+                                float lb, ub;
+                                code_bounds(a.metric, dot, qs_s[qxc], mt, mt.w, lb, ub);
+                                a.surv[static_cast<int64_t>(qi_s[qxc]) * a.cap + slot] =
+                                    make_uint4(ob_s[qxc] + static_cast<uint32_t>(r), static_cast<uint32_t>(rb0) + static_cast<uint32_t>(r),
+                                               __float_as_uint(lb), __float_as_uint(ub));
+                            }
                         }
-                        rm = -kInf;
-                        rc = 0;
-                    }
-                    runm[qx] = rm;
-                    runc[qx] = rc;
-                }
-                if (pb) {  // (most blocks of most lists append nothing)
-                    uint32_t base = 0;
-                    if (col == 0 && n > 0)
-                        base = __hip_atomic_fetch_add(a.surv_cnt + qi_s[qxc], static_cast<uint32_t>(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    base = __shfl(base, half * 32, kWave);
-                    if (pass) {
-                        const uint32_t slot = base + __popc(pm & ((1u << col) - 1u));
-                        if (slot < a.cap)
-                            a.surv[static_cast<int64_t>(qi_s[qxc]) * a.cap + slot] =
-                                make_uint4(ob_s[qxc] + static_cast<uint32_t>(r), static_cast<uint32_t>(rb0) + static_cast<uint32_t>(r),
-                                           __float_as_uint(lb), 0u);
                     }
                 }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // the next columns overwrite tile_w
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the next columns overwrite tile_w
             }
             continue;
         }
-        // ---- wide groups: lane = query, sixteen rows each.  Four registers at a time in a real loop (unrolled, the
-        // sixteen bounds with their row terms cost 180 registers and the kernel half its occupancy)
+        // ---- wide groups: lane = query, sixteen rows each: five operations per (query, row) -- convert, multiply, two
+        // fused multiply-adds, compare -- and one LDS broadcast of the row's terms
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // meta_s written by lanes 0-31 above is read by every lane below
-        {
-            const float tg = tau_decode(tnow);
-            my_tau = tg < my_tau ? tg : my_tau;
-        }
-        const bool l2 = a.metric == METRIC_L2;
-        uint32_t vmask = 0, pmask = 0;
-        float bmax = -kInf, wmax = -kInf;  // Euclidean: bmax = the largest squared upper term, wmax = the largest W
-        // Euclidean: lb > tau  <=>  lo > (tau + W)^2 (tau, W >= 0), tested with a margin above the rounding of the square
-#pragma unroll 1
-        for (int j = 0; j < 4; j++) {
-            const int a0 = j == 0 ? acc[0] : (j == 1 ? acc[4] : (j == 2 ? acc[8] : acc[12]));
-            const int a1 = j == 0 ? acc[1] : (j == 1 ? acc[5] : (j == 2 ? acc[9] : acc[13]));
-            const int a2 = j == 0 ? acc[2] : (j == 1 ? acc[6] : (j == 2 ? acc[10] : acc[14]));
-            const int a3 = j == 0 ? acc[3] : (j == 1 ? acc[7] : (j == 2 ? acc[11] : acc[15]));
-            const int av4[4] = {a0, a1, a2, a3};
+        uint32_t pmask = 0;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int i = 8 * j + 4 * half + t;
-                const int r = rel + i;
-                const float4 mt = meta_s[i];
-                const bool valid = r >= rel0 && r < rel1;
-                if (l2) {
-                    float lo, hi, W;
-                    l2_bound_terms(av4[t], myqs, mt, lo, hi, W);
-                    if (valid) {
-                        vmask |= 1u << (4 * j + t);
-                        hi = hi == hi ? hi : kInf;
-                        const float Wn = W == W ? W : kInf;
-                        bmax = hi > bmax ? hi : bmax;
-                        wmax = Wn > wmax ? Wn : wmax;
-                        const float tw = my_tau + W;
-                        if (!(lo > tw * tw * (1.0f + 1.0e-6f))) pmask |= 1u << (4 * j + t);  // NaN survives
-                    }
-                } else {
-                    float lb, ub;
-                    code_bounds(a.metric, av4[t], myqs, mt, mt.w, lb, ub);
-                    if (valid) {
-                        vmask |= 1u << (4 * j + t);
-                        ub = ub == ub ? ub : kInf;
-                        bmax = ub > bmax ? ub : bmax;
-                        if (!(lb > my_tau)) pmask |= 1u << (4 * j + t);  // NaN (no bound) survives
-                    }
-                }
+        for (int j = 0; j < 4; j++) {  // registers 4j .. 4j+3 = rows 8j + 4 half + (0..3): their terms are adjacent in LDS
+            const v4f_t X = *reinterpret_cast<const v4f_t *>(terms_w + 8 * j + 4 * half);
+            const v4f_t Y = *reinterpret_cast<const v4f_t *>(terms_w + 32 + 8 * j + 4 * half);
+            const v4f_t Z = *reinterpret_cast<const v4f_t *>(terms_w + 64 + 8 * j + 4 * half);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {  // two rows per (packed) operation, written out: left to itself the compiler pairs
+                                           // rows across vectors and keeps twenty copies of the three query terms
+                const v2f_t d = {static_cast<float>(acc[4 * j + 2 * h]), static_cast<float>(acc[4 * j + 2 * h + 1])};
+                const v2f_t x = {X[2 * h], X[2 * h + 1]}, y = {Y[2 * h], Y[2 * h + 1]}, z = {Z[2 * h], Z[2 * h + 1]};
+                const v2f_t lhs = d * x;
+                const v2f_t rhs = __builtin_elementwise_fma(nQ2, y, __builtin_elementwise_fma(z, K2, P2));
+                if (!(lhs[0] < rhs[0])) pmask |= 1u << (4 * j + 2 * h);
+                if (!(lhs[1] < rhs[1])) pmask |= 1u << (4 * j + 2 * h + 1);
             }
         }
         if (!live) pmask = 0;
-        int bcnt = __popc(vmask);
-        if (l2) bmax = bcnt > 0 ? __builtin_sqrtf(bmax) * (1.0f + 1.0e-6f) + wmax : -kInf;  // >= every row's ub
-        {  // the other half of the block's rows of this query
-            const float om = __shfl_xor(bmax, 32, kWave);
-            bcnt += __shfl_xor(bcnt, 32, kWave);
-            bmax = om > bmax ? om : bmax;
-        }
-        run_max = bmax > run_max ? bmax : run_max;
-        run_cnt += bcnt;
-        all_max = bmax > all_max ? bmax : all_max;
-        all_cnt += bcnt;
-        if (run_cnt >= a.k) {  // k candidates of this query are at most run_max away: D_k <= run_max
-            if (run_max < my_tau) {
-                my_tau = run_max;
-                if (live && half == 0)
-                    (void)__hip_atomic_fetch_min(a.tau + myq, tau_encode(run_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (rel < rel0 || rel + 32 > rel1) {  // the first and the last block of a chunk: rows of the neighbours
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                const int i = rel + (g & 3) + 8 * (g >> 2) + 4 * half;
+                if (i < rel0 || i >= rel1) pmask &= ~(1u << g);
             }
-            run_max = -kInf;
-            run_cnt = 0;
         }
         const int n = __popc(pmask);
-        const int on = __shfl_xor(n, 32, kWave);
         if (__ballot(n > 0)) {  // (most blocks of most lists append nothing)
+            // the products go to LDS and each lane walks ITS set bits: kept in registers and picked by index, the tile
+            // would stay live through this path in two copies and cost the kernel half its occupancy
+#pragma unroll
+            for (int g = 0; g < 16; g++) tile_w[g * kWave + lane] = acc[g];
+            const int on = __shfl_xor(n, 32, kWave);
             uint32_t base = 0;
             if (half == 0 && n + on > 0)
                 base = __hip_atomic_fetch_add(a.surv_cnt + myq, static_cast<uint32_t>(n + on), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             base = __shfl(base, col, kWave);
             if (half) base += on;  // half 1 writes behind half 0's `on` entries
-#pragma unroll 1
-            for (int j = 0; j < 4; j++) {
-                if (((pmask >> (4 * j)) & 15u) == 0) continue;
-                const int a0 = j == 0 ? acc[0] : (j == 1 ? acc[4] : (j == 2 ? acc[8] : acc[12]));
-                const int a1 = j == 0 ? acc[1] : (j == 1 ? acc[5] : (j == 2 ? acc[9] : acc[13]));
-                const int a2 = j == 0 ? acc[2] : (j == 1 ? acc[6] : (j == 2 ? acc[10] : acc[14]));
-                const int a3 = j == 0 ? acc[3] : (j == 1 ? acc[7] : (j == 2 ? acc[11] : acc[15]));
-                const int av4[4] = {a0, a1, a2, a3};
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    if ((pmask >> (4 * j + t)) & 1u) {
-                        const int i = 8 * j + 4 * half + t;
-                        const float4 mt = meta_s[i];
-                        const float lb = code_lower_bound(a.metric, av4[t], myqs, mt, mt.w);
-                        const uint32_t r = static_cast<uint32_t>(rel + i);
-                        if (base < a.cap)
-                            dst[base] = make_uint4(myob + r, static_cast<uint32_t>(rb0) + r, __float_as_uint(lb), 0u);
-                        base++;
+            if (n > 0) {
+                const QueryScal myqs = qs_s[col];
+                for (uint32_t pm = pmask; pm; pm &= pm - 1, base++) {
+                    const int g = __ffs(pm) - 1;
+                    const uint32_t r = static_cast<uint32_t>(rel + (g & 3) + 8 * (g >> 2) + 4 * half);
+                    if (base < a.cap) {
+                        const float4 mt = a.cmeta[rb0 + r];
+                        float lb, ub;
+                        code_bounds(a.metric, tile_w[g * kWave + lane], myqs, mt, mt.w, lb, ub);
+                        dst[base] = make_uint4(myob + r, static_cast<uint32_t>(rb0) + r, __float_as_uint(lb), __float_as_uint(ub));
                     }
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();  // the next block overwrites meta_s
     }
-    // the whole chunk as one block of candidates: for a k no single wave reaches
-    if (!narrow && half == 0) {
-        wmax_s[wave * 32 + col] = all_max;
-        wcnt_s[wave * 32 + col] = all_cnt;
-    }
-    __syncthreads();
-    if (wave == 0 && half == 0 && live) {
-        float m = -kInf;
-        int c = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Step 1b (batches from a few hundred queries up): the survivors once more, against HALF-precision rows.
+//
+// What the int8 bounds cannot separate is a band of 2 W around the k-th distance (W ~ 0.017 in cosine units at 768
+// dimensions: on clustered data ~3 % of a query's candidates, ~1000 rows of 3 KB each -- at batch 1024 the exact pass
+// moves 3 GB and is the largest kernel of the search).  A second copy of the list rows in fp16 (1.5 KB, with a power-of-two
+// scale per row) narrows the band seventy-fold: |q.v - q.v'| <= |q| |v - v'| with |v - v'| ~ 2^-12 |v| MEASURED per row when
+// the copy is made.  This kernel fetches the half row of every survivor, replaces the entry's (lb, ub) by the tighter
+// pair, and the finish kernel -- whose first act is the k-th smallest upper bound of the list -- then fetches f32 rows
+// for little more than k candidates.  The distances, and with them every result bit, still come from the f32 rows.
+//
+//   cosine   c = 1 - s (q.h) / (|q||v|)              lb/ub = c -/+ E,      E = 1.01 res / |v| + 4e-5
+//   dot      d = -s (q.h)                            lb/ub = d -/+ |q| E,  E = 1.01 res + 2e-5 |v|
+//   L2       r = sqrt(sum (q_i - s h_i)^2)           lb/ub = r (1 -/+ 8e-6) -/+ E,  E = 1.01 res    (triangle inequality)
+// res = |v - s h| as computed from the stored halves; the absolute terms carry the f32 rounding of BOTH summations (this
+// one and the exact pass's: < (4 NCH + 8) 2^-24 relative to |q||v| each, 3.4e-6 at 3072 dimensions) and of the norms.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+
+template <int NCH>
+__global__ __launch_bounds__(kWG) void quantize_rows_half_kernel(const float *rows, int64_t ld, int64_t n, int metric,
+                                                                 uint2 *half, float4 *meta) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kNWave + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int nvec = static_cast<int>(ld / 4);
+    float4 r[NCH];
+    load_row<NCH>(r, rows + row * ld, nvec, lane, true);
+    bool bad;
+    const float mx = wave_absmax<NCH>(r, bad);
+    // s = 2^(e - 14), e = the exponent of the largest component: the scaled row fills fp16's range from the top
+    int field = static_cast<int>((__float_as_uint(mx) >> 23) & 0xffu) - 14;
+    field = field < 1 ? 1 : (field > 253 ? 253 : field);
+    const float s = __uint_as_float(static_cast<uint32_t>(field) << 23), is = __uint_as_float(static_cast<uint32_t>(254 - field) << 23);
+    float res = 0.0f;
+    uint2 *dst = half + row * nvec;
 #pragma unroll
-        for (int w = 0; w < kTileWaves; w++) {
-            const float x = wmax_s[w * 32 + col];
-            m = x > m ? x : m;
-            c += wcnt_s[w * 32 + col];
+    for (int c = 0; c < NCH; c++) {
+        const float e[4] = {r[c].x, r[c].y, r[c].z, r[c].w};
+        h4_t h;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            h[j] = static_cast<_Float16>(e[j] * is);
+            const float d = e[j] - static_cast<float>(h[j]) * s;
+            res = __builtin_fmaf(d, d, res);
         }
-        // (only when it improves on what this wave knows: an agent-scope atomic on ONE address costs ~1 us and they queue --
-        // issued by every workgroup, this line alone doubled the kernel's time)
-        const float known = narrow ? tauw[col] : my_tau;
-        if (c >= a.k && m < known)
-            (void)__hip_atomic_fetch_min(a.tau + myq, tau_encode(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c * kWave + lane < nvec) dst[c * kWave + lane] = __builtin_bit_cast(uint2, h);
+    }
+    res = __builtin_sqrtf(wave_sum(res));
+    const float nv = __builtin_sqrtf(wave_sum(lane_partial<NCH, false>(r, r)));
+    float E;
+    if (metric == METRIC_COS) E = 1.01f * res / nv + 4.0e-5f;
+    else if (metric == METRIC_DOT) E = 1.01f * res + 2.0e-5f * nv;
+    else E = 1.01f * res;
+    if (bad || !(E >= 0.0f)) E = __uint_as_float(0x7fc00000u);  // NaN: no bound, the exact path
+    if (lane == 0) meta[row] = make_float4(s, E, 0.0f, 1.0f / nv);
+}
+
+__device__ __forceinline__ void half_bounds(int metric, float sum, float qn, float4 mt, float &lb, float &ub) {
+    if (metric == METRIC_L2) {
+        const float r = __builtin_sqrtf(sum);
+        lb = r * (1.0f - 8.0e-6f) - mt.y;
+        ub = r * (1.0f + 8.0e-6f) + mt.y;
+        return;
+    }
+    const float dh = sum * mt.x;
+    if (metric == METRIC_DOT) {
+        const float W = qn * mt.y;
+        lb = -dh - W;
+        ub = -dh + W;
+        return;
+    }
+    const float c = 1.0f - dh * ((1.0f / qn) * mt.w);  // |q| or |v| zero: NaN, no bound
+    lb = c - mt.y;
+    ub = c + mt.y;
+}
+
+struct MidArgs {
+    uint4 *surv;               // [nq][cap] (order key, list row, lb bits, ub bits): lb / ub are replaced
+    const uint32_t *surv_cnt;
+    int64_t cap;
+    int32_t nq, slices;
+    const int32_t *qorder;     // optional (slices == 1): the queries in the order of their nearest list (as the finish kernel)
+    const uint2 *half;         // [rows][ld / 4] four halves each
+    const float4 *hmeta;       // (scale, E, 0, 1 / |v|)
+    int64_t ld;
+    const float *Q;
+    int64_t qld;
+    int32_t dim, metric;
+};
+
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    int qi = blockIdx.x % a.nq;
+    const int sl = a.qorder ? 0 : blockIdx.x / a.nq;
+    if (a.qorder) {  // workgroup b runs on XCD b % 8: XCD x takes a contiguous eighth of the ordered queries
+        const int per = (a.nq + 7) >> 3;
+        const int pos = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (pos >= a.nq || (blockIdx.x >> 3) >= per) return;
+        qi = a.qorder[pos];
+    }
+    const uint32_t nsv = a.surv_cnt[qi];
+    if (nsv > a.cap) return;  // the list overflowed: the finish kernel walks the candidate stream instead
+    constexpr int gran = kNWave * kWave;
+    int64_t per = (static_cast<int64_t>(nsv) + a.slices - 1) / a.slices;
+    per = (per + gran - 1) / gran * gran;
+    const int64_t i0 = static_cast<int64_t>(sl) * per;
+    const int64_t i1 = i0 + per < nsv ? i0 + per : nsv;
+    if (i0 >= i1) return;
+    const int nvec = static_cast<int>(a.ld / 4);
+    float4 q[NCH];
+    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+    const float qn = L2 ? 0.0f : query_norm<NCH>(q);
+    uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
+    for (int64_t base = i0 + wave * kWave; base < i1; base += gran) {
+        const int64_t i = base + lane;
+        const bool in = i < i1;
+        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+        float4 mt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (in) {
+            e = sv[i];
+            mt = a.hmeta[e.y];
+        }
+        uint64_t m = __ballot(in);
+        float mysum = 0.0f;
+        while (m) {
+            uint2 w[RB][NCH];
+            int js[RB];
+            float sc[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                js[b] = -1;
+                sc[b] = 0.0f;
+                if (m) {
+                    js[b] = __ffsll(static_cast<unsigned long long>(m)) - 1;
+                    m &= m - 1;
+                    const int64_t row = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e.y), js[b]));
+                    sc[b] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mt.x), js[b]));
+                    const uint2 *rp = a.half + row * nvec;
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) w[b][c] = c * kWave + lane < nvec ? rp[c * kWave + lane] : make_uint2(0u, 0u);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                if (js[b] < 0) break;
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const h4_t h = __builtin_bit_cast(h4_t, w[b][c]);
+                    const float hv[4] = {static_cast<float>(h[0]), static_cast<float>(h[1]), static_cast<float>(h[2]), static_cast<float>(h[3])};
+                    const float qv[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (L2) {
+                            const float d = qv[j] - hv[j] * sc[b];
+                            acc = __builtin_fmaf(d, d, acc);
+                        } else {
+                            acc = __builtin_fmaf(qv[j], hv[j], acc);
+                        }
+                    }
+                }
+                const float sum = wave_sum(acc);
+                mysum = lane == js[b] ? sum : mysum;
+            }
+        }
+        if (in) {
+            float lb, ub;
+            half_bounds(a.metric, mysum, qn, mt, lb, ub);
+            // (both pairs hold: the tighter of each -- v_max / v_min return the other operand for a NaN)
+            lb = __builtin_fmaxf(lb, __uint_as_float(e.z));
+            ub = __builtin_fminf(ub, __uint_as_float(e.w));
+            *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(sv + i) + 2) = make_uint2(__float_as_uint(lb), __float_as_uint(ub));
+        }
     }
 }
 
@@ -600,7 +708,7 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
 // Step 2: survivors -> f32 distances -> the k nearest -> results.
 // ------------------------------------------------------------------------------------------------
 struct FinishArgs {
-    const uint4 *surv;     // (order key, list row, lb bits, 0)
+    const uint4 *surv;     // (order key, list row, lb bits, ub bits)
     const uint32_t *surv_cnt;
     uint32_t *tau;         // keeps falling while the survivors are evaluated
     int64_t cap;
@@ -623,12 +731,15 @@ struct FinishArgs {
     float *out_dist;       // [nq][k]
     uint32_t *out_gord;    // optional [nq][k]
     unsigned long long *stats;  // optional: [0] += f32 rows evaluated, [1] += candidates
+    int32_t prepass;       // the upper bounds are worth a look first (ivf_mid_kernel has tightened them)
 };
 
 template <int NCH, int RB, bool L2>
 __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int tail_last;
+    __shared__ __align__(16) uint32_t ub_s[kWG];
+    __shared__ uint32_t ub_kth;
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem);  // [kNWave][k] (+ the tail's final list and results)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -660,6 +771,34 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     uint64_t *mylist = lists + wave * a.k;
     int cnt = 0;
     uint64_t thr = ~0ull, mine = ~0ull;
+    // ---- before any f32 row is fetched: the survivors' UPPER bounds give a threshold of their own.  k candidates whose
+    // upper bounds are <= T are k candidates at most T away, so D_k <= T; T = the k-th smallest of the 256 threads'
+    // minima over a strided share of the list each (the k smallest upper bounds sit in k different shares but for the odd
+    // collision, which costs one rank).  Only behind ivf_mid_kernel: the int8 upper bounds are no tighter than the
+    // threshold the bounds pass ran with (measured: not one row fewer), the half-precision ones leave little more than k
+    // candidates.  (Every workgroup of a query reads the whole list: 16 B per survivor, from L2.)
+    if (a.prepass && !over && a.k <= kWG) {
+        float m = __builtin_inff();
+        for (uint32_t i = threadIdx.x; i < nsv; i += kWG) {
+            const float u = __uint_as_float(sv[i].w);
+            m = u < m ? u : m;  // (NaN: no upper bound, not counted)
+        }
+        const uint32_t v = tau_encode(m);
+        ub_s[threadIdx.x] = v;
+        __syncthreads();
+        int rank = 0;
+        for (int j = 0; j < kWG; j += 4) {
+            const uint4 o = *reinterpret_cast<const uint4 *>(ub_s + j);  // uniform address: an LDS broadcast
+            rank += (o.x < v || (o.x == v && j < static_cast<int>(threadIdx.x))) ? 1 : 0;
+            rank += (o.y < v || (o.y == v && j + 1 < static_cast<int>(threadIdx.x))) ? 1 : 0;
+            rank += (o.z < v || (o.z == v && j + 2 < static_cast<int>(threadIdx.x))) ? 1 : 0;
+            rank += (o.w < v || (o.w == v && j + 3 < static_cast<int>(threadIdx.x))) ? 1 : 0;
+        }
+        if (rank == a.k - 1) ub_kth = v;  // ranks are a permutation of 0..255: exactly one thread
+        __syncthreads();
+        const float T = tau_decode(ub_kth);
+        tau = T < tau ? T : tau;
+    }
     const int nvec = static_cast<int>(a.ld / 4);
     float4 q[NCH];
     load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);

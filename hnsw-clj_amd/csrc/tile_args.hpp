@@ -63,8 +63,6 @@ struct GroupMember {
     int64_t out_base;  // distances of this (query, segment) go to out[out_base + (row - row_begin)]
 };
 
-struct QueryScal;
-
 struct TileArgs {
     const float *rows;
     const float *row_norms;
@@ -99,15 +97,6 @@ struct TileArgs {
     // best make_key(distance, row) is folded in registers and merged with one 64-bit atomicMin per wave
     // (implicit groups only; the caller presets out_key[q] = ~0)
     unsigned long long *out_key;
-    // code_bounds_kernel (code_kernels.hpp): int8 rows of the segments + per-row (scale, bound terms), the batch's query
-    // codes and bound scalars; out receives LOWER BOUNDS
-    const uint32_t *crows;
-    const uint32_t *ctile;  // the same codes in the MFMA tile layout (code_mfma_body), or null
-    // which body of code_bounds_kernel serves the batch: decided by the plan kernel on the device (1 = matrix cores)
-    const int32_t *sel;
-    const float4 *cmeta;
-    const uint32_t *qcodes;
-    const QueryScal *qscal;
     int32_t gemv_order;  // cosine / dot through the register-row group kernel (GEMV summation order) instead of MFMA tiles
     int32_t dbg;  // developer ablation switches (HNSWGPU_TILE_DBG); 0 in production
     unsigned long long *dbg_buf;  // diagnostic builds only: per-workgroup {start, end, hw id, tiles} stamps

@@ -156,6 +156,17 @@ class Index:
         check(lib().hnswgpu_distance_bounds(self._h, _p(q), _p(ids), len(ids), _p(lb), _p(ub)))
         return lb, ub
 
+    def ivf_half_bounds(self, q, list_rows):
+        """(lower, upper) bounds of d(q, list row) from the half-precision list rows (batches of 128 queries and more
+        filter the int8 survivors with them); rows are positions in list order.  NaN = no bound."""
+        q = _f32(q).reshape(-1)
+        if len(q) != self.dim:
+            raise ValueError("query has %d elements, index dim is %d" % (len(q), self.dim))
+        rows = np.ascontiguousarray(list_rows, np.int32)
+        lb, ub = np.empty(len(rows), np.float32), np.empty(len(rows), np.float32)
+        check(lib().hnswgpu_ivf_half_bounds(self._h, _p(q), _p(rows), len(rows), _p(lb), _p(ub)))
+        return lb, ub
+
     def norms(self):
         out = np.empty(self.n, np.float32)
         check(lib().hnswgpu_norms(self._h, _p(out)))

@@ -255,6 +255,14 @@ int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *
  * above it: both sides have to hold for its result to be the full f32 scan's. */
 int hnswgpu_distance_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out_lb,
                             float *out_ub);
+/* Batches of 128 queries and more put a second filter between the int8 bounds and the f32 rows: a HALF-precision copy of
+ * the list rows (fp16 with a power-of-two scale per row, 2 * dim bytes per row, made with the int8 copy; HNSWGPU_IVF_HALF=0
+ * in the environment leaves it out) whose bounds are ~70 times narrower -- the survivors of the int8 pass meet it first,
+ * and f32 rows are fetched for little more than k candidates per query instead of ~3 % of the probed lists.  This entry
+ * reports those bounds for `m` rows of the LIST order (positions as hnswgpu_get_ivf's list_ids numbers them) against one
+ * query, by the kernel the searches run: out_lb[i] <= distance <= out_ub[i], NaN where a row or the query has no bound. */
+int hnswgpu_ivf_half_bounds(hnswgpu_index *idx, const float *q, const int32_t *list_rows, int32_t m, float *out_lb,
+                            float *out_ub);
 int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode);
 /* While profiling is on the traversal counts the neighbours it evaluated and the f32 rows it had to fetch for them
  * (everything with the test off): the bytes a search really moved = neighbours * (int8 row + 16 B) + f32_rows * 4 * dim. */

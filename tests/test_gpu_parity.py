@@ -777,6 +777,102 @@ def test_rejection_bounds_never_exceed_the_distance(eng, metric, dim):
                 assert gap_u.max() < 0.04, gap_u.max()
 
 
+@pytest.mark.parametrize("dim", [24, 300, 768, 3072])
+@pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
+def test_half_precision_bounds_hold_and_are_tight(eng, metric, dim):
+    """Batches of 128 queries and more filter the int8 survivors of an IVF search with HALF-precision list rows
+    (stream_kernels.hpp step 1b) before any f32 row is fetched: a candidate is dropped when its lower bound is above
+    the k-th smallest upper bound.  Both sides must hold against the distance the exact path computes -- rows of very
+    different scale (the per-row power-of-two scale), a zero row, a huge component (fp16 would overflow unscaled), tiny
+    rows (fp16 would flush unscaled), duplicates of the query, a zero query; non-finite rows abstain -- and they must be
+    TIGHT: within 1e-3 of the distance scale, forty times narrower than the int8 bounds, or the pass would filter
+    nothing."""
+    rs = np.random.RandomState(dim + 1)
+    n = 600
+    base = rs.randn(n, dim).astype(np.float32) * np.exp(rs.uniform(-6, 6, (n, 1))).astype(np.float32)
+    base[:200] = rs.randn(200, dim).astype(np.float32)
+    base[200] = 0.0
+    base[201, 3] = 1.0e6
+    base[202] = base[5]
+    base[203, 1] = np.inf
+    base[204, 2] = np.nan
+    base[205] = (rs.randn(dim) * 1e-9).astype(np.float32)
+    base[206] = (rs.randn(dim) * 1e9).astype(np.float32)
+    # lists by hand (k-means on non-finite rows is not the subject): three lists, rows dealt round-robin
+    lids = np.concatenate([np.arange(l, n, 3) for l in range(3)]).astype(np.int32)
+    off = np.cumsum([0] + [len(np.arange(l, n, 3)) for l in range(3)]).astype(np.int64)
+    pos = np.empty(n, np.int32)
+    pos[lids] = np.arange(n, dtype=np.int32)                  # list position of base row i
+    queries = [rs.randn(dim).astype(np.float32), base[5].copy(), (base[7] * 1000).astype(np.float32),
+               np.zeros(dim, np.float32), base[201].copy(), base[205].copy()]
+    with eng.Index(base, metric) as idx:
+        idx.set_rejection_test(2)
+        idx.set_ivf(base[:3].copy(), off, lids)
+        rows = np.arange(n, dtype=np.int32)                   # every list position
+        for qi, q in enumerate(queries):
+            lb, ub = idx.ivf_half_bounds(q, rows)
+            d = idx.batch_distances(q, lids)                  # the exact path, same order
+            ok = ~np.isnan(lb) & ~np.isnan(d)
+            assert np.all(lb[ok] <= d[ok]), "metric %s dim %d query %d: lower bound above the distance at list rows %s" % (
+                metric, dim, qi, np.nonzero(ok & ~(lb <= d))[0][:8])
+            oku = ~np.isnan(ub) & ~np.isnan(d)
+            assert np.all(d[oku] <= ub[oku]), "metric %s dim %d query %d: upper bound below the distance at list rows %s" % (
+                metric, dim, qi, np.nonzero(oku & ~(d <= ub))[0][:8])
+            for bad in (203, 204):
+                assert np.isnan(lb[pos[bad]]) and not (ub[pos[bad]] < np.inf)
+            if qi == 0:
+                blk = pos[:200]
+                qn, vn = np.linalg.norm(q), np.linalg.norm(base[:200], axis=1)
+                scale = {"cosine": 1.0, "dot": qn * vn, "l2": qn + vn}[metric]
+                assert ok[blk].all()
+                assert ((d[blk] - lb[blk]) / scale).max() < 1e-3 and ((ub[blk] - d[blk]) / scale).max() < 1e-3
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
+def test_ivf_half_precision_pass(eng, oracle, metric, monkeypatch):
+    """The half-precision pass between the int8 bounds and the f32 rows (production: batches of 128 queries and more),
+    bit-equal to the oracle: at its production threshold (a Euclidean batch of 150), forced on for small batches in
+    every slice configuration, next to survivor lists that overflow (those queries skip it and take the fallback), and
+    with it the finish kernel's threshold from upper bounds -- for a k of one, a k beyond a wave, and ties."""
+    O = oracle
+    code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
+    base = _data(O, 9000, 200, "clustered", num_clusters=40, noise_level=0.25, seed=73)
+    base[4000:4030] = base[11]                               # exact ties
+    Q = np.concatenate([_data(O, 149, 200, "clustered", num_clusters=40, noise_level=0.25, seed=74), base[11:12]]).astype(np.float32)
+    with eng.Index(base, metric) as idx:
+        idx.ivf_build(50, 4, 42)
+        cen, off, lids = idx.get_ivf()
+        idx.set_rejection_test(2)
+        idx.set_profiling(True)
+
+        def check(nq, k, nprobe, what, expect_few=True):
+            idx.rejection_stats(reset=True)
+            ids, d = idx.ivf_search(Q[-nq:], k, nprobe)
+            surv, cand = idx.rejection_stats(reset=True)
+            oi, od, _ = O.ivf_search(base, cen, off, lids, Q[-nq:], k, nprobe, metric=code, mode=O.MODE_DEV)
+            assert_exact(ids, d, oi, od, "%s %s nq=%d k=%d nprobe=%d" % (what, metric, nq, k, nprobe))
+            if expect_few:                                    # it ran: f32 rows for little more than k candidates
+                assert cand > 0 and surv <= nq * (k + 40), (what, surv, cand, nq, k)
+
+        if metric == "l2":                                   # (cosine / dot: 150 x 5 pairs over 50 lists is the tile scan's)
+            check(150, 10, 5, "production threshold")
+        monkeypatch.setenv("HNSWGPU_IVF_CODES", "1")
+        monkeypatch.setenv("HNSWGPU_STREAM_MID", "1")        # from one query on
+        for nq, k, nprobe in [(1, 10, 8), (3, 1, 12), (12, 10, 12), (41, 10, 5), (41, 70, 12)]:
+            if metric != "l2" and nq * nprobe > 12 * 50:
+                continue
+            check(nq, k, nprobe, "forced")
+        for sl in ("1", "3", "64"):
+            monkeypatch.setenv("HNSWGPU_MID_SLICES", sl)
+            monkeypatch.setenv("HNSWGPU_FINISH_SLICES", sl)
+            check(12, 10, 12, "slices " + sl)
+        monkeypatch.delenv("HNSWGPU_MID_SLICES")
+        monkeypatch.delenv("HNSWGPU_FINISH_SLICES")
+        monkeypatch.setenv("HNSWGPU_STREAM_CAP", "300")      # some survivor lists overflow: those queries take the fallback
+        check(12, 10, 12, "mixed fallback", expect_few=False)
+        idx.set_profiling(False)
+
+
 @pytest.mark.parametrize("n,dim,nlist,metric", [(6000, 48, 40, 0), (3000, 100, 17, 2), (2500, 32, 12, 1)])
 def test_ivf_build_exact_in_engine_arithmetic(eng, oracle, n, dim, nlist, metric):
     """hnswgpu_ivf_build against the oracle's restatement of the SAME arithmetic (f32 distances in kernel order,
