@@ -476,9 +476,9 @@ def ivf_roofline(engine, dev, args, traffic):
     _, off, _ = idx.get_ivf()
     lens = np.diff(off)
     out = {}
-    for nq in (1, 32, 256, 1024, 4096, "32_f32"):
-        f32_only = nq == "32_f32"                      # the same batch of 32 with the int8 bounds pass switched off
-        key, nq = nq, 32 if f32_only else nq
+    for nq in (1, 32, 256, 1024, 4096, "32_f32", "4096_f32"):
+        f32_only = isinstance(nq, str)                 # the same batch with the int8 / half-precision rows switched off
+        key, nq = nq, int(nq.split("_")[0]) if f32_only else nq
         idx.set_rejection_test(0 if f32_only else 1)
         Q = Qa[:nq].contiguous()
         _, _, probes = idx.ivf_search(Q.cpu().numpy(), K, nprobe, want_probes=True)
@@ -525,16 +525,16 @@ def ivf_roofline(engine, dev, args, traffic):
     torch.cuda.synchronize()
     rec = recall_at_k(ii, ti)
     idx.close()
-    # Three regimes, each against its own bound:
-    #  * batch 32 -> scan_kernel (one GEMV per (query, list) pair, BASELINE.json configs[2] "fused GEMV"): HBM-bound.
-    #    This is the `roofline` object.
+    # The regimes, each against its own bound:
+    #  * batch 32 -> the survivor stream's bounds kernel over the int8 list rows: HBM-bound.  This is the `roofline` object
+    #    (f32_scan: the same batch by one f32 GEMV per (query, list) pair, BASELINE.json configs[2] "fused GEMV").
     #  * batch 1 (configs[2] names no batch): the same kernel with nothing to share -- every list is read once.
-    #  * batch 4096 -> the pairs are grouped by list and scanned by the f32-MFMA tile kernel: rows are fetched once per
-    #    32-query group, so the bound is the f32 matrix rate, not HBM.  (Batch 1024 -- configs[3]'s batch -- is served by
-    #    the survivor stream since round 3: batch_1024.)
+    #  * batches 256 / 1024 (configs[3]'s batch) / 4096: the stream again, with the half-precision pass behind the bounds.
+    #  * batch 4096 on a handle WITHOUT int8 rows -> pairs grouped by list, the f32-MFMA tile kernel: rows are fetched once
+    #    per 32-query group, the bound is the f32 matrix rate (batched_mfma).
     r = out[32]
     f = out["32_f32"]
-    b = out[4096]         # 128 (query, list) pairs per list: beyond the survivor stream's 48, the MFMA tile scan
+    b = out["4096_f32"]   # 128 (query, list) pairs per list without the int8 rows: the MFMA tile scan
     o = out[1]
     m = out[256]
     flops = 2.0 * b["algorithmic_GB"] * 1e9 / (4 * DIM + 4) * DIM      # 2 * rows scanned * D
@@ -585,6 +585,10 @@ def ivf_roofline(engine, dev, args, traffic):
            "batch_32": r,
            "batch_256": m,
            "batch_1024": out[1024],
+           "batch_4096": out[4096],
+           "stream_note": "batches of 64 queries and more pass the int8 survivors (survivors_per_query of batch_32: ~3 % of the "
+                          "candidates) through half-precision list rows before any f32 row is fetched: survivors_per_query "
+                          "of batch_256 / 1024 / 4096 counts the f32 rows that remain",
            "batch_1": {"kernel_ms": o["avg_scan_ms"], "algorithmic_bytes": int(o["algorithmic_GB"] * 1e9),
                        "int8_bytes": int(o["unique_rows"] * code_row), "survivors": o["survivors_per_query"],
                        "achieved": round(o["unique_rows"] * code_row / 1e9 / (o["avg_scan_ms"] * 1e-3), 1), "unit": "GB/s",
@@ -596,8 +600,9 @@ def ivf_roofline(engine, dev, args, traffic):
                                "the bounds kernel's time); end to end = routing, bounds, finish in one call + sync, priced at "
                                "the reference algorithm's f32 bytes"},
            "batched_mfma": {"bound": "mfma", "kernel": "tile_scan_kernel (v_mfma_f32_32x32x2_f32)",
-                            "workload": "same index, batch of 4096 queries per launch (128 pairs per list: past the boundary of 48 up "
-                                        "to which the survivor stream serves cosine batches), pairs grouped by list",
+                            "workload": "same index, batch of 4096 queries per launch WITHOUT the int8 / half-precision rows "
+                                        "(hnswgpu_set_rejection_test 0; 128 pairs per list: past the boundary of 12), pairs grouped "
+                                        "by list.  With them (the default) the survivor stream serves this batch too: batch_4096",
                             "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                             "avg_launch_ms": b["avg_scan_ms"], "qps_end_to_end": b["qps"],
                             "algorithmic_GBs": b["algorithmic_GBs"], "unique_GB": b["unique_GB"],
@@ -634,7 +639,7 @@ PMC_SCAN_KERNEL = "stream_bounds_kernel<3, true>"    # the bounds kernel for dim
 PMC_F32_KERNEL = "scan_kernel<3, 8, false, 0>"       # ROLE_LIST_SCAN instantiation: the f32 scan (bounds pass off)
 # every kernel of one batch-32 search through the survivor stream (roofline.search)
 PMC_SEARCH_KERNELS = ("ivf_route_kernel", "ivf_route_dist_kernel", "ivf_route_tail_kernel", "ivf_worklist_kernel",
-                      "stream_bounds_kernel", "ivf_finish_kernel")
+                      "stream_bounds_kernel", "ivf_mid_kernel", "ivf_finish_kernel")
 PMC_CHILD_SEARCHES = 6
 
 

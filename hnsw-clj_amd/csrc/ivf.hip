@@ -873,7 +873,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     }
     // from a few hundred queries up the exact pass is the largest kernel (its rows are 3 KB each and every query fetches its
     // own): the survivors first meet their half-precision rows.  Below, the extra launch costs more than the rows it saves.
-    const int64_t mid_min = env_now("HNSWGPU_STREAM_MID", 128);  // 0 = never (A/B)
+    const int64_t mid_min = env_now("HNSWGPU_STREAM_MID", 64);  // 0 = never (A/B)
     const bool mid = idx->d_lhalf != nullptr && mid_min > 0 && nq >= mid_min;
     if (mid) {
         MidArgs ma;
@@ -942,7 +942,12 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
 //    2.67 -- the tile scan reads every probed list in f32 whatever the batch, the stream a quarter of that plus the
 //    survivors' rows per query.
 //  * Without them it is 12: the f32 GEMV-order scans re-read a list per pair (or per group of queries at the VALU's rate).
-constexpr int64_t kTilePairs = 12, kTilePairsCoded = 48;
+//  * With the half-precision rows as well (the default) there is no boundary: the stream's f32 traffic no longer grows
+//    with the survivors (~15 rows per query instead of ~970), and it stays ahead at every batch size measured -- same
+//    index, stream vs tile scan, end to end: batch 2048: 1.08 vs 1.66 ms; 4096: 1.82 vs 2.67; 8192: 3.2 vs 5.0;
+//    16384: 5.9 vs 9.6.  Per query the tile scan reads 32 lists x 977 rows x 3 KB / 32 queries of a group = 3 MB and is
+//    bound by the f32 matrix rate besides; the stream reads a quarter of that in int8 plus 1.5 MB of half rows.
+constexpr int64_t kTilePairs = 12, kTilePairsCoded = 48, kTilePairsNever = 1LL << 40;
 constexpr int32_t kStreamMaxK = 256;  // largest k the bounds pass serves (larger k: the f32 scans)
 
 // can this search go through the survivor stream at all (int8 list rows present and switched on, k within its range)?
@@ -954,7 +959,9 @@ static bool ivf_codes_usable(const hnswgpu_index *idx, int32_t k) {
 // at 12 so that its small indexes still reach the tile path)
 static int64_t ivf_tile_pairs(const hnswgpu_index *idx, int32_t k) {
     const int64_t e = env_now("HNSWGPU_TILE_PAIRS", 0);
-    return e > 0 ? e : (ivf_codes_usable(idx, k) ? kTilePairsCoded : kTilePairs);
+    if (e > 0) return e;
+    if (!ivf_codes_usable(idx, k)) return kTilePairs;
+    return idx->d_lhalf ? kTilePairsNever : kTilePairsCoded;
 }
 
 static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,

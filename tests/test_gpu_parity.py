@@ -708,9 +708,10 @@ def test_ivf_survivor_stream_regimes(eng, oracle, metric, monkeypatch):
 
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
 def test_ivf_production_boundary(eng, oracle, metric, monkeypatch):
-    """The default boundary between the two summation orders of a cosine / dot IVF search: with int8 rows (and k <= 256)
-    the survivor stream -- GEMV order -- serves up to 48 (query, list) pairs per list, the MFMA tile scan beyond; without
-    them (mode 0), or for a k the stream does not serve, the boundary is 12.  (The suite otherwise pins it at 12.)"""
+    """The default boundary between the two summation orders of a cosine / dot IVF search: with int8 and half-precision
+    list rows (and k <= 256) the survivor stream -- GEMV order -- serves EVERY batch size; without them (mode 0), or for
+    a k the stream does not serve, the MFMA tile scan takes over beyond 12 (query, list) pairs per list.  (The suite
+    otherwise pins the boundary at 12.)"""
     O = oracle
     code = {"cosine": O.COSINE, "dot": O.DOT}[metric]
     monkeypatch.delenv("HNSWGPU_TILE_PAIRS")
@@ -722,7 +723,7 @@ def test_ivf_production_boundary(eng, oracle, metric, monkeypatch):
         cen, off, lids = idx.get_ivf()
         for nq, k, mode_rej, want in [(40, 10, 2, O.MODE_DEV),       # 20 pairs per list, int8 rows: the stream
                                       (96, 10, 2, O.MODE_DEV),       # 48: still the stream
-                                      (100, 10, 2, O.MODE_MFMA),     # 50: the tile scan
+                                      (120, 10, 2, O.MODE_DEV),      # 60: and still (the half-precision pass on top)
                                       (40, 300, 2, O.MODE_MFMA),     # a k the stream does not serve: boundary 12
                                       (40, 10, 0, O.MODE_MFMA),      # no int8 rows: boundary 12
                                       (20, 10, 0, O.MODE_DEV)]:      # 10 pairs per list without them: the f32 GEMV order

@@ -11,7 +11,8 @@ import bench
 from hnsw_clj_amd import engine
 
 dev = torch.device("cuda", 0)
-x, Qa = bench.ivf_dataset(dev, 1_000_000, 1024, 4096)
+_nqs = [int(a) for a in sys.argv[1:]] or [256, 1024, 4096]
+x, Qa = bench.ivf_dataset(dev, 1_000_000, 1024, max(4096, max(_nqs)))
 metric = os.environ.get("METRIC", "cosine")   # METRIC=l2: no tile path, every batch size on the GEMV scan
 idx = engine.Index(x, metric, 0)
 del x
@@ -22,7 +23,7 @@ _lens = np.diff(_off)
 _, _, _pr = idx.ivf_search(Qa[:32].cpu().numpy(), 10, 32, want_probes=True)
 print("lists: max %d, mean %.0f; candidates per query at nprobe 32: %.0f; distinct lists probed by 32 queries: %d" % (
     _lens.max(), _lens.mean(), _lens[_pr.ravel()].sum() / 32.0, len(np.unique(_pr))), flush=True)
-for nq in [int(a) for a in sys.argv[1:]] or [256, 1024, 4096]:
+for nq in _nqs:
     Q = Qa[:nq].contiguous()
     for _ in range(3):
         idx.ivf_search_dev(Q, 10, 32)
