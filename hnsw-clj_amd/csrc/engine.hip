@@ -163,7 +163,8 @@ int launch_finish(const FinishArgs &a, int nch, hipStream_t st) {
     if (blocks <= 0) return 0;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "finish grid too large");
     // W lists + final list + (ord, dist) of the result + the probed lists' stream offsets
-    const size_t lds = sizeof(uint64_t) * (kNWave + 2) * a.k + sizeof(uint32_t) * a.nprobe;
+    const size_t lds = sizeof(uint64_t) * (kNWave + 2) * a.k + (sizeof(int64_t) + 2 * sizeof(uint32_t)) * ((a.nprobe + 1) & ~1) +
+                       (a.k <= kWave ? sizeof(uint64_t) * kNWave * a.k : 0);  // ... + the bisection merge's scratch
     HG_REQUIRE(lds <= 64 * 1024, HNSWGPU_ELIMIT, "k too large for the finish kernel (k=%d)", a.k);
     const bool l2 = a.metric == METRIC_L2;
 #define CALL(N, R, L)                                                                                                   \
@@ -415,7 +416,19 @@ struct RouteArgs {
     uint32_t *bk_cnt;        // [nlist] members filed per list (zeroed before the launch), or null
     uint2 *bk_mem;           // [nlist][bk_cap] (query, offset of the list in the query's candidate stream)
     int32_t bk_cap;
+    unsigned long long *dbg;  // -DHG_IVF_STAMPS diagnostic builds only
 };
+
+// The nprobe <= 64 nearest of a query's centroid distances (keys (distance, position): the stable order of
+// ivf_flat.clj:266-268), ascending: topk_small_wg (kernels.hpp).  Returns the keys in LDS to wave 0, null to the others.
+template <bool COH>
+__device__ __forceinline__ const uint64_t *select_small_wg(const float *in, int64_t n, int k, unsigned char *smem) {
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);  // [kNWave][k] | fin [k] | scratch [kNWave][k]
+    return topk_small_wg(n, k, lists, lists + kNWave * k, lists + (kNWave + 1) * k, [&](int64_t i) {
+        const float v = COH ? coherent_load(in + i) : in[i];
+        return make_key(v, static_cast<uint32_t>(i));
+    });
+}
 
 // The tail of the routing of query qi, run by one whole workgroup once all of the query's centroid distances are in
 // a.dense: pick the nprobe nearest, write the probe table, file the pairs by list, seed the threshold.  COH: the
@@ -440,7 +453,13 @@ __device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsign
     s.out_ord = nullptr;  // the probed lists stay in LDS: the probe table below is all that leaves
     s.out_dist = nullptr;
     const uint64_t *keys = nullptr;
-    select_topk_wg<COH>(s, qi, kNWave, smem, &keys);
+    HG_IVF_STAMP(a.dbg, 17, qi == 0 && threadIdx.x == 0);  // tail begins
+    // (the query for the threshold seed at the end: on its way while the lists are picked)
+    float4 q[NCH];
+    if (a.tau) load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+    if (a.nprobe <= kWave) keys = select_small_wg<COH>(a.dense + static_cast<int64_t>(qi) * a.nlist, a.nlist, a.nprobe, smem);
+    else select_topk_wg<COH>(s, qi, kNWave, smem, &keys);
+    HG_IVF_STAMP(a.dbg, 18, qi == 0 && threadIdx.x == 0);  // nprobe nearest centroids selected
     if (wave == 0) {
         // the query's probe table: offsets of the probed lists in its candidate stream (probe_pairs_kernel, one wave)
         uint32_t carry = 0, gcarry = 0;
@@ -498,18 +517,18 @@ __device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsign
             if (a.surv_cnt) a.surv_cnt[qi] = any_over ? 0x80000000u : 0u;
         }
         wait_stores_acked();  // the probe table may be read back by the other waves below
+        HG_IVF_STAMP(a.dbg, 19, qi == 0 && threadIdx.x == 0);  // probe table written, pairs filed
     }
     if (!a.tau) return;
     // survivor stream: the first threshold, from the head of the query's candidate stream
     __syncthreads();
-    float4 q[NCH];
-    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
     const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
     // the head's table entries are in LDS (no dependent global reads) when they cover the rows the seed looks at
     const bool head_ok = a.nprobe <= kHead || tail_cover >= static_cast<uint32_t>(kSeedMax);
     const Pair *pp = head_ok ? head_s : a.pairs + static_cast<int64_t>(qi) * a.nprobe;
     seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, pp, head_ok ? (a.nprobe < kHead ? a.nprobe : kHead) : a.nprobe, tail_qcnt, a.k,
                              a.rows, a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi, a.nq >= 1024 ? 16 : 64);
+    HG_IVF_STAMP(a.dbg, 20, qi == 0 && threadIdx.x == 0);  // threshold seeded
 }
 
 // int8 codes + bound scalars of query qi (the survivor stream's bounds pass): one wave
@@ -529,6 +548,7 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int qi = blockIdx.x / a.blocks_per_query, bx = blockIdx.x % a.blocks_per_query;
+    HG_IVF_STAMP(a.dbg, 16, blockIdx.x == 0 && threadIdx.x == 0);  // first workgroup of the routing kernel starts
     const int64_t r0 = static_cast<int64_t>(bx) * a.rows_per_block;
     const int64_t r1 = r0 + a.rows_per_block < a.nlist ? r0 + a.rows_per_block : a.nlist;
     if (r0 < r1) {
@@ -642,6 +662,7 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
         a.bk_mem = rs->bk_mem;
         a.bk_cap = rs->bk_cap;
     }
+    a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions
     a.rows = idx->d_lrows;
     a.row_norms = idx->d_lnorms;
     a.cent = idx->d_cent;
@@ -671,7 +692,7 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
     a.pairs = pairs;
     a.probes = probes;
     a.qcnt = qcnt;
-    const size_t lds = std::max<size_t>(sizeof(uint64_t) * (kNWave + 1) * nprobe, sizeof(float) * kSeedMax);
+    const size_t lds = std::max<size_t>(sizeof(uint64_t) * ((nprobe <= kWave ? 2 * kNWave : kNWave) + 1) * nprobe, sizeof(float) * kSeedMax);
     HG_REQUIRE(lds <= 48 * 1024, HNSWGPU_ELIMIT, "nprobe too large for the fused routing kernel");
     const bool l2 = a.metric == METRIC_L2;
     if (two_launches) {

@@ -846,6 +846,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     b.surv = idx->s_tile.as<uint4>();
     b.cap = cap;
     b.dbg = static_cast<int32_t>(env_now("HNSWGPU_STREAM_DBG", 0));
+    b.stamps = g_tile_dbg_buf;  // null outside diagnostic sessions
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);
     // which epilogue: few queries per probed list -> lane = row (a list probed by more takes several passes); many -> lane = query
@@ -897,6 +898,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     FinishArgs f;
     memset(&f, 0, sizeof(f));
     f.prepass = mid ? 1 : 0;
+    f.dbg = g_tile_dbg_buf;
     f.surv = b.surv;
     f.surv_cnt = b.surv_cnt;
     f.tau = b.tau;

@@ -237,6 +237,128 @@ __device__ __forceinline__ uint64_t kth_bound(uint64_t lane_min, int k, int lane
     return b == 0xffffffffu ? ~0ull : (static_cast<uint64_t>(b) + 1) << 32;
 }
 
+// The k smallest (k <= 64) of the S + 1 keys every lane of a wave holds (S x 64 fresh keys + `carry`: the wave's best
+// so far in lanes < k, all-ones elsewhere), ascending, into out[0..k) (LDS, all-ones padded) -- without walking keys
+// through a list one at a time.  The insertion fold above costs a serial ~0.15 us per accepted key: picking 32 probed
+// lists out of 1024 centroid distances took 17 us of a 66-us single-query search.  Here the wave bisects the KEY SPACE for
+// the k-th smallest key -- a step is S + 1 compares, ballots and popcounts, and it stops as soon as exactly k keys are at
+// or below the pivot (~20 steps for float distances) -- compacts the k keys into LDS and sorts them by rank.  Keys are
+// distinct (they carry their position), all-ones = none.  scratch: k keys of LDS of this wave's own.
+template <int S>
+__device__ __forceinline__ void wave_topk_sorted(const uint64_t (&key)[S], uint64_t carry, int k, uint64_t *scratch, uint64_t *out,
+                                                 int lane) {
+    // the distance words first (32-bit compares at full rate; a 64-bit compare costs four times as much): the smallest dT
+    // with count(distance word <= dT) >= k
+    uint32_t hw[S + 1];
+#pragma unroll
+    for (int s = 0; s < S; s++) hw[s] = static_cast<uint32_t>(key[s] >> 32);
+    hw[S] = static_cast<uint32_t>(carry >> 32);
+    uint32_t lo = 0, hi = 0xffffffffu;
+    bool exact = false;  // exactly k keys at or below hi: no tie to break
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int s = 0; s <= S; s++) c += __popcll(__ballot(hw[s] <= mid));
+        if (c == k) {
+            hi = mid;
+            exact = true;
+            break;
+        }
+        if (c > k) hi = mid;
+        else lo = mid + 1;
+    }
+    uint64_t T = (static_cast<uint64_t>(hi) << 32) | 0xffffffffu;
+    if (!exact) {
+        int c_le = 0, c_lt = 0;
+#pragma unroll
+        for (int s = 0; s <= S; s++) {
+            c_le += __popcll(__ballot(hw[s] <= hi));
+            c_lt += __popcll(__ballot(hw[s] < hi));
+        }
+        if (c_le > k) {  // equal distances across the boundary: the k - c_lt smallest positions among them
+            const int r = k - c_lt;
+            uint32_t plo = 0, phi = 0xffffffffu;
+            while (plo < phi) {
+                const uint32_t mid = plo + ((phi - plo) >> 1);
+                int c = __popcll(__ballot(hw[S] == hi && static_cast<uint32_t>(carry) <= mid));
+#pragma unroll
+                for (int s = 0; s < S; s++) c += __popcll(__ballot(hw[s] == hi && static_cast<uint32_t>(key[s]) <= mid));
+                if (c >= r) phi = mid;
+                else plo = mid + 1;
+            }
+            T = (static_cast<uint64_t>(hi) << 32) | phi;
+        }
+    }
+    if (T == ~0ull) T = ~0ull - 1;  // (fewer than k keys: all of them, never the all-ones fillers)
+    if (lane < k) out[lane] = ~0ull;
+    // compact the keys <= T (k of them, fewer if fewer exist) ...
+    int base = 0;
+    {
+        const uint64_t m = __ballot(carry <= T);
+        if (carry <= T) scratch[base + __popcll(m & ((1ull << lane) - 1ull))] = carry;
+        base += __popcll(m);
+    }
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        const uint64_t m = __ballot(key[s] <= T);
+        if (key[s] <= T) scratch[base + __popcll(m & ((1ull << lane) - 1ull))] = key[s];
+        base += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ... and place each at its rank
+    if (lane < base) {
+        const uint64_t v = scratch[lane];
+        int rank = 0;
+        int j = 0;
+        for (; j + 8 <= base; j += 8) {  // uniform addresses: LDS broadcasts, eight in flight (one at a time, the loop is 32 LDS latencies)
+            uint64_t o[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) o[u] = scratch[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) rank += o[u] < v ? 1 : 0;
+        }
+        for (; j < base; j++) rank += scratch[j] < v ? 1 : 0;
+        out[rank] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The k <= 64 smallest of n keys (key_of(i), i < n; distinct; all-ones = none), ascending, by the four waves of a
+// workgroup: each wave picks the k smallest of its interleaved quarter (chunks of 4 x 256 keys, the best so far carried
+// along), wave 0 the k smallest of the four lists.  Returns fin (k keys, all-ones padded) to wave 0, null to the others
+// (which may go on: they touch none of the buffers again).  lists: [kNWave][k], fin: [k], scratch: [kNWave][k] of LDS.
+template <class KeyOf>
+__device__ __forceinline__ const uint64_t *topk_small_wg(int64_t n, int k, uint64_t *lists, uint64_t *fin, uint64_t *scratch,
+                                                         KeyOf key_of) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    constexpr int S = 4;
+    uint64_t *myscr = scratch + wave * k;
+    uint64_t *mylist = lists + wave * k;
+    uint64_t carry = ~0ull;
+    if (n <= 0 && lane < k) mylist[lane] = ~0ull;
+    for (int64_t base = 0; base < n; base += S * kWG) {
+        uint64_t key[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const int64_t i = base + s * kWG + wave * kWave + lane;
+            key[s] = i < n ? key_of(i) : ~0ull;
+        }
+        wave_topk_sorted<S>(key, carry, k, myscr, mylist, lane);
+        carry = lane < k ? mylist[lane] : ~0ull;
+    }
+    __syncthreads();
+    if (wave != 0) return nullptr;
+    uint64_t key[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) key[s] = s * kWave + lane < kNWave * k ? lists[s * kWave + lane] : ~0ull;
+    wave_topk_sorted<S>(key, ~0ull, k, myscr, fin, lane);
+    return fin;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Row norms (ivf_flat.clj:171-177): one wave per row.
 // ------------------------------------------------------------------------------------------------
@@ -1019,6 +1141,18 @@ struct HnswArgs {
     unsigned long long *rej_stats;  // profiling: [0] += f32 rows fetched, [1] += neighbours evaluated (null otherwise)
     unsigned long long *dbg;  // -DHG_HNSW_STAMPS diagnostic builds only: per-phase s_memrealtime totals
 };
+
+// -DHG_IVF_STAMPS diagnostic builds (tools/build_stamps.sh): absolute wall_clock64 stamps (100 MHz) of the phases of ONE
+// IVF search's latency chain -- routing tail and finish kernel of query 0 -- into the buffer of
+// hnswgpu_debug_set_tile_stamps: slots 16.. (tools/ivf_phase_stamps.py names them)
+#ifdef HG_IVF_STAMPS
+#define HG_IVF_STAMP(buf, slot, cond)                                      \
+    do {                                                                   \
+        if ((buf) && (cond)) (buf)[slot] = wall_clock64();                 \
+    } while (0)
+#else
+#define HG_IVF_STAMP(buf, slot, cond) do { } while (0)
+#endif
 
 #ifdef HG_HNSW_STAMPS
 #define HG_STAMP(slot)                                                  \

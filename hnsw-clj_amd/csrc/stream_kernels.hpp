@@ -130,11 +130,19 @@ __device__ __forceinline__ void seed_tau_wg(const float4 (&q)[NCH], float qn, in
         }
     }
     __syncthreads();
-    if (tid < m) {
+    if (tid < m) {  // (m is a multiple of 32 or the whole stream)
         const float v = dist_s[tid];
         int rank = 0;
-        for (int j = 0; j < m; j++) {
-            const float o = dist_s[j];  // uniform address: an LDS broadcast
+        int j = 0;
+        for (; j + 4 <= m; j += 4) {  // uniform addresses: LDS broadcasts, four values each
+            const float4 o = *reinterpret_cast<const float4 *>(dist_s + j);
+            rank += (o.x < v || (o.x == v && j < tid)) ? 1 : 0;
+            rank += (o.y < v || (o.y == v && j + 1 < tid)) ? 1 : 0;
+            rank += (o.z < v || (o.z == v && j + 2 < tid)) ? 1 : 0;
+            rank += (o.w < v || (o.w == v && j + 3 < tid)) ? 1 : 0;
+        }
+        for (; j < m; j++) {
+            const float o = dist_s[j];
             rank += (o < v || (o == v && j < tid)) ? 1 : 0;
         }
         if (rank == k - 1) *tau_out = tau_encode(v);  // ranks are a permutation of 0..m-1: exactly one thread
@@ -160,7 +168,7 @@ struct PrepArgs {
 
 template <int NCH, int RB, bool L2>
 __global__ __launch_bounds__(kWG) void ivf_query_prep_kernel(PrepArgs a) {
-    __shared__ float dist_s[kSeedMax];
+    __shared__ __align__(16) float dist_s[kSeedMax];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int qi = blockIdx.x;
     float4 q[NCH];
@@ -206,6 +214,7 @@ struct StreamArgs {
     uint4 *surv;         // [nq][cap] (order key, list row, lb bits, ub bits)
     int64_t cap;
     int32_t dbg;         // developer ablation switches (HNSWGPU_STREAM_DBG); 0 in production
+    unsigned long long *stamps;  // -DHG_IVF_STAMPS diagnostic builds only
 };
 
 
@@ -288,6 +297,7 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
 
     const int col = lane & 31, half = lane >> 5;
     constexpr bool narrow = NARROW;
+    HG_IVF_STAMP(a.stamps, 22, blockIdx.x == 0 && threadIdx.x == 0);  // first workgroup of the bounds kernel starts
     const v4i_t *tile = reinterpret_cast<const v4i_t *>(a.ctile);
     // ---- work item
     int64_t rb0, r0, r1;
@@ -732,6 +742,7 @@ struct FinishArgs {
     uint32_t *out_gord;    // optional [nq][k]
     unsigned long long *stats;  // optional: [0] += f32 rows evaluated, [1] += candidates
     int32_t prepass;       // the upper bounds are worth a look first (ivf_mid_kernel has tightened them)
+    unsigned long long *dbg;  // -DHG_IVF_STAMPS diagnostic builds only
 };
 
 template <int NCH, int RB, bool L2>
@@ -753,10 +764,19 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
         if (pos >= a.nq || (blockIdx.x >> 3) >= per) return;
         qi = a.qorder[pos];
     }
+    HG_IVF_STAMP(a.dbg, 24, blockIdx.x == 0 && threadIdx.x == 0);  // first workgroup of the finish kernel starts
     const uint32_t nsv = a.surv_cnt[qi];
     const bool over = nsv > a.cap;  // survivors did not fit: walk the candidate stream itself (the plain f32 scan)
     const int64_t total = over ? a.q_cnt[qi] : nsv;
-    const int span = a.span, gran = kNWave * span;
+    // entries a wave looks at per step: no more than spreads the list over every wave of the query's workgroups (a wave
+    // fetches four rows at a time: sixteen entries are four dependent round trips, four entries one)
+    int span = a.span;
+    {
+        int64_t need = (total + static_cast<int64_t>(a.slices) * kNWave - 1) / (static_cast<int64_t>(a.slices) * kNWave);
+        need = (need + 3) & ~3LL;
+        span = need < 4 ? 4 : (need < span ? static_cast<int>(need) : span);
+    }
+    const int gran = kNWave * span;
     int64_t per = (total + a.slices - 1) / a.slices;
     per = (per + gran - 1) / gran * gran;
     const int64_t i0 = static_cast<int64_t>(sl) * per;
@@ -895,6 +915,7 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
             }
         }
     }
+    HG_IVF_STAMP(a.dbg, 25, blockIdx.x == 0 && threadIdx.x == 0);  // ... has evaluated its survivors
     // profiling only; few atomics on purpose (one per wave WITH survivors, one per query)
     if (a.stats && lane == 0) {
         if (nsurv) atomicAdd(a.stats, nsurv);
@@ -930,21 +951,44 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     }
     __syncthreads();
     if (!tail_last) return;
-    MergeArgs mg;
-    mg.partial = a.partial;
-    mg.keys_per_query = static_cast<int64_t>(a.slices) * (regk ? 1 : kNWave) * a.k;
-    mg.nq = 0;
-    mg.k = a.k;
-    mg.out_ord = nullptr;
-    mg.out_dist = nullptr;
+    HG_IVF_STAMP(a.dbg, 26, qi == 0 && threadIdx.x == 0);  // the last workgroup of query 0 begins the merge
+    const int64_t nkeys = static_cast<int64_t>(a.slices) * (regk ? 1 : kNWave) * a.k;
     uint32_t *ord_s = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (kNWave + 1) * a.k);  // [k]
     float *dist_s = reinterpret_cast<float *>(ord_s + a.k);                                         // [k]
-    // (the offsets of the probed lists in the candidate stream, fetched side by side while the lists are merged: the
-    // winners are then resolved against LDS instead of a chain of dependent global reads)
-    uint32_t *pob_s = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (kNWave + 2) * a.k);  // [nprobe]
+    // (the probe table of the query -- where each probed list starts in the candidate stream and in the list rows -- is
+    // fetched side by side while the lists are merged: the winners are then resolved against LDS instead of a chain of
+    // dependent global reads)
+    int64_t *prb_s = reinterpret_cast<int64_t *>(smem + sizeof(uint64_t) * (kNWave + 2) * a.k);  // [nprobe] row_begin
+    const int npe = (a.nprobe + 1) & ~1;
+    uint32_t *pob_s = reinterpret_cast<uint32_t *>(prb_s + a.nprobe);                             // [nprobe] ord_base
+    uint32_t *pgo_s = pob_s + npe;                                                                // [nprobe] gord_base
     if (wave == kNWave - 1)
-        for (int p = lane; p < a.nprobe; p += kWave) pob_s[p] = pp[p].ord_base;
-    merge_topk_wg<true>(mg, qi, kNWave, smem, ord_s, dist_s);  // waves 1..3 return from it after its barrier
+        for (int p = lane; p < a.nprobe; p += kWave) {
+            const Pair pr = pp[p];
+            prb_s[p] = pr.row_begin;
+            pob_s[p] = pr.ord_base;
+            pgo_s[p] = pr.gord_base;
+        }
+    if (regk) {  // k <= 64: the k smallest of the partial lists by bisection (topk_small_wg), not by insertion
+        const uint64_t *part = a.partial + static_cast<int64_t>(qi) * nkeys;
+        uint64_t *scr = reinterpret_cast<uint64_t *>(pgo_s + npe);  // [kNWave][k]
+        const uint64_t *fin = topk_small_wg(nkeys, a.k, lists, lists + kNWave * a.k, scr, [&](int64_t i) { return coherent_load(part + i); });
+        if (wave != 0) return;
+        if (lane < a.k) {
+            const uint64_t key = fin[lane];
+            ord_s[lane] = key != ~0ull ? static_cast<uint32_t>(key) : 0xffffffffu;
+            dist_s[lane] = key != ~0ull ? key_dist(key) : __uint_as_float(0x7f800000u);
+        }
+    } else {
+        MergeArgs mg;
+        mg.partial = a.partial;
+        mg.keys_per_query = nkeys;
+        mg.nq = 0;
+        mg.k = a.k;
+        mg.out_ord = nullptr;
+        mg.out_dist = nullptr;
+        merge_topk_wg<true>(mg, qi, kNWave, smem, ord_s, dist_s);  // waves 1..3 return from it after its barrier
+    }
     if (wave != 0) return;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -959,14 +1003,14 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
                 if (pob_s[mid] <= o) p = mid;
                 else hi = mid - 1;
             }
-            const Pair pr = pp[p];
-            id = a.listids[pr.row_begin + (o - pr.ord_base)];
-            go = pr.gord_base + (o - pr.ord_base);
+            id = a.listids[prb_s[p] + (o - pob_s[p])];
+            go = pgo_s[p] + (o - pob_s[p]);
         }
         a.out_ids[static_cast<int64_t>(qi) * a.k + i] = id;
         a.out_dist[static_cast<int64_t>(qi) * a.k + i] = dist_s[i];
         if (a.out_gord) a.out_gord[static_cast<int64_t>(qi) * a.k + i] = go;
     }
+    HG_IVF_STAMP(a.dbg, 27, qi == 0 && lane == 0);  // results written
 }
 
 // ------------------------------------------------------------------------------------------------

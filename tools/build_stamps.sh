@@ -1,11 +1,11 @@
 #!/bin/bash
-# Diagnostic build of the library with per-phase time stamps in the HNSW kernel (never the product build).
+# Diagnostic build of the library with per-phase time stamps in the HNSW kernel and along an IVF search (never the product build).
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_dbg
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -DHG_HNSW_STAMPS"
-for f in engine ivf hnsw persist; do
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -DHG_HNSW_STAMPS -DHG_IVF_STAMPS"
+for f in engine ivf hnsw persist group; do
   /opt/rocm/bin/hipcc $FLAGS -c hnsw-clj_amd/csrc/$f.hip -o build_dbg/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build_dbg/libhnswgpu_stamps.so build_dbg/{engine,ivf,hnsw,persist}.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build_dbg/libhnswgpu_stamps.so build_dbg/{engine,ivf,hnsw,persist,group}.o
