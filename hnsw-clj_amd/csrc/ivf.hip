@@ -898,6 +898,8 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     FinishArgs f;
     memset(&f, 0, sizeof(f));
     f.prepass = mid ? 1 : 0;
+    f.adapt = static_cast<int32_t>(env_now("HNSWGPU_FINISH_ADAPT", 1));        // A/B
+    f.bisect_min = static_cast<int32_t>(env_now("HNSWGPU_FINISH_BISECT", 1));  // A/B
     f.dbg = g_tile_dbg_buf;
     f.surv = b.surv;
     f.surv_cnt = b.surv_cnt;

@@ -741,6 +741,8 @@ struct FinishArgs {
     float *out_dist;       // [nq][k]
     uint32_t *out_gord;    // optional [nq][k]
     unsigned long long *stats;  // optional: [0] += f32 rows evaluated, [1] += candidates
+    int32_t bisect_min;    // smallest k whose final merge bisects the key space (A/B: by insertion below it)
+    int32_t adapt;         // spread a short survivor list over all the waves of the query's workgroups (see span)
     int32_t prepass;       // the upper bounds are worth a look first (ivf_mid_kernel has tightened them)
     unsigned long long *dbg;  // -DHG_IVF_STAMPS diagnostic builds only
 };
@@ -771,7 +773,7 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     // entries a wave looks at per step: no more than spreads the list over every wave of the query's workgroups (a wave
     // fetches four rows at a time: sixteen entries are four dependent round trips, four entries one)
     int span = a.span;
-    {
+    if (a.adapt) {
         int64_t need = (total + static_cast<int64_t>(a.slices) * kNWave - 1) / (static_cast<int64_t>(a.slices) * kNWave);
         need = (need + 3) & ~3LL;
         span = need < 4 ? 4 : (need < span ? static_cast<int>(need) : span);
@@ -933,8 +935,10 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
                     wave_insert_reg(mine, cnt, a.k, key, lane);
                     thr = wave_kth_reg(mine, a.k);
                 }
-            uint64_t *dstp = a.partial + (static_cast<int64_t>(qi) * a.slices + sl) * a.k;
-            if (lane < a.k) coherent_store(dstp + lane, mine);
+            if (a.slices > 1) {
+                uint64_t *dstp = a.partial + (static_cast<int64_t>(qi) * a.slices + sl) * a.k;
+                if (lane < a.k) coherent_store(dstp + lane, mine);
+            }
         }
     } else {
         uint64_t *dstp = a.partial + ((static_cast<int64_t>(qi) * a.slices + sl) * kNWave + wave) * a.k;
@@ -942,15 +946,18 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     }
     // ---- tail: the last workgroup of query qi merges the partial lists, maps the winners to row ids
     // (ivf_flat.clj:291-294) and writes the results (the hand-over protocol of scan_kernel's fused tail)
-    wait_stores_acked();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t prev = __hip_atomic_fetch_add(a.done + qi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tail_last = prev == static_cast<uint32_t>(a.slices) - 1 ? 1 : 0;
-        if (tail_last) __hip_atomic_store(a.done + qi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool alone = regk && a.slices == 1;  // the query's only workgroup: wave 0 holds the result, nothing to hand over
+    if (!alone) {
+        wait_stores_acked();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t prev = __hip_atomic_fetch_add(a.done + qi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tail_last = prev == static_cast<uint32_t>(a.slices) - 1 ? 1 : 0;
+            if (tail_last) __hip_atomic_store(a.done + qi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!tail_last) return;
     }
-    __syncthreads();
-    if (!tail_last) return;
     HG_IVF_STAMP(a.dbg, 26, qi == 0 && threadIdx.x == 0);  // the last workgroup of query 0 begins the merge
     const int64_t nkeys = static_cast<int64_t>(a.slices) * (regk ? 1 : kNWave) * a.k;
     uint32_t *ord_s = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (kNWave + 1) * a.k);  // [k]
@@ -969,7 +976,14 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
             pob_s[p] = pr.ord_base;
             pgo_s[p] = pr.gord_base;
         }
-    if (regk) {  // k <= 64: the k smallest of the partial lists by bisection (topk_small_wg), not by insertion
+    if (alone) {
+        __syncthreads();  // (the probe table in LDS)
+        if (wave != 0) return;
+        if (lane < a.k) {
+            ord_s[lane] = mine != ~0ull ? static_cast<uint32_t>(mine) : 0xffffffffu;
+            dist_s[lane] = mine != ~0ull ? key_dist(mine) : __uint_as_float(0x7f800000u);
+        }
+    } else if (regk && a.k >= a.bisect_min) {  // the k smallest of the partial lists by bisection (topk_small_wg), not by insertion
         const uint64_t *part = a.partial + static_cast<int64_t>(qi) * nkeys;
         uint64_t *scr = reinterpret_cast<uint64_t *>(pgo_s + npe);  // [kNWave][k]
         const uint64_t *fin = topk_small_wg(nkeys, a.k, lists, lists + kNWave * a.k, scr, [&](int64_t i) { return coherent_load(part + i); });
