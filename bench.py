@@ -557,7 +557,7 @@ def ivf_roofline(engine, dev, args, traffic):
            "achieved_from": "PMC traffic / kernel time" if tr else "requested bytes / kernel time (no PMC pass in this run: "
                             "--no-pmc, N > 1 or rocprofv3 unavailable; a lower bound of the traffic; profiles/ holds a PMC run)",
            "frac_of_copy_ceiling": round(achieved / 6290.0, 4),
-           "kernel": "stream_bounds_kernel<3, true> (v_mfma_i32_32x32x32_i8; 1.6 queries per probed list at this batch: the "
+           "kernel": "stream_bounds_kernel<3, true, false> (v_mfma_i32_32x32x32_i8; 1.6 queries per probed list at this batch: the "
                      "lane = row epilogue)",
            "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch: bounds of every candidate "
                        "from the int8 list rows against the query's running threshold, %.0f survivors per query appended "
@@ -586,7 +586,7 @@ def ivf_roofline(engine, dev, args, traffic):
            "batch_256": m,
            "batch_1024": out[1024],
            "batch_4096": out[4096],
-           "stream_note": "batches of 64 queries and more pass the int8 survivors (survivors_per_query of batch_32: ~3 % of the "
+           "stream_note": "batches of 1.5 M candidates and more (48 queries here) pass the int8 survivors (survivors_per_query of batch_32: ~3 % of the "
                           "candidates) through half-precision list rows before any f32 row is fetched: survivors_per_query "
                           "of batch_256 / 1024 / 4096 counts the f32 rows that remain",
            "batch_1": {"kernel_ms": o["avg_scan_ms"], "algorithmic_bytes": int(o["algorithmic_GB"] * 1e9),
@@ -635,7 +635,7 @@ def ivf_dataset(dev, n, nlist, nq_all):
     return x, Qa
 
 
-PMC_SCAN_KERNEL = "stream_bounds_kernel<3, true>"    # the bounds kernel for dim 768 (batch 32: the lane = row epilogue)
+PMC_SCAN_KERNEL = "stream_bounds_kernel<3, true, false>"    # the bounds kernel for dim 768 (batch 32: the lane = row epilogue)
 PMC_F32_KERNEL = "scan_kernel<3, 8, false, 0>"       # ROLE_LIST_SCAN instantiation: the f32 scan (bounds pass off)
 # every kernel of one batch-32 search through the survivor stream (roofline.search)
 PMC_SEARCH_KERNELS = ("ivf_route_kernel", "ivf_route_dist_kernel", "ivf_route_tail_kernel", "ivf_worklist_kernel",

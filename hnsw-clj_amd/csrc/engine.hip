@@ -137,18 +137,19 @@ int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narr
     if (blocks <= 0) return 0;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "bounds pass grid too large");
     const size_t lds = stream_lds_bytes(nch, narrow);
-#define CALLV(N, NARROW)                                                                                               \
+#define CALLV(N, NARROW, DEFER)                                                                                        \
     do {                                                                                                               \
         static bool attr_done[64] = {};                                                                                \
         if (lds > 48 * 1024 && attr_needed(attr_done))                                                                 \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_bounds_kernel<N, NARROW>),               \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_bounds_kernel<N, NARROW, DEFER>),        \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
-        hipLaunchKernelGGL((stream_bounds_kernel<N, NARROW>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, a); \
+        hipLaunchKernelGGL((stream_bounds_kernel<N, NARROW, DEFER>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, a); \
     } while (0)
-#define CALL(N, R, L)             \
-    do {                          \
-        if (narrow) CALLV(N, true); \
-        else CALLV(N, false);     \
+#define CALL(N, R, L)                         \
+    do {                                      \
+        if (narrow) CALLV(N, true, false);    \
+        else if (a.defer) CALLV(N, false, true); \
+        else CALLV(N, false, false);          \
     } while (0)
     HG_DISPATCH(nch, false, CALL);
 #undef CALL

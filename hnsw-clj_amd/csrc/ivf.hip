@@ -847,6 +847,15 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     b.cap = cap;
     b.dbg = static_cast<int32_t>(env_now("HNSWGPU_STREAM_DBG", 0));
     b.stamps = g_tile_dbg_buf;  // null outside diagnostic sessions
+    // Once the exact pass would be the largest kernel (its rows are 3 KB each and every query fetches its own) the survivors
+    // first meet their half-precision rows.  The survivors are a few per cent of the candidates: from ~1.5 M candidates per
+    // batch (48 queries x 32 lists x 977 rows; 5 queries at 10 M rows) the pass saves more than its launch costs -- measured
+    // at 1M x 768: batch 32 0.183 ms without vs 0.195 with, 64: 0.250 vs 0.243, 128: 0.298 vs 0.277.
+    // HNSWGPU_STREAM_MID=<queries> overrides (tests: 1 = always; 0 = never).
+    const int64_t mid_env = env_now("HNSWGPU_STREAM_MID", -1);
+    const int64_t cand = npairs * mean;
+    const bool mid = idx->d_lhalf != nullptr && (mid_env >= 0 ? (mid_env > 0 && nq >= mid_env) : cand >= 1500000);
+    b.defer = mid ? 1 : 0;
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);
     // which epilogue: few queries per probed list -> lane = row (a list probed by more takes several passes); many -> lane = query
@@ -872,10 +881,6 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         HG_HIP(hipGetLastError());
         qorder = idx->s_stats.as<int32_t>();
     }
-    // from a few hundred queries up the exact pass is the largest kernel (its rows are 3 KB each and every query fetches its
-    // own): the survivors first meet their half-precision rows.  Below, the extra launch costs more than the rows it saves.
-    const int64_t mid_min = env_now("HNSWGPU_STREAM_MID", 64);  // 0 = never (A/B)
-    const bool mid = idx->d_lhalf != nullptr && mid_min > 0 && nq >= mid_min;
     if (mid) {
         MidArgs ma;
         memset(&ma, 0, sizeof(ma));

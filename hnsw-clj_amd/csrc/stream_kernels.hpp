@@ -214,6 +214,7 @@ struct StreamArgs {
     uint4 *surv;         // [nq][cap] (order key, list row, lb bits, ub bits)
     int64_t cap;
     int32_t dbg;         // developer ablation switches (HNSWGPU_STREAM_DBG); 0 in production
+    int32_t defer;       // the half-precision pass follows: the wide epilogue appends entries without bounds (template DEFER)
     unsigned long long *stamps;  // -DHG_IVF_STAMPS diagnostic builds only
 };
 
@@ -277,7 +278,7 @@ __device__ __forceinline__ bool stream_reject(int dot, float4 r, float4 qt) {
     return static_cast<float>(dot) * r.x < __builtin_fmaf(-qt.y, r.y, __builtin_fmaf(r.z, qt.z, qt.x));
 }
 
-template <int NCH, bool NARROW>
+template <int NCH, bool NARROW, bool DEFER>
 __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs a) {
     constexpr int S = NCH * 8;  // steps of 32 bytes
     constexpr int PF = 8;       // operand loads in flight per wave
@@ -505,28 +506,40 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
                 if (i < rel0 || i >= rel1) pmask &= ~(1u << g);
             }
         }
+        if (a.dbg & 8) pmask = pmask == 0x12345u ? 1u : 0u;  // ablation: the test, no append (results are wrong)
         const int n = __popc(pmask);
         if (__ballot(n > 0)) {  // (most blocks of most lists append nothing)
-            // the products go to LDS and each lane walks ITS set bits: kept in registers and picked by index, the tile
-            // would stay live through this path in two copies and cost the kernel half its occupancy
-#pragma unroll
-            for (int g = 0; g < 16; g++) tile_w[g * kWave + lane] = acc[g];
             const int on = __shfl_xor(n, 32, kWave);
             uint32_t base = 0;
-            if (half == 0 && n + on > 0)
+            if (half == 0 && n + on > 0 && !(a.dbg & 4))  // (ablation 4: no counter, every entry lands on slot 0..)
                 base = __hip_atomic_fetch_add(a.surv_cnt + myq, static_cast<uint32_t>(n + on), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             base = __shfl(base, col, kWave);
             if (half) base += on;  // half 1 writes behind half 0's `on` entries
-            if (n > 0) {
-                const QueryScal myqs = qs_s[col];
+            if (DEFER) {
+                // the half-precision pass follows and replaces the bounds of every entry: none are computed here (with them
+                // -- the products parked in LDS, the row's terms re-read, two square roots per entry -- appending 3 % of the
+                // candidates cost as much as the matrix work of all of them: 75 of 214 us at batch 1024)
                 for (uint32_t pm = pmask; pm; pm &= pm - 1, base++) {
                     const int g = __ffs(pm) - 1;
                     const uint32_t r = static_cast<uint32_t>(rel + (g & 3) + 8 * (g >> 2) + 4 * half);
-                    if (base < a.cap) {
-                        const float4 mt = a.cmeta[rb0 + r];
-                        float lb, ub;
-                        code_bounds(a.metric, tile_w[g * kWave + lane], myqs, mt, mt.w, lb, ub);
-                        dst[base] = make_uint4(myob + r, static_cast<uint32_t>(rb0) + r, __float_as_uint(lb), __float_as_uint(ub));
+                    if (base < a.cap) dst[base] = make_uint4(myob + r, static_cast<uint32_t>(rb0) + r, 0xff800000u, 0x7f800000u);  // [-inf, +inf]
+                }
+            } else {
+                // the products go to LDS and each lane walks ITS set bits: kept in registers and picked by index, the tile
+                // would stay live through this path in two copies and cost the kernel half its occupancy
+#pragma unroll
+                for (int g = 0; g < 16; g++) tile_w[g * kWave + lane] = acc[g];
+                if (n > 0) {
+                    const QueryScal myqs = qs_s[col];
+                    for (uint32_t pm = pmask; pm; pm &= pm - 1, base++) {
+                        const int g = __ffs(pm) - 1;
+                        const uint32_t r = static_cast<uint32_t>(rel + (g & 3) + 8 * (g >> 2) + 4 * half);
+                        if (base < a.cap) {
+                            const float4 mt = a.cmeta[rb0 + r];
+                            float lb, ub;
+                            code_bounds(a.metric, tile_w[g * kWave + lane], myqs, mt, mt.w, lb, ub);
+                            dst[base] = make_uint4(myob + r, static_cast<uint32_t>(rb0) + r, __float_as_uint(lb), __float_as_uint(ub));
+                        }
                     }
                 }
             }

@@ -157,7 +157,7 @@ class Index:
         return lb, ub
 
     def ivf_half_bounds(self, q, list_rows):
-        """(lower, upper) bounds of d(q, list row) from the half-precision list rows (batches of 128 queries and more
+        """(lower, upper) bounds of d(q, list row) from the half-precision list rows (batches of 1.5 M candidates and more
         filter the int8 survivors with them); rows are positions in list order.  NaN = no bound."""
         q = _f32(q).reshape(-1)
         if len(q) != self.dim:

@@ -255,7 +255,7 @@ int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *
  * above it: both sides have to hold for its result to be the full f32 scan's. */
 int hnswgpu_distance_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out_lb,
                             float *out_ub);
-/* Batches of 128 queries and more put a second filter between the int8 bounds and the f32 rows: a HALF-precision copy of
+/* Batches with 1.5 M candidates and more (48 queries x 32 lists of ~1000 rows) put a second filter between the int8 bounds and the f32 rows: a HALF-precision copy of
  * the list rows (fp16 with a power-of-two scale per row, 2 * dim bytes per row, made with the int8 copy; HNSWGPU_IVF_HALF=0
  * in the environment leaves it out) whose bounds are ~70 times narrower -- the survivors of the int8 pass meet it first,
  * and f32 rows are fetched for little more than k candidates per query instead of ~3 % of the probed lists.  This entry
