@@ -126,7 +126,9 @@ int launch_mid(const MidArgs &a, int nch, hipStream_t st) {
     if (blocks <= 0) return 0;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "half-precision pass grid too large");
     const bool l2 = a.metric == METRIC_L2;
-#define CALL(N, R, L) hipLaunchKernelGGL((ivf_mid_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), 0, st, a)
+    const size_t lds = sizeof(float) * static_cast<size_t>(std::max(a.compact, 0));
+    HG_REQUIRE(lds <= 48 * 1024, HNSWGPU_ELIMIT, "half-precision pass: compaction buffer too large");
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_mid_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a)
     HG_DISPATCH(nch, l2, CALL);
 #undef CALL
     HG_HIP(hipGetLastError());

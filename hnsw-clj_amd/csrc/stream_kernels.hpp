@@ -395,6 +395,7 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
     const v4i_t *qb_mine = qb_s + half * 32 + col;   // B operand of step s: qb_mine[s * 64]
     for (; b < b1; b += kTileWaves, ap += static_cast<int64_t>(kTileWaves) * S * 64) {
         // the row's side of the test: lane & 31 is the row whose terms these are (rows outside the chunk: zeros)
+        const float4 mraw = narrow ? metar : make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // (narrow epilogue: an appended row's bounds come from these)
         const float4 mcur = stream_row_terms(a.metric, metar);
         if (!narrow && lane < 32) {  // [3][32]: a lane reads the terms of its four adjacent rows as one vector each
             terms_w[lane] = mcur.x;
@@ -462,9 +463,8 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
                         if (pass) {
                             const uint32_t slot = base + __popc(pm & ((1u << col) - 1u));
                             if (slot < a.cap) {
-                                const float4 mt = a.cmeta[rb0 + r];
                                 float lb, ub;
-                                code_bounds(a.metric, dot, qs_s[qxc], mt, mt.w, lb, ub);
+                                code_bounds(a.metric, dot, qs_s[qxc], mraw, mraw.w, lb, ub);
                                 a.surv[static_cast<int64_t>(qi_s[qxc]) * a.cap + slot] =
                                     make_uint4(ob_s[qxc] + static_cast<uint32_t>(r), static_cast<uint32_t>(rb0) + static_cast<uint32_t>(r),
                                                __float_as_uint(lb), __float_as_uint(ub));
@@ -627,9 +627,12 @@ __device__ __forceinline__ void half_bounds(int metric, float sum, float qn, flo
 
 struct MidArgs {
     uint4 *surv;               // [nq][cap] (order key, list row, lb bits, ub bits): lb / ub are replaced
-    const uint32_t *surv_cnt;
+    uint32_t *surv_cnt;
+    uint32_t *tau;
     int64_t cap;
     int32_t nq, slices;
+    int32_t k;                 // compact > 0 (slices == 1): the workgroup sees the query's whole list and leaves only the
+    int32_t compact;           // entries the k-th smallest upper bound does not exclude (dynamic LDS: 4 B x compact entries)
     const int32_t *qorder;     // optional (slices == 1): the queries in the order of their nearest list (as the finish kernel)
     const uint2 *half;         // [rows][ld / 4] four halves each
     const float4 *hmeta;       // (scale, E, 0, 1 / |v|)
@@ -664,6 +667,10 @@ __global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
     load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
     const float qn = L2 ? 0.0f : query_norm<NCH>(q);
     uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *lb_s = reinterpret_cast<float *>(smem);  // [compact] the entries' new lower bounds
+    const bool compact = a.compact > 0 && nsv <= static_cast<uint32_t>(a.compact) && a.k <= kWG;
+    float ub_min = __builtin_inff();                // over this thread's entries
     for (int64_t base = i0 + wave * kWave; base < i1; base += gran) {
         const int64_t i = base + lane;
         const bool in = i < i1;
@@ -723,7 +730,62 @@ __global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
             lb = __builtin_fmaxf(lb, __uint_as_float(e.z));
             ub = __builtin_fminf(ub, __uint_as_float(e.w));
             *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(sv + i) + 2) = make_uint2(__float_as_uint(lb), __float_as_uint(ub));
+            if (compact) {
+                lb_s[i] = lb;
+                ub_min = ub < ub_min ? ub : ub_min;  // (NaN: no upper bound, not counted)
+            }
         }
+    }
+    if (!compact) return;
+    // ---- the query's whole list went through this workgroup: the threshold the finish kernel would derive from the upper
+    // bounds (the k-th smallest of the 256 threads' minima: k candidates at most that far) is applied here, and the list
+    // shrinks to the entries it does not exclude -- little more than k -- before the finish kernel reads it
+    __shared__ __align__(16) uint32_t ubv_s[kWG];
+    __shared__ uint32_t kth_s, wcnt_s[kNWave];
+    const uint32_t v = tau_encode(ub_min);
+    ubv_s[threadIdx.x] = v;
+    __syncthreads();
+    {
+        int rank = 0;
+        for (int j = 0; j < kWG; j += 4) {
+            const uint4 o = *reinterpret_cast<const uint4 *>(ubv_s + j);  // uniform address: an LDS broadcast
+            rank += (o.x < v || (o.x == v && j < static_cast<int>(threadIdx.x))) ? 1 : 0;
+            rank += (o.y < v || (o.y == v && j + 1 < static_cast<int>(threadIdx.x))) ? 1 : 0;
+            rank += (o.z < v || (o.z == v && j + 2 < static_cast<int>(threadIdx.x))) ? 1 : 0;
+            rank += (o.w < v || (o.w == v && j + 3 < static_cast<int>(threadIdx.x))) ? 1 : 0;
+        }
+        if (rank == a.k - 1) kth_s = v;  // ranks are a permutation of 0..255: exactly one thread
+    }
+    __syncthreads();
+    const float T = tau_decode(kth_s);
+    uint32_t nout = 0;  // entries kept so far (uniform)
+    for (uint32_t base = 0; base < nsv; base += kWG) {
+        // in place: a step reads its 256 entries before anything is written, and writes below base + 256
+        const uint32_t i = base + threadIdx.x;
+        const bool keep = i < nsv && !(lb_s[i] > T);  // NaN (no bound) stays
+        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+        if (keep) {
+            const uint2 head = *reinterpret_cast<const uint2 *>(sv + i);  // (order key, list row): written by the bounds pass
+            e = make_uint4(head.x, head.y, __float_as_uint(lb_s[i]), 0x7f800000u);
+        }
+        const uint64_t m = __ballot(keep);
+        if (lane == 0) wcnt_s[wave] = static_cast<uint32_t>(__popcll(m));
+        wait_stores_acked();  // (s_waitcnt vmcnt(0): this step's reads have returned before any wave writes)
+        __syncthreads();
+        uint32_t off = nout, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kNWave; w++) {
+            const uint32_t c = wcnt_s[w];
+            off += w < wave ? c : 0u;
+            tot += c;
+        }
+        if (keep) sv[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
+        nout += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.surv_cnt[qi] = nout;
+        if (T < __builtin_inff()) (void)__hip_atomic_fetch_min(a.tau + qi, tau_encode(T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
