@@ -1,5 +1,5 @@
-// stream_kernels.hpp -- the IVF list scan as a SURVIVOR STREAM: int8 bounds with a running per-query threshold, then
-// ONE launch that evaluates the survivors in f32, keeps the k nearest and writes the results.
+// stream_kernels.hpp -- the IVF list scan as a SURVIVOR STREAM: a candidate passes up to three filters of rising cost --
+// its int8 codes, its half-precision row, its f32 row -- and only the last one produces distances.
 //
 // search-partition scores every row of every probed list (ivf_flat.clj:217-234) and search-ivf-flat keeps the k smallest
 // (:281-294).  Every list row also exists as int8 codes with its exact residual (kernels.hpp: quantize_rows_kernel), so
@@ -7,19 +7,21 @@
 // for every (query, candidate).  Round 2 wrote every lb into a dense [query][candidate] array, selected the k smallest,
 // derived a threshold, rewrote the array with f32 distances and selected again: eleven launches, the array touched four
 // times.  Here:
+//   0. the routing step seeds tau[q], an upper bound of the query's k-th nearest distance D_k: the k-th smallest f32
+//      distance among the head of its candidate stream (seed_tau_wg: k candidates are at most that far).
 //   1. stream_bounds_kernel (matrix cores, v_mfma_i32_32x32x32_i8: a group of <= 32 queries against 32 list rows per
-//      wave step, each probed list read ONCE per group in int8).  tau[q] is a running upper bound of the query's k-th
-//      nearest distance D_k: whenever a wave has seen m >= k candidates of a query, the largest of their ub is >= D_k
-//      (k candidates are at least that near) and is folded into tau[q] with an agent-scope atomic min on the orderable
-//      bits.  A candidate with lb > tau[q] has d >= lb > tau >= D_k: it can neither be among the k nearest nor tie with
-//      the k-th, and is dropped on the spot; every other candidate is appended -- (order key, lb), 8 bytes -- to the
-//      query's survivor list (one atomic add per query and wave step reserves the slots).
-//   2. ivf_finish_kernel: filters the list once more against the FINAL tau (and against the k-th distance found so
+//      wave step, each probed list read ONCE per group in int8).  A candidate with lb > tau[q] has d >= lb > tau >= D_k:
+//      it can neither be among the k nearest nor tie with the k-th, and is dropped on the spot; every other candidate is
+//      appended -- (order key, list row, lb, ub), 16 bytes -- to the query's survivor list (one atomic add per query and
+//      wave step reserves the slots).
+//   2. ivf_mid_kernel (large batches): the survivors' half-precision rows give bounds seventy times narrower; the k-th
+//      smallest UPPER bound of the list is a threshold of its own and leaves little more than k entries.
+//   3. ivf_finish_kernel: filters the list once more against the threshold (and against the k-th distance found so
 //      far), computes the f32 distance of what is left by the GEMV scan's own arithmetic (lane_partial + wave butterfly +
 //      finish_dist: the same bits), keeps the k smallest (distance, order key) per wave in registers, and the last
 //      workgroup of a query merges the partial lists, maps the winners to row ids and writes ids / distances.
-// tau only ever decides what is NOT computed; every candidate with d <= D_k survives any valid tau, so the result is
-// exactly the full f32 scan's whatever order the workgroups run in.  A query whose survivors do not fit its list (data
+// A threshold only ever decides what is NOT computed; every candidate with d <= D_k survives any valid one, so the result
+// is exactly the full f32 scan's whatever order the workgroups run in.  A query whose survivors do not fit its list (data
 // on which int8 bounds separate nothing) is flagged by its counter and served by the same finish kernel from the
 // candidate stream itself -- the plain f32 scan -- so memory stays bounded and the answer exact.
 #pragma once
@@ -224,11 +226,12 @@ struct StreamArgs {
 // loads of its NEXT block before the epilogue of the current one -- and of its first block before the group is set up,
 // since the rows to read depend on the work item alone.
 //
-// Two epilogues turn the 32 x 32 integer tile into bounds.  A group of up to kNarrow queries (small batches: one or two
+// Two epilogues turn the 32 x 32 integer tile into decisions.  A group of up to kNarrow queries (small batches: one or two
 // queries per probed list) parks its few live columns in LDS and lets every LANE take a ROW -- one pass over 32 rows per
 // pair of queries, survivors written side by side -- instead of sixteen passes in which one or two lanes work.  Wider
-// groups keep the MFMA's own distribution (lane = query, sixteen rows each); the Euclidean test is done on the squared
-// bound there, so that a block costs one square root per lane, not thirty-two.
+// groups keep the MFMA's own distribution (lane = query, sixteen rows each) and run the test as packed two-row operations
+// against row terms read from LDS four rows at a time.  DEFER (wide groups, the half-precision pass follows): entries are
+// appended without bounds -- that pass replaces them.
 constexpr int kNarrow = 8;
 
 __host__ __device__ constexpr int stream_epilogue_words(bool narrow) { return narrow ? kNarrow * 33 : 16 * kWave; }
@@ -993,10 +996,17 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
         }
     }
     HG_IVF_STAMP(a.dbg, 25, blockIdx.x == 0 && threadIdx.x == 0);  // ... has evaluated its survivors
-    // profiling only; few atomics on purpose (one per wave WITH survivors, one per query)
-    if (a.stats && lane == 0) {
-        if (nsurv) atomicAdd(a.stats, nsurv);
-        if (wave == 0 && sl == 0) atomicAdd(a.stats + 1, static_cast<unsigned long long>(a.q_cnt[qi]));
+    // profiling only; few atomics on purpose (one per workgroup WITH survivors, one per query: they all hit one address)
+    if (a.stats) {
+        __shared__ unsigned long long nsurv_s[kNWave];
+        if (lane == 0) nsurv_s[wave] = nsurv;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long tot = 0;
+            for (int w = 0; w < kNWave; w++) tot += nsurv_s[w];
+            if (tot) atomicAdd(a.stats, tot);
+            if (sl == 0) atomicAdd(a.stats + 1, static_cast<unsigned long long>(a.q_cnt[qi]));
+        }
     }
     // ---- this workgroup's partial list (k <= 64: its four lists merged into one first)
     if (regk) {

@@ -138,14 +138,15 @@ int hnswgpu_hnsw_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, in
  * hnswgpu_ivf_search: search-ivf-flat (ivf_flat.clj:236-294) with explicit nprobe for a batch of
  *   queries: centroid routing (:261-269), brute-force scan of the probed lists with precomputed
  *   norms (:217-234), merge, take k.  out_probes optional (nq x nprobe list ids).
- *   Two summation orders serve this call (cosine / dot).  Up to B (query, list) pairs per list (nq * nprobe <= B * nlist)
- *   the GEMV order (wave-strided f32 chain + butterfly): with the int8 copies of hnswgpu_set_rejection_test (and k <= 256)
- *   only the candidates whose lower bound can still reach the k nearest are evaluated at all, B = 48; without them every
- *   pair is one GEMV (from 1.5 pairs per list the pairs of a list share one pass over its rows), B = 12 -- same chain,
- *   same bits either way.  Larger batches are grouped by list and scanned by the f32-MFMA tile kernel (k-ordered f32
- *   chain).  Both orders are within 1e-6 of the f64 reference, but a query's distance BITS (and the order of candidates
- *   that tie within that) depend on which side of the boundary its batch falls: search-batch* over nq queries is not bit
- *   for bit nq single search-knn calls.  Calls combined from
+ *   Two summation orders exist for this call (cosine / dot).  The GEMV order (wave-strided f32 chain + butterfly) serves
+ *   EVERY batch size on a handle with the int8 and half-precision copies of its lists (hnswgpu_set_rejection_test 1 / 2
+ *   with dim >= 128, the default; k <= 256): only the candidates whose bounds can still reach the k nearest are evaluated
+ *   at all, and nq queries in one call return bit for bit what nq single calls return.  Without the copies (mode 0,
+ *   dim < 128, HNSWGPU_IVF_HALF=0 leaves a boundary of 48) or for k > 256, the GEMV order serves up to 12 (query, list)
+ *   pairs per list (nq * nprobe <= 12 * nlist: one GEMV per pair; from 1.5 pairs per list the pairs of a list share one
+ *   pass over its rows -- same chain, same bits) and larger batches are grouped by list and scanned by the f32-MFMA tile
+ *   kernel (k-ordered f32 chain): both orders are within 1e-6 of the f64 reference, but there a query's distance BITS (and
+ *   the order of candidates that tie within that) depend on which side of the boundary its batch falls.  Calls combined from
  *   concurrent host threads never change the kernel a call would get alone.  Euclidean: one arithmetic throughout. */
 int hnswgpu_ivf_build(hnswgpu_index *idx, int32_t nlist, int32_t max_iter, int64_t seed);
 int hnswgpu_set_ivf(hnswgpu_index *idx, const float *centroids, int32_t nlist, const int64_t *list_off,
@@ -245,8 +246,8 @@ int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
  * hnswgpu_set_rejection_test: mode 0 = off (no int8 copy is made: saves n * dim bytes; the bounds entry then fails),
  * 1 = launches of at least two queries per CU, where the traversal is bandwidth-bound, and only for dim >= 128 (an int8
  * row of a shorter vector saves no cache line) (default), 2 = every launch, every dim.  The same setting decides whether
- * the IVF lists get their int8 copy for the bounds pass of the list scan (every batch up to 48 (query, list) pairs per
- * list; every Euclidean batch; k <= 256).
+ * the IVF lists get their int8 copy (and with it the half-precision copy, below) for the bounds pass of the list scan
+ * (every batch size; k <= 256).
  * HNSWGPU_PREFILTER=<mode> in the environment sets the default of new handles.  Results never depend on the mode. */
 int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out);
 /* The same with the UPPER bounds beside them (out_ub, may be NULL): out_lb[i] <= distance <= out_ub[i].  The IVF search's
