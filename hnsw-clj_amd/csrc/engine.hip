@@ -598,6 +598,9 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
 // GEMV per query reads the whole table per query: 805 MB out of L2 for 256 queries x 1024 centroids x 768.)
 template <int NCH, int RB, bool L2>
 __global__ __launch_bounds__(kWG) void ivf_route_dist_kernel(RouteArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float4 *qs = reinterpret_cast<float4 *>(smem);  // [qgroup][NCH][64]: the group's queries in the lane layout
+    __shared__ float qn_s[16];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int grp = blockIdx.x / a.blocks_per_query, bx = blockIdx.x % a.blocks_per_query;
@@ -606,18 +609,32 @@ __global__ __launch_bounds__(kWG) void ivf_route_dist_kernel(RouteArgs a) {
     const int64_t r0 = static_cast<int64_t>(bx) * a.rows_per_block;
     const int64_t r1 = r0 + a.rows_per_block < a.nlist ? r0 + a.rows_per_block : a.nlist;
     const int nvec = static_cast<int>(a.ld / 4);
-    for (int64_t base = r0 + wave * RB; base < r1; base += kNWave * RB) {
-        float4 r[RB][NCH];
-        const float myrn = (a.metric == METRIC_COS && lane < RB && base + lane < r1) ? a.cnorms[base + lane] : 0.0f;
+    int64_t base = r0 + wave * RB;
+    float4 r[RB][NCH];
+    float myrn = (a.metric == METRIC_COS && lane < RB && base + lane < r1) ? a.cnorms[base + lane] : 0.0f;
 #pragma unroll
-        for (int b = 0; b < RB; b++) load_row<NCH>(r[b], a.cent + (base + b) * a.ld, nvec, lane, base + b < r1);
-        float4 q[NCH];
-        load_query<NCH>(q, a.Q + static_cast<int64_t>(q0) * a.qld, a.dim, lane);
+    for (int b = 0; b < RB; b++) load_row<NCH>(r[b], a.cent + (base + b) * a.ld, nvec, lane, base + b < r1);
+    // the group's queries (and their norms) into LDS once per workgroup, while the first rows are on their way: read from
+    // global memory inside the loop -- one query ahead -- every step waited out an L2 round trip (batch 1024: 106 us for
+    // what is 50 us of arithmetic)
+    for (int g = wave; g < qn_here; g += kNWave) {
+        float4 qq[NCH];
+        load_query<NCH>(qq, a.Q + static_cast<int64_t>(q0 + g) * a.qld, a.dim, lane);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) qs[(g * NCH + c) * kWave + lane] = qq[c];
+        if (a.metric == METRIC_COS) {
+            const float n = query_norm<NCH>(qq);
+            if (lane == 0) qn_s[g] = n;
+        }
+    }
+    __syncthreads();
+    for (; base < r1; base += kNWave * RB) {
         for (int g = 0; g < qn_here; g++) {
             const int qi = q0 + g;
-            float4 qnext[NCH];
-            load_query<NCH>(qnext, a.Q + static_cast<int64_t>(g + 1 < qn_here ? qi + 1 : qi) * a.qld, a.dim, lane);
-            const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+            float4 q[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) q[c] = qs[(g * NCH + c) * kWave + lane];
+            const float qn = a.metric == METRIC_COS ? qn_s[g] : 0.0f;
             float sm[RB];
 #pragma unroll
             for (int b = 0; b < RB; b++) sm[b] = lane_partial<NCH, L2>(q, r[b]);
@@ -629,8 +646,12 @@ __global__ __launch_bounds__(kWG) void ivf_route_dist_kernel(RouteArgs a) {
             for (int b = 0; b < RB; b++) mine = lane == b ? sm[b] : mine;
             if (lane < RB && base + lane < r1)
                 a.dense[static_cast<int64_t>(qi) * a.nlist + base + lane] = finish_dist(a.metric, mine, qn, myrn);
+        }
+        const int64_t nb = base + kNWave * RB;
+        if (nb < r1) {
+            myrn = (a.metric == METRIC_COS && lane < RB && nb + lane < r1) ? a.cnorms[nb + lane] : 0.0f;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) q[c] = qnext[c];
+            for (int b = 0; b < RB; b++) load_row<NCH>(r[b], a.cent + (nb + b) * a.ld, nvec, lane, nb + b < r1);
         }
     }
 }
@@ -701,15 +722,21 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
     if (two_launches) {
         // larger batches: the distances by workgroups that share their centroid rows among a group of queries, then the tail
         // as a launch of its own (plain loads: the distances come from an earlier launch)
-        a.qgroup = static_cast<int32_t>(std::max(2, std::min(16, nq / 16)));
+        // (the group's queries are staged in LDS: 1 KB x NCH each, 48 KB at most)
+        a.qgroup = static_cast<int32_t>(std::max(2, std::min(std::min(16, 48 / idx->nch), nq / 16)));
         const int64_t ngroups = (nq + a.qgroup - 1) / a.qgroup;
-        int64_t wb = std::max<int64_t>(1, 2048 / ngroups);
+        static const int64_t route_wgs = []() {
+            const char *e = getenv("HNSWGPU_ROUTE_WGS");  // tuning override
+            return e ? atoll(e) : 2048LL;
+        }();
+        int64_t wb = std::max<int64_t>(1, route_wgs / ngroups);
         int64_t rp = (idx->nlist + wb - 1) / wb;
         rp = std::max<int64_t>(per_iter, (rp + per_iter - 1) / per_iter * per_iter);
         a.rows_per_block = static_cast<int32_t>(rp);
         a.blocks_per_query = static_cast<int32_t>((idx->nlist + rp - 1) / rp);
         const int64_t dblocks = ngroups * a.blocks_per_query;
-#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_dist_kernel<N, R, L>), dim3(static_cast<unsigned>(dblocks)), dim3(kWG), 0, st, a)
+        const size_t qlds = sizeof(float4) * kWave * idx->nch * a.qgroup;
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_dist_kernel<N, R, L>), dim3(static_cast<unsigned>(dblocks)), dim3(kWG), qlds, st, a)
         HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
         HG_HIP(hipGetLastError());
