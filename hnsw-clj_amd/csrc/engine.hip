@@ -108,8 +108,15 @@ int ensure_list_half(hnswgpu_index *idx, hipStream_t st) {
     }();
     if (!wanted || !idx->d_lctile || idx->d_lhalf || idx->n <= 0 || idx->nlist <= 0) return 0;
     const int64_t n = idx->n;
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lhalf), sizeof(uint16_t) * static_cast<size_t>(n) * idx->ld));
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_lhmeta), sizeof(float4) * n));
+    // (an optional accelerator: a device too full for it -- +50 % of the base -- searches without it)
+    if (hipMalloc(reinterpret_cast<void **>(&idx->d_lhalf), sizeof(uint16_t) * static_cast<size_t>(n) * idx->ld) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&idx->d_lhmeta), sizeof(float4) * n) != hipSuccess) {
+        (void)hipGetLastError();
+        if (idx->d_lhalf) (void)hipFree(idx->d_lhalf);
+        idx->d_lhalf = nullptr;
+        idx->d_lhmeta = nullptr;
+        return 0;
+    }
     unsigned grid = static_cast<unsigned>((n + kNWave - 1) / kNWave);
 #define CALL(N, R, L)                                                                                                   \
     hipLaunchKernelGGL((quantize_rows_half_kernel<N>), dim3(grid), dim3(kWG), 0, st, idx->d_lrows, idx->ld, n, idx->metric, \

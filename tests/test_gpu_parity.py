@@ -1059,6 +1059,40 @@ def test_ivf_survivor_stream_every_row_width(eng, oracle, metric, dim):
         idx.set_profiling(False)
 
 
+@pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
+def test_ivf_routing_and_merge_break_ties_by_position(eng, oracle, metric, monkeypatch):
+    """The probed lists and the final k are picked by bisecting the KEY space (kernels.hpp: wave_topk_sorted): the
+    distance words first, then -- only when equal distances straddle the k-th place -- the positions.  Centroids in
+    identical groups of eight make the nprobe-th place fall inside a tie for every query (ivf_flat.clj:266-268 sorts
+    stably: the lower centroid index wins), many lists (2100 > 4 x 256: the carried chunks of the per-wave selection),
+    duplicated rows put ties across the k-th result; nprobe and k from 1 to 64, one query and a batch, with and without
+    the half-precision pass."""
+    O = oracle
+    code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
+    rs = np.random.RandomState(5)
+    dim, nlist, n = 136, 2100, 6300
+    uniq = rs.randn(nlist // 8 + 1, dim).astype(np.float32)
+    cen = np.repeat(uniq, 8, axis=0)[:nlist].copy()              # centroid c == centroid c ^ 1 == ... within its group of eight
+    base = (cen[rs.randint(0, nlist, n)] + 0.05 * rs.randn(n, dim)).astype(np.float32)
+    base[100:140] = base[7]                                      # forty identical rows: ties across the k-th place
+    lids = rs.permutation(n).astype(np.int32)                    # rows dealt to the lists at random: three per list
+    off = (np.arange(nlist + 1, dtype=np.int64) * 3)
+    Q = np.concatenate([base[7:8], cen[40:41], (cen[rs.randint(0, nlist, 20)] + 0.05 * rs.randn(20, dim))]).astype(np.float32)
+    with eng.Index(base, metric) as idx:
+        idx.set_rejection_test(2)
+        idx.set_ivf(cen, off, lids)
+        monkeypatch.setenv("HNSWGPU_IVF_CODES", "1")
+        for mid in ("0", "1"):
+            monkeypatch.setenv("HNSWGPU_STREAM_MID", mid)
+            for nq, nprobe, k in [(1, 5, 10), (1, 64, 64), (3, 1, 1), (22, 12, 33), (22, 33, 10), (5, 60, 5)]:
+                if metric != "l2" and nq * nprobe > 12 * nlist:
+                    continue
+                ids, d, probes = idx.ivf_search(Q[:nq], k, nprobe, want_probes=True)
+                oi, od, op = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=code, mode=O.MODE_DEV)
+                np.testing.assert_array_equal(probes, op)
+                assert_exact(ids, d, oi, od, "ties %s mid=%s nq=%d nprobe=%d k=%d" % (metric, mid, nq, nprobe, k))
+
+
 @pytest.mark.parametrize("dim", [900, 1536, 2500])
 def test_ivf_tile_path_several_k_phases(eng, oracle, dim):
     """Rows longer than 896 floats: the query group is resident in LDS one 768-column phase at a time and is refilled
