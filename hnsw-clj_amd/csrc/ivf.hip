@@ -77,8 +77,7 @@ __global__ __launch_bounds__(kWG) void probe_pairs_kernel(const uint32_t *ord, i
 // ---- execution order of the GEMV list scan: pairs sorted by the list they probe (counting sort in one workgroup;
 // the order inside a list is whatever the atomics give -- it only decides WHEN a pair runs, not what it computes)
 constexpr int kOrderMaxLists = 16384;  // LDS histogram: 64 KiB
-__global__ __launch_bounds__(1024) void pair_order_kernel(const int32_t *probes, int npairs, int nlist, int32_t *order,
-                                                          int stride = 1) {  // item i probes list probes[i * stride]
+__device__ __forceinline__ void pair_order_wg(const int32_t *probes, int npairs, int nlist, int32_t *order, int stride) {
     extern __shared__ int32_t ocnt[];  // [nlist + 1] (bucket nlist: pairs without a list), then [1024] scan scratch
     int32_t *part = ocnt + nlist + 1;
     const int tid = threadIdx.x, nb = nlist + 1;
@@ -113,15 +112,26 @@ __global__ __launch_bounds__(1024) void pair_order_kernel(const int32_t *probes,
         order[atomicAdd(&ocnt[l >= 0 && l < nlist ? l : nlist], 1)] = i;
     }
 }
+__global__ __launch_bounds__(1024) void pair_order_kernel(const int32_t *probes, int npairs, int nlist, int32_t *order,
+                                                          int stride = 1) {  // item i probes list probes[i * stride]
+    pair_order_wg(probes, npairs, nlist, order, stride);
+}
 
 // ---- work list of the grouped bounds pass (stream_kernels.hpp) --------------------------------------------------
 // The routing step has filed every (query, list) pair under its list (bk_cnt / bk_mem); this turns the per-list counts
 // into the dense list of work items (list, group of <= 32 members, chunk of rows), chunk-major inside a list so that the
 // groups reading the same rows are neighbours.  One workgroup: a scan over the lists' item counts, then every thread
 // fills items by bisection into the scanned offsets (a hot list's hundreds of items are not one thread's job).
+// A second workgroup, when launched, is pair_order_kernel for the query order of the later kernels (ord_*): two one-workgroup
+// jobs of a large batch side by side instead of one behind the other.
 __global__ __launch_bounds__(1024) void ivf_worklist_kernel(uint32_t *bk_cnt, int32_t bk_cap, int nlist,
                                                             const int64_t *list_off, int64_t chunk_rows, int max_chunks,
-                                                            WorkDesc *desc, int32_t *nitems) {
+                                                            WorkDesc *desc, int32_t *nitems, const int32_t *ord_probes,
+                                                            int ord_nq, int32_t *ord_out, int ord_stride) {
+    if (blockIdx.x == 1) {
+        pair_order_wg(ord_probes, ord_nq, nlist, ord_out, ord_stride);
+        return;
+    }
     __shared__ int32_t off_s[1025];  // exclusive offsets of this pass's lists
     __shared__ int32_t part[16];
     __shared__ int32_t carry_s;
@@ -794,6 +804,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     StreamArgs b;
     memset(&b, 0, sizeof(b));
     int64_t blocks;
+    const int32_t *qorder = nullptr;  // large batches: the queries in the order of their nearest list (below)
     const int64_t stride = (static_cast<int64_t>(nprobe) * idx->max_list_len + 3) / 4 * 4;
     // rows per workgroup: whole tiles; enough working workgroups to fill the chip a few times over
     const int64_t mean = std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1));
@@ -815,8 +826,22 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         HG_TRY(idx->s_misc2.ensure(sizeof(WorkDesc) * static_cast<size_t>(wbound) + 64));
         WorkDesc *desc = idx->s_misc2.as<WorkDesc>();
         int32_t *nit = reinterpret_cast<int32_t *>(desc + wbound);
-        hipLaunchKernelGGL(ivf_worklist_kernel, dim3(1), dim3(1024), 0, st, sc.bk_cnt, sc.bk_cap, idx->nlist, idx->d_listoff, cr,
-                           b.nchunks, desc, nit);
+        // (large batches: the query order of the half-precision pass and the finish kernel by a second workgroup of this launch)
+        const int64_t order_min = env_now("HNSWGPU_FINISH_ORDER", 512);  // 0 = never (A/B)
+        size_t olds = 0;
+        if (d_probes && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists) {
+            HG_TRY(idx->s_stats.ensure(sizeof(int32_t) * static_cast<size_t>(nq)));  // (s_ids / s_outd may be the caller's outputs)
+            olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);
+            if (olds > 32 * 1024) {  // (+ the work list's static 4 KB)
+                static bool attr_done[64] = {};
+                if (attr_needed(attr_done))
+                    HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_worklist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(sizeof(int32_t) * (kOrderMaxLists + 1 + 1024))));
+            }
+            qorder = idx->s_stats.as<int32_t>();
+        }
+        hipLaunchKernelGGL(ivf_worklist_kernel, dim3(qorder ? 2 : 1), dim3(1024), olds, st, sc.bk_cnt, sc.bk_cap, idx->nlist,
+                           idx->d_listoff, cr, b.nchunks, desc, nit, d_probes, nq, idx->s_stats.as<int32_t>(), nprobe);
         HG_HIP(hipGetLastError());
         idx->bk_dirty = false;  // (the kernel leaves the counters zero)
         b.wi_desc = desc;
@@ -866,9 +891,8 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     // Large batches: a query's survivors are, above all, its nearest list -- and several queries share one.  The queries are
     // taken in the order of their nearest list, a contiguous eighth of that order per XCD, so that the queries which read
     // the same rows run side by side on ONE L2 (each XCD otherwise fetches the list for itself).
-    const int32_t *qorder = nullptr;
     const int64_t order_min = env_now("HNSWGPU_FINISH_ORDER", 512);  // 0 = never (A/B)
-    if (d_probes && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists) {
+    if (!qorder && d_probes && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists) {  // (ungrouped launches)
         HG_TRY(idx->s_stats.ensure(sizeof(int32_t) * static_cast<size_t>(nq)));  // (s_ids / s_outd may be the caller's outputs)
         const size_t olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);
         if (olds > 48 * 1024) {

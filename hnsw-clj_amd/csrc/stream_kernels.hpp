@@ -877,7 +877,7 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     // collision, which costs one rank).  Only behind ivf_mid_kernel: the int8 upper bounds are no tighter than the
     // threshold the bounds pass ran with (measured: not one row fewer), the half-precision ones leave little more than k
     // candidates.  (Every workgroup of a query reads the whole list: 16 B per survivor, from L2.)
-    if (a.prepass && !over && a.k <= kWG) {
+    if (a.prepass && !over && a.k <= kWG && nsv > 2u * kWave) {  // (a list one step evaluates anyway gains nothing -- e.g. a compacted one)
         float m = __builtin_inff();
         for (uint32_t i = threadIdx.x; i < nsv; i += kWG) {
             const float u = __uint_as_float(sv[i].w);

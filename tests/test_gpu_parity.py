@@ -853,7 +853,7 @@ def test_ivf_half_precision_pass(eng, oracle, metric, monkeypatch):
             oi, od, _ = O.ivf_search(base, cen, off, lids, Q[-nq:], k, nprobe, metric=code, mode=O.MODE_DEV)
             assert_exact(ids, d, oi, od, "%s %s nq=%d k=%d nprobe=%d" % (what, metric, nq, k, nprobe))
             if expect_few:                                    # it ran: f32 rows for little more than k candidates
-                assert cand > 0 and surv <= nq * (k + 40), (what, surv, cand, nq, k)
+                assert cand > 0 and surv <= nq * max(k + 40, 128), (what, surv, cand, nq, k)   # (<= 128 int8 survivors: all fetched)
 
         if metric == "l2":                                   # (cosine / dot: the suite pins such a batch to the tile scan)
             check(170, 10, 50, "production threshold")       # 170 x 9000 candidates
