@@ -537,7 +537,7 @@ __device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsign
     const bool head_ok = a.nprobe <= kHead || tail_cover >= static_cast<uint32_t>(kSeedMax);
     const Pair *pp = head_ok ? head_s : a.pairs + static_cast<int64_t>(qi) * a.nprobe;
     seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, pp, head_ok ? (a.nprobe < kHead ? a.nprobe : kHead) : a.nprobe, tail_qcnt, a.k,
-                             a.rows, a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi, a.nq >= 1024 ? 16 : 64);
+                             a.rows, a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi, a.nq >= 1024 ? 16 : (a.nq <= 8 ? 32 : 64));
     HG_IVF_STAMP(a.dbg, 20, qi == 0 && threadIdx.x == 0);  // threshold seeded
 }
 

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kWG) void ivf_query_prep_kernel(PrepArgs a) {
         if (lane == 0) a.qscal[qi] = qc.sc;
     }
     seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, a.pairs + static_cast<int64_t>(qi) * a.nprobe, a.nprobe, a.qcnt[qi], a.k, a.rows,
-                             a.row_norms, a.ld, dist_s, a.tau + qi, a.nq >= 1024 ? 16 : 64);
+                             a.row_norms, a.ld, dist_s, a.tau + qi, a.nq >= 1024 ? 16 : (a.nq <= 8 ? 32 : 64));
 }
 
 // One work item of the grouped bounds pass: rows [rb0 + r0_off, rb0 + r1_off) of inverted list `list` (which starts at row
