@@ -1031,11 +1031,12 @@ def test_ivf_many_equal_distances(eng, oracle, metric):
 
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
 @pytest.mark.parametrize("dim", [5, 300, 768, 1000, 1536, 2048, 3072])
-def test_ivf_survivor_stream_every_row_width(eng, oracle, metric, dim):
+def test_ivf_survivor_stream_every_row_width(eng, oracle, metric, dim, monkeypatch):
     """The survivor stream for every row-loader width (NCH = 1, 2, 3, 4, 6, 8, 12: 8 .. 96 MFMA steps per 32-row block, the
     operand pipeline with zero to eleven trips of its main loop), with both epilogues -- a handful of queries (one work item
     per pair), few queries per list (lane = row), many (lane = query) --, ragged lists over several tiles, exact ties and
-    a zero row: ids and distance bits equal the oracle's device-order mode."""
+    a zero row, without and with the half-precision pass (its row loader per width, entries appended without bounds by the
+    wide epilogue): ids and distance bits equal the oracle's device-order mode."""
     O = oracle
     code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
     n = 2600
@@ -1050,12 +1051,14 @@ def test_ivf_survivor_stream_every_row_width(eng, oracle, metric, dim):
         idx.set_profiling(True)
         for nq, nprobe, k in [(2, 4, 10), (11, 3, 10), (61, 7, 10) if metric == "l2" else (12, 7, 40)]:
             assert metric == "l2" or nq * nprobe <= 12 * 7        # the GEMV-order side of the (pinned) boundary
-            idx.rejection_stats(reset=True)
-            ids, d = idx.ivf_search(Q[:nq], k, nprobe)
-            surv, cand = idx.rejection_stats(reset=True)
-            assert cand > 0, "the bounds pass did not run"
             oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=code, mode=O.MODE_DEV)
-            assert_exact(ids, d, oi, od, "stream %s dim=%d nq=%d nprobe=%d k=%d" % (metric, dim, nq, nprobe, k))
+            for mid in ("0", "1"):
+                monkeypatch.setenv("HNSWGPU_STREAM_MID", mid)
+                idx.rejection_stats(reset=True)
+                ids, d = idx.ivf_search(Q[:nq], k, nprobe)
+                surv, cand = idx.rejection_stats(reset=True)
+                assert cand > 0, "the bounds pass did not run"
+                assert_exact(ids, d, oi, od, "stream %s dim=%d nq=%d nprobe=%d k=%d mid=%s" % (metric, dim, nq, nprobe, k, mid))
         idx.set_profiling(False)
 
 
