@@ -127,6 +127,12 @@ int ensure_list_half(hnswgpu_index *idx, hipStream_t st) {
     return 0;
 }
 
+// LDS of finish_wg: W lists + final list + (ord, dist) of the result + the query's probe table + the bisection merge's scratch
+static size_t finish_lds_bytes(int k, int nprobe) {
+    return sizeof(uint64_t) * (kNWave + 2) * k + (sizeof(int64_t) + 2 * sizeof(uint32_t)) * ((nprobe + 1) & ~1) +
+           (k <= kWave ? sizeof(uint64_t) * kNWave * k : 0);
+}
+
 int launch_mid(const MidArgs &a, int nch, hipStream_t st) {
     int64_t blocks = static_cast<int64_t>(a.nq) * a.slices;
     if (a.qorder) blocks = (static_cast<int64_t>(a.nq) + 7) / 8 * 8;  // ordered queries: whole rounds over the eight XCDs
@@ -172,9 +178,7 @@ int launch_finish(const FinishArgs &a, int nch, hipStream_t st) {
     if (a.qorder) blocks = (static_cast<int64_t>(a.nq) + 7) / 8 * 8;  // ordered queries: whole rounds over the eight XCDs
     if (blocks <= 0) return 0;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "finish grid too large");
-    // W lists + final list + (ord, dist) of the result + the probed lists' stream offsets
-    const size_t lds = sizeof(uint64_t) * (kNWave + 2) * a.k + (sizeof(int64_t) + 2 * sizeof(uint32_t)) * ((a.nprobe + 1) & ~1) +
-                       (a.k <= kWave ? sizeof(uint64_t) * kNWave * a.k : 0);  // ... + the bisection merge's scratch
+    const size_t lds = finish_lds_bytes(a.k, a.nprobe);
     HG_REQUIRE(lds <= 64 * 1024, HNSWGPU_ELIMIT, "k too large for the finish kernel (k=%d)", a.k);
     const bool l2 = a.metric == METRIC_L2;
 #define CALL(N, R, L)                                                                                                   \

@@ -905,30 +905,6 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         HG_HIP(hipGetLastError());
         qorder = idx->s_stats.as<int32_t>();
     }
-    if (mid) {
-        MidArgs ma;
-        memset(&ma, 0, sizeof(ma));
-        ma.surv = b.surv;
-        ma.surv_cnt = b.surv_cnt;
-        ma.cap = cap;
-        ma.nq = nq;
-        ma.slices = qorder ? 1 : static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(16, 4096 / nq)));
-        if (const int64_t sl = env_now("HNSWGPU_MID_SLICES", 0)) ma.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(sl, 64)));  // tuning
-        ma.qorder = ma.slices == 1 ? qorder : nullptr;
-        // one workgroup per query sees the whole list: it also applies the threshold of the upper bounds and compacts the
-        // list (up to 4096 entries: 16 KB of LDS -- more would cost the kernel its occupancy; a longer list is left to the finish kernel's own pass)
-        ma.tau = b.tau;
-        ma.k = k;
-        ma.compact = ma.slices == 1 && env_now("HNSWGPU_MID_COMPACT", 1) ? static_cast<int32_t>(std::min<int64_t>(cap, 4096)) : 0;
-        ma.half = idx->d_lhalf;
-        ma.hmeta = idx->d_lhmeta;
-        ma.ld = idx->ld;
-        ma.Q = d_Q;
-        ma.qld = idx->dim;
-        ma.dim = idx->dim;
-        ma.metric = idx->metric;
-        HG_TRY(launch_mid(ma, idx->nch, st));
-    }
     FinishArgs f;
     memset(&f, 0, sizeof(f));
     f.prepass = mid ? 1 : 0;
@@ -970,6 +946,30 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     f.out_gord = d_out_gord;
     f.stats = idx->prof ? idx->d_rej_stats : nullptr;
     f.qorder = f.slices == 1 ? qorder : nullptr;
+    if (mid) {
+        MidArgs ma;
+        memset(&ma, 0, sizeof(ma));
+        ma.surv = b.surv;
+        ma.surv_cnt = b.surv_cnt;
+        ma.cap = cap;
+        ma.nq = nq;
+        ma.slices = qorder ? 1 : static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(16, 4096 / nq)));
+        if (const int64_t sl = env_now("HNSWGPU_MID_SLICES", 0)) ma.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(sl, 64)));  // tuning
+        ma.qorder = ma.slices == 1 ? qorder : nullptr;
+        // one workgroup per query sees the whole list: it also applies the threshold of the upper bounds and compacts the
+        // list (up to 4096 entries: 16 KB of LDS -- more would cost the kernel its occupancy; a longer list is left to the finish kernel's own pass)
+        ma.tau = b.tau;
+        ma.k = k;
+        ma.compact = ma.slices == 1 && env_now("HNSWGPU_MID_COMPACT", 1) ? static_cast<int32_t>(std::min<int64_t>(cap, 4096)) : 0;
+        ma.half = idx->d_lhalf;
+        ma.hmeta = idx->d_lhmeta;
+        ma.ld = idx->ld;
+        ma.Q = d_Q;
+        ma.qld = idx->dim;
+        ma.dim = idx->dim;
+        ma.metric = idx->metric;
+        HG_TRY(launch_mid(ma, idx->nch, st));
+    }
     return launch_finish(f, idx->nch, st);
 }
 

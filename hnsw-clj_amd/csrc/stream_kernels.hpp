@@ -628,170 +628,6 @@ __device__ __forceinline__ void half_bounds(int metric, float sum, float qn, flo
     ub = c + mt.y;
 }
 
-struct MidArgs {
-    uint4 *surv;               // [nq][cap] (order key, list row, lb bits, ub bits): lb / ub are replaced
-    uint32_t *surv_cnt;
-    uint32_t *tau;
-    int64_t cap;
-    int32_t nq, slices;
-    int32_t k;                 // compact > 0 (slices == 1): the workgroup sees the query's whole list and leaves only the
-    int32_t compact;           // entries the k-th smallest upper bound does not exclude (dynamic LDS: 4 B x compact entries)
-    const int32_t *qorder;     // optional (slices == 1): the queries in the order of their nearest list (as the finish kernel)
-    const uint2 *half;         // [rows][ld / 4] four halves each
-    const float4 *hmeta;       // (scale, E, 0, 1 / |v|)
-    int64_t ld;
-    const float *Q;
-    int64_t qld;
-    int32_t dim, metric;
-};
-
-template <int NCH, int RB, bool L2>
-__global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    int qi = blockIdx.x % a.nq;
-    const int sl = a.qorder ? 0 : blockIdx.x / a.nq;
-    if (a.qorder) {  // workgroup b runs on XCD b % 8: XCD x takes a contiguous eighth of the ordered queries
-        const int per = (a.nq + 7) >> 3;
-        const int pos = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        if (pos >= a.nq || (blockIdx.x >> 3) >= per) return;
-        qi = a.qorder[pos];
-    }
-    const uint32_t nsv = a.surv_cnt[qi];
-    if (nsv > a.cap) return;  // the list overflowed: the finish kernel walks the candidate stream instead
-    constexpr int gran = kNWave * kWave;
-    int64_t per = (static_cast<int64_t>(nsv) + a.slices - 1) / a.slices;
-    per = (per + gran - 1) / gran * gran;
-    const int64_t i0 = static_cast<int64_t>(sl) * per;
-    const int64_t i1 = i0 + per < nsv ? i0 + per : nsv;
-    if (i0 >= i1) return;
-    const int nvec = static_cast<int>(a.ld / 4);
-    float4 q[NCH];
-    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
-    const float qn = L2 ? 0.0f : query_norm<NCH>(q);
-    uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
-    extern __shared__ __align__(16) unsigned char smem[];
-    float *lb_s = reinterpret_cast<float *>(smem);  // [compact] the entries' new lower bounds
-    const bool compact = a.compact > 0 && nsv <= static_cast<uint32_t>(a.compact) && a.k <= kWG;
-    float ub_min = __builtin_inff();                // over this thread's entries
-    for (int64_t base = i0 + wave * kWave; base < i1; base += gran) {
-        const int64_t i = base + lane;
-        const bool in = i < i1;
-        uint4 e = make_uint4(0u, 0u, 0u, 0u);
-        float4 mt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (in) {
-            e = sv[i];
-            mt = a.hmeta[e.y];
-        }
-        uint64_t m = __ballot(in);
-        float mysum = 0.0f;
-        while (m) {
-            uint2 w[RB][NCH];
-            int js[RB];
-            float sc[RB];
-#pragma unroll
-            for (int b = 0; b < RB; b++) {
-                js[b] = -1;
-                sc[b] = 0.0f;
-                if (m) {
-                    js[b] = __ffsll(static_cast<unsigned long long>(m)) - 1;
-                    m &= m - 1;
-                    const int64_t row = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e.y), js[b]));
-                    sc[b] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mt.x), js[b]));
-                    const uint2 *rp = a.half + row * nvec;
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) w[b][c] = c * kWave + lane < nvec ? rp[c * kWave + lane] : make_uint2(0u, 0u);
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < RB; b++) {
-                if (js[b] < 0) break;
-                float acc = 0.0f;
-#pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    const h4_t h = __builtin_bit_cast(h4_t, w[b][c]);
-                    const float hv[4] = {static_cast<float>(h[0]), static_cast<float>(h[1]), static_cast<float>(h[2]), static_cast<float>(h[3])};
-                    const float qv[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (L2) {
-                            const float d = qv[j] - hv[j] * sc[b];
-                            acc = __builtin_fmaf(d, d, acc);
-                        } else {
-                            acc = __builtin_fmaf(qv[j], hv[j], acc);
-                        }
-                    }
-                }
-                const float sum = wave_sum(acc);
-                mysum = lane == js[b] ? sum : mysum;
-            }
-        }
-        if (in) {
-            float lb, ub;
-            half_bounds(a.metric, mysum, qn, mt, lb, ub);
-            // (both pairs hold: the tighter of each -- v_max / v_min return the other operand for a NaN)
-            lb = __builtin_fmaxf(lb, __uint_as_float(e.z));
-            ub = __builtin_fminf(ub, __uint_as_float(e.w));
-            *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(sv + i) + 2) = make_uint2(__float_as_uint(lb), __float_as_uint(ub));
-            if (compact) {
-                lb_s[i] = lb;
-                ub_min = ub < ub_min ? ub : ub_min;  // (NaN: no upper bound, not counted)
-            }
-        }
-    }
-    if (!compact) return;
-    // ---- the query's whole list went through this workgroup: the threshold the finish kernel would derive from the upper
-    // bounds (the k-th smallest of the 256 threads' minima: k candidates at most that far) is applied here, and the list
-    // shrinks to the entries it does not exclude -- little more than k -- before the finish kernel reads it
-    __shared__ __align__(16) uint32_t ubv_s[kWG];
-    __shared__ uint32_t kth_s, wcnt_s[kNWave];
-    const uint32_t v = tau_encode(ub_min);
-    ubv_s[threadIdx.x] = v;
-    __syncthreads();
-    {
-        int rank = 0;
-        for (int j = 0; j < kWG; j += 4) {
-            const uint4 o = *reinterpret_cast<const uint4 *>(ubv_s + j);  // uniform address: an LDS broadcast
-            rank += (o.x < v || (o.x == v && j < static_cast<int>(threadIdx.x))) ? 1 : 0;
-            rank += (o.y < v || (o.y == v && j + 1 < static_cast<int>(threadIdx.x))) ? 1 : 0;
-            rank += (o.z < v || (o.z == v && j + 2 < static_cast<int>(threadIdx.x))) ? 1 : 0;
-            rank += (o.w < v || (o.w == v && j + 3 < static_cast<int>(threadIdx.x))) ? 1 : 0;
-        }
-        if (rank == a.k - 1) kth_s = v;  // ranks are a permutation of 0..255: exactly one thread
-    }
-    __syncthreads();
-    const float T = tau_decode(kth_s);
-    uint32_t nout = 0;  // entries kept so far (uniform)
-    for (uint32_t base = 0; base < nsv; base += kWG) {
-        // in place: a step reads its 256 entries before anything is written, and writes below base + 256
-        const uint32_t i = base + threadIdx.x;
-        const bool keep = i < nsv && !(lb_s[i] > T);  // NaN (no bound) stays
-        uint4 e = make_uint4(0u, 0u, 0u, 0u);
-        if (keep) {
-            const uint2 head = *reinterpret_cast<const uint2 *>(sv + i);  // (order key, list row): written by the bounds pass
-            e = make_uint4(head.x, head.y, __float_as_uint(lb_s[i]), 0x7f800000u);
-        }
-        const uint64_t m = __ballot(keep);
-        if (lane == 0) wcnt_s[wave] = static_cast<uint32_t>(__popcll(m));
-        wait_stores_acked();  // (s_waitcnt vmcnt(0): this step's reads have returned before any wave writes)
-        __syncthreads();
-        uint32_t off = nout, tot = 0;
-#pragma unroll
-        for (int w = 0; w < kNWave; w++) {
-            const uint32_t c = wcnt_s[w];
-            off += w < wave ? c : 0u;
-            tot += c;
-        }
-        if (keep) sv[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
-        nout += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        a.surv_cnt[qi] = nout;
-        if (T < __builtin_inff()) (void)__hip_atomic_fetch_min(a.tau + qi, tau_encode(T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Step 2: survivors -> f32 distances -> the k nearest -> results.
 // ------------------------------------------------------------------------------------------------
@@ -825,27 +661,16 @@ struct FinishArgs {
     unsigned long long *dbg;  // -DHG_IVF_STAMPS diagnostic builds only
 };
 
+// One workgroup's share of query qi: slice sl of its nsv survivors (or, nsv > cap, of its candidate stream), and -- as the
+// last workgroup of the query -- the merge and the results.  The body of ivf_finish_kernel.
 template <int NCH, int RB, bool L2>
-__global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, uint32_t nsv, float tau, unsigned char *smem) {
     __shared__ int tail_last;
     __shared__ __align__(16) uint32_t ub_s[kWG];
     __shared__ uint32_t ub_kth;
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem);  // [kNWave][k] (+ the tail's final list and results)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    // slice-major: a query's survivors sit in the first slices of its list when it is short, and query-major order would
-    // put the busy workgroups of all queries on the same XCDs
-    int qi = blockIdx.x % a.nq;
-    const int sl = a.qorder ? 0 : blockIdx.x / a.nq;  // (ordered queries: one slice, the grid is padded to whole XCD rounds)
-    if (a.qorder) {  // workgroup b runs on XCD b % 8: XCD x takes a contiguous eighth of the ordered queries
-        const int per = (a.nq + 7) >> 3;
-        const int pos = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        if (pos >= a.nq || (blockIdx.x >> 3) >= per) return;
-        qi = a.qorder[pos];
-    }
-    HG_IVF_STAMP(a.dbg, 24, blockIdx.x == 0 && threadIdx.x == 0);  // first workgroup of the finish kernel starts
-    const uint32_t nsv = a.surv_cnt[qi];
     const bool over = nsv > a.cap;  // survivors did not fit: walk the candidate stream itself (the plain f32 scan)
     const int64_t total = over ? a.q_cnt[qi] : nsv;
     // entries a wave looks at per step: no more than spreads the list over every wave of the query's workgroups (a wave
@@ -863,7 +688,6 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     const int64_t i1 = i0 + per < total ? i0 + per : total;
     // the threshold keeps falling in this kernel too: a wave that holds k exact distances folds its k-th into tau[qi]
     // (k candidates are at most that far), every wave re-reads it once per step
-    float tau = tau_decode(a.tau[qi]);
     const bool share = a.slices <= 8;
     const uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
     const Pair *pp = a.pairs + static_cast<int64_t>(qi) * a.nprobe;
@@ -1111,6 +935,192 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     }
     HG_IVF_STAMP(a.dbg, 27, qi == 0 && lane == 0);  // results written
 }
+
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    // slice-major: a query's survivors sit in the first slices of its list when it is short, and query-major order would
+    // put the busy workgroups of all queries on the same XCDs
+    int qi = blockIdx.x % a.nq;
+    const int sl = a.qorder ? 0 : blockIdx.x / a.nq;  // (ordered queries: one slice, the grid is padded to whole XCD rounds)
+    if (a.qorder) {  // workgroup b runs on XCD b % 8: XCD x takes a contiguous eighth of the ordered queries
+        const int per = (a.nq + 7) >> 3;
+        const int pos = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (pos >= a.nq || (blockIdx.x >> 3) >= per) return;
+        qi = a.qorder[pos];
+    }
+    HG_IVF_STAMP(a.dbg, 24, blockIdx.x == 0 && threadIdx.x == 0);  // first workgroup of the finish kernel starts
+    const uint32_t nsv = a.surv_cnt[qi];
+    finish_wg<NCH, RB, L2>(a, qi, sl, nsv, tau_decode(a.tau[qi]), smem);
+}
+
+struct MidArgs {
+    uint4 *surv;               // [nq][cap] (order key, list row, lb bits, ub bits): lb / ub are replaced
+    uint32_t *surv_cnt;
+    uint32_t *tau;
+    int64_t cap;
+    int32_t nq, slices;
+    int32_t k;                 // compact > 0 (slices == 1): the workgroup sees the query's whole list and leaves only the
+    int32_t compact;           // entries the k-th smallest upper bound does not exclude (dynamic LDS: 4 B x compact entries)
+    const int32_t *qorder;     // optional (slices == 1): the queries in the order of their nearest list (as the finish kernel)
+    const uint2 *half;         // [rows][ld / 4] four halves each
+    const float4 *hmeta;       // (scale, E, 0, 1 / |v|)
+    int64_t ld;
+    const float *Q;
+    int64_t qld;
+    int32_t dim, metric;
+};
+
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    int qi = blockIdx.x % a.nq;
+    const int sl = a.qorder ? 0 : blockIdx.x / a.nq;
+    if (a.qorder) {  // workgroup b runs on XCD b % 8: XCD x takes a contiguous eighth of the ordered queries
+        const int per = (a.nq + 7) >> 3;
+        const int pos = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (pos >= a.nq || (blockIdx.x >> 3) >= per) return;
+        qi = a.qorder[pos];
+    }
+    const uint32_t nsv = a.surv_cnt[qi];
+    if (nsv > a.cap) return;  // the list overflowed: the finish kernel walks the candidate stream instead
+    constexpr int gran = kNWave * kWave;
+    int64_t per = (static_cast<int64_t>(nsv) + a.slices - 1) / a.slices;
+    per = (per + gran - 1) / gran * gran;
+    const int64_t i0 = static_cast<int64_t>(sl) * per;
+    const int64_t i1 = i0 + per < nsv ? i0 + per : nsv;
+    if (i0 >= i1) return;
+    const int nvec = static_cast<int>(a.ld / 4);
+    float4 q[NCH];
+    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+    const float qn = L2 ? 0.0f : query_norm<NCH>(q);
+    uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *lb_s = reinterpret_cast<float *>(smem);  // [compact] the entries' new lower bounds
+    const bool compact = a.compact > 0 && nsv <= static_cast<uint32_t>(a.compact) && a.k <= kWG;
+    float ub_min = __builtin_inff();                // over this thread's entries
+    for (int64_t base = i0 + wave * kWave; base < i1; base += gran) {
+        const int64_t i = base + lane;
+        const bool in = i < i1;
+        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+        float4 mt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (in) {
+            e = sv[i];
+            mt = a.hmeta[e.y];
+        }
+        uint64_t m = __ballot(in);
+        float mysum = 0.0f;
+        while (m) {
+            uint2 w[RB][NCH];
+            int js[RB];
+            float sc[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                js[b] = -1;
+                sc[b] = 0.0f;
+                if (m) {
+                    js[b] = __ffsll(static_cast<unsigned long long>(m)) - 1;
+                    m &= m - 1;
+                    const int64_t row = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e.y), js[b]));
+                    sc[b] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mt.x), js[b]));
+                    const uint2 *rp = a.half + row * nvec;
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) w[b][c] = c * kWave + lane < nvec ? rp[c * kWave + lane] : make_uint2(0u, 0u);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                if (js[b] < 0) break;
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const h4_t h = __builtin_bit_cast(h4_t, w[b][c]);
+                    const float hv[4] = {static_cast<float>(h[0]), static_cast<float>(h[1]), static_cast<float>(h[2]), static_cast<float>(h[3])};
+                    const float qv[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (L2) {
+                            const float d = qv[j] - hv[j] * sc[b];
+                            acc = __builtin_fmaf(d, d, acc);
+                        } else {
+                            acc = __builtin_fmaf(qv[j], hv[j], acc);
+                        }
+                    }
+                }
+                const float sum = wave_sum(acc);
+                mysum = lane == js[b] ? sum : mysum;
+            }
+        }
+        if (in) {
+            float lb, ub;
+            half_bounds(a.metric, mysum, qn, mt, lb, ub);
+            // (both pairs hold: the tighter of each -- v_max / v_min return the other operand for a NaN)
+            lb = __builtin_fmaxf(lb, __uint_as_float(e.z));
+            ub = __builtin_fminf(ub, __uint_as_float(e.w));
+            *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(sv + i) + 2) = make_uint2(__float_as_uint(lb), __float_as_uint(ub));
+            if (compact) {
+                lb_s[i] = lb;
+                ub_min = ub < ub_min ? ub : ub_min;  // (NaN: no upper bound, not counted)
+            }
+        }
+    }
+    if (!compact) return;
+    // ---- the query's whole list went through this workgroup: the threshold the finish kernel would derive from the upper
+    // bounds (the k-th smallest of the 256 threads' minima: k candidates at most that far) is applied here, and the list
+    // shrinks to the entries it does not exclude -- little more than k -- before the finish kernel reads it
+    __shared__ __align__(16) uint32_t ubv_s[kWG];
+    __shared__ uint32_t kth_s, wcnt_s[kNWave];
+    const uint32_t v = tau_encode(ub_min);
+    ubv_s[threadIdx.x] = v;
+    __syncthreads();
+    {
+        int rank = 0;
+        for (int j = 0; j < kWG; j += 4) {
+            const uint4 o = *reinterpret_cast<const uint4 *>(ubv_s + j);  // uniform address: an LDS broadcast
+            rank += (o.x < v || (o.x == v && j < static_cast<int>(threadIdx.x))) ? 1 : 0;
+            rank += (o.y < v || (o.y == v && j + 1 < static_cast<int>(threadIdx.x))) ? 1 : 0;
+            rank += (o.z < v || (o.z == v && j + 2 < static_cast<int>(threadIdx.x))) ? 1 : 0;
+            rank += (o.w < v || (o.w == v && j + 3 < static_cast<int>(threadIdx.x))) ? 1 : 0;
+        }
+        if (rank == a.k - 1) kth_s = v;  // ranks are a permutation of 0..255: exactly one thread
+    }
+    __syncthreads();
+    const float T = tau_decode(kth_s);
+    uint32_t nout = 0;  // entries kept so far (uniform)
+    for (uint32_t base = 0; base < nsv; base += kWG) {
+        // in place: a step reads its 256 entries before anything is written, and writes below base + 256
+        const uint32_t i = base + threadIdx.x;
+        const bool keep = i < nsv && !(lb_s[i] > T);  // NaN (no bound) stays
+        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+        if (keep) {
+            const uint2 head = *reinterpret_cast<const uint2 *>(sv + i);  // (order key, list row): written by the bounds pass
+            e = make_uint4(head.x, head.y, __float_as_uint(lb_s[i]), 0x7f800000u);
+        }
+        const uint64_t m = __ballot(keep);
+        if (lane == 0) wcnt_s[wave] = static_cast<uint32_t>(__popcll(m));
+        wait_stores_acked();  // (s_waitcnt vmcnt(0): this step's reads have returned before any wave writes)
+        __syncthreads();
+        uint32_t off = nout, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kNWave; w++) {
+            const uint32_t c = wcnt_s[w];
+            off += w < wave ? c : 0u;
+            tot += c;
+        }
+        if (keep) sv[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
+        nout += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.surv_cnt[qi] = nout;
+        if (T < __builtin_inff()) (void)__hip_atomic_fetch_min(a.tau + qi, tau_encode(T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (Tried: finishing the query right here -- finish_wg on the ~15 entries left, no second launch for it.  The finish
+    // body needs 132 VGPRs against this kernel's 84; with it inlined the bandwidth-bound half of this kernel lost half its
+    // occupancy and batch 4096 went from 1.32 to 2.0 ms; as a real call the compiler reserved 264 registers and scratch.)
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // k-means++ seeding (ivf_flat.clj:43-49) as a bounds pass: a round folds the distances to ONE new centre into every
