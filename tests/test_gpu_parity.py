@@ -1096,6 +1096,37 @@ def test_ivf_routing_and_merge_break_ties_by_position(eng, oracle, metric, monke
                 assert_exact(ids, d, oi, od, "ties %s mid=%s nq=%d nprobe=%d k=%d" % (metric, mid, nq, nprobe, k))
 
 
+@pytest.mark.parametrize("kind", ["gaussian", "clustered"])
+def test_ivf_stream_equals_the_f32_scan_at_scale(eng, kind):
+    """A size-independent property at a size the oracle does not reach: the Euclidean IVF search has ONE arithmetic, so the
+    survivor stream (int8 bounds, half-precision pass, compaction, ordered queries: a batch of 700 over 150k rows) must
+    return exactly what the plain f32 scans return with the compact copies switched off -- on clustered rows, where the
+    bounds leave a handful of candidates, and on i.i.d. gaussian rows, where distances concentrate and they leave many."""
+    rs = np.random.RandomState(11)
+    n, dim, nlist, nprobe, nq, k = 150_000, 160, 128, 16, 700, 10
+    if kind == "gaussian":
+        base = rs.randn(n, dim).astype(np.float32)
+        Q = rs.randn(nq, dim).astype(np.float32)
+    else:
+        cen = rs.randn(nlist, dim).astype(np.float32)
+        base = (cen[rs.randint(0, nlist, n)] + 0.3 * rs.randn(n, dim)).astype(np.float32)
+        Q = (cen[rs.randint(0, nlist, nq)] + 0.3 * rs.randn(nq, dim)).astype(np.float32)
+    with eng.Index(base, "l2") as idx:
+        idx.ivf_build(nlist, 3, 42)
+        idx.set_profiling(True)
+        got = {}
+        for mode in (2, 0):
+            idx.set_rejection_test(mode)
+            idx.rejection_stats(reset=True)
+            got[mode] = idx.ivf_search(Q, k, nprobe)
+            surv, cand = idx.rejection_stats(reset=True)
+            assert (cand > 0) == (mode == 2)
+        idx.set_profiling(False)
+        np.testing.assert_array_equal(got[2][0], got[0][0])
+        np.testing.assert_array_equal(got[2][1].view(np.uint32), got[0][1].view(np.uint32))
+        assert (got[2][0] >= 0).all() and (np.diff(got[2][1], axis=1) >= 0).all()
+
+
 @pytest.mark.parametrize("dim", [900, 1536, 2500])
 def test_ivf_tile_path_several_k_phases(eng, oracle, dim):
     """Rows longer than 896 floats: the query group is resident in LDS one 768-column phase at a time and is refilled
