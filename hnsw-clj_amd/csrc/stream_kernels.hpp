@@ -773,21 +773,20 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, u
             float4 r[RB][NCH];
             int js[RB];
 #pragma unroll
-            for (int b = 0; b < RB; b++) {
-                js[b] = -1;
-                if (m) {
-                    js[b] = __ffsll(static_cast<unsigned long long>(m)) - 1;
-                    m &= m - 1;
-                    const int64_t row = (static_cast<int64_t>(__builtin_amdgcn_readlane(rhi, js[b])) << 32) |
-                                        static_cast<uint32_t>(__builtin_amdgcn_readlane(rlo, js[b]));
-                    load_row<NCH>(r[b], a.rows + row * a.ld, nvec, lane, true);
-                }
+            for (int b = 0; b < RB; b++) {  // (straight-line: with the loads under `if (m)` and a `break` below, RB = 2 cost 57 registers more than RB = 1)
+                const bool has = m != 0;
+                const int j = has ? __ffsll(static_cast<unsigned long long>(m)) - 1 : 0;
+                js[b] = has ? j : -1;
+                m &= m - 1;  // (0 stays 0)
+                const int64_t row = (static_cast<int64_t>(__builtin_amdgcn_readlane(rhi, j)) << 32) |
+                                    static_cast<uint32_t>(__builtin_amdgcn_readlane(rlo, j));
+                load_row<NCH>(r[b], a.rows + (has ? row : 0) * a.ld, nvec, lane, has);
             }
 #pragma unroll
             for (int b = 0; b < RB; b++) {
-                if (js[b] < 0) break;
+                const int j = js[b] < 0 ? 0 : js[b];
                 const float sum = wave_sum(lane_partial<NCH, L2>(q, r[b]));
-                const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), js[b]));
+                const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), j));
                 const float dv = finish_dist(a.metric, sum, qn, rn);
                 dmine = lane == js[b] ? dv : dmine;
             }
@@ -1016,22 +1015,19 @@ __global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
             int js[RB];
             float sc[RB];
 #pragma unroll
-            for (int b = 0; b < RB; b++) {
-                js[b] = -1;
-                sc[b] = 0.0f;
-                if (m) {
-                    js[b] = __ffsll(static_cast<unsigned long long>(m)) - 1;
-                    m &= m - 1;
-                    const int64_t row = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e.y), js[b]));
-                    sc[b] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mt.x), js[b]));
-                    const uint2 *rp = a.half + row * nvec;
+            for (int b = 0; b < RB; b++) {  // (straight-line, as in finish_wg: conditional loads and a `break` cost registers)
+                const bool has = m != 0;
+                const int j = has ? __ffsll(static_cast<unsigned long long>(m)) - 1 : 0;
+                js[b] = has ? j : -1;
+                m &= m - 1;  // (0 stays 0)
+                const int64_t row = has ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e.y), j)) : 0;
+                sc[b] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mt.x), j));
+                const uint2 *rp = a.half + row * nvec;
 #pragma unroll
-                    for (int c = 0; c < NCH; c++) w[b][c] = c * kWave + lane < nvec ? rp[c * kWave + lane] : make_uint2(0u, 0u);
-                }
+                for (int c = 0; c < NCH; c++) w[b][c] = has && c * kWave + lane < nvec ? rp[c * kWave + lane] : make_uint2(0u, 0u);
             }
 #pragma unroll
             for (int b = 0; b < RB; b++) {
-                if (js[b] < 0) break;
                 float acc = 0.0f;
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
