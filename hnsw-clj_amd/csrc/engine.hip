@@ -141,7 +141,18 @@ int launch_mid(const MidArgs &a, int nch, hipStream_t st) {
     const bool l2 = a.metric == METRIC_L2;
     const size_t lds = sizeof(float) * static_cast<size_t>(std::max(a.compact, 0));
     HG_REQUIRE(lds <= 48 * 1024, HNSWGPU_ELIMIT, "half-precision pass: compaction buffer too large");
-#define CALL(N, R, L) hipLaunchKernelGGL((ivf_mid_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a)
+    static const bool wide_env = []() {
+        const char *e = getenv("HNSWGPU_MID_WIDE");  // 0 = never (A/B)
+        return !e || atoi(e) != 0;
+    }();
+    // eight waves per query where the grid alone does not fill the chip (cosine batch 1024: 235 -> 216 us; the Euclidean kernel,
+    // heavier per element, measured 2 - 3 % slower with them and keeps four)
+    const bool wide = wide_env && a.slices == 1 && a.nq < 2048 && a.k <= 8 * kWave && a.metric != METRIC_L2;
+#define CALL(N, R, L)                                                                                                             \
+    do {                                                                                                                          \
+        if (wide) hipLaunchKernelGGL((ivf_mid_kernel<N, R, L, 8>), dim3(static_cast<unsigned>(blocks)), dim3(8 * kWave), lds, st, a); \
+        else hipLaunchKernelGGL((ivf_mid_kernel<N, R, L, 4>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a);        \
+    } while (0)
     HG_DISPATCH(nch, l2, CALL);
 #undef CALL
     HG_HIP(hipGetLastError());

@@ -970,8 +970,11 @@ struct MidArgs {
     int32_t dim, metric;
 };
 
-template <int NCH, int RB, bool L2>
-__global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
+// NW waves per workgroup: 4, or 8 for the one-workgroup-per-query launches of batches that do not fill the chip otherwise
+// (batch 1024: 1024 workgroups of four waves are 16 waves per CU, under half of what fits)
+template <int NCH, int RB, bool L2, int NW>
+__global__ __launch_bounds__(NW * kWave) void ivf_mid_kernel(MidArgs a) {
+    constexpr int kT = NW * kWave;  // threads
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     int qi = blockIdx.x % a.nq;
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
     }
     const uint32_t nsv = a.surv_cnt[qi];
     if (nsv > a.cap) return;  // the list overflowed: the finish kernel walks the candidate stream instead
-    constexpr int gran = kNWave * kWave;
+    constexpr int gran = kT;
     int64_t per = (static_cast<int64_t>(nsv) + a.slices - 1) / a.slices;
     per = (per + gran - 1) / gran * gran;
     const int64_t i0 = static_cast<int64_t>(sl) * per;
@@ -997,7 +1000,7 @@ __global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
     uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
     extern __shared__ __align__(16) unsigned char smem[];
     float *lb_s = reinterpret_cast<float *>(smem);  // [compact] the entries' new lower bounds
-    const bool compact = a.compact > 0 && nsv <= static_cast<uint32_t>(a.compact) && a.k <= kWG;
+    const bool compact = a.compact > 0 && nsv <= static_cast<uint32_t>(a.compact) && a.k <= kT;
     float ub_min = __builtin_inff();                // over this thread's entries
     for (int64_t base = i0 + wave * kWave; base < i1; base += gran) {
         const int64_t i = base + lane;
@@ -1065,14 +1068,14 @@ __global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
     // ---- the query's whole list went through this workgroup: the threshold the finish kernel would derive from the upper
     // bounds (the k-th smallest of the 256 threads' minima: k candidates at most that far) is applied here, and the list
     // shrinks to the entries it does not exclude -- little more than k -- before the finish kernel reads it
-    __shared__ __align__(16) uint32_t ubv_s[kWG];
-    __shared__ uint32_t kth_s, wcnt_s[kNWave];
+    __shared__ __align__(16) uint32_t ubv_s[kT];
+    __shared__ uint32_t kth_s, wcnt_s[NW];
     const uint32_t v = tau_encode(ub_min);
     ubv_s[threadIdx.x] = v;
     __syncthreads();
     {
         int rank = 0;
-        for (int j = 0; j < kWG; j += 4) {
+        for (int j = 0; j < kT; j += 4) {
             const uint4 o = *reinterpret_cast<const uint4 *>(ubv_s + j);  // uniform address: an LDS broadcast
             rank += (o.x < v || (o.x == v && j < static_cast<int>(threadIdx.x))) ? 1 : 0;
             rank += (o.y < v || (o.y == v && j + 1 < static_cast<int>(threadIdx.x))) ? 1 : 0;
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
     __syncthreads();
     const float T = tau_decode(kth_s);
     uint32_t nout = 0;  // entries kept so far (uniform)
-    for (uint32_t base = 0; base < nsv; base += kWG) {
+    for (uint32_t base = 0; base < nsv; base += kT) {
         // in place: a step reads its 256 entries before anything is written, and writes below base + 256
         const uint32_t i = base + threadIdx.x;
         const bool keep = i < nsv && !(lb_s[i] > T);  // NaN (no bound) stays
@@ -1099,7 +1102,7 @@ __global__ __launch_bounds__(kWG) void ivf_mid_kernel(MidArgs a) {
         __syncthreads();
         uint32_t off = nout, tot = 0;
 #pragma unroll
-        for (int w = 0; w < kNWave; w++) {
+        for (int w = 0; w < NW; w++) {
             const uint32_t c = wcnt_s[w];
             off += w < wave ? c : 0u;
             tot += c;
