@@ -133,10 +133,20 @@ static size_t finish_lds_bytes(int k, int nprobe) {
            (k <= kWave ? sizeof(uint64_t) * kNWave * k : 0);
 }
 
+int launch_heavy(const HeavyArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(ivf_heavy_kernel, dim3(1), dim3(1024), 0, st, a);
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_mid(const MidArgs &a, int nch, hipStream_t st) {
     int64_t blocks = static_cast<int64_t>(a.nq) * a.slices;
     if (a.qorder) blocks = (static_cast<int64_t>(a.nq) + 7) / 8 * 8;  // ordered queries: whole rounds over the eight XCDs
     if (blocks <= 0) return 0;
+    if (a.heavy_cnt) {  // + the workgroups that walk the list of heavy queries
+        HG_REQUIRE(a.main_blocks == blocks, HNSWGPU_EINVAL, "half-precision pass: main_blocks does not match the grid");
+        blocks += static_cast<int64_t>(kHeavySlots) * a.heavy_slices;
+    }
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "half-precision pass grid too large");
     const bool l2 = a.metric == METRIC_L2;
     const size_t lds = sizeof(float) * static_cast<size_t>(std::max(a.compact, 0));
@@ -200,6 +210,8 @@ int launch_finish(const FinishArgs &a, int nch, hipStream_t st) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));                         \
         /* half the rows in flight of the streaming kernels: a gathered row costs this kernel 24 registers */          \
         hipLaunchKernelGGL((ivf_finish_kernel<N, (R > 2 ? R / 2 : R), L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a); \
+        if (a.heavy_cnt) /* the heavy queries, heavy_slices workgroups each */                                          \
+            hipLaunchKernelGGL((ivf_finish_heavy_kernel<N, (R > 2 ? R / 2 : R), L>), dim3(kHeavySlots * a.heavy_slices), dim3(kWG), lds, st, a); \
     } while (0)
     HG_DISPATCH(nch, l2, CALL);
 #undef CALL
@@ -1513,7 +1525,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf *bufs[] = {&idx->s_q,   &idx->s_partial, &idx->s_ord,   &idx->s_dist, &idx->s_pairs, &idx->s_ids,
-                      &idx->s_outd, &idx->s_probes,  &idx->s_stats, &idx->s_misc, &idx->s_misc2, &idx->s_vis, &idx->s_qp, &idx->s_qn, &idx->s_tile, &idx->s_grp, &idx->s_done, &idx->s_pf, &idx->s_bk};
+                      &idx->s_outd, &idx->s_probes,  &idx->s_stats, &idx->s_misc, &idx->s_misc2, &idx->s_vis, &idx->s_qp, &idx->s_qn, &idx->s_tile, &idx->s_grp, &idx->s_done, &idx->s_pf, &idx->s_bk, &idx->s_heavy};
     for (DevBuf *b : bufs) b->release();
     for (int s = 0; s < PROF_N; s++)
         for (auto &pr : idx->prof_ev[s]) {

@@ -935,8 +935,27 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     f.qld = idx->dim;
     f.dim = idx->dim;
     f.metric = idx->metric;
-    const size_t keys = static_cast<size_t>(nq) * f.slices * (k <= kWave ? 1 : kNWave) * k;
+    // Queries one workgroup cannot serve (see ivf_heavy_kernel): when the half-precision pass or the finish kernel gives a
+    // query fewer than eight, the queries with more than 4096 survivors -- and the overflowed ones, whose finish is the
+    // plain f32 scan of every candidate -- are listed, and 32 x 64 extra workgroups per launch take them in 64 slices.
+    const int64_t mid_slices = !mid ? 0 : (qorder ? 1 : std::max<int64_t>(1, std::min<int64_t>(16, 4096 / nq)));
+    const bool heavy = env_now("HNSWGPU_STREAM_HEAVY", 1) != 0 && ((mid && mid_slices < 8) || f.slices < 8);
+    constexpr int kHeavySlices = 64;
+    const size_t keys = static_cast<size_t>(nq) * (heavy ? std::max(f.slices, kHeavySlices) : f.slices) * (k <= kWave ? 1 : kNWave) * k;
     HG_TRY(idx->s_partial.ensure(sizeof(uint64_t) * keys));
+    if (heavy) {
+        HG_TRY(idx->s_heavy.ensure(sizeof(int32_t) * (static_cast<size_t>(nq) + 4)));
+        HeavyArgs ha;
+        ha.surv_cnt = b.surv_cnt;
+        ha.nq = nq;
+        ha.thr = static_cast<uint32_t>(std::min<int64_t>(cap, env_now("HNSWGPU_STREAM_HEAVY_MIN", 4096)));
+        ha.cnt = idx->s_heavy.as<uint32_t>();
+        ha.list = idx->s_heavy.as<int32_t>() + 4;
+        HG_TRY(launch_heavy(ha, st));
+        f.heavy_cnt = ha.cnt;
+        f.heavy_list = ha.list;
+        f.heavy_slices = kHeavySlices;
+    }
     HG_TRY(ensure_counters(idx, nq, st));
     f.partial = idx->s_partial.as<uint64_t>();
     f.done = idx->s_done.as<uint32_t>();
@@ -946,6 +965,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     f.out_gord = d_out_gord;
     f.stats = idx->prof ? idx->d_rej_stats : nullptr;
     f.qorder = f.slices == 1 ? qorder : nullptr;
+    f.main_blocks = static_cast<int32_t>(f.qorder ? (static_cast<int64_t>(nq) + 7) / 8 * 8 : static_cast<int64_t>(nq) * f.slices);
     if (mid) {
         MidArgs ma;
         memset(&ma, 0, sizeof(ma));
@@ -968,6 +988,12 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         ma.qld = idx->dim;
         ma.dim = idx->dim;
         ma.metric = idx->metric;
+        if (heavy) {
+            ma.heavy_cnt = f.heavy_cnt;
+            ma.heavy_list = f.heavy_list;
+            ma.heavy_slices = kHeavySlices;
+            ma.main_blocks = static_cast<int32_t>(ma.qorder ? (static_cast<int64_t>(nq) + 7) / 8 * 8 : static_cast<int64_t>(nq) * ma.slices);
+        }
         HG_TRY(launch_mid(ma, idx->nch, st));
     }
     return launch_finish(f, idx->nch, st);

@@ -631,6 +631,37 @@ __device__ __forceinline__ void half_bounds(int metric, float sum, float qn, flo
 // ------------------------------------------------------------------------------------------------
 // Step 2: survivors -> f32 distances -> the k nearest -> results.
 // ------------------------------------------------------------------------------------------------
+// ---- queries that are too much for one workgroup -------------------------------------------------------------------
+// Large batches give a query ONE workgroup in the half-precision pass and in the finish kernel (its list is short: ~1000
+// int8 survivors, then ~15).  A query with far more -- rows the int8 bounds cannot separate from its k-th neighbour by the
+// thousand, or a list that overflowed and sends it through the plain f32 scan of all its candidates -- would hold the
+// whole launch for milliseconds (measured: one such query of 1024, 5.4 ms).  ivf_heavy_kernel flags them (bit 30 of
+// surv_cnt) and lists them; the workgroups of the main grids skip a flagged query, and kHeavySlots x heavy_slices extra
+// workgroups appended to the same launches walk the list with many slices per query.
+constexpr uint32_t kHeavyBit = 0x40000000u;
+constexpr int kHeavySlots = 32;
+struct HeavyArgs {
+    uint32_t *surv_cnt;
+    int32_t nq;
+    uint32_t thr;      // survivors from which a query is heavy (an overflowed list, marked or counted, always is)
+    uint32_t *cnt;     // [1]
+    int32_t *list;     // [nq]
+};
+static __global__ __launch_bounds__(1024) void ivf_heavy_kernel(HeavyArgs a) {
+    __shared__ uint32_t n_s;
+    if (threadIdx.x == 0) n_s = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.nq; i += 1024) {
+        const uint32_t raw = a.surv_cnt[i];
+        if (raw > a.thr) {
+            a.list[atomicAdd(&n_s, 1u)] = i;
+            a.surv_cnt[i] = raw | kHeavyBit;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *a.cnt = n_s;
+}
+
 struct FinishArgs {
     const uint4 *surv;     // (order key, list row, lb bits, ub bits)
     const uint32_t *surv_cnt;
@@ -656,6 +687,9 @@ struct FinishArgs {
     uint32_t *out_gord;    // optional [nq][k]
     unsigned long long *stats;  // optional: [0] += f32 rows evaluated, [1] += candidates
     int32_t bisect_min;    // smallest k whose final merge bisects the key space (A/B: by insertion below it)
+    const uint32_t *heavy_cnt;  // optional (ivf_heavy_kernel): ivf_finish_heavy_kernel walks heavy_list with heavy_slices
+    const int32_t *heavy_list;  // workgroups per query; the main kernel skips the queries flagged kHeavyBit
+    int32_t heavy_slices, main_blocks;
     int32_t adapt;         // spread a short survivor list over all the waves of the query's workgroups (see span)
     int32_t prepass;       // the upper bounds are worth a look first (ivf_mid_kernel has tightened them)
     unsigned long long *dbg;  // -DHG_IVF_STAMPS diagnostic builds only
@@ -664,7 +698,7 @@ struct FinishArgs {
 // One workgroup's share of query qi: slice sl of its nsv survivors (or, nsv > cap, of its candidate stream), and -- as the
 // last workgroup of the query -- the merge and the results.  The body of ivf_finish_kernel.
 template <int NCH, int RB, bool L2>
-__device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, uint32_t nsv, float tau, unsigned char *smem) {
+__device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, int slices, uint32_t nsv, float tau, unsigned char *smem) {
     __shared__ int tail_last;
     __shared__ __align__(16) uint32_t ub_s[kWG];
     __shared__ uint32_t ub_kth;
@@ -677,18 +711,18 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, u
     // fetches four rows at a time: sixteen entries are four dependent round trips, four entries one)
     int span = a.span;
     if (a.adapt) {
-        int64_t need = (total + static_cast<int64_t>(a.slices) * kNWave - 1) / (static_cast<int64_t>(a.slices) * kNWave);
+        int64_t need = (total + static_cast<int64_t>(slices) * kNWave - 1) / (static_cast<int64_t>(slices) * kNWave);
         need = (need + 3) & ~3LL;
         span = need < 4 ? 4 : (need < span ? static_cast<int>(need) : span);
     }
     const int gran = kNWave * span;
-    int64_t per = (total + a.slices - 1) / a.slices;
+    int64_t per = (total + slices - 1) / slices;
     per = (per + gran - 1) / gran * gran;
     const int64_t i0 = static_cast<int64_t>(sl) * per;
     const int64_t i1 = i0 + per < total ? i0 + per : total;
     // the threshold keeps falling in this kernel too: a wave that holds k exact distances folds its k-th into tau[qi]
     // (k candidates are at most that far), every wave re-reads it once per step
-    const bool share = a.slices <= 8;
+    const bool share = slices <= 8;
     const uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
     const Pair *pp = a.pairs + static_cast<int64_t>(qi) * a.nprobe;
     const bool regk = a.k <= kWave;
@@ -843,31 +877,31 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, u
                     wave_insert_reg(mine, cnt, a.k, key, lane);
                     thr = wave_kth_reg(mine, a.k);
                 }
-            if (a.slices > 1) {
-                uint64_t *dstp = a.partial + (static_cast<int64_t>(qi) * a.slices + sl) * a.k;
+            if (slices > 1) {
+                uint64_t *dstp = a.partial + (static_cast<int64_t>(qi) * slices + sl) * a.k;
                 if (lane < a.k) coherent_store(dstp + lane, mine);
             }
         }
     } else {
-        uint64_t *dstp = a.partial + ((static_cast<int64_t>(qi) * a.slices + sl) * kNWave + wave) * a.k;
+        uint64_t *dstp = a.partial + ((static_cast<int64_t>(qi) * slices + sl) * kNWave + wave) * a.k;
         for (int i = lane; i < a.k; i += kWave) coherent_store(dstp + i, i < cnt ? mylist[i] : static_cast<uint64_t>(~0ull));
     }
     // ---- tail: the last workgroup of query qi merges the partial lists, maps the winners to row ids
     // (ivf_flat.clj:291-294) and writes the results (the hand-over protocol of scan_kernel's fused tail)
-    const bool alone = regk && a.slices == 1;  // the query's only workgroup: wave 0 holds the result, nothing to hand over
+    const bool alone = regk && slices == 1;  // the query's only workgroup: wave 0 holds the result, nothing to hand over
     if (!alone) {
         wait_stores_acked();
         __syncthreads();
         if (threadIdx.x == 0) {
             const uint32_t prev = __hip_atomic_fetch_add(a.done + qi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tail_last = prev == static_cast<uint32_t>(a.slices) - 1 ? 1 : 0;
+            tail_last = prev == static_cast<uint32_t>(slices) - 1 ? 1 : 0;
             if (tail_last) __hip_atomic_store(a.done + qi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (!tail_last) return;
     }
     HG_IVF_STAMP(a.dbg, 26, qi == 0 && threadIdx.x == 0);  // the last workgroup of query 0 begins the merge
-    const int64_t nkeys = static_cast<int64_t>(a.slices) * (regk ? 1 : kNWave) * a.k;
+    const int64_t nkeys = static_cast<int64_t>(slices) * (regk ? 1 : kNWave) * a.k;
     uint32_t *ord_s = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (kNWave + 1) * a.k);  // [k]
     float *dist_s = reinterpret_cast<float *>(ord_s + a.k);                                         // [k]
     // (the probe table of the query -- where each probed list starts in the candidate stream and in the list rows -- is
@@ -950,7 +984,23 @@ __global__ __launch_bounds__(kWG) void ivf_finish_kernel(FinishArgs a) {
     }
     HG_IVF_STAMP(a.dbg, 24, blockIdx.x == 0 && threadIdx.x == 0);  // first workgroup of the finish kernel starts
     const uint32_t nsv = a.surv_cnt[qi];
-    finish_wg<NCH, RB, L2>(a, qi, sl, nsv, tau_decode(a.tau[qi]), smem);
+    if (a.heavy_cnt && (nsv & kHeavyBit)) return;  // served by ivf_finish_heavy_kernel
+    finish_wg<NCH, RB, L2>(a, qi, sl, a.slices, nsv, tau_decode(a.tau[qi]), smem);
+}
+
+// The heavy queries (ivf_heavy_kernel), heavy_slices workgroups each: kHeavySlots x heavy_slices workgroups walk the list.
+// (A launch of its own: with the loop around it, the finish body costs 160 registers instead of 95, and the main grid --
+// thousands of latency chains -- lives on its occupancy.  When no query is heavy, its workgroups read one word and leave.)
+template <int NCH, int RB, bool L2>
+__global__ __launch_bounds__(kWG) void ivf_finish_heavy_kernel(FinishArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int slot = blockIdx.x % kHeavySlots, sl = blockIdx.x / kHeavySlots;
+    const int n = static_cast<int>(*a.heavy_cnt);
+    for (int t = slot; t < n; t += kHeavySlots) {
+        const int qi = a.heavy_list[t];
+        finish_wg<NCH, RB, L2>(a, qi, sl, a.heavy_slices, a.surv_cnt[qi] & ~kHeavyBit, tau_decode(a.tau[qi]), smem);
+        __syncthreads();  // (wave 0 may still be writing the results from LDS the next query's waves would overwrite)
+    }
 }
 
 struct MidArgs {
@@ -968,27 +1018,22 @@ struct MidArgs {
     const float *Q;
     int64_t qld;
     int32_t dim, metric;
+    const uint32_t *heavy_cnt;  // optional (ivf_heavy_kernel), as in FinishArgs
+    const int32_t *heavy_list;
+    int32_t heavy_slices, main_blocks;
 };
 
 // NW waves per workgroup: 4, or 8 for the one-workgroup-per-query launches of batches that do not fill the chip otherwise
 // (batch 1024: 1024 workgroups of four waves are 16 waves per CU, under half of what fits)
 template <int NCH, int RB, bool L2, int NW>
-__global__ __launch_bounds__(NW * kWave) void ivf_mid_kernel(MidArgs a) {
+__device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, int slices, uint32_t nsv, bool may_compact,
+                                             unsigned char *smem) {
     constexpr int kT = NW * kWave;  // threads
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    int qi = blockIdx.x % a.nq;
-    const int sl = a.qorder ? 0 : blockIdx.x / a.nq;
-    if (a.qorder) {  // workgroup b runs on XCD b % 8: XCD x takes a contiguous eighth of the ordered queries
-        const int per = (a.nq + 7) >> 3;
-        const int pos = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        if (pos >= a.nq || (blockIdx.x >> 3) >= per) return;
-        qi = a.qorder[pos];
-    }
-    const uint32_t nsv = a.surv_cnt[qi];
     if (nsv > a.cap) return;  // the list overflowed: the finish kernel walks the candidate stream instead
     constexpr int gran = kT;
-    int64_t per = (static_cast<int64_t>(nsv) + a.slices - 1) / a.slices;
+    int64_t per = (static_cast<int64_t>(nsv) + slices - 1) / slices;
     per = (per + gran - 1) / gran * gran;
     const int64_t i0 = static_cast<int64_t>(sl) * per;
     const int64_t i1 = i0 + per < nsv ? i0 + per : nsv;
@@ -998,9 +1043,8 @@ __global__ __launch_bounds__(NW * kWave) void ivf_mid_kernel(MidArgs a) {
     load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
     const float qn = L2 ? 0.0f : query_norm<NCH>(q);
     uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
-    extern __shared__ __align__(16) unsigned char smem[];
     float *lb_s = reinterpret_cast<float *>(smem);  // [compact] the entries' new lower bounds
-    const bool compact = a.compact > 0 && nsv <= static_cast<uint32_t>(a.compact) && a.k <= kT;
+    const bool compact = may_compact && a.compact > 0 && nsv <= static_cast<uint32_t>(a.compact) && a.k <= kT;
     float ub_min = __builtin_inff();                // over this thread's entries
     for (int64_t base = i0 + wave * kWave; base < i1; base += gran) {
         const int64_t i = base + lane;
@@ -1118,6 +1162,31 @@ __global__ __launch_bounds__(NW * kWave) void ivf_mid_kernel(MidArgs a) {
     // (Tried: finishing the query right here -- finish_wg on the ~15 entries left, no second launch for it.  The finish
     // body needs 132 VGPRs against this kernel's 84; with it inlined the bandwidth-bound half of this kernel lost half its
     // occupancy and batch 4096 went from 1.32 to 2.0 ms; as a real call the compiler reserved 264 registers and scratch.)
+}
+
+template <int NCH, int RB, bool L2, int NW>
+__global__ __launch_bounds__(NW * kWave) void ivf_mid_kernel(MidArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (a.heavy_cnt && static_cast<int>(blockIdx.x) >= a.main_blocks) {  // the heavy queries, heavy_slices workgroups each
+        const int hb = static_cast<int>(blockIdx.x) - a.main_blocks, slot = hb % kHeavySlots, hsl = hb / kHeavySlots;
+        const int n = static_cast<int>(*a.heavy_cnt);
+        for (int t = slot; t < n; t += kHeavySlots) {
+            const int hq = a.heavy_list[t];
+            mid_query_wg<NCH, RB, L2, NW>(a, hq, hsl, a.heavy_slices, a.surv_cnt[hq] & ~kHeavyBit, false, smem);
+        }
+        return;
+    }
+    int qi = blockIdx.x % a.nq;
+    const int sl = a.qorder ? 0 : blockIdx.x / a.nq;
+    if (a.qorder) {  // workgroup b runs on XCD b % 8: XCD x takes a contiguous eighth of the ordered queries
+        const int per = (a.nq + 7) >> 3;
+        const int pos = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (pos >= a.nq || (blockIdx.x >> 3) >= per) return;
+        qi = a.qorder[pos];
+    }
+    const uint32_t nsv = a.surv_cnt[qi];
+    if (a.heavy_cnt && (nsv & kHeavyBit)) return;  // served by the workgroups above
+    mid_query_wg<NCH, RB, L2, NW>(a, qi, sl, a.slices, nsv, true, smem);
 }
 
 

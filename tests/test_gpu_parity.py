@@ -872,6 +872,19 @@ def test_ivf_half_precision_pass(eng, oracle, metric, monkeypatch):
         monkeypatch.delenv("HNSWGPU_FINISH_SLICES")
         monkeypatch.setenv("HNSWGPU_STREAM_CAP", "300")      # some survivor lists overflow: those queries take the fallback
         check(12, 10, 12, "mixed fallback", expect_few=False)
+        # large batches give a query ONE workgroup per pass; the queries that is too little for (many survivors, or the
+        # fallback's scan of every candidate) are listed and served by 64 slices each (ivf_heavy_kernel): forced here by
+        # ordering from one query on (one workgroup per query) and a threshold of 8 / 100 survivors
+        monkeypatch.setenv("HNSWGPU_FINISH_ORDER", "1")
+        monkeypatch.setenv("HNSWGPU_FINISH_SLICES", "1")
+        for thr in ("8", "100"):
+            monkeypatch.setenv("HNSWGPU_STREAM_HEAVY_MIN", thr)
+            check(12, 10, 12, "heavy + fallback, threshold " + thr, expect_few=False)
+            check(41, 33, 12 if metric == "l2" else 5, "heavy + fallback, threshold " + thr, expect_few=False)
+        monkeypatch.delenv("HNSWGPU_STREAM_CAP")
+        monkeypatch.setenv("HNSWGPU_STREAM_HEAVY_MIN", "8")
+        check(41, 10, 5, "every query heavy", expect_few=False)
+        check(3, 1, 12, "every query heavy", expect_few=False)
         idx.set_profiling(False)
 
 
