@@ -948,6 +948,8 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         HeavyArgs ha;
         ha.surv_cnt = b.surv_cnt;
         ha.nq = nq;
+        ha.cap = static_cast<uint32_t>(cap);
+        ha.times_mean = static_cast<uint32_t>(env_now("HNSWGPU_STREAM_HEAVY_MEAN", 4));
         ha.thr = static_cast<uint32_t>(std::min<int64_t>(cap, env_now("HNSWGPU_STREAM_HEAVY_MIN", 4096)));
         ha.cnt = idx->s_heavy.as<uint32_t>();
         ha.list = idx->s_heavy.as<int32_t>() + 4;

@@ -643,17 +643,35 @@ constexpr int kHeavySlots = 32;
 struct HeavyArgs {
     uint32_t *surv_cnt;
     int32_t nq;
-    uint32_t thr;      // survivors from which a query is heavy (an overflowed list, marked or counted, always is)
+    uint32_t thr;      // fewest survivors of a heavy query (an overflowed list, marked or counted, always is one)
+    uint32_t cap;      // survivors that fit a list
+    uint32_t times_mean;  // ... and at least this many times the batch's mean (4; tests: 0)
     uint32_t *cnt;     // [1]
     int32_t *list;     // [nq]
 };
 static __global__ __launch_bounds__(1024) void ivf_heavy_kernel(HeavyArgs a) {
     __shared__ uint32_t n_s;
-    if (threadIdx.x == 0) n_s = 0;
+    __shared__ unsigned long long sum_s;
+    if (threadIdx.x == 0) {
+        n_s = 0;
+        sum_s = 0;
+    }
     __syncthreads();
+    // heavy = far above what this batch's queries typically carry (four times the mean, and at least a.thr), or overflowed:
+    // on a 10M-row index every query has ~10k survivors, and one workgroup each is the right share of the chip for them
+    unsigned long long mine = 0;
     for (int i = threadIdx.x; i < a.nq; i += 1024) {
         const uint32_t raw = a.surv_cnt[i];
-        if (raw > a.thr) {
+        if (raw <= a.cap) mine += raw;
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && mine) atomicAdd(&sum_s, mine);
+    __syncthreads();
+    const unsigned long long four_mean = static_cast<unsigned long long>(a.times_mean) * sum_s / static_cast<unsigned long long>(a.nq > 0 ? a.nq : 1);
+    const uint32_t thr = four_mean > a.thr ? (four_mean < a.cap ? static_cast<uint32_t>(four_mean) : a.cap) : a.thr;
+    for (int i = threadIdx.x; i < a.nq; i += 1024) {
+        const uint32_t raw = a.surv_cnt[i];
+        if (raw > thr) {
             a.list[atomicAdd(&n_s, 1u)] = i;
             a.surv_cnt[i] = raw | kHeavyBit;
         }

@@ -877,6 +877,7 @@ def test_ivf_half_precision_pass(eng, oracle, metric, monkeypatch):
         # ordering from one query on (one workgroup per query) and a threshold of 8 / 100 survivors
         monkeypatch.setenv("HNSWGPU_FINISH_ORDER", "1")
         monkeypatch.setenv("HNSWGPU_FINISH_SLICES", "1")
+        monkeypatch.setenv("HNSWGPU_STREAM_HEAVY_MEAN", "0")  # (production: also at least four times the batch's mean)
         for thr in ("8", "100"):
             monkeypatch.setenv("HNSWGPU_STREAM_HEAVY_MIN", thr)
             check(12, 10, 12, "heavy + fallback, threshold " + thr, expect_few=False)
@@ -885,6 +886,8 @@ def test_ivf_half_precision_pass(eng, oracle, metric, monkeypatch):
         monkeypatch.setenv("HNSWGPU_STREAM_HEAVY_MIN", "8")
         check(41, 10, 5, "every query heavy", expect_few=False)
         check(3, 1, 12, "every query heavy", expect_few=False)
+        monkeypatch.setenv("HNSWGPU_STREAM_HEAVY_MEAN", "1")  # above the mean: about half of them
+        check(41, 10, 5, "half the queries heavy", expect_few=False)
         idx.set_profiling(False)
 
 
