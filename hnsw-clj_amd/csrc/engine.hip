@@ -448,6 +448,7 @@ struct RouteArgs {
     QueryScal *qscal;
     uint32_t *tau, *surv_cnt;
     int32_t k;               // of the search: the first threshold is the k-th smallest distance of the stream's head
+    int32_t seed_rows;       // ... of its first max(k, seed_rows) rows (stream_seed_rows)
     const float *rows;       // list rows (f32) + norms
     const float *row_norms;
     uint32_t *bk_cnt;        // [nlist] members filed per list (zeroed before the launch), or null
@@ -564,7 +565,7 @@ __device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsign
     const bool head_ok = a.nprobe <= kHead || tail_cover >= static_cast<uint32_t>(kSeedMax);
     const Pair *pp = head_ok ? head_s : a.pairs + static_cast<int64_t>(qi) * a.nprobe;
     seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, pp, head_ok ? (a.nprobe < kHead ? a.nprobe : kHead) : a.nprobe, tail_qcnt, a.k,
-                             a.rows, a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi, a.nq >= 1024 ? 16 : (a.nq <= 8 ? 32 : 64));
+                             a.rows, a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi, a.seed_rows);
     HG_IVF_STAMP(a.dbg, 20, qi == 0 && threadIdx.x == 0);  // threshold seeded
 }
 
@@ -716,6 +717,7 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
         a.tau = rs->tau;
         a.surv_cnt = rs->surv_cnt;
         a.k = rs->k;
+        a.seed_rows = stream_seed_rows(nq, idx->n, idx->nlist);
         a.bk_cnt = rs->bk_cnt;
         a.bk_mem = rs->bk_mem;
         a.bk_cap = rs->bk_cap;

@@ -1017,10 +1017,20 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
 constexpr int64_t kTilePairs = 12, kTilePairsCoded = 48, kTilePairsNever = 1LL << 40;
 constexpr int32_t kStreamMaxK = 256;  // largest k the bounds pass serves (larger k: the f32 scans)
 
+// The largest k the stream serves on this handle: its first threshold is the k-th smallest distance of a sample of the
+// query's nearest list (stream_seed_rows), and a list of several thousand rows holds several of the data's clusters -- of a
+// sample of 256 rows only 256 / (mean length / 1024) can be expected in the query's own.  A larger k gets a threshold from a
+// foreign cluster, every survivor list overflows and the search is the f32 scan behind a wasted bounds pass (1M rows in 128
+// lists, k = 100, batch 1024: 147 ms against 25): such searches take the f32 paths.
+static int32_t ivf_stream_max_k(const hnswgpu_index *idx) {
+    const int64_t mean = idx->n / std::max(idx->nlist, 1);
+    const int64_t scale = std::max<int64_t>(1, std::min<int64_t>(8, mean / 1024));
+    return static_cast<int32_t>(kStreamMaxK / scale);
+}
 // can this search go through the survivor stream at all (int8 list rows present and switched on, k within its range)?
 static bool ivf_codes_usable(const hnswgpu_index *idx, int32_t k) {
     return idx->d_lctile != nullptr && (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128)) &&
-           tile_mode() != 0 && k <= kStreamMaxK && env_now("HNSWGPU_IVF_CODES", 1) > 0;
+           tile_mode() != 0 && k <= ivf_stream_max_k(idx) && env_now("HNSWGPU_IVF_CODES", 1) > 0;
 }
 // the boundary of the two summation orders for this handle and k (HNSWGPU_TILE_PAIRS overrides: the parity suite pins it
 // at 12 so that its small indexes still reach the tile path)
@@ -1050,7 +1060,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     const int code_env = static_cast<int>(env_now("HNSWGPU_IVF_CODES", 1));  // 0 = never (A/B), N > 0 = from N queries per batch
     // the survivor stream (stream_kernels.hpp): k up to a tile chunk's rows can get a threshold from one chunk
     const bool codes_ok = idx->d_lctile != nullptr && (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128)) &&
-                          code_env > 0 && nq >= code_env && tm != 0 && k <= kStreamMaxK;
+                          code_env > 0 && nq >= code_env && tm != 0 && k <= ivf_stream_max_k(idx);
     // (Euclidean has one arithmetic at every batch size -- its "tile" path is the register-row group kernel -- so the
     // bounds pipeline below serves all its batches: batch 1024 at 1M x 768: 4.8 -> 2.8 ms)
     const int64_t tile_pairs = ivf_tile_pairs(idx, k);
@@ -1178,6 +1188,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
             pa.nq = nq;
             pa.nprobe = nprobe;
             pa.k = k;
+            pa.seed_rows = stream_seed_rows(nq, idx->n, idx->nlist);
             pa.pairs = idx->s_pairs.as<Pair>();
             pa.qcnt = qcnt_buf;
             pa.rows = idx->d_lrows;

@@ -86,6 +86,19 @@ __device__ __forceinline__ float tau_decode(uint32_t u) {
 // those distances: k candidates are at most that far, hence D_k <= tau0.  All threads of a 256-thread workgroup call it.
 constexpr int kSeedMax = 256;  // rows evaluated at most (>= the largest k the bounds pass serves)
 
+// Rows of the head sample: 64 (32 for a handful of queries: one gather round; 16 for thousands: thousands of queries x 64 rows
+// is the index again) -- times the mean list length over 1024, up to eight times: a list of several thousand rows holds
+// several of the data's clusters, and a sample that catches fewer than k rows of the query's own yields a threshold from
+// another cluster, i.e. none (1M rows in 128 lists, k = 10: every survivor list overflowed and the search took 94 ms instead
+// of 23 by the plain f32 scan; with 256 rows sampled the stream is ahead again).
+__host__ inline int stream_seed_rows(int nq, int64_t n, int nlist) {
+    const int base = nq >= 1024 ? 16 : (nq <= 8 ? 32 : 64);
+    const int64_t mean = n / (nlist > 0 ? nlist : 1);
+    const int64_t scale = mean / 1024 < 1 ? 1 : (mean / 1024 > 8 ? 8 : mean / 1024);
+    const int64_t rows = (base * scale + 15) / 16 * 16;
+    return static_cast<int>(rows < 16 ? 16 : (rows > kSeedMax ? kSeedMax : rows));
+}
+
 template <int NCH, int RB, bool L2>
 __device__ __forceinline__ void seed_tau_wg(const float4 (&q)[NCH], float qn, int metric, const Pair *pp, int nprobe,
                                             int64_t qcnt, int k, const float *rows, const float *row_norms, int64_t ld,
@@ -158,6 +171,7 @@ struct PrepArgs {
     const float *Q;
     int64_t qld;
     int32_t dim, metric, nq, nprobe, k;
+    int32_t seed_rows;  // stream_seed_rows
     const Pair *pairs;
     const int32_t *qcnt;
     const float *rows;
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(kWG) void ivf_query_prep_kernel(PrepArgs a) {
         if (lane == 0) a.qscal[qi] = qc.sc;
     }
     seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, a.pairs + static_cast<int64_t>(qi) * a.nprobe, a.nprobe, a.qcnt[qi], a.k, a.rows,
-                             a.row_norms, a.ld, dist_s, a.tau + qi, a.nq >= 1024 ? 16 : (a.nq <= 8 ? 32 : 64));
+                             a.row_norms, a.ld, dist_s, a.tau + qi, a.seed_rows);
 }
 
 // One work item of the grouped bounds pass: rows [rb0 + r0_off, rb0 + r1_off) of inverted list `list` (which starts at row

@@ -140,7 +140,8 @@ int hnswgpu_hnsw_search_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, in
  *   norms (:217-234), merge, take k.  out_probes optional (nq x nprobe list ids).
  *   Two summation orders exist for this call (cosine / dot).  The GEMV order (wave-strided f32 chain + butterfly) serves
  *   EVERY batch size on a handle with the int8 and half-precision copies of its lists (hnswgpu_set_rejection_test 1 / 2
- *   with dim >= 128, the default; k <= 256): only the candidates whose bounds can still reach the k nearest are evaluated
+ *   with dim >= 128, the default; k <= 256 -- divided by (mean list length / 1024) on lists longer than 2048 rows on
+ *   average: k <= 36 at 7800 rows per list): only the candidates whose bounds can still reach the k nearest are evaluated
  *   at all, and nq queries in one call return bit for bit what nq single calls return.  Without the copies (mode 0,
  *   dim < 128, HNSWGPU_IVF_HALF=0 leaves a boundary of 48) or for k > 256, the GEMV order serves up to 12 (query, list)
  *   pairs per list (nq * nprobe <= 12 * nlist: one GEMV per pair; from 1.5 pairs per list the pairs of a list share one
@@ -247,7 +248,7 @@ int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
  * 1 = launches of at least two queries per CU, where the traversal is bandwidth-bound, and only for dim >= 128 (an int8
  * row of a shorter vector saves no cache line) (default), 2 = every launch, every dim.  The same setting decides whether
  * the IVF lists get their int8 copy (and with it the half-precision copy, below) for the bounds pass of the list scan
- * (every batch size; k <= 256).
+ * (every batch size; k <= 256, fewer on very long lists: see hnswgpu_ivf_search).
  * HNSWGPU_PREFILTER=<mode> in the environment sets the default of new handles.  Results never depend on the mode. */
 int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out);
 /* The same with the UPPER bounds beside them (out_ub, may be NULL): out_lb[i] <= distance <= out_ub[i].  The IVF search's
