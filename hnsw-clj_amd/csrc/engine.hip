@@ -2007,6 +2007,7 @@ int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode) {
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     idx->rejection_mode = mode;
+    idx->ivf_calibrated = idx->ivf_stream_off = false;  // (mode 1 measures again at the next IVF search)
     if (mode != 0 && (idx->has_graph || idx->nlist > 0)) {  // int8 rows now for what exists, else with the graph / lists
         hipStream_t st = idx->stream;
         HG_TRY(begin_call(idx, st));

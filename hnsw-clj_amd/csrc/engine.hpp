@@ -94,6 +94,9 @@ struct hnswgpu_index {
     float4 *d_lhmeta = nullptr;
     unsigned long long *d_rej_stats = nullptr;  // [2], counted by the traversal while profiling is on
     int rejection_mode = 1;  // 0 = off, 1 = batches that fill the chip (launch_hnsw_idx), 2 = every launch
+    // IVF, mode 1: the first search measures what the int8 bounds separate on THIS data (ivf_calibrate) and switches the
+    // survivor stream off for the handle when they leave more than a quarter of the candidates
+    bool ivf_calibrated = false, ivf_calibrating = false, ivf_stream_off = false;
     int cus = 256;
     hipStream_t stream = nullptr;
     std::mutex mu;

@@ -417,6 +417,7 @@ static void free_ivf(hnswgpu_index *idx) {
     idx->d_lctile = nullptr;
     idx->d_lhalf = nullptr;
     idx->d_lhmeta = nullptr;
+    idx->ivf_calibrated = idx->ivf_stream_off = false;
     idx->d_listoff = idx->d_glistoff = nullptr;
     idx->d_listids = nullptr;
     idx->lrows_alias = false;
@@ -879,7 +880,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     // HNSWGPU_STREAM_MID=<queries> overrides (tests: 1 = always; 0 = never).
     const int64_t mid_env = env_now("HNSWGPU_STREAM_MID", -1);
     const int64_t cand = npairs * mean;
-    const bool mid = idx->d_lhalf != nullptr && (mid_env >= 0 ? (mid_env > 0 && nq >= mid_env) : cand >= 1500000);
+    const bool mid = idx->d_lhalf != nullptr && !idx->ivf_calibrating && (mid_env >= 0 ? (mid_env > 0 && nq >= mid_env) : cand >= 1500000);
     b.defer = mid ? 1 : 0;
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);
@@ -1029,7 +1030,8 @@ static int32_t ivf_stream_max_k(const hnswgpu_index *idx) {
 }
 // can this search go through the survivor stream at all (int8 list rows present and switched on, k within its range)?
 static bool ivf_codes_usable(const hnswgpu_index *idx, int32_t k) {
-    return idx->d_lctile != nullptr && (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128)) &&
+    return idx->d_lctile != nullptr &&
+           (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128 && !idx->ivf_stream_off)) &&
            tile_mode() != 0 && k <= ivf_stream_max_k(idx) && env_now("HNSWGPU_IVF_CODES", 1) > 0;
 }
 // the boundary of the two summation orders for this handle and k (HNSWGPU_TILE_PAIRS overrides: the parity suite pins it
@@ -1043,7 +1045,61 @@ static int64_t ivf_tile_pairs(const hnswgpu_index *idx, int32_t k) {
 
 static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
                               int32_t *d_out_ids, float *d_out_dist, int32_t *d_out_probes, hipStream_t st,
-                              const int32_t *d_given_probes = nullptr, uint32_t *d_out_gord = nullptr) {
+                              const int32_t *d_given_probes = nullptr, uint32_t *d_out_gord = nullptr);
+
+// What do the int8 bounds separate on THIS handle's rows?  On data with cluster structure they leave a query its home
+// cluster (3 % of the candidates on the bench index); on rows without any -- i.i.d. gaussian: distances concentrate, every
+// candidate lies within the bounds' width of the k-th -- they leave everything, and the stream is the f32 scan behind a
+// wasted bounds pass (1M x 768 gaussian, batch 1024: 17 ms against the tile scan's 1.0).  Mode 1 (automatic) therefore
+// measures once per set of lists, at the first search: 32 list rows as queries, k = 10, up to 32 probes, the int8 pass
+// alone; more than a quarter of the candidates fetched in f32 switches the stream off for the handle (mode 2 forces it,
+// mode 0 never builds it).  The decision depends on the rows and the lists only: the same handle always takes the same path.
+static int ivf_calibrate(hnswgpu_index *idx, hipStream_t st) {
+    idx->ivf_calibrated = true;
+    if (idx->rejection_mode != 1 || !idx->d_lctile || idx->dim < 128 || idx->n < 4096 || env_now("HNSWGPU_IVF_CALIBRATE", 1) == 0) return 0;
+    const int32_t cq = 32, ck = 10, cp = std::min(32, idx->nlist);
+    float *d_q = nullptr;
+    int32_t *d_i = nullptr;
+    float *d_d = nullptr;
+    unsigned long long *d_st = nullptr, saved[2] = {0, 0}, got[2] = {0, 0};
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&d_q), sizeof(float) * cq * idx->dim));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&d_i), sizeof(int32_t) * cq * ck));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&d_d), sizeof(float) * cq * ck));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&d_st), sizeof(saved)));
+    const int64_t step = idx->n / cq;
+    for (int i = 0; i < cq; i++)  // evenly spaced list rows as queries
+        HG_HIP(hipMemcpyAsync(d_q + static_cast<int64_t>(i) * idx->dim, idx->d_lrows + (static_cast<int64_t>(i) * step + step / 2) * idx->ld,
+                              sizeof(float) * idx->dim, hipMemcpyDeviceToDevice, st));
+    HG_HIP(hipMemsetAsync(d_st, 0, sizeof(saved), st));
+    unsigned long long *const old_stats = idx->d_rej_stats;
+    const bool old_prof = idx->prof;
+    idx->d_rej_stats = d_st;
+    idx->prof = true;
+    idx->ivf_calibrating = true;
+    const int rc = ivf_search_enqueue(idx, d_q, cq, ck, cp, d_i, d_d, nullptr, st);
+    idx->ivf_calibrating = false;
+    idx->prof = old_prof;
+    idx->d_rej_stats = old_stats;
+    if (rc == 0) {
+        HG_HIP(hipMemcpyAsync(got, d_st, sizeof(got), hipMemcpyDeviceToHost, st));
+        HG_HIP(hipStreamSynchronize(st));
+        // [0] = f32 rows fetched, [1] = candidates
+        if (got[1] >= static_cast<unsigned long long>(cq) * 256 && got[0] * 4 > got[1]) idx->ivf_stream_off = true;
+    } else {
+        (void)hipStreamSynchronize(st);
+    }
+    (void)saved;
+    (void)hipFree(d_q);
+    (void)hipFree(d_i);
+    (void)hipFree(d_d);
+    (void)hipFree(d_st);
+    return rc;
+}
+
+static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
+                              int32_t *d_out_ids, float *d_out_dist, int32_t *d_out_probes, hipStream_t st,
+                              const int32_t *d_given_probes, uint32_t *d_out_gord) {
+    if (!idx->ivf_calibrated) HG_TRY(ivf_calibrate(idx, st));
     const int64_t *glistoff = idx->d_glistoff ? idx->d_glistoff : idx->d_listoff;
     if (nprobe > idx->nlist && !d_given_probes) nprobe = idx->nlist;
     // 1. centroid routing (:261-269): top-nprobe of the centroid table, stable on the centroid index
@@ -1059,7 +1115,8 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     const int tm = tile_mode();
     const int code_env = static_cast<int>(env_now("HNSWGPU_IVF_CODES", 1));  // 0 = never (A/B), N > 0 = from N queries per batch
     // the survivor stream (stream_kernels.hpp): k up to a tile chunk's rows can get a threshold from one chunk
-    const bool codes_ok = idx->d_lctile != nullptr && (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128)) &&
+    const bool codes_ok = idx->d_lctile != nullptr &&
+                          (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128 && !idx->ivf_stream_off)) &&
                           code_env > 0 && nq >= code_env && tm != 0 && k <= ivf_stream_max_k(idx);
     // (Euclidean has one arithmetic at every batch size -- its "tile" path is the register-row group kernel -- so the
     // bounds pipeline below serves all its batches: batch 1024 at 1M x 768: 4.8 -> 2.8 ms)

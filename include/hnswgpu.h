@@ -247,7 +247,10 @@ int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
  * hnswgpu_set_rejection_test: mode 0 = off (no int8 copy is made: saves n * dim bytes; the bounds entry then fails),
  * 1 = launches of at least two queries per CU, where the traversal is bandwidth-bound, and only for dim >= 128 (an int8
  * row of a shorter vector saves no cache line) (default), 2 = every launch, every dim.  The same setting decides whether
- * the IVF lists get their int8 copy (and with it the half-precision copy, below) for the bounds pass of the list scan
+ * the IVF lists get their int8 copy (and with it the half-precision copy, below) for the bounds pass of the list scan;
+ * in mode 1 the first IVF search of a handle measures once what those bounds separate on its rows (32 list rows as
+ * queries) and keeps the bounds pass only if it leaves less than a quarter of the candidates -- on rows without cluster
+ * structure (i.i.d. gaussian) it leaves everything, and the handle takes the plain f32 scans instead; mode 2 forces it
  * (every batch size; k <= 256, fewer on very long lists: see hnswgpu_ivf_search).
  * HNSWGPU_PREFILTER=<mode> in the environment sets the default of new handles.  Results never depend on the mode. */
 int hnswgpu_rejection_bounds(hnswgpu_index *idx, const float *q, const int32_t *ids, int32_t m, float *out);

@@ -1113,6 +1113,39 @@ def test_ivf_routing_and_merge_break_ties_by_position(eng, oracle, metric, monke
 
 
 @pytest.mark.parametrize("kind", ["gaussian", "clustered"])
+def test_ivf_calibration_keeps_the_stream_for_data_it_helps(eng, oracle, kind):
+    """Mode 1 (the default outside this suite) measures once per set of lists what the int8 bounds separate on the
+    handle's rows (ivf.hip: ivf_calibrate): on i.i.d. gaussian rows every candidate lies within the bounds' width of the
+    k-th -- the stream would be the f32 scan behind a wasted bounds pass -- and the handle takes the f32 paths from
+    then on; on clustered rows the stream stays.  Either way the results are the oracle's; mode 2 forces the stream, and
+    setting the mode measures again."""
+    O = oracle
+    rs = np.random.RandomState(21)
+    n, dim, nlist, nprobe, k = 12_000, 768, 16, 8, 10
+    if kind == "gaussian":
+        base = rs.randn(n, dim).astype(np.float32)
+        Q = rs.randn(40, dim).astype(np.float32)
+    else:
+        cen = rs.randn(nlist, dim).astype(np.float32)
+        base = (cen[rs.randint(0, nlist, n)] + 0.3 * rs.randn(n, dim)).astype(np.float32)
+        Q = (cen[rs.randint(0, nlist, 40)] + 0.3 * rs.randn(40, dim)).astype(np.float32)
+    with eng.Index(base, "l2") as idx:
+        idx.ivf_build(nlist, 3, 42)
+        cen_, off, lids = idx.get_ivf()
+        oi, od, _ = O.ivf_search(base, cen_, off, lids, Q, k, nprobe, metric=O.L2, mode=O.MODE_DEV)
+        idx.set_profiling(True)
+        for mode, expect_stream in [(1, kind == "clustered"), (2, True), (1, kind == "clustered")]:
+            idx.set_rejection_test(mode)
+            for rep in range(2):                               # the first search of a mode-1 handle calibrates
+                idx.rejection_stats(reset=True)
+                ids, d = idx.ivf_search(Q, k, nprobe)
+                surv, cand = idx.rejection_stats(reset=True)
+                assert_exact(ids, d, oi, od, "%s mode %d rep %d" % (kind, mode, rep))
+                assert (cand > 0) == expect_stream, (kind, mode, rep, surv, cand)
+        idx.set_profiling(False)
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "clustered"])
 def test_ivf_stream_equals_the_f32_scan_at_scale(eng, kind):
     """A size-independent property at a size the oracle does not reach: the Euclidean IVF search has ONE arithmetic, so the
     survivor stream (int8 bounds, half-precision pass, compaction, ordered queries: a batch of 700 over 150k rows) must
