@@ -776,15 +776,7 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
         HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
         HG_HIP(hipGetLastError());
-        // (batches of 1024 and more seed the threshold from 16 rows: four rows in flight per wave do it in one round, and the
-        // kernel needs 72 registers instead of 120 -- twice the workgroups per CU for a launch of thousands of latency chains)
-#define CALL(N, R, L)                                                                                                            \
-    do {                                                                                                                         \
-        if (nq >= 1024)                                                                                                          \
-            hipLaunchKernelGGL((ivf_route_tail_kernel<N, (R > 4 ? R / 2 : R), L>), dim3(static_cast<unsigned>(nq)), dim3(kWG), lds, st, a); \
-        else                                                                                                                     \
-            hipLaunchKernelGGL((ivf_route_tail_kernel<N, R, L>), dim3(static_cast<unsigned>(nq)), dim3(kWG), lds, st, a);        \
-    } while (0)
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_tail_kernel<N, R, L>), dim3(static_cast<unsigned>(nq)), dim3(kWG), lds, st, a)
         HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
         HG_HIP(hipGetLastError());

@@ -1012,8 +1012,8 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
 //  * Without them it is 12: the f32 GEMV-order scans re-read a list per pair (or per group of queries at the VALU's rate).
 //  * With the half-precision rows as well (the default) there is no boundary: the stream's f32 traffic no longer grows
 //    with the survivors (~15 rows per query instead of ~970), and it stays ahead at every batch size measured -- same
-//    index, stream vs tile scan, end to end: batch 1024: 0.54 vs 1.09 ms; 2048: 0.82 vs 1.51; 4096: 1.28 vs 2.67;
-//    8192: 2.14 vs 4.97; 16384: 3.84 vs 9.59.  Per query the tile scan reads 32 lists x 977 rows x 3 KB / 32 queries of a group = 3 MB and is
+//    index, stream vs tile scan, end to end: batch 1024: 0.565 vs 1.09 ms; 2048: 0.85 vs 1.51; 4096: 1.33 vs 2.67;
+//    8192: 2.26 vs 4.97; 16384: 4.05 vs 9.59.  Per query the tile scan reads 32 lists x 977 rows x 3 KB / 32 queries of a group = 3 MB and is
 //    bound by the f32 matrix rate besides; the stream reads a quarter of that in int8 plus 1.5 MB of half rows.
 constexpr int64_t kTilePairs = 12, kTilePairsCoded = 48, kTilePairsNever = 1LL << 40;
 constexpr int32_t kStreamMaxK = 256;  // largest k the bounds pass serves (larger k: the f32 scans)

@@ -86,13 +86,14 @@ __device__ __forceinline__ float tau_decode(uint32_t u) {
 // those distances: k candidates are at most that far, hence D_k <= tau0.  All threads of a 256-thread workgroup call it.
 constexpr int kSeedMax = 256;  // rows evaluated at most (>= the largest k the bounds pass serves)
 
-// Rows of the head sample: 64 (32 for a handful of queries: one gather round; 16 for thousands: thousands of queries x 64 rows
-// is the index again) -- times the mean list length over 1024, up to eight times: a list of several thousand rows holds
+// Rows of the head sample: 64 (32 for a handful of queries: one gather round) -- at every batch size: with 32 rows for
+// batches of 1024 and more, 2 % of the bench index's queries under the dot metric caught fewer than k rows of their own
+// cluster, got no threshold, and the batch took 1.0 ms instead of 0.57 -- times the mean list length over 1024, up to eight times: a list of several thousand rows holds
 // several of the data's clusters, and a sample that catches fewer than k rows of the query's own yields a threshold from
 // another cluster, i.e. none (1M rows in 128 lists, k = 10: every survivor list overflowed and the search took 94 ms instead
 // of 23 by the plain f32 scan; with 256 rows sampled the stream is ahead again).
 __host__ inline int stream_seed_rows(int nq, int64_t n, int nlist) {
-    const int base = nq >= 1024 ? 16 : (nq <= 8 ? 32 : 64);
+    const int base = nq <= 8 ? 32 : 64;
     const int64_t mean = n / (nlist > 0 ? nlist : 1);
     const int64_t scale = mean / 1024 < 1 ? 1 : (mean / 1024 > 8 ? 8 : mean / 1024);
     const int64_t rows = (base * scale + 15) / 16 * 16;
