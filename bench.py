@@ -467,13 +467,14 @@ def ivf_roofline(engine, dev, args, traffic):
     above 1; without a PMC pass (N > 1, --no-pmc) they fall back to the unique bytes, a lower bound of the traffic."""
     n, nlist, nprobe = args.ivf_n, 1024, 32
     x, Qa = ivf_dataset(dev, n, nlist, 4096)
+    base_h = None if args.no_cpu else x.cpu().numpy()   # for the oracle beside every timed batch size (ivf_parity_check)
     idx = engine.Index(x, "cosine", dev.index)
     del x
     t0 = time.time()
     idx.ivf_build(nlist, 10, 42)
     build_s = time.time() - t0
     log("ivf build (k-means++ + 10 Lloyd on device) %.1fs" % build_s)
-    _, off, _ = idx.get_ivf()
+    cent_h, off, lids_h = idx.get_ivf()
     lens = np.diff(off)
     out = {}
     for nq in (1, 32, 256, 1024, 4096, "32_f32", "4096_f32"):
@@ -509,6 +510,8 @@ def ivf_roofline(engine, dev, args, traffic):
                    "unique_GB": round(uniq * (4 * DIM + 4) / 1e9, 4),
                    "algorithmic_GBs": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
                    "unique_GBs": round(uniq * (4 * DIM + 4) / (avg_ms * 1e-3) / 1e9, 1)}
+        if base_h is not None:
+            out[key]["parity_checked"] = ivf_parity_check(idx, base_h, cent_h, off, lids_h, Q, nprobe, surv / max(steps * nq, 1))
     idx.set_rejection_test(1)
     # single query, true latency: one call, one sync, host timer
     lat = []
@@ -617,6 +620,44 @@ def ivf_roofline(engine, dev, args, traffic):
         res["traffic_note"] = traffic["traffic_note"]
         res["raw_fetch_size_bytes"] = traffic["raw_fetch_size_bytes"]
     return res
+
+
+_IVF_NORMS = {}
+
+
+def ivf_parity_check(idx, base, cent, off, lids, Q, nprobe, f32_rows_per_query, n=16):
+    """The timed IVF launch against the oracle, outside the timed region (ivf_flat.clj:217-294): the batch that was
+    timed is issued once more on the same handle (same batch size, so the same kernels) and `n` of its queries, spread
+    over the batch, are compared with the oracle on the same centroids and lists -- ids and distance bits against its
+    device (GEMV) order (the f32 MFMA tile scan of handles without int8 rows: against its MFMA order), ids and distances
+    against its f64 reference order within the north_star's tolerance (1e-4 relative)."""
+    from oracle import oracle as O
+
+    nq = Q.shape[0]
+    gi, gd = idx.ivf_search_dev(Q, K, nprobe)
+    torch.cuda.synchronize()
+    sub = np.unique(np.linspace(0, nq - 1, min(n, nq)).astype(np.int64))
+    gi, gd = gi.cpu().numpy()[sub], gd.cpu().numpy()[sub]
+    qh = Q.cpu().numpy()[sub]
+    res = {}
+    for name, mode in (("gemv", O.MODE_DEV), ("mfma", O.MODE_MFMA)):
+        if mode not in _IVF_NORMS:                      # the oracle's row norms in that summation order, once per run
+            _IVF_NORMS[mode] = O.norms(base, mode)
+        oi, od, _ = O.ivf_search(base, cent, off, lids, qh, K, nprobe, mode=mode, base_norms=_IVF_NORMS[mode])
+        od32 = np.asarray(od, np.float64).astype(np.float32)
+        res[name] = bool(np.array_equal(gi, oi)), bool(np.array_equal(gd.view(np.uint32), od32.view(np.uint32)))
+        if all(res[name]):
+            break
+    order = "gemv" if all(res["gemv"]) else ("mfma" if all(res.get("mfma", (False,))) else "none")
+    fi, fd, _ = O.ivf_search(base, cent, off, lids, qh, K, nprobe)
+    close = np.abs(gd.astype(np.float64) - fd) <= 1e-4 * np.abs(fd) + 1e-6
+    best = res[order] if order != "none" else res["gemv"]
+    return {"queries": int(len(sub)), "launch": "%d queries, nprobe %d (the timed configuration)" % (nq, nprobe),
+            "summation_order_matched": order,
+            "ids_equal_oracle": best[0], "distance_bits_equal_oracle": best[1],
+            "within_1e-4_of_f64_reference_order": bool(close.all()),
+            "id_sets_equal_f64_reference_order": bool(all(set(a.tolist()) == set(b.tolist()) for a, b in zip(gi, fi))),
+            "f32_rows_per_query_of_the_timed_launches": round(float(f32_rows_per_query), 1)}
 
 
 def ivf_dataset(dev, n, nlist, nq_all):

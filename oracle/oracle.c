@@ -763,7 +763,7 @@ double orc_hnsw_search_batch(const float *base, int64_t n, int dim, int metric, 
     return now_ms() - t0;
 }
 
-/* ---- graph builder (src/hnsw/ultra_fast.clj:122-147, 216-330) ------------------------------
+/* ---- graph builder (src/hnsw/ultra_fast.clj:122-147, 216-330; src/hnsw/graph.clj:162-295) --
  * Follows the reference's structure: level = floor(ml * -ln U) with ml = 1/ln 2 (:133,143-147);
  * start at lc = min(level, entry-level) with nearest = [entry], no greedy descent (:247-248);
  * per layer search with ef = (if lc>0 1 ef-construction) (:250-251); connect to m candidates,
@@ -772,9 +772,40 @@ double orc_hnsw_search_batch(const float *base, int64_t n, int dim, int metric, 
  * level (:271-273).  Deliberate differences ("N"): the level RNG is a seeded
  * java.util.Random (the reference's is unseeded, so its graphs are not reproducible anyway), and
  * `(take m candidates)` takes the m CLOSEST candidates -- the reference takes the first m in
- * PriorityQueue array order, which is unspecified.  Set farthest_quirk=1 to take them from the far
- * end instead (a max-heap's array starts with its worst elements), to study that quirk.
+ * PriorityQueue array order, which is unspecified.  ORC_BUILD_FARTHEST takes them from the far end
+ * instead (a max-heap's array starts with its worst elements), to study that quirk.
+ *
+ * `flags` select the pieces of src/hnsw/graph.clj's builder (the namespace behind README's
+ * hnsw.hnsw-search, reached through ann/graph/pure_hnsw.clj) on the same skeleton:
+ *   ORC_BUILD_HEURISTIC  neighbour selection by get-neighbors-heuristic (graph.clj:162-198): candidates
+ *                        ascending by (distance, id) (:165-171); the closest is taken; every further one is
+ *                        taken unless it is closer to an already taken one than to the base node (:181-188),
+ *                        until M are taken (:177).  Used for the new node's own links and -- as
+ *                        prune-connections does (graph.clj:208-232, extend-candidates? false) -- for an over-full
+ *                        neighbour list.  The reference's insert links the new node to EVERY candidate its second
+ *                        search returns (graph.clj:280-287: with ef-construction entry points and num-closest M,
+ *                        search-layer returns all of them) and only prunes the neighbours; an adjacency row of this
+ *                        build holds at most m = 2M / M ids (graph.clj:281 computes that m and never uses it), so
+ *                        the new node's links are chosen by the same heuristic -- what prune-connections would make
+ *                        of its list at the first later insert that touches it.
+ *   ORC_BUILD_EXTEND     extend-candidates? = true for the new node's selection: discarded candidates fill the list
+ *                        up to M in their order (graph.clj:191-195)
+ *   ORC_BUILD_UPPER_EFC  ef-construction on every layer from min(level, entry-level) down (graph.clj:275-278;
+ *                        `(if (> lc level) 1 ef-construction)` is always ef-construction there) instead of 1 above
+ *                        layer 0 (ultra_fast.clj:250-251)
+ *   ORC_BUILD_SYMMETRIC  an edge dropped by a pruning is removed from BOTH lists (graph.clj:226-231); without it the
+ *                        reverse edge stays, as in prune-connections-ultra (ultra_fast.clj:279-299)
+ *   ORC_BUILD_DESCEND    a greedy ef = 1 walk from the entry's level down to level + 1 first (what the device's
+ *                        batched build does, and what graph/search-knn does on the way down: graph.clj:307-311),
+ *                        instead of starting at min(level, entry-level) with the entry point itself
  * The graph is an INPUT to the search-parity tests, so none of this affects search parity. */
+#define ORC_BUILD_FARTHEST 1
+#define ORC_BUILD_HEURISTIC 2
+#define ORC_BUILD_EXTEND 4
+#define ORC_BUILD_UPPER_EFC 8
+#define ORC_BUILD_SYMMETRIC 16
+#define ORC_BUILD_DESCEND 32
+
 typedef struct {
     int64_t n;
     int dim, M, M0;
@@ -809,10 +840,70 @@ static int prune_cmp(const void *x, const void *y) {
     if (a->d > b->d) return 1;
     return a->ord - b->ord; /* stable, like Clojure's sort-by */
 }
+/* graph.clj:165-171: the sorted set's comparator -- by distance, equal distances by id */
+static int heur_cmp(const void *x, const void *y) {
+    const prune_t *a = (const prune_t *)x, *b = (const prune_t *)y;
+    if (a->d < b->d) return -1;
+    if (a->d > b->d) return 1;
+    return (a->id > b->id) - (a->id < b->id);
+}
 
-int orc_hnsw_build(const float *base, int64_t n, int dim, int metric, int mode, int M, int efc, int64_t seed,
-                   int farthest_quirk, int32_t *levels_out, int32_t *l0_adj_out, int64_t *up_off_out,
-                   int32_t *up_adj_out, int64_t up_adj_cap, int32_t *entry_out, int32_t *max_level_out) {
+/* (distance graph id1 id2) graph.clj:109-115: dist-fn on the two stored vectors, id1's first */
+static double pair_dist(const dist_ctx *c0, int32_t i, int32_t j) {
+    dist_ctx c = *c0;
+    const float *q = c.base + (int64_t)i * c.dim;
+    if (c.norms) { /* the rows' stored norms (device order): what the engine's edge distances use for both sides */
+        c.q = q;
+        c.qnorm = c.norms[i];
+    } else {
+        ctx_set_query(&c, q);
+    }
+    return ctx_dist(&c, j);
+}
+
+/* get-neighbors-heuristic, graph.clj:162-198.  cand[0..n): (id, distance to the base node); sorted here.  Returns the
+ * number selected (<= m), ids in selection order in out[], their distances in out_d[] (may be NULL).  n_eval counts the
+ * (distance graph ...) calls. */
+static int select_heuristic(const dist_ctx *c, prune_t *cand, int n, int m, int extend, int32_t *out, double *out_d,
+                            prune_t *disc, int64_t *n_eval) {
+    qsort(cand, (size_t)n, sizeof(prune_t), heur_cmp);
+    int nres = 0, ndisc = 0;
+    for (int i = 0; i < n && nres < m; i++) { /* (while (and (not (empty? @nearest)) (< (count @result) M)) :177 */
+        int closer = 0;
+        for (int r = 0; r < nres && !closer; r++) { /* (some ... @result) :183-186 */
+            (*n_eval)++;
+            if (pair_dist(c, cand[i].id, out[r]) < cand[i].d) closer = 1;
+        }
+        if (closer) {
+            disc[ndisc++] = cand[i];
+        } else {
+            if (out_d) out_d[nres] = cand[i].d;
+            out[nres++] = cand[i].id;
+        }
+    }
+    if (extend) /* :191-195 */
+        for (int i = 0; i < ndisc && nres < m; i++) {
+            if (out_d) out_d[nres] = disc[i].d;
+            out[nres++] = disc[i].id;
+        }
+    return nres;
+}
+
+static void list_remove(int32_t *a, int32_t *cnt, int32_t x) {
+    for (int j = 0; j < *cnt; j++)
+        if (a[j] == x) {
+            for (int t = j; t + 1 < *cnt; t++) a[t] = a[t + 1];
+            a[--(*cnt)] = -1;
+            return;
+        }
+}
+
+int orc_hnsw_build_ex(const float *base, int64_t n, int dim, int metric, int mode, int M, int efc, int64_t seed,
+                      int flags, int32_t *levels_out, int32_t *l0_adj_out, int64_t *up_off_out, int32_t *up_adj_out,
+                      int64_t up_adj_cap, int32_t *entry_out, int32_t *max_level_out, int64_t *counters) {
+    const int farthest_quirk = flags & ORC_BUILD_FARTHEST, heur = flags & ORC_BUILD_HEURISTIC;
+    const int extend = (flags & ORC_BUILD_EXTEND) != 0, upper_efc = flags & ORC_BUILD_UPPER_EFC;
+    const int symmetric = flags & ORC_BUILD_SYMMETRIC, descend = flags & ORC_BUILD_DESCEND;
     build_t b;
     b.n = n;
     b.dim = dim;
@@ -828,7 +919,7 @@ int orc_hnsw_build(const float *base, int64_t n, int dim, int metric, int mode, 
         double u = jr_next_double(&rng);
         int lv = (int)(ml * (-log(u))); /* (long (* ml (- (Math/log U)))) :143-147 */
         if (u == 0.0) lv = 64;
-        if (lv > 62) lv = 62;
+        if (lv > 30) lv = 30; /* the engine's cap (hnsw.hip: draw_levels); 2^-31 per row */
         b.levels[i] = lv;
         b.up_off[i] = tot;
         tot += lv;
@@ -859,9 +950,13 @@ int orc_hnsw_build(const float *base, int64_t n, int dim, int metric, int mode, 
     cand_t *buf = (cand_t *)malloc(sizeof(cand_t) * (size_t)(efmax + 4));
     int32_t *eps = (int32_t *)malloc(sizeof(int32_t) * (size_t)(efmax + 4));
     double *epd = (double *)malloc(sizeof(double) * (size_t)(efmax + 4));
-    prune_t *pr = (prune_t *)malloc(sizeof(prune_t) * (size_t)(b.M0 + 4));
+    int prcap = (efmax > b.M0 ? efmax : b.M0) + 4;
+    prune_t *pr = (prune_t *)malloc(sizeof(prune_t) * (size_t)prcap);
+    prune_t *disc = (prune_t *)malloc(sizeof(prune_t) * (size_t)prcap);
+    int32_t *sel = (int32_t *)malloc(sizeof(int32_t) * (size_t)(b.M0 + 4));
+    int32_t *keep = (int32_t *)malloc(sizeof(int32_t) * (size_t)(b.M0 + 4));
     int entry = -1, top = -1;
-    int64_t ev = 0, hp = 0;
+    int64_t ev = 0, hp = 0, hev = 0, nprune = 0;
 
     /* a graph_view over the build arrays needs fixed strides; search_layer reads through gv_adj,
      * so give it strides M0+1 / M+1 by lying about M0/M (unused slots hold -1). */
@@ -887,16 +982,36 @@ int orc_hnsw_build(const float *base, int64_t n, int dim, int metric, int mode, 
         int neps = 1;
         eps[0] = entry;
         int use_d = 0;
+        g.max_level = top;
+        g.entry = entry;
+        if (descend)
+            for (int lc = top; lc > level; lc--) { /* graph.clj:307-311 on the way down: one nearest per layer */
+                int cnt = search_layer(&g, &c, eps, use_d ? epd : NULL, neps, 1, lc, &vis, buf, &ev, &hp);
+                neps = cnt < 1 ? 0 : 1;
+                if (cnt > 0) {
+                    eps[0] = buf[0].id;
+                    epd[0] = buf[0].d;
+                    use_d = 1;
+                }
+            }
         for (int lc = level < top ? level : top; lc >= 0; lc--) {
-            g.max_level = top;
-            g.entry = entry;
-            int ef = lc > 0 ? 1 : efc;
+            int ef = (lc > 0 && !upper_efc) ? 1 : efc;
             int cnt = search_layer(&g, &c, eps, use_d ? epd : NULL, neps, ef, lc, &vis, buf, &ev, &hp);
             int m = lc == 0 ? b.M0 : M;
-            int take = cnt < m ? cnt : m;
+            int take;
+            if (heur) {
+                for (int t = 0; t < cnt; t++) {
+                    pr[t].d = buf[t].d;
+                    pr[t].id = buf[t].id;
+                    pr[t].ord = t;
+                }
+                take = select_heuristic(&c, pr, cnt, m, extend, sel, NULL, disc, &hev);
+            } else {
+                take = cnt < m ? cnt : m;
+                for (int t = 0; t < take; t++) sel[t] = farthest_quirk ? buf[cnt - 1 - t].id : buf[t].id;
+            }
             for (int t = 0; t < take; t++) {
-                cand_t nbc = farthest_quirk ? buf[cnt - 1 - t] : buf[t];
-                int32_t nb = nbc.id;
+                int32_t nb = sel[t];
                 if (b.levels[nb] < lc) continue; /* :258 */
                 int32_t *cn, *cq;
                 int capn, capq;
@@ -904,18 +1019,42 @@ int orc_hnsw_build(const float *base, int64_t n, int dim, int metric, int mode, 
                 int32_t *aq = bld_adj(&b, (int32_t)id, lc, &cq, &capq);
                 if (*cq < capq) aq[(*cq)++] = nb; /* new node never exceeds m (take <= m) */
                 an[(*cn)++] = (int32_t)id;
-                if (*cn > m) { /* prune-connections-ultra :279-299 */
+                if (*cn > m) {
+                    nprune++;
                     dist_ctx c2 = c;
-                    ctx_set_query(&c2, base + (int64_t)nb * dim);
-                    for (int j = 0; j < *cn; j++) {
+                    if (c2.norms) {
+                        c2.q = base + (int64_t)nb * dim;
+                        c2.qnorm = c2.norms[nb];
+                    } else {
+                        ctx_set_query(&c2, base + (int64_t)nb * dim);
+                    }
+                    const int have = *cn;
+                    for (int j = 0; j < have; j++) {
                         pr[j].d = ctx_dist(&c2, an[j]);
                         pr[j].id = an[j];
                         pr[j].ord = j;
                     }
-                    qsort(pr, (size_t)*cn, sizeof(prune_t), prune_cmp);
-                    for (int j = 0; j < m; j++) an[j] = pr[j].id;
-                    for (int j = m; j < capn; j++) an[j] = -1;
-                    *cn = m;
+                    if (heur) { /* prune-connections graph.clj:208-232 */
+                        int nk = select_heuristic(&c, pr, have, m, 0, keep, NULL, disc, &hev);
+                        if (symmetric) /* :226-231: the dropped edge leaves the other list as well */
+                            for (int j = 0; j < have; j++) {
+                                int kept = 0;
+                                for (int r = 0; r < nk; r++) kept |= keep[r] == pr[j].id;
+                                if (kept) continue;
+                                int32_t *cz;
+                                int capz;
+                                int32_t *az = bld_adj(&b, pr[j].id, lc, &cz, &capz);
+                                list_remove(az, cz, nb);
+                            }
+                        for (int j = 0; j < nk; j++) an[j] = keep[j];
+                        for (int j = nk; j < capn; j++) an[j] = -1;
+                        *cn = nk;
+                    } else { /* prune-connections-ultra ultra_fast.clj:279-299 */
+                        qsort(pr, (size_t)have, sizeof(prune_t), prune_cmp);
+                        for (int j = 0; j < m; j++) an[j] = pr[j].id;
+                        for (int j = m; j < capn; j++) an[j] = -1;
+                        *cn = m;
+                    }
                 }
             }
             /* (recur (dec lc) candidates) :268 -- all candidates become the next entry points */
@@ -938,6 +1077,12 @@ int orc_hnsw_build(const float *base, int64_t n, int dim, int metric, int mode, 
         for (int j = 0; j < M; j++) up_adj_out[blk * M + j] = b.up_adj[blk * (M + 1) + j];
     *entry_out = entry;
     *max_level_out = top < 0 ? 0 : top;
+    if (counters) {
+        counters[0] = ev;     /* distance evaluations of the layer searches */
+        counters[1] = hp;     /* expansions */
+        counters[2] = hev;    /* (distance graph ...) calls of the heuristic */
+        counters[3] = nprune; /* prunings */
+    }
     free(b.l0_adj);
     free(b.l0_cnt);
     free(b.up_adj);
@@ -948,8 +1093,18 @@ int orc_hnsw_build(const float *base, int64_t n, int dim, int metric, int mode, 
     free(eps);
     free(epd);
     free(pr);
+    free(disc);
+    free(sel);
+    free(keep);
     free(bnorms);
     return 0;
+}
+
+int orc_hnsw_build(const float *base, int64_t n, int dim, int metric, int mode, int M, int efc, int64_t seed,
+                   int farthest_quirk, int32_t *levels_out, int32_t *l0_adj_out, int64_t *up_off_out,
+                   int32_t *up_adj_out, int64_t up_adj_cap, int32_t *entry_out, int32_t *max_level_out) {
+    return orc_hnsw_build_ex(base, n, dim, metric, mode, M, efc, seed, farthest_quirk ? ORC_BUILD_FARTHEST : 0, levels_out,
+                             l0_adj_out, up_off_out, up_adj_out, up_adj_cap, entry_out, max_level_out, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------ */

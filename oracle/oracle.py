@@ -65,6 +65,8 @@ def lib():
                                                i32, i32, p, p, p, p]
         _lib.orc_hnsw_build.restype = i32
         _lib.orc_hnsw_build.argtypes = [p, i64, i32, i32, i32, i32, i32, i64, i32, p, p, p, p, i64, p, p]
+        _lib.orc_hnsw_build_ex.restype = i32
+        _lib.orc_hnsw_build_ex.argtypes = [p, i64, i32, i32, i32, i32, i32, i64, i32, p, p, p, p, i64, p, p, p]
         _lib.orc_exact_knn.restype = d
         _lib.orc_exact_knn.argtypes = [p, i64, i32, i32, i32, p, p, i32, i32, i32, p, p]
         _lib.orc_recall.restype = d
@@ -215,6 +217,34 @@ class Graph:
         self.n = len(self.levels)
 
 
+BUILD_FARTHEST, BUILD_HEURISTIC, BUILD_EXTEND, BUILD_UPPER_EFC, BUILD_SYMMETRIC, BUILD_DESCEND = 1, 2, 4, 8, 16, 32
+# src/hnsw/graph.clj's builder on the array graph (oracle.c: orc_hnsw_build_ex): heuristic selection, symmetric pruning,
+# ef-construction on every layer
+BUILD_GRAPH_CLJ = BUILD_HEURISTIC | BUILD_SYMMETRIC | BUILD_UPPER_EFC
+
+
+def hnsw_build_ex(base, metric=COSINE, M=16, ef_construction=200, seed=42, flags=0, mode=MODE_F64, want_counters=False):
+    """Sequential insertion on the skeleton of src/hnsw/ultra_fast.clj:216-344 with the pieces of
+    src/hnsw/graph.clj:162-295 that `flags` select (oracle.c: orc_hnsw_build_ex)."""
+    base = _f32(base)
+    n, dim = base.shape
+    levels = np.zeros(n, np.int32)
+    l0 = np.full((n, 2 * M), -1, np.int32)
+    up_off = np.zeros(n + 1, np.int64)
+    cap = (n * 3 + 64) * M
+    up = np.full(cap, -1, np.int32)
+    entry = C.c_int32(-1)
+    maxl = C.c_int32(0)
+    cnt = np.zeros(4, np.int64)
+    rc = lib().orc_hnsw_build_ex(_p(base), n, dim, int(metric), int(mode), M, ef_construction, int(seed), int(flags),
+                                 _p(levels), _p(l0), _p(up_off), _p(up), cap, C.byref(entry), C.byref(maxl), _p(cnt))
+    if rc != 0:
+        raise RuntimeError("oracle hnsw_build: upper-level capacity exceeded")
+    tot = int(up_off[n])
+    g = Graph(levels, l0, up_off, up[: tot * M].copy(), M, entry.value, maxl.value)
+    return (g, cnt) if want_counters else g
+
+
 def hnsw_build(base, metric=COSINE, M=16, ef_construction=200, seed=42, farthest_quirk=False, mode=MODE_F64):
     """src/hnsw/ultra_fast.clj:216-344 (sequential insertion; see oracle.c for the stated deviations)."""
     base = _f32(base)
@@ -345,8 +375,10 @@ def lists_from_assign(assign, nlist):
     return off, order
 
 
-def ivf_search(base, centroids, list_off, list_ids, Q, k, nprobe, metric=COSINE, mode=MODE_F64, scan_mode=None):
-    """src/hnsw/ann/partition/ivf_flat.clj:236-294 with explicit nprobe; centroids float32 (engine storage)."""
+def ivf_search(base, centroids, list_off, list_ids, Q, k, nprobe, metric=COSINE, mode=MODE_F64, scan_mode=None,
+               base_norms=None):
+    """src/hnsw/ann/partition/ivf_flat.clj:236-294 with explicit nprobe; centroids float32 (engine storage).
+    base_norms: norms(base, mode) of an earlier call (a million-row base takes seconds per call otherwise)."""
     base, Q = _f32(base), _f32(Q)
     if Q.ndim == 1:
         Q = Q[None, :]
@@ -358,7 +390,7 @@ def ivf_search(base, centroids, list_off, list_ids, Q, k, nprobe, metric=COSINE,
     scan_mode = mode if scan_mode is None else scan_mode
     nr = cn = None
     if mode != MODE_F64 and metric == COSINE:
-        nr, cn = norms(base, mode), norms(cen, mode)
+        nr, cn = (norms(base, mode) if base_norms is None else _f32(base_norms)), norms(cen, mode)
     off = np.ascontiguousarray(list_off, np.int64)
     lids = np.ascontiguousarray(list_ids, np.int32)
     ids = np.full((nq, k), -1, np.int32)

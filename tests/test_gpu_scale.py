@@ -33,63 +33,124 @@ def _check_topk(ids, d, n, k):
     assert all(len(set(r.tolist())) == k for r in ids), "duplicate ids in a result"
 
 
-def test_config3_ivf_per_gpu_shard(eng, oracle):
-    """1.25M x 768, nlist 1024 (k-means++ seed 42, 10 Lloyd passes on the device), nprobe 32, k 10, batch 1024 (MFMA
-    tile scan) and batch 32 (GEMV scan, the HBM-bound regime)."""
+@pytest.fixture(scope="module")
+def shard3(eng):
+    """One GPU's share of configs[3]: 1.25M x 768 clustered-normalised rows (1024 true centres), nlist 1024 built on the
+    device (k-means++ seed 42, 10 Lloyd passes), 4096 held-out queries of the same mixture.  Shared by the tests below."""
     import torch
 
-    O = oracle
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(42)
-    n, nlist, nprobe, k = N_SHARD, 1024, 32, 10
+    n, nlist = N_SHARD, 1024
     cen = torch.randn(nlist, 768, generator=g, device=dev)
     x = cen[torch.randint(0, nlist, (n,), generator=g, device=dev)] + 0.3 * torch.randn(n, 768, generator=g, device=dev)
     x /= x.norm(dim=1, keepdim=True)
     g.manual_seed(43)
-    Q = cen[torch.randint(0, nlist, (1024,), generator=g, device=dev)] + 0.3 * torch.randn(1024, 768, generator=g, device=dev)
+    Q = cen[torch.randint(0, nlist, (4096,), generator=g, device=dev)] + 0.3 * torch.randn(4096, 768, generator=g, device=dev)
     Q = (Q / Q.norm(dim=1, keepdim=True)).contiguous()
     base = x.cpu().numpy()
     qh = Q.cpu().numpy()
-    with eng.Index(x, "cosine") as idx:
-        del x
-        idx.ivf_build(nlist, 10, 42)
-        cent, off, lids = idx.get_ivf()
-        assert off[0] == 0 and off[-1] == n and np.array_equal(np.sort(lids), np.arange(n, dtype=np.int32))
-        res = {}
-        for nq in (1024, 32):
-            Qb = Q[:nq].contiguous()
-            i1, d1 = idx.ivf_search_dev(Qb, k, nprobe)
-            i2, d2 = idx.ivf_search_dev(Qb, k, nprobe)
-            torch.cuda.synchronize()
-            assert torch.equal(i1, i2) and torch.equal(d1.view(torch.int32), d2.view(torch.int32)), "not idempotent"
-            ids, d = i1.cpu().numpy(), d1.cpu().numpy()
-            _check_topk(ids, d, n, k)
-            res[nq] = (ids, d)
-            # every returned distance is the true distance of that id (gather order: bit-equal on the GEMV path,
-            # within the tolerance of the two summation orders on the MFMA path)
-            for r in (0, nq // 2, nq - 1):
-                true = idx.batch_distances(qh[r], ids[r])
-                if nq == 32:
-                    np.testing.assert_array_equal(true.view(np.uint32), d[r].view(np.uint32))
-                else:
-                    assert close(d[r], true).all()
-        # the two kernels agree within tolerance; recall against GPU brute force over all 1.25M rows
-        assert_topk_parity(res[32][0], res[32][1], res[1024][0][:32], res[1024][1][:32], "gemv vs tile at 1.25M")
-        ei, _ = idx.exact_knn_dev(Q[:128].contiguous(), k)
+    idx = eng.Index(x, "cosine")
+    del x
+    idx.ivf_build(nlist, 10, 42)
+    cent, off, lids = idx.get_ivf()
+    assert off[0] == 0 and off[-1] == n and np.array_equal(np.sort(lids), np.arange(n, dtype=np.int32))
+    yield dict(idx=idx, base=base, Q=Q, qh=qh, cent=cent, off=off, lids=lids, n=n, nlist=nlist)
+    idx.close()
+
+
+def test_config3_ivf_per_gpu_shard(eng, oracle, shard3):
+    """1.25M x 768, nlist 1024, nprobe 32, k 10, with the suite's pinned boundary (HNSWGPU_TILE_PAIRS = 12,
+    tests/conftest.py): batch 1024 goes through the f32 MFMA tile scan (the kernel of handles without int8 rows and of
+    k > 256), batch 32 through the survivor stream (GEMV order), each against the oracle's matching order."""
+    import torch
+
+    O = oracle
+    s = shard3
+    idx, base, Q, qh, cent, off, lids, n = s["idx"], s["base"], s["Q"], s["qh"], s["cent"], s["off"], s["lids"], s["n"]
+    nprobe, k = 32, 10
+    res = {}
+    for nq in (1024, 32):
+        Qb = Q[:nq].contiguous()
+        i1, d1 = idx.ivf_search_dev(Qb, k, nprobe)
+        i2, d2 = idx.ivf_search_dev(Qb, k, nprobe)
         torch.cuda.synchronize()
-        ei = ei.cpu().numpy()
-        rec = np.mean([len(set(res[1024][0][r]) & set(ei[r])) / k for r in range(128)])
-        assert rec >= 0.9, rec
-        # oracle, same centroids and lists, 64-query subsample: the batch-1024 answers in MFMA order, a 64-query batch
-        # (64 * 32 pairs = 2 per list: still the GEMV scan) in the GEMV order -- ids and distance bits
-        oi, od, _ = O.ivf_search(base, cent, off, lids, qh[:64], k, nprobe, mode=O.MODE_MFMA)
-        assert_exact(res[1024][0][:64], res[1024][1][:64], oi, od, "config3 batch 1024 vs oracle (MFMA order)")
-        i64, d64 = idx.ivf_search(qh[:64], k, nprobe)
-        oi, od, _ = O.ivf_search(base, cent, off, lids, qh[:64], k, nprobe, mode=O.MODE_DEV)
-        assert_exact(i64, d64, oi, od, "config3 batch 64 vs oracle (GEMV order)")
-        fi, fd, _ = O.ivf_search(base, cent, off, lids, qh[:16], k, nprobe)           # f64 reference order
-        assert_topk_parity(res[1024][0][:16], res[1024][1][:16], fi, fd, "config3 vs f64 oracle")
+        assert torch.equal(i1, i2) and torch.equal(d1.view(torch.int32), d2.view(torch.int32)), "not idempotent"
+        ids, d = i1.cpu().numpy(), d1.cpu().numpy()
+        _check_topk(ids, d, n, k)
+        res[nq] = (ids, d)
+        # every returned distance is the true distance of that id (gather order: bit-equal on the GEMV path,
+        # within the tolerance of the two summation orders on the MFMA path)
+        for r in (0, nq // 2, nq - 1):
+            true = idx.batch_distances(qh[r], ids[r])
+            if nq == 32:
+                np.testing.assert_array_equal(true.view(np.uint32), d[r].view(np.uint32))
+            else:
+                assert close(d[r], true).all()
+    # the two kernels agree within tolerance; recall against GPU brute force over all 1.25M rows
+    assert_topk_parity(res[32][0], res[32][1], res[1024][0][:32], res[1024][1][:32], "gemv vs tile at 1.25M")
+    ei, _ = idx.exact_knn_dev(Q[:128].contiguous(), k)
+    torch.cuda.synchronize()
+    ei = ei.cpu().numpy()
+    rec = np.mean([len(set(res[1024][0][r]) & set(ei[r])) / k for r in range(128)])
+    assert rec >= 0.9, rec
+    # oracle, same centroids and lists, 64-query subsample: the batch-1024 answers in MFMA order, a 64-query batch
+    # (64 * 32 pairs = 2 per list: the survivor stream) in the GEMV order -- ids and distance bits
+    oi, od, _ = O.ivf_search(base, cent, off, lids, qh[:64], k, nprobe, mode=O.MODE_MFMA)
+    assert_exact(res[1024][0][:64], res[1024][1][:64], oi, od, "config3 batch 1024 vs oracle (MFMA order)")
+    i64, d64 = idx.ivf_search(qh[:64], k, nprobe)
+    oi, od, _ = O.ivf_search(base, cent, off, lids, qh[:64], k, nprobe, mode=O.MODE_DEV)
+    assert_exact(i64, d64, oi, od, "config3 batch 64 vs oracle (GEMV order)")
+    fi, fd, _ = O.ivf_search(base, cent, off, lids, qh[:16], k, nprobe)           # f64 reference order
+    assert_topk_parity(res[1024][0][:16], res[1024][1][:16], fi, fd, "config3 vs f64 oracle")
+
+
+@pytest.mark.parametrize("nq", [256, 1024, 4096])
+def test_config3_ivf_production_path_against_oracle(eng, oracle, shard3, nq, monkeypatch):
+    """The path a DEFAULT handle takes (what bench.py times and `profiles/` report): no pinned boundary, rejection mode 1
+    with its first-search calibration -- int8 bounds on the matrix cores -> half-precision pass -> f32 finish, cosine --
+    at 1.25M x 768 / nlist 1024 / nprobe 32 / k 10 and batches of 256 / 1024 / 4096 (ivf_flat.clj:217-294).  A 64-query
+    subsample spread over the batch is compared with the oracle: ids and distance bits against its device (GEMV) order,
+    ids and distances within 1e-4 against its f64 reference order; the counters say that the stream and the
+    half-precision pass really ran (a handle whose calibration had switched the stream off would take the f32 scans)."""
+    import torch
+
+    O = oracle
+    s = shard3
+    idx, base, Q, qh, cent, off, lids, n = s["idx"], s["base"], s["Q"], s["qh"], s["cent"], s["off"], s["lids"], s["n"]
+    nprobe, k = 32, 10
+    monkeypatch.delenv("HNSWGPU_TILE_PAIRS", raising=False)
+    idx.set_rejection_test(1)                 # the default mode: calibrates at the next IVF search
+    try:
+        Qb = Q[:nq].contiguous()
+        idx.ivf_search_dev(Qb, k, nprobe)     # (calibration + scratch growth happen here)
+        idx.set_profiling(True)
+        idx.rejection_stats(reset=True)
+        i1, d1 = idx.ivf_search_dev(Qb, k, nprobe)
+        torch.cuda.synchronize()
+        f32_rows, cand = idx.rejection_stats(reset=True)
+        idx.set_profiling(False)
+        i2, d2 = idx.ivf_search_dev(Qb, k, nprobe)
+        torch.cuda.synchronize()
+        assert torch.equal(i1, i2) and torch.equal(d1.view(torch.int32), d2.view(torch.int32)), "not idempotent"
+        ids, d = i1.cpu().numpy(), d1.cpu().numpy()
+        _check_topk(ids, d, n, k)
+        # the survivor stream ran (candidates counted by its finish kernel), and behind the half-precision pass:
+        # a few dozen f32 rows per query remain of ~39,000 candidates (the int8 pass alone leaves ~1,200)
+        assert cand >= nq * nprobe * 600, (f32_rows, cand)
+        assert f32_rows < 0.005 * cand, "f32 rows per query %.1f of %.1f candidates: the half-precision pass did not run" % (
+            f32_rows / nq, cand / nq)
+        sub = np.unique(np.linspace(0, nq - 1, 64).astype(np.int64))
+        oi, od, _ = O.ivf_search(base, cent, off, lids, qh[sub], k, nprobe, mode=O.MODE_DEV)
+        assert_exact(ids[sub], d[sub], oi, od, "config3 production path, batch %d, vs oracle (GEMV order)" % nq)
+        fi, fd, _ = O.ivf_search(base, cent, off, lids, qh[sub[:16]], k, nprobe)          # f64 reference order
+        assert_topk_parity(ids[sub[:16]], d[sub[:16]], fi, fd, "config3 production path, batch %d, vs f64 oracle" % nq)
+        for r in (0, nq // 2, nq - 1):        # returned distance == the row's true distance, bit for bit
+            np.testing.assert_array_equal(idx.batch_distances(qh[r], ids[r]).view(np.uint32), d[r].view(np.uint32))
+    finally:
+        idx.set_profiling(False)
+        idx.set_rejection_test(2)             # the suite's mode for the tests that share this index
 
 
 def test_config4_hnsw_per_gpu_shard(eng, oracle):
