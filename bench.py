@@ -690,7 +690,7 @@ def pmc_child(args):
     the launches `roofline.achieved` is quoted on."""
     from hnsw_clj_amd import engine
 
-    os.environ["HNSWGPU_IVF_CALIBRATE"] = "0"             # (the handle's one-off calibration search is not one of the six)
+    engine.set_tuning("IVF_CALIBRATE", 0)                 # (the handle's one-off calibration search is not one of the six)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     x, Qa = ivf_dataset(dev, args.ivf_n, 1024, 4096)       # the same query draws as ivf_roofline()

@@ -83,6 +83,8 @@ _SIGS = {
     "hnswgpu_ivf_half_bounds": ["p", "p", "p", "i32", "p", "p"],
     "hnswgpu_set_rejection_test": ["p", "i32"],
     "hnswgpu_get_rejection_stats": ["p", "p", "p", "i32"],
+    "hnswgpu_set_tuning": ["i32", "i64"],
+    "hnswgpu_get_tuning": ["i32", "p", "p"],
     "hnswgpu_group_create": ["p", "i32", "i32", "i32", "p"],
     "hnswgpu_group_destroy": ["p"],
     "hnswgpu_group_info": ["p", "p", "p", "p", "p"],
@@ -91,6 +93,24 @@ _SIGS = {
     "hnswgpu_group_hnsw_build": ["p", "p", "i64", "i32", "i32", "i64"],
     "hnswgpu_group_hnsw_search": ["p", "p", "i32", "i32", "i32", "p", "p"],
 }
+# keys of hnswgpu_set_tuning (include/hnswgpu.h: HNSWGPU_TUNE_*), in the header's order
+TUNE_KEYS = ['TILE_PAIRS', 'PREFILTER', 'IVF_HALF', 'IVF_CALIBRATE', 'BUILD_THREADS', 'PREFETCH', 'SEED_BOUNDS', 'TILE_WGS', 'TILE_PERSIST', 'STREAM_BUCKET', 'STREAM_WGS', 'FINISH_ORDER', 'STREAM_CAP', 'STREAM_MID', 'STREAM_NARROW', 'FINISH_ADAPT', 'FINISH_BISECT', 'FINISH_SLICES', 'FINISH_SPAN', 'STREAM_HEAVY', 'STREAM_HEAVY_MEAN', 'STREAM_HEAVY_MIN', 'MID_SLICES', 'MID_COMPACT', 'IVF_CODES', 'SCAN_ORDER', 'IVF_FUSED', 'IVF_GROUP', 'STREAM_ROUTE', 'STREAM_GROUP', 'ROUTE_GROUP', 'MID_WIDE', 'MERGE_W', 'SCAN_BLOCKS', 'ROUTE_WGS', 'TILE', 'SELECT_W', 'HNSW_NW', 'VIS_GLOBAL', 'PF_HINTS', 'PF_EVAL', 'ZEROCOPY', 'BUILD_TIMING']
+TUNE_DEFAULT = -(1 << 63)
+
+
+def set_tuning(name, value=None):
+    """hnswgpu_set_tuning by name (lower or upper case); value None restores the default.  Process-wide."""
+    key = TUNE_KEYS.index(name.upper())
+    check(lib().hnswgpu_set_tuning(key, TUNE_DEFAULT if value is None else int(value)))
+
+
+def get_tuning(name):
+    """The value set for a key, or None while it is at its default."""
+    v, is_set = C.c_int64(0), C.c_int32(0)
+    check(lib().hnswgpu_get_tuning(TUNE_KEYS.index(name.upper()), C.byref(v), C.byref(is_set)))
+    return v.value if is_set.value else None
+
+
 _T = {"p": C.c_void_p, "i32": C.c_int32, "i64": C.c_int64}
 
 EXPORTS = sorted(list(_SIGS) + ["hnswgpu_last_error", "hnswgpu_group_member"])
@@ -120,6 +140,12 @@ def lib():
     L.hnswgpu_group_member.restype = C.c_void_p
     L.hnswgpu_group_member.argtypes = [C.c_void_p, C.c_int32]
     _lib = L
+    # developer convenience of this Python wrapper (the library itself reads six documented names, once):
+    # HNSWGPU_TUNE="KEY=value,KEY=value" applies hnswgpu_set_tuning at load (tools/*.py A/B runs)
+    for kv in os.environ.get("HNSWGPU_TUNE", "").split(","):
+        if "=" in kv:
+            k, v = kv.split("=", 1)
+            set_tuning(k.strip(), int(v))
     return L
 
 

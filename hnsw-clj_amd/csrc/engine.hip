@@ -102,10 +102,7 @@ int ensure_list_codes(hnswgpu_index *idx, hipStream_t st) {
 // per row.  Half the size of the f32 rows again; HNSWGPU_IVF_HALF=0 leaves it out (the searches then go from the int8
 // bounds straight to the f32 rows at every batch size).
 int ensure_list_half(hnswgpu_index *idx, hipStream_t st) {
-    static const bool wanted = []() {
-        const char *e = getenv("HNSWGPU_IVF_HALF");
-        return !e || atoi(e) != 0;
-    }();
+    const bool wanted = tune(HNSWGPU_TUNE_IVF_HALF, 1) != 0;
     if (!wanted || !idx->d_lctile || idx->d_lhalf || idx->n <= 0 || idx->nlist <= 0) return 0;
     const int64_t n = idx->n;
     // (an optional accelerator: a device too full for it -- +50 % of the base -- searches without it)
@@ -151,10 +148,7 @@ int launch_mid(const MidArgs &a, int nch, hipStream_t st) {
     const bool l2 = a.metric == METRIC_L2;
     const size_t lds = sizeof(float) * static_cast<size_t>(std::max(a.compact, 0));
     HG_REQUIRE(lds <= 48 * 1024, HNSWGPU_ELIMIT, "half-precision pass: compaction buffer too large");
-    static const bool wide_env = []() {
-        const char *e = getenv("HNSWGPU_MID_WIDE");  // 0 = never (A/B)
-        return !e || atoi(e) != 0;
-    }();
+    const bool wide_env = tune(HNSWGPU_TUNE_MID_WIDE, 1) != 0;  // 0 = never (A/B)
     // eight waves per query where the grid alone does not fill the chip (cosine batch 1024: 235 -> 216 us; the Euclidean kernel,
     // heavier per element, measured 2 - 3 % slower with them and keeps four)
     const bool wide = wide_env && a.slices == 1 && a.nq < 2048 && a.k <= 8 * kWave && a.metric != METRIC_L2;
@@ -280,7 +274,7 @@ int launch_merge(const MergeArgs &a, hipStream_t st) {
     // waves per query: ~2048 keys per wave, but never more workgroup-waves than the batch needs to fill the chip
     int64_t w = std::min<int64_t>(16, std::max<int64_t>(1, a.keys_per_query / 2048));
     while (w > 1 && static_cast<int64_t>(a.nq) * w > 8192) w /= 2;
-    if (const char *e = getenv("HNSWGPU_MERGE_W")) w = std::max(1, atoi(e));
+    if (const int64_t e = tune(HNSWGPU_TUNE_MERGE_W, 0)) w = std::max<int64_t>(1, e);
     size_t lds = sizeof(uint64_t) * (w + 1) * a.k;
     HG_REQUIRE(lds <= 150 * 1024, HNSWGPU_ELIMIT, "k too large for the merge kernel");
     if (lds > 48 * 1024) {
@@ -339,8 +333,7 @@ int plan_chunks(int nch, int64_t max_rows, int64_t mean_rows, int64_t npairs, in
     if (max_rows < 1) max_rows = 1;
     if (mean_rows < 1) mean_rows = 1;
     if (mean_rows > max_rows) mean_rows = max_rows;
-    const char *env_e = getenv("HNSWGPU_SCAN_BLOCKS");  // tuning override (re-read per call: in-process sweeps)
-    const int64_t env_blocks = env_e ? atoll(env_e) : 0LL;
+    const int64_t env_blocks = tune(HNSWGPU_TUNE_SCAN_BLOCKS, 0);  // tuning override
     // measured on 1M x 768 / 1024 k-means lists (tools/sweep_scan_blocks.py).  (query, list) pairs run in list
     // order: a target of 4096-6144 workgroups is best for every small batch (batch 32: 0.348 ms against 0.43 at 32768
     // and 0.45 at 1024; batch 16: 0.215 against 0.237; batch 8: 0.135 against 0.144) -- ~250 rows per workgroup, a
@@ -761,10 +754,7 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
         // (the group's queries are staged in LDS: 1 KB x NCH each, 48 KB at most)
         a.qgroup = static_cast<int32_t>(std::max(2, std::min(std::min(16, 48 / idx->nch), nq / 16)));
         const int64_t ngroups = (nq + a.qgroup - 1) / a.qgroup;
-        static const int64_t route_wgs = []() {
-            const char *e = getenv("HNSWGPU_ROUTE_WGS");  // tuning override
-            return e ? atoll(e) : 2048LL;
-        }();
+        const int64_t route_wgs = tune(HNSWGPU_TUNE_ROUTE_WGS, 2048);
         int64_t wb = std::max<int64_t>(1, route_wgs / ngroups);
         int64_t rp = (idx->nlist + wb - 1) / wb;
         rp = std::max<int64_t>(per_iter, (rp + per_iter - 1) / per_iter * per_iter);
@@ -1083,13 +1073,26 @@ bool tile_path_ok(const hnswgpu_index *idx) {
     return idx->metric == METRIC_L2 ? idx->dim <= kL2MaxDim : idx->dim <= kTileMaxDim;
 }
 
-int tile_mode() {
-    static const int m = []() {
-        const char *e = getenv("HNSWGPU_TILE");
-        return e ? atoi(e) : -1;
-    }();
-    return m;
-}
+int tile_mode() { return static_cast<int>(tune(HNSWGPU_TUNE_TILE, -1)); }
+
+std::atomic<int64_t> g_tune[HNSWGPU_TUNE_COUNT];
+// The six environment variables include/hnswgpu.h documents, read once when the library is loaded.
+static const struct TuneInit {
+    TuneInit() {
+        for (auto &t : g_tune) t.store(kTuneUnset, std::memory_order_relaxed);
+        static const struct {
+            const char *name;
+            int key;
+        } env[] = {{"HNSWGPU_TILE_PAIRS", HNSWGPU_TUNE_TILE_PAIRS},       {"HNSWGPU_PREFILTER", HNSWGPU_TUNE_PREFILTER},
+                   {"HNSWGPU_IVF_HALF", HNSWGPU_TUNE_IVF_HALF},           {"HNSWGPU_IVF_CALIBRATE", HNSWGPU_TUNE_IVF_CALIBRATE},
+                   {"HNSWGPU_BUILD_THREADS", HNSWGPU_TUNE_BUILD_THREADS}, {"HNSWGPU_PREFETCH", HNSWGPU_TUNE_PREFETCH}};
+        for (const auto &e : env)
+            if (const char *v = getenv(e.name)) g_tune[e.key].store(atoll(v), std::memory_order_relaxed);
+    }
+} g_tune_init;
+#ifdef HG_DIAG
+int g_stream_dbg = 0, g_tile_dbg = 0;  // hnswgpu_debug_set_ablation: kernels with parts cut out, for timing only
+#endif
 
 unsigned long long *g_tile_dbg_buf = nullptr;  // set through hnswgpu_debug_set_tile_stamps (diagnostics only)
 
@@ -1144,12 +1147,12 @@ int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t s
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_scan_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    static const int dbg = []() {
-        const char *e = getenv("HNSWGPU_TILE_DBG");
-        return e ? atoi(e) : 0;
-    }();
     TileArgs b = a;
-    b.dbg = dbg;
+#ifdef HG_DIAG
+    b.dbg = g_tile_dbg;  // ablation timing only (results are wrong on purpose)
+#else
+    b.dbg = 0;
+#endif
     b.dbg_buf = g_tile_dbg_buf;
     hipLaunchKernelGGL(tile_scan_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, b);
     HG_HIP(hipGetLastError());
@@ -1167,7 +1170,7 @@ int launch_select(const SelectArgs &a0, hipStream_t st) {
     const int64_t per_wave = a.nq <= 128 ? 4096 : 16384;
     int w = 1;
     while (w < 16 && cand >= per_wave * w && static_cast<int64_t>(a.nq) * w * 2 <= 16384) w *= 2;
-    if (const char *e = getenv("HNSWGPU_SELECT_W")) w = std::max(1, std::min(16, atoi(e)));  // tuning override
+    if (const int64_t e = tune(HNSWGPU_TUNE_SELECT_W, 0)) w = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(16, e)));  // tuning override
     while (w & (w - 1)) w &= w - 1;
     a.wpq = w;
     a.vec4 = (a.stride % 4 == 0 && reinterpret_cast<uintptr_t>(a.dist) % 16 == 0) ? 1 : 0;
@@ -1428,12 +1431,8 @@ static int create_common(int64_t n, int32_t dim, int32_t metric, int32_t device,
     idx->dim = dim;
     idx->ld = ld;
     idx->nch = nch;
-    static const int rejection_env = []() {
-        const char *e = getenv("HNSWGPU_PREFILTER");  // default of hnswgpu_set_rejection_test
-        const int v = e ? atoi(e) : 1;
-        return v < 0 || v > 2 ? 1 : v;
-    }();
-    idx->rejection_mode = rejection_env;
+    const int64_t rej = tune(HNSWGPU_TUNE_PREFILTER, 1);  // default of hnswgpu_set_rejection_test
+    idx->rejection_mode = rej < 0 || rej > 2 ? 1 : static_cast<int>(rej);
     (void)hipDeviceGetAttribute(&idx->cus, hipDeviceAttributeMultiprocessorCount, device);
     if (idx->cus <= 0) idx->cus = 256;
     idx->cmb_hnsw.max_inflight = 2;  // two Slots: small synchronous HNSW batches overlap on the device
@@ -2011,6 +2010,28 @@ int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode) {
     }
     return 0;
 }
+
+int hnswgpu_set_tuning(int32_t key, int64_t value) {
+    HG_REQUIRE(key >= 0 && key < HNSWGPU_TUNE_COUNT, HNSWGPU_EINVAL, "no such tuning key: %d", key);
+    hg::g_tune[key].store(value, std::memory_order_relaxed);
+    return 0;
+}
+
+int hnswgpu_get_tuning(int32_t key, int64_t *value, int32_t *is_set) {
+    HG_REQUIRE(key >= 0 && key < HNSWGPU_TUNE_COUNT, HNSWGPU_EINVAL, "no such tuning key: %d", key);
+    const int64_t v = hg::g_tune[key].load(std::memory_order_relaxed);
+    if (value) *value = v;
+    if (is_set) *is_set = v != hg::kTuneUnset;
+    return 0;
+}
+
+#ifdef HG_DIAG
+// -DHG_DIAG builds only: which == 0 the bounds pass (stream_kernels.hpp StreamArgs::dbg), 1 the tile scan (TileArgs::dbg)
+int hnswgpu_debug_set_ablation(int32_t which, int32_t value) {
+    (which == 0 ? hg::g_stream_dbg : hg::g_tile_dbg) = value;
+    return 0;
+}
+#endif
 
 int hnswgpu_debug_set_tile_stamps(void *device_buffer) {
     hg::g_tile_dbg_buf = static_cast<unsigned long long *>(device_buffer);

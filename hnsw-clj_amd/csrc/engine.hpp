@@ -12,6 +12,8 @@
 #include <utility>
 #include <vector>
 
+#include "tuning.hpp"
+
 #include "../../include/hnswgpu.h"
 #include "kernels.hpp"
 #include "tile_args.hpp"
@@ -277,6 +279,9 @@ int ensure_counters(hnswgpu_index *idx, size_t n, hipStream_t st);
 int scan_fused(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_query, int64_t max_rows, int64_t mean_rows,
                hipStream_t st, int prof_slot);
 extern unsigned long long *g_tile_dbg_buf;
+#ifdef HG_DIAG
+extern int g_stream_dbg, g_tile_dbg;
+#endif
 int launch_gather(int nch, GatherArgs a, int32_t nq, hipStream_t st);
 int scan_rows_per_iter(int nch);  // kNWave * RB
 
@@ -295,7 +300,7 @@ int upload_queries(hnswgpu_index *idx, const float *Q, int32_t nq, hipStream_t s
 
 // --- tiled (MFMA) scan path -------------------------------------------------------------------------
 bool tile_path_ok(const hnswgpu_index *idx);  // metric != L2 and dim fits the LDS-resident query group
-int tile_mode();                               // HNSWGPU_TILE: -1 auto, 0 never, 1 whenever possible
+int tile_mode();                               // HNSWGPU_TUNE_TILE: -1 auto, 0 never, 1 whenever possible
 int launch_tile(const TileArgs &a, int64_t ngroups_bound, int dim, hipStream_t st);
 int launch_select(const SelectArgs &a, hipStream_t st);
 // queries (nq x dim, row stride qld) -> s_qp (nq x ld, zero padded) + s_qn (device-order norms)

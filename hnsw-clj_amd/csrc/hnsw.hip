@@ -24,28 +24,23 @@ static size_t hnsw_lds_bytes(int cap, int nwords, int nw) {
 
 constexpr size_t kMaxLds = 160 * 1024;
 
-// tuning override (HNSWGPU_HNSW_NW=1|2|4), read once; 0 = choose by batch size
-static int g_hnsw_nw = []() {
-    const char *e = getenv("HNSWGPU_HNSW_NW");
-    int v = e ? atoi(e) : 0;
-    return (v == 1 || v == 2 || v == 4) ? v : 0;
-}();
+// tuning override (HNSWGPU_TUNE_HNSW_NW = 1 | 2 | 4); 0 = choose by batch size
+static int hnsw_nw() {
+    const int64_t v = tune(HNSWGPU_TUNE_HNSW_NW, 0);
+    return (v == 1 || v == 2 || v == 4) ? static_cast<int>(v) : 0;
+}
 
 // Visited-set placement: an LDS bitset while it leaves room for several workgroups per CU, otherwise
 // generation stamps in HBM (4 B per row per resident workgroup; 288 GB makes that cheap).
 constexpr int64_t kLdsVisitedMaxRows = 262144;  // 32 KiB bitset
-static int g_force_vg = []() {
-    const char *e = getenv("HNSWGPU_VIS");  // testing override: "global" forces the HBM stamps
-    return (e && e[0] == 'g') ? 1 : 0;
-}();
+static bool force_vg() { return tune(HNSWGPU_TUNE_VIS_GLOBAL, 0) != 0; }  // testing override: the HBM stamps at every size
 
 // helper workgroups per query that prefetch neighbour rows into the query's XCD L2 (kernels.hpp, HnswArgs::pf_mail);
-// HNSWGPU_PREFETCH=<G> overrides (0 = off)
-static const int g_pf_groups = []() {
-    const char *e = getenv("HNSWGPU_PREFETCH");
-    const int v = e ? atoi(e) : 4;
-    return v < 0 ? 0 : (v > 16 ? 16 : v);
-}();
+// HNSWGPU_TUNE_PREFETCH = <G> overrides (0 = off)
+static int pf_groups() {
+    const int64_t v = tune(HNSWGPU_TUNE_PREFETCH, 4);
+    return v < 0 ? 0 : (v > 16 ? 16 : static_cast<int>(v));
+}
 constexpr int kPfMaxQueries = 128;  // up to half a CU count of queries: every traversal and at least one helper per query get a CU
 
 int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
@@ -58,16 +53,16 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     // 31k x 768, ef 100, ms per launch without / with: 256 queries 0.537 / 0.571, 512: 0.607 / 0.590, 768: 0.817 /
     // 0.611, 1024: 1.05 / 0.74, 10000: 9.9 / 4.4 (tools/hnsw_batch_sweep.py) -- on from two queries per CU.
     if (!(idx->rejection_mode == 2 || (idx->rejection_mode == 1 && a.nq >= 2 * idx->cus && idx->dim >= 128))) a.qrows = nullptr;
-    const bool vg = g_force_vg || a.n > kLdsVisitedMaxRows;
-    const bool pf = g_pf_groups > 0 && !vg && !a.q_rows && !a.q_index && a.nq <= kPfMaxQueries && g_hnsw_nw == 0 &&
+    const bool vg = force_vg() || a.n > kLdsVisitedMaxRows;
+    const bool pf = pf_groups() > 0 && !vg && !a.q_rows && !a.q_index && a.nq <= kPfMaxQueries && hnsw_nw() == 0 &&
                     a.n < (1LL << 31) && a.M0 <= kMaxDeg;
     // waves per query.  Measured on 31k x 768, ef 128 (tools/tune_hnsw.py): a query takes 1.1 / 1.4 / 2.0 ms
     // with 4 / 2 / 1 waves, and a CU holds 3 / 6 / 12 such workgroups (VGPR-limited), so once a batch
     // exceeds one residency round fewer waves per query win: 10,000 queries run at 601k / 776k / 802k QPS.
-    int nw = g_hnsw_nw > 0 ? g_hnsw_nw : (a.nq > 1536 ? 1 : (a.nq > 768 ? 2 : 4));
+    int nw = hnsw_nw() > 0 ? hnsw_nw() : (a.nq > 1536 ? 1 : (a.nq > 768 ? 2 : 4));
     // with the rejection test (fewer f32 rows in flight, below) a CU holds 4 / 8 / 20 such workgroups up to dim 768:
     // 1,024 queries 0.60 / 0.68 / 0.96 ms with 4 / 2 / 1 waves, 2,048: 1.15 / 0.93 / 1.06, 3,072: 1.68 / 1.51 / 1.36
-    if (g_hnsw_nw == 0 && a.qrows && nch <= 3) nw = a.nq > 2048 ? 1 : (a.nq > 1024 ? 2 : 4);
+    if (hnsw_nw() == 0 && a.qrows && nch <= 3) nw = a.nq > 2048 ? 1 : (a.nq > 1024 ? 2 : 4);
     int grid = a.nq;
     if (a.q_index) {  // repeat pass: few (usually no) work items, one large-list workgroup per CU at most
         nw = 4;
@@ -77,13 +72,8 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
         // one mailbox per query; four regions in rotation, so that launches in flight (two Slots) never share one
         nw = 4;
         // as many helper workgroups per query as find a CU of their own beside the traversals (at most the configured number)
-        a.pf_groups = std::max(1, std::min(g_pf_groups, idx->cus / std::max(a.nq, 1) - 1));
-        static const int hints = []() {
-            const char *e = getenv("HNSWGPU_PF_HINTS");
-            const int v = e ? atoi(e) : 4;
-            return v < 1 ? 1 : (v > 32 ? 32 : v);
-        }();
-        a.pf_hints = hints;
+        a.pf_groups = std::max(1, std::min(pf_groups(), idx->cus / std::max(a.nq, 1) - 1));
+        a.pf_hints = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(32, tune(HNSWGPU_TUNE_PF_HINTS, 4))));
         grid = 8 * ((a.nq + 7) / 8) * (1 + a.pf_groups);
         // per region: the mailboxes, then the helpers' published bounds [query][ring slot][neighbour slot]
         const size_t mail_bytes = sizeof(uint32_t) * kPfMailWords * kPfMaxQueries;
@@ -108,10 +98,7 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
         a.pf_seq = idx->pf_seq;
         char *reg = static_cast<char *>(idx->s_pf.p) + (idx->pf_seq & 3) * region;
         a.pf_mail = reinterpret_cast<uint32_t *>(reg);
-        static const int pf_eval = []() {
-            const char *e = getenv("HNSWGPU_PF_EVAL");  // 0 = the helpers only warm the L2 (A/B)
-            return e ? atoi(e) : 1;
-        }();
+        const bool pf_eval = tune(HNSWGPU_TUNE_PF_EVAL, 1) != 0;  // 0 = the helpers only warm the L2 (A/B)
         if (pf_eval) {
             // the helpers evaluate the neighbours of the hinted nodes and publish the distances (kernels.hpp: pf_res); the
             // traversal's own int8 bounds pass stays off: for a handful of queries it costs what it saves
@@ -305,7 +292,7 @@ static int search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int3
     // ... and are repeated, on the device and without a host round trip, with the largest candidate list the LDS
     // holds, so that every tie the reference would still expand (ultra_fast.clj:175-178, `<=`) is kept.  The pass
     // finds no work item on ordinary data (a few microseconds).
-    const int vgw = (g_force_vg || idx->n > kLdsVisitedMaxRows) ? 0 : static_cast<int>((idx->n + 31) / 32);
+    const int vgw = (force_vg() || idx->n > kLdsVisitedMaxRows) ? 0 : static_cast<int>((idx->n + 31) / 32);
     const size_t fixed = hnsw_lds_bytes(0, vgw, 4);
     const int64_t cap_max = static_cast<int64_t>((kMaxLds - fixed) / (2 * sizeof(uint2) + sizeof(int32_t)));
     const int32_t big = static_cast<int32_t>(std::min<int64_t>(cap_max - ef, idx->n));
@@ -671,10 +658,7 @@ static int check_hnsw_args(const hnswgpu_index *idx, const void *Q, int32_t nq, 
     return 0;
 }
 
-static const bool g_zero_copy = []() {
-    const char *e = getenv("HNSWGPU_ZEROCOPY");  // 0 = always stage through copies (A/B measurements)
-    return !e || atoi(e) != 0;
-}();
+static bool zero_copy() { return tune(HNSWGPU_TUNE_ZEROCOPY, 1) != 0; }  // 0 = always stage through copies (A/B measurements)
 
 // Small combined batches (at most one workgroup per CU): the queries are written into a block of mapped pinned host
 // memory, the traversal kernel reads them from there and writes ids / distances / counters back into the same block,
@@ -754,7 +738,7 @@ static int hnsw_search_batch_slot(hnswgpu_index *idx, const std::vector<hnswgpu_
 // One launch for a set of queued synchronous requests with the same (k, ef): queries concatenated on the host,
 // results scattered back (see hnswgpu_index::SearchReq).
 static int hnsw_search_batch(hnswgpu_index *idx, const std::vector<hnswgpu_index::SearchReq *> &batch, int32_t total) {
-    if (g_zero_copy && total <= kZcMaxQueries && !g_force_vg && idx->n <= kLdsVisitedMaxRows)
+    if (zero_copy() && total <= kZcMaxQueries && !force_vg() && idx->n <= kLdsVisitedMaxRows)
         return hnsw_search_batch_slot(idx, batch, total);
     const int32_t k = batch[0]->k, ef = batch[0]->ef;
     const int64_t cnt = static_cast<int64_t>(total) * k;
@@ -923,12 +907,12 @@ static int insert_batches(hnswgpu_index *idx, HostGraph &g, int64_t done, int ef
     g.flagu.assign(std::max<int64_t>(blocks, 1), 0);
     // linker threads: at most 16 (a GPU box's CPU share per GPU), HNSWGPU_BUILD_THREADS overrides (1 = sequential)
     int nthreads = static_cast<int>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
-    if (const char *e = getenv("HNSWGPU_BUILD_THREADS")) nthreads = std::max(1, std::min(64, atoi(e)));
+    if (const int64_t e = tune(HNSWGPU_TUNE_BUILD_THREADS, 0)) nthreads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(64, e)));
     if (n - done < 256) nthreads = 1;  // a handful of rows: no pool to start
     LinkPool pool(nthreads);
     std::vector<HostGraph::Dirty> dirties(pool.size());
     PinnedBuf pin;
-    const bool timing = getenv("HNSWGPU_BUILD_TIMING") != nullptr;  // developer switch: where a build spends its time
+    const bool timing = tune(HNSWGPU_TUNE_BUILD_TIMING, 0) != 0;  // developer switch: where a build spends its time
     double t_gpu = 0.0, t_link = 0.0, t_up = 0.0;
     int64_t nbatch = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

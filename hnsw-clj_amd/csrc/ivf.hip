@@ -12,11 +12,6 @@
 
 namespace hg {
 
-// tuning / test switches that are read on EVERY call (the tests flip them inside one process)
-static int64_t env_now(const char *name, int64_t dflt) {
-    const char *e = getenv(name);
-    return e ? atoll(e) : dflt;
-}
 
 // probes[q][p] = p-th nearest centroid; pairs[q*nprobe+p] = that list's row range + the offset of
 // its rows in the query's concatenated candidate stream (ties are broken in that order, which is
@@ -530,10 +525,7 @@ static int kmeanspp_device(hnswgpu_index *idx, int32_t nlist, int64_t seed, std:
     chosen[0] = cur;
     // with int8 rows a round reads them and fetches f32 rows only where the new centre may be nearest (seed_update_kernel):
     // the same minima (1M x 768 / 1024 lists: 0.47 -> ~0.12 ms per round, the whole build 0.78 -> 0.42 s)
-    static const int seed_bounds = []() {
-        const char *e = getenv("HNSWGPU_SEED_BOUNDS");  // 0 = every round a full f32 pass (A/B)
-        return e ? atoi(e) : 1;
-    }();
+    const int seed_bounds = static_cast<int>(tune(HNSWGPU_TUNE_SEED_BOUNDS, 1));  // 0 = every round a full f32 pass (A/B)
     if (seed_bounds) HG_TRY(ensure_qrows(idx, st));
     for (int c = 1; c < nlist; c++) {
         if (seed_bounds && idx->d_qrows) {
@@ -639,10 +631,7 @@ static int plan_groups(hnswgpu_index *idx, int32_t nq, int32_t nprobe, const int
     const int64_t mean = std::max<int64_t>(1, idx->n / std::max(nlist, 1));
     const int64_t est_groups = std::max<int64_t>(1, npairs / tq + nlist / 2);
     const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows;
-    static const int64_t tgt = []() {
-        const char *e = getenv("HNSWGPU_TILE_WGS");  // tuning override
-        return e ? atoll(e) : 2048LL;
-    }();
+    const int64_t tgt = tune(HNSWGPU_TUNE_TILE_WGS, 2048);
     const int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + est_groups - 1) / est_groups));
     int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows;
     if (ptiles > 0) cr = std::max<int64_t>(1, std::min<int64_t>(ptiles, mean_tiles)) * kTileRows;
@@ -695,10 +684,7 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
     const int tq = tile_tq(idx->dim);
     // persistent workgroups pulling items off a queue (tile_scan_kernel): items of up to `ptiles` tiles, however many
     // there are -- the queue balances them.  0 = one workgroup per item, items sized to fill the chip (round 1)
-    static const int64_t ptiles_env = []() {
-        const char *e = getenv("HNSWGPU_TILE_PERSIST");
-        return e ? atoll(e) : 4LL;
-    }();
+    const int64_t ptiles_env = tune(HNSWGPU_TUNE_TILE_PERSIST, 4);
     // the L2 group kernel takes one item per workgroup; few groups: shorter items, so that every CU has several
     const int64_t est_groups = std::max<int64_t>(1, npairs / tq + idx->nlist / 2);
     const int64_t ptiles = idx->metric == METRIC_L2 || gemv_order ? 0 : (ptiles_env == 4 && est_groups < 1200 ? 2 : ptiles_env);
@@ -768,7 +754,7 @@ static int stream_buckets(hnswgpu_index *idx, int32_t nq, int32_t nprobe, Stream
     (void)npairs;
     int64_t cap = std::max<int64_t>(64, (32LL << 20) / std::max(idx->nlist, 1) / 32 * 32);  // <= 256 MB of members
     cap = std::min<int64_t>(cap, (static_cast<int64_t>(nq) + 31) / 32 * 32);
-    const int64_t cap_env = env_now("HNSWGPU_STREAM_BUCKET", 0);  // tests: tiny buckets force the fallback
+    const int64_t cap_env = tune(HNSWGPU_TUNE_STREAM_BUCKET, 0);  // tests: tiny buckets force the fallback
     if (cap_env > 0) cap = cap_env;
     // members in s_misc; the counters in a buffer of their own that is zero between searches (a 4 KB memset is a 6 us
     // launch: a thirtieth of a batch-32 search)
@@ -810,10 +796,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     // rows per workgroup: whole tiles; enough working workgroups to fill the chip a few times over
     const int64_t mean = std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1));
     const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows, max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows;
-    static const int64_t tgt = []() {
-        const char *e = getenv("HNSWGPU_STREAM_WGS");  // tuning override
-        return e ? atoll(e) : 2048LL;
-    }();
+    const int64_t tgt = tune(HNSWGPU_TUNE_STREAM_WGS, 2048);
     const bool grouped = sc.bk_cnt != nullptr;
     const int64_t units = grouped ? std::min<int64_t>(npairs, idx->nlist) : npairs;  // lists (or pairs) that have work
     const int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + units - 1) / std::max<int64_t>(units, 1)));
@@ -828,7 +811,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         WorkDesc *desc = idx->s_misc2.as<WorkDesc>();
         int32_t *nit = reinterpret_cast<int32_t *>(desc + wbound);
         // (large batches: the query order of the half-precision pass and the finish kernel by a second workgroup of this launch)
-        const int64_t order_min = env_now("HNSWGPU_FINISH_ORDER", 512);  // 0 = never (A/B)
+        const int64_t order_min = tune(HNSWGPU_TUNE_FINISH_ORDER, 512);  // 0 = never (A/B)
         size_t olds = 0;
         if (d_probes && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists) {
             HG_TRY(idx->s_stats.ensure(sizeof(int32_t) * static_cast<size_t>(nq)));  // (s_ids / s_outd may be the caller's outputs)
@@ -856,7 +839,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         blocks = npairs * b.nchunks;
     }
     // survivors per query that fit; a query with more takes the finish kernel's fallback (the plain f32 scan)
-    const int64_t cap_env = env_now("HNSWGPU_STREAM_CAP", 0);  // tests: a tiny list forces the fallback
+    const int64_t cap_env = tune(HNSWGPU_TUNE_STREAM_CAP, 0);  // tests: a tiny list forces the fallback
     int64_t cap = std::min<int64_t>(stride, std::max<int64_t>(4096, 4 * idx->max_list_len));
     if (cap_env > 0) cap = cap_env;
     cap = std::max<int64_t>(cap, 1);
@@ -871,28 +854,32 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     b.surv_cnt = sc.surv_cnt;
     b.surv = idx->s_tile.as<uint4>();
     b.cap = cap;
-    b.dbg = static_cast<int32_t>(env_now("HNSWGPU_STREAM_DBG", 0));
+#ifdef HG_DIAG
+    b.dbg = g_stream_dbg;  // ablation timing only (results are wrong on purpose): hnswgpu_debug_set_ablation
+#else
+    b.dbg = 0;
+#endif
     b.stamps = g_tile_dbg_buf;  // null outside diagnostic sessions
     // Once the exact pass would be the largest kernel (its rows are 3 KB each and every query fetches its own) the survivors
     // first meet their half-precision rows.  The survivors are a few per cent of the candidates: from ~1.5 M candidates per
     // batch (48 queries x 32 lists x 977 rows; 5 queries at 10 M rows) the pass saves more than its launch costs -- measured
     // at 1M x 768: batch 32 0.183 ms without vs 0.195 with, 64: 0.250 vs 0.243, 128: 0.298 vs 0.277.
     // HNSWGPU_STREAM_MID=<queries> overrides (tests: 1 = always; 0 = never).
-    const int64_t mid_env = env_now("HNSWGPU_STREAM_MID", -1);
+    const int64_t mid_env = tune(HNSWGPU_TUNE_STREAM_MID, -1);
     const int64_t cand = npairs * mean;
     const bool mid = idx->d_lhalf != nullptr && !idx->ivf_calibrating && (mid_env >= 0 ? (mid_env > 0 && nq >= mid_env) : cand >= 1500000);
     b.defer = mid ? 1 : 0;
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);
     // which epilogue: few queries per probed list -> lane = row (a list probed by more takes several passes); many -> lane = query
-    const int64_t narrow_env = env_now("HNSWGPU_STREAM_NARROW", -1);  // A/B: 0 / 1 force
+    const int64_t narrow_env = tune(HNSWGPU_TUNE_STREAM_NARROW, -1);  // A/B: 0 / 1 force
     const bool narrow = narrow_env >= 0 ? narrow_env != 0 : npairs < 6LL * idx->nlist;
     HG_TRY(launch_stream_bounds(b, blocks, idx->nch, narrow, st));
     prof_end(idx, PROF_IVF_SCAN, st, e0);
     // Large batches: a query's survivors are, above all, its nearest list -- and several queries share one.  The queries are
     // taken in the order of their nearest list, a contiguous eighth of that order per XCD, so that the queries which read
     // the same rows run side by side on ONE L2 (each XCD otherwise fetches the list for itself).
-    const int64_t order_min = env_now("HNSWGPU_FINISH_ORDER", 512);  // 0 = never (A/B)
+    const int64_t order_min = tune(HNSWGPU_TUNE_FINISH_ORDER, 512);  // 0 = never (A/B)
     if (!qorder && d_probes && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists) {  // (ungrouped launches)
         HG_TRY(idx->s_stats.ensure(sizeof(int32_t) * static_cast<size_t>(nq)));  // (s_ids / s_outd may be the caller's outputs)
         const size_t olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);
@@ -909,8 +896,8 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     FinishArgs f;
     memset(&f, 0, sizeof(f));
     f.prepass = mid ? 1 : 0;
-    f.adapt = static_cast<int32_t>(env_now("HNSWGPU_FINISH_ADAPT", 1));        // A/B
-    f.bisect_min = static_cast<int32_t>(env_now("HNSWGPU_FINISH_BISECT", 1));  // A/B
+    f.adapt = static_cast<int32_t>(tune(HNSWGPU_TUNE_FINISH_ADAPT, 1));        // A/B
+    f.bisect_min = static_cast<int32_t>(tune(HNSWGPU_TUNE_FINISH_BISECT, 1));  // A/B
     f.dbg = g_tile_dbg_buf;
     f.surv = b.surv;
     f.surv_cnt = b.surv_cnt;
@@ -927,8 +914,8 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     // (measured at batch 32, slices 16 / 32 / 64 / 128: 0.176 / 0.169 / 0.176 / 0.184 ms; one query: 64 is best)
     f.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(64, (mid ? 512 : (nq <= 64 ? 1024 : 2048)) / nq)));
     f.span = nq <= 32 ? 16 : 64;
-    if (const int64_t sl = env_now("HNSWGPU_FINISH_SLICES", 0)) f.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(sl, 256)));  // tuning
-    if (const int64_t sp = env_now("HNSWGPU_FINISH_SPAN", 0)) f.span = sp >= 64 ? 64 : (sp >= 32 ? 32 : 16);
+    if (const int64_t sl = tune(HNSWGPU_TUNE_FINISH_SLICES, 0)) f.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(sl, 256)));  // tuning
+    if (const int64_t sp = tune(HNSWGPU_TUNE_FINISH_SPAN, 0)) f.span = sp >= 64 ? 64 : (sp >= 32 ? 32 : 16);
     f.rows = idx->d_lrows;
     f.row_norms = idx->d_lnorms;
     f.ld = idx->ld;
@@ -940,7 +927,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     // query fewer than eight, the queries with more than 4096 survivors -- and the overflowed ones, whose finish is the
     // plain f32 scan of every candidate -- are listed, and 32 x 64 extra workgroups per launch take them in 64 slices.
     const int64_t mid_slices = !mid ? 0 : (qorder ? 1 : std::max<int64_t>(1, std::min<int64_t>(16, 4096 / nq)));
-    const bool heavy = env_now("HNSWGPU_STREAM_HEAVY", 1) != 0 && ((mid && mid_slices < 8) || f.slices < 8);
+    const bool heavy = tune(HNSWGPU_TUNE_STREAM_HEAVY, 1) != 0 && ((mid && mid_slices < 8) || f.slices < 8);
     constexpr int kHeavySlices = 64;
     const size_t keys = static_cast<size_t>(nq) * (heavy ? std::max(f.slices, kHeavySlices) : f.slices) * (k <= kWave ? 1 : kNWave) * k;
     HG_TRY(idx->s_partial.ensure(sizeof(uint64_t) * keys));
@@ -950,8 +937,8 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         ha.surv_cnt = b.surv_cnt;
         ha.nq = nq;
         ha.cap = static_cast<uint32_t>(cap);
-        ha.times_mean = static_cast<uint32_t>(env_now("HNSWGPU_STREAM_HEAVY_MEAN", 4));
-        ha.thr = static_cast<uint32_t>(std::min<int64_t>(cap, env_now("HNSWGPU_STREAM_HEAVY_MIN", 4096)));
+        ha.times_mean = static_cast<uint32_t>(tune(HNSWGPU_TUNE_STREAM_HEAVY_MEAN, 4));
+        ha.thr = static_cast<uint32_t>(std::min<int64_t>(cap, tune(HNSWGPU_TUNE_STREAM_HEAVY_MIN, 4096)));
         ha.cnt = idx->s_heavy.as<uint32_t>();
         ha.list = idx->s_heavy.as<int32_t>() + 4;
         HG_TRY(launch_heavy(ha, st));
@@ -977,13 +964,13 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         ma.cap = cap;
         ma.nq = nq;
         ma.slices = qorder ? 1 : static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(16, 4096 / nq)));
-        if (const int64_t sl = env_now("HNSWGPU_MID_SLICES", 0)) ma.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(sl, 64)));  // tuning
+        if (const int64_t sl = tune(HNSWGPU_TUNE_MID_SLICES, 0)) ma.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(sl, 64)));  // tuning
         ma.qorder = ma.slices == 1 ? qorder : nullptr;
         // one workgroup per query sees the whole list: it also applies the threshold of the upper bounds and compacts the
         // list (up to 4096 entries: 16 KB of LDS -- more would cost the kernel its occupancy; a longer list is left to the finish kernel's own pass)
         ma.tau = b.tau;
         ma.k = k;
-        ma.compact = ma.slices == 1 && env_now("HNSWGPU_MID_COMPACT", 1) ? static_cast<int32_t>(std::min<int64_t>(cap, 4096)) : 0;
+        ma.compact = ma.slices == 1 && tune(HNSWGPU_TUNE_MID_COMPACT, 1) ? static_cast<int32_t>(std::min<int64_t>(cap, 4096)) : 0;
         ma.half = idx->d_lhalf;
         ma.hmeta = idx->d_lhmeta;
         ma.ld = idx->ld;
@@ -1032,12 +1019,12 @@ static int32_t ivf_stream_max_k(const hnswgpu_index *idx) {
 static bool ivf_codes_usable(const hnswgpu_index *idx, int32_t k) {
     return idx->d_lctile != nullptr &&
            (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128 && !idx->ivf_stream_off)) &&
-           tile_mode() != 0 && k <= ivf_stream_max_k(idx) && env_now("HNSWGPU_IVF_CODES", 1) > 0;
+           tile_mode() != 0 && k <= ivf_stream_max_k(idx) && tune(HNSWGPU_TUNE_IVF_CODES, 1) > 0;
 }
 // the boundary of the two summation orders for this handle and k (HNSWGPU_TILE_PAIRS overrides: the parity suite pins it
 // at 12 so that its small indexes still reach the tile path)
 static int64_t ivf_tile_pairs(const hnswgpu_index *idx, int32_t k) {
-    const int64_t e = env_now("HNSWGPU_TILE_PAIRS", 0);
+    const int64_t e = tune(HNSWGPU_TUNE_TILE_PAIRS, 0);
     if (e > 0) return e;
     if (!ivf_codes_usable(idx, k)) return kTilePairs;
     return idx->d_lhalf ? kTilePairsNever : kTilePairsCoded;
@@ -1056,7 +1043,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
 // mode 0 never builds it).  The decision depends on the rows and the lists only: the same handle always takes the same path.
 static int ivf_calibrate(hnswgpu_index *idx, hipStream_t st) {
     idx->ivf_calibrated = true;
-    if (idx->rejection_mode != 1 || !idx->d_lctile || idx->dim < 128 || idx->n < 4096 || env_now("HNSWGPU_IVF_CALIBRATE", 1) == 0) return 0;
+    if (idx->rejection_mode != 1 || !idx->d_lctile || idx->dim < 128 || idx->n < 4096 || tune(HNSWGPU_TUNE_IVF_CALIBRATE, 1) == 0) return 0;
     const int32_t cq = 32, ck = 10, cp = std::min(32, idx->nlist);
     float *d_q = nullptr;
     int32_t *d_i = nullptr;
@@ -1113,7 +1100,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     // GEMV vs tiled, end to end): batch 32: 0.42 vs 0.56 ms; 48: 0.54 vs 0.61; 64: 0.64 vs 0.64; 80: 0.72 vs 0.65;
     // 96: 0.82 vs 0.71; 128: 1.03 vs 0.71.
     const int tm = tile_mode();
-    const int code_env = static_cast<int>(env_now("HNSWGPU_IVF_CODES", 1));  // 0 = never (A/B), N > 0 = from N queries per batch
+    const int code_env = static_cast<int>(tune(HNSWGPU_TUNE_IVF_CODES, 1));  // 0 = never (A/B), N > 0 = from N queries per batch
     // the survivor stream (stream_kernels.hpp): k up to a tile chunk's rows can get a threshold from one chunk
     const bool codes_ok = idx->d_lctile != nullptr &&
                           (idx->rejection_mode == 2 || (idx->rejection_mode == 1 && idx->dim >= 128 && !idx->ivf_stream_off)) &&
@@ -1132,18 +1119,12 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     int32_t *qcnt_buf = nullptr;
     // GEMV scan with enough pairs for lists to be probed twice: run the pairs in list order (see ScanArgs::order).
     // Below half a pair per list there is next to nothing to share and the sort's ~10 us would be all cost.
-    static const int order_mode = []() {
-        const char *e = getenv("HNSWGPU_SCAN_ORDER");  // 0 = never (A/B)
-        return e ? atoi(e) : 1;
-    }();
+    const int order_mode = static_cast<int>(tune(HNSWGPU_TUNE_SCAN_ORDER, 1));  // 0 = never (A/B)
     // A handful of queries: the launches around the list scan (select, probe table, merge, decode, copy) cost as much as
     // the scan, so their work is folded into the routing and scan kernels' last workgroups (two launches instead of
     // seven; 1M x 768, one query: 99 -> 88 us per call, 78 -> 74 us back to back).  Larger batches keep the separate
     // launches: their merge runs one workgroup per query in parallel, and a tail would only lengthen the scan kernel.
-    static const int fused_env = []() {
-        const char *e = getenv("HNSWGPU_IVF_FUSED");  // 0 = never, 1 = small batches (default), 2 = every GEMV-path batch
-        return e ? atoi(e) : 1;
-    }();
+    const int fused_env = static_cast<int>(tune(HNSWGPU_TUNE_IVF_FUSED, 1));  // 0 = never, 1 = small batches (default), 2 = every GEMV-path batch
     const bool fused_mode = !use_code && (fused_env == 2 || (fused_env == 1 && nq <= 8));
     // Without int8 rows, from 1.5 pairs per list up to that boundary: the register-row group kernel (l2_kernels.hpp) fetches a list once for
     // all the queries probing it and keeps the GEMV summation order, so the results stay bit-identical to the GEMV
@@ -1151,10 +1132,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     // Same index, GEMV vs group, list-scan kernel / end to end: batch 32: 0.356 / 0.423 vs 0.331 / 0.423 ms;
     // 48: 0.464 / 0.531 vs 0.431 / 0.527; 64: 0.572 / 0.643 vs 0.488 / 0.589 (about 885 distinct lists x 3 MB at
     // ~5.5 TB/s).  The three extra launches (histogram, plan, scatter) cost what the kernel gains below 1.5 pairs per list.
-    static const int group_env = []() {
-        const char *e = getenv("HNSWGPU_IVF_GROUP");  // 0 = never (A/B), 2 = from half a pair per list
-        return e ? atoi(e) : 1;
-    }();
+    const int group_env = static_cast<int>(tune(HNSWGPU_TUNE_IVF_GROUP, 1));  // 0 = never (A/B), 2 = from half a pair per list
     const bool use_group = !use_tile && !use_code && !fused_mode && group_env && tm != 0 && idx->dim <= kL2MaxDim &&
                            (group_env == 2 ? npairs * 2 >= idx->nlist : npairs * 2 >= 3LL * idx->nlist);
     const bool use_order = !use_tile && !use_group && !use_code && order_mode && idx->nlist <= kOrderMaxLists &&
@@ -1171,17 +1149,16 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     // still use both for padded queries and norms, and must not move s_qn afterwards)
     StreamScratch sc;
     memset(&sc, 0, sizeof(sc));
-    const int stream_route_max = static_cast<int>(env_now("HNSWGPU_STREAM_ROUTE", 12));  // largest batch routed by the one-launch routing kernel
-    const int stream_group_min = static_cast<int>(env_now("HNSWGPU_STREAM_GROUP", 5));    // queries from which the bounds pass groups the pairs by list
+    const int stream_route_max = static_cast<int>(tune(HNSWGPU_TUNE_STREAM_ROUTE, 12));  // largest batch routed by the one-launch routing kernel
+    const int stream_group_min = static_cast<int>(tune(HNSWGPU_TUNE_STREAM_GROUP, 5));    // queries from which the bounds pass groups the pairs by list
     if (use_code) {
         HG_TRY(stream_scratch(idx, nq, sc));
         if (nq >= stream_group_min) HG_TRY(stream_buckets(idx, nq, nprobe, sc, st));  // (zeroes the per-list counters)
     }
     bool codes_done = false;
-    static const int route_group_min = []() {
-        const char *e = getenv("HNSWGPU_ROUTE_GROUP");  // queries from which a GEMV-order batch routes through the group kernel
-        return e ? atoi(e) : 1024;  // Euclidean 1M x 768: 512 queries 0.85 vs 0.87 ms (GEMV vs group), 1024: 1.50 vs 1.43, 4096: 5.08 vs 4.70
-    }();
+    // queries from which a GEMV-order batch routes through the group kernel
+    // (Euclidean 1M x 768: 512 queries 0.85 vs 0.87 ms (GEMV vs group), 1024: 1.50 vs 1.43, 4096: 5.08 vs 4.70)
+    const int route_group_min = static_cast<int>(tune(HNSWGPU_TUNE_ROUTE_GROUP, 1024));
     if (d_given_probes) {  // caller-chosen lists (the :turbo mode's random partitions, :271-272); -1 = none
         hipLaunchKernelGGL(probe_pairs_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st,
                            reinterpret_cast<const uint32_t *>(d_given_probes), nq, nprobe, idx->d_listoff, glistoff,

@@ -230,7 +230,7 @@ struct StreamArgs {
     uint32_t *surv_cnt;  // [nq] survivors appended so far (may exceed cap: the query then takes the fallback)
     uint4 *surv;         // [nq][cap] (order key, list row, lb bits, ub bits)
     int64_t cap;
-    int32_t dbg;         // developer ablation switches (HNSWGPU_STREAM_DBG); 0 in production
+    int32_t dbg;         // developer ablation switches (-DHG_DIAG builds: hnswgpu_debug_set_ablation); 0 in the product
     int32_t defer;       // the half-precision pass follows: the wide epilogue appends entries without bounds (template DEFER)
     unsigned long long *stamps;  // -DHG_IVF_STAMPS diagnostic builds only
 };

@@ -98,7 +98,7 @@ struct TileArgs {
     // (implicit groups only; the caller presets out_key[q] = ~0)
     unsigned long long *out_key;
     int32_t gemv_order;  // cosine / dot through the register-row group kernel (GEMV summation order) instead of MFMA tiles
-    int32_t dbg;  // developer ablation switches (HNSWGPU_TILE_DBG); 0 in production
+    int32_t dbg;  // developer ablation switches (-DHG_DIAG builds: hnswgpu_debug_set_ablation); 0 in the product
     unsigned long long *dbg_buf;  // diagnostic builds only: per-workgroup {start, end, hw id, tiles} stamps
 };
 

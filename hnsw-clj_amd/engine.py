@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native
-from ._native import COSINE, DOT, L2, check, lib
+from ._native import COSINE, DOT, L2, check, get_tuning, lib, set_tuning  # noqa: F401
 
 METRICS = {"cosine": COSINE, "l2": L2, "euclidean": L2, "dot": DOT, COSINE: COSINE, L2: L2, DOT: DOT}
 PROF_IVF_SCAN, PROF_HNSW, PROF_ASSIGN = 0, 1, 2

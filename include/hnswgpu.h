@@ -274,6 +274,63 @@ int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode);
 int hnswgpu_get_rejection_stats(hnswgpu_index *idx, int64_t *f32_rows, int64_t *neighbours, int32_t reset);
 int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int64_t *launches, int32_t reset);
 
+/* ---- tuning and test switches --------------------------------------------------------------------------------------
+ * One process-wide table of 64-bit values.  NONE of them changes what a search returns within the contract of the path
+ * it selects (ids, distance bits, tie order -- the GEMV and the MFMA summation orders differ in the last bits, and
+ * TILE_PAIRS / TILE / IVF_CODES / PREFILTER choose between them exactly as the batch size otherwise does): they pick
+ * between equivalent schedules, or shrink scratch buffers so that tests reach the fallback paths at test size
+ * (tests/test_gpu_parity.py).  The library calls getenv for SIX names only, once, when it is loaded (the keys marked
+ * `env`); no search path reads the environment.  HNSWGPU_TUNE_DEFAULT as the value restores a key's default.
+ * Diagnostic switches that make results WRONG on purpose (kernels with their epilogue cut out, for ablation timing)
+ * exist only in -DHG_DIAG builds (tools/build_stamps.sh), not in this library. */
+#define HNSWGPU_TUNE_DEFAULT INT64_MIN
+#define HNSWGPU_TUNE_TILE_PAIRS 0 /* (query, list) pairs per list beyond which a cosine / dot IVF batch takes the f32 MFMA tile scan (k-ordered sums) instead of the GEMV-order paths; 0 = the handle's own rule (never on handles with int8 + half-precision list rows, 12 without).  env HNSWGPU_TILE_PAIRS */
+#define HNSWGPU_TUNE_PREFILTER 1 /* default hnswgpu_set_rejection_test mode of NEW handles (0 / 1 / 2).  env HNSWGPU_PREFILTER */
+#define HNSWGPU_TUNE_IVF_HALF 2 /* 0 = no half-precision copy of the IVF list rows (+50 % of the base).  env HNSWGPU_IVF_HALF */
+#define HNSWGPU_TUNE_IVF_CALIBRATE 3 /* 0 = mode-1 handles skip the first-search measurement of what the int8 bounds separate.  env HNSWGPU_IVF_CALIBRATE */
+#define HNSWGPU_TUNE_BUILD_THREADS 4 /* host threads of the HNSW linker (0 = min(16, cores)); the graph does not depend on it.  env HNSWGPU_BUILD_THREADS */
+#define HNSWGPU_TUNE_PREFETCH 5 /* helper workgroups per query of small HNSW launches (0 = none, default 4).  env HNSWGPU_PREFETCH */
+#define HNSWGPU_TUNE_SEED_BOUNDS 6 /* 0 = every k-means++ round a full f32 pass (A/B) */
+#define HNSWGPU_TUNE_TILE_WGS 7 /* target workgroup count of the tile scan's work list */
+#define HNSWGPU_TUNE_TILE_PERSIST 8 /* tiles per work item of the persistent tile scan (0 = one workgroup per item) */
+#define HNSWGPU_TUNE_STREAM_BUCKET 9 /* capacity of a list's bucket of (query, list) pairs; tests: tiny buckets force the fallback */
+#define HNSWGPU_TUNE_STREAM_WGS 10 /* target workgroup count of the bounds pass */
+#define HNSWGPU_TUNE_FINISH_ORDER 11 /* batch size from which queries are served in the order of their nearest list (0 = never) */
+#define HNSWGPU_TUNE_STREAM_CAP 12 /* survivors per query that fit; tests: a tiny list forces the f32-scan fallback */
+#define HNSWGPU_TUNE_STREAM_MID 13 /* batch size from which the half-precision pass runs (-1 = by candidate count, 0 = never, 1 = always) */
+#define HNSWGPU_TUNE_STREAM_NARROW 14 /* bounds-pass epilogue: -1 auto, 0 lane = query, 1 lane = row */
+#define HNSWGPU_TUNE_FINISH_ADAPT 15 /* 0 = short survivor lists are not spread over all waves (A/B) */
+#define HNSWGPU_TUNE_FINISH_BISECT 16 /* smallest k whose final merge bisects the key space (A/B) */
+#define HNSWGPU_TUNE_FINISH_SLICES 17 /* workgroups per query of the finish kernel (0 = auto) */
+#define HNSWGPU_TUNE_FINISH_SPAN 18 /* entries a finish wave looks at per step (0 = auto) */
+#define HNSWGPU_TUNE_STREAM_HEAVY 19 /* 0 = no separate service of heavy queries */
+#define HNSWGPU_TUNE_STREAM_HEAVY_MEAN 20 /* a heavy query has this many times the batch's mean survivors (default 4) */
+#define HNSWGPU_TUNE_STREAM_HEAVY_MIN 21 /* ... and at least this many (default 4096) */
+#define HNSWGPU_TUNE_MID_SLICES 22 /* workgroups per query of the half-precision pass (0 = auto) */
+#define HNSWGPU_TUNE_MID_COMPACT 23 /* 0 = the half-precision pass does not compact the list (A/B) */
+#define HNSWGPU_TUNE_IVF_CODES 24 /* 0 = never the survivor stream, N = from N queries per batch (default 1) */
+#define HNSWGPU_TUNE_SCAN_ORDER 25 /* 0 = GEMV list scans never run in list order (A/B) */
+#define HNSWGPU_TUNE_IVF_FUSED 26 /* 0 = never the fused two-launch search, 1 = small batches (default), 2 = every GEMV-path batch */
+#define HNSWGPU_TUNE_IVF_GROUP 27 /* 0 = never the register-row group kernel, 2 = from half a pair per list */
+#define HNSWGPU_TUNE_STREAM_ROUTE 28 /* largest batch routed by the one-launch routing kernel (default 12) */
+#define HNSWGPU_TUNE_STREAM_GROUP 29 /* queries from which the bounds pass groups the pairs by list (default 5) */
+#define HNSWGPU_TUNE_ROUTE_GROUP 30 /* queries from which a GEMV-order batch routes through the group kernel (default 1024) */
+#define HNSWGPU_TUNE_MID_WIDE 31 /* 0 = never eight waves per query in the half-precision pass (A/B) */
+#define HNSWGPU_TUNE_MERGE_W 32 /* waves per query of merge_topk_kernel (0 = auto) */
+#define HNSWGPU_TUNE_SCAN_BLOCKS 33 /* target workgroup count of the GEMV scan (0 = auto) */
+#define HNSWGPU_TUNE_ROUTE_WGS 34 /* target workgroup count of the routing distance pass */
+#define HNSWGPU_TUNE_TILE 35 /* -1 auto, 0 never the MFMA tile kernel, 1 whenever possible */
+#define HNSWGPU_TUNE_SELECT_W 36 /* waves per query of select_topk_kernel (0 = auto) */
+#define HNSWGPU_TUNE_HNSW_NW 37 /* waves per query of the traversal kernel: 1 / 2 / 4 (0 = by batch size) */
+#define HNSWGPU_TUNE_VIS_GLOBAL 38 /* 1 = the traversal's visited set in HBM stamps whatever the index size (tests) */
+#define HNSWGPU_TUNE_PF_HINTS 39 /* unexpanded list entries the traversal posts to its helpers per expansion (default 4) */
+#define HNSWGPU_TUNE_PF_EVAL 40 /* 0 = the helpers only warm the L2 (A/B) */
+#define HNSWGPU_TUNE_ZEROCOPY 41 /* 0 = small synchronous HNSW calls stage through copies instead of mapped pinned memory (A/B) */
+#define HNSWGPU_TUNE_BUILD_TIMING 42 /* 1 = hnswgpu_hnsw_build prints where its time went to stderr */
+#define HNSWGPU_TUNE_COUNT 43
+int hnswgpu_set_tuning(int32_t key, int64_t value);
+int hnswgpu_get_tuning(int32_t key, int64_t *value, int32_t *is_set);
+
 /* ---- ONE index over several GPUs (hnsw-clj_amd/csrc/group.hip) ---------------------------------------------------
  * The reference shards inside one process: search-partitioned scatters a query to its partitions, takes a top-k per
  * partition, concatenates, sorts and takes k (src/hnsw/ann/partition/partitioned_hnsw.clj:149-196).  A group gives the

@@ -16,6 +16,8 @@ os.environ.setdefault("HNSWGPU_PREFILTER", "2")
 # list on a handle with int8 rows, 12 without: the parity tests' small indexes sit on both sides of 12, so the test
 # processes pin it there (every regime then runs at test size); test_ivf_production_boundary covers the default.
 os.environ.setdefault("HNSWGPU_TILE_PAIRS", "12")
+# (both are among the six names the library reads from the environment, once, when it is loaded; every other switch a
+# test flips goes through hnswgpu_set_tuning: the `tune` fixture below)
 
 
 def pytest_configure(config):
@@ -37,3 +39,30 @@ def native_lib():
 
     _native.build()
     return _native
+
+
+class _Tune:
+    """hnswgpu_set_tuning for one test: set(name, value) / unset(name); every key goes back to what it was afterwards."""
+
+    def __init__(self, native):
+        self._n, self._saved = native, {}
+
+    def set(self, name, value):
+        self._saved.setdefault(name, self._n.get_tuning(name))
+        self._n.set_tuning(name, int(value))
+
+    def unset(self, name):
+        self._saved.setdefault(name, self._n.get_tuning(name))
+        self._n.set_tuning(name, None)
+
+    def restore(self):
+        for name, v in self._saved.items():
+            self._n.set_tuning(name, v)
+        self._saved.clear()
+
+
+@pytest.fixture
+def tune(native_lib):
+    t = _Tune(native_lib)
+    yield t
+    t.restore()

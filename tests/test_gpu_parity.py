@@ -331,7 +331,7 @@ def test_hnsw_build_small_and_degenerate(eng, oracle):
                 np.testing.assert_array_equal(st, ost, err_msg=tag)
 
 
-def test_hnsw_build_linker_threads_do_not_change_the_graph(eng, oracle, monkeypatch):
+def test_hnsw_build_linker_threads_do_not_change_the_graph(eng, oracle, tune):
     """The host linker applies a batch's edges with several threads (own lists by node range, reverse edges by
     target node mod T): every adjacency list must see the sequential loop's update sequence, so the graph is
     identical for 1, 3 and 16 threads -- levels, both adjacency arrays, entry point."""
@@ -341,7 +341,7 @@ def test_hnsw_build_linker_threads_do_not_change_the_graph(eng, oracle, monkeypa
     graphs = []
     with eng.Index(base) as idx:
         for nt in ("1", "3", "16"):
-            monkeypatch.setenv("HNSWGPU_BUILD_THREADS", nt)
+            tune.set("BUILD_THREADS", nt)
             idx.hnsw_build(8, 64, 7)
             graphs.append(idx.get_graph())
     for g in graphs[1:]:
@@ -657,7 +657,7 @@ def test_ivf_bounds_pass_agrees_and_rejects(eng, oracle, metric):
 
 
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
-def test_ivf_survivor_stream_regimes(eng, oracle, metric, monkeypatch):
+def test_ivf_survivor_stream_regimes(eng, oracle, metric, tune):
     """The survivor stream of the IVF list scan (stream_kernels.hpp) in each of its regimes, all bit-equal to the oracle:
     a handful of queries (every pair its own work item, no plan launch), grouped batches, survivor lists too small for
     what the bounds let through (HNSWGPU_STREAM_CAP: the finish kernel falls back to the candidate stream itself, i.e. the
@@ -681,40 +681,40 @@ def test_ivf_survivor_stream_regimes(eng, oracle, metric, monkeypatch):
             ids, d = idx.ivf_search(Q[:nq], k, nprobe)
             assert_exact(ids, d, want[key][0], want[key][1], "%s %s nq=%d k=%d nprobe=%d" % (what, metric, nq, k, nprobe))
 
-        monkeypatch.setenv("HNSWGPU_IVF_CODES", "1")         # the bounds pass from one query on
+        tune.set("IVF_CODES", "1")         # the bounds pass from one query on
         for nq, k, nprobe in [(1, 10, 8), (3, 5, 12), (4, 70, 6), (5, 10, 8), (12, 10, 12), (41, 10, 5), (41, 33, 12)]:
             if metric != "l2" and nq * nprobe > 12 * 50:
                 continue                                      # beyond 12 pairs per list cosine / dot take the MFMA order
             check(nq, k, nprobe, "stream")
-        monkeypatch.setenv("HNSWGPU_STREAM_CAP", "7")        # nothing fits: every query through the fallback
+        tune.set("STREAM_CAP", "7")        # nothing fits: every query through the fallback
         for nq, k, nprobe in [(1, 10, 8), (12, 10, 12), (41, 33, 12)]:
             if metric != "l2" and nq * nprobe > 12 * 50:
                 continue
             check(nq, k, nprobe, "fallback")
-        monkeypatch.setenv("HNSWGPU_STREAM_CAP", "300")      # some queries fit, some do not
+        tune.set("STREAM_CAP", "300")      # some queries fit, some do not
         check(12, 10, 12, "mixed fallback")
-        monkeypatch.delenv("HNSWGPU_STREAM_CAP")
-        monkeypatch.setenv("HNSWGPU_STREAM_BUCKET", "3")     # three pairs fit a list's bucket: most queries take the fallback
+        tune.unset("STREAM_CAP")
+        tune.set("STREAM_BUCKET", "3")     # three pairs fit a list's bucket: most queries take the fallback
         check(12, 10, 12, "full buckets")
         check(41, 10, 5, "full buckets")
-        monkeypatch.setenv("HNSWGPU_STREAM_ROUTE", "0")      # ... filed by the separate routing launches
+        tune.set("STREAM_ROUTE", "0")      # ... filed by the separate routing launches
         check(41, 33, 12 if metric == "l2" else 5, "full buckets, separate routing")
-        monkeypatch.delenv("HNSWGPU_STREAM_BUCKET")
-        monkeypatch.setenv("HNSWGPU_STREAM_ROUTE", "0")      # routing by the separate launches
+        tune.unset("STREAM_BUCKET")
+        tune.set("STREAM_ROUTE", "0")      # routing by the separate launches
         check(12, 10, 12, "separate routing")
-        monkeypatch.setenv("HNSWGPU_STREAM_GROUP", "1000")   # ungrouped work items for a mid-size batch as well
+        tune.set("STREAM_GROUP", "1000")   # ungrouped work items for a mid-size batch as well
         check(12, 10, 12, "ungrouped")
 
 
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
-def test_ivf_production_boundary(eng, oracle, metric, monkeypatch):
+def test_ivf_production_boundary(eng, oracle, metric, tune):
     """The default boundary between the two summation orders of a cosine / dot IVF search: with int8 and half-precision
     list rows (and k <= 256) the survivor stream -- GEMV order -- serves EVERY batch size; without them (mode 0), or for
     a k the stream does not serve, the MFMA tile scan takes over beyond 12 (query, list) pairs per list.  (The suite
     otherwise pins the boundary at 12.)"""
     O = oracle
     code = {"cosine": O.COSINE, "dot": O.DOT}[metric]
-    monkeypatch.delenv("HNSWGPU_TILE_PAIRS")
+    tune.unset("TILE_PAIRS")
     nlist, nprobe = 20, 10
     base = _data(O, 8000, 136, "clustered", num_clusters=20, noise_level=0.3, seed=81)
     Q = _data(O, 120, 136, "clustered", num_clusters=20, noise_level=0.3, seed=82)
@@ -830,7 +830,7 @@ def test_half_precision_bounds_hold_and_are_tight(eng, metric, dim):
 
 
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
-def test_ivf_half_precision_pass(eng, oracle, metric, monkeypatch):
+def test_ivf_half_precision_pass(eng, oracle, metric, tune):
     """The half-precision pass between the int8 bounds and the f32 rows (production: batches with 1.5 M candidates and
     more), bit-equal to the oracle: at its production threshold (a Euclidean batch of 170 over all 9000 rows), forced on for small batches in
     every slice configuration, next to survivor lists that overflow (those queries skip it and take the fallback), and
@@ -858,35 +858,35 @@ def test_ivf_half_precision_pass(eng, oracle, metric, monkeypatch):
         if metric == "l2":                                   # (cosine / dot: the suite pins such a batch to the tile scan)
             check(170, 10, 50, "production threshold")       # 170 x 9000 candidates
             check(150, 10, 50, "below the threshold", expect_few=False)
-        monkeypatch.setenv("HNSWGPU_IVF_CODES", "1")
-        monkeypatch.setenv("HNSWGPU_STREAM_MID", "1")        # from one query on
+        tune.set("IVF_CODES", "1")
+        tune.set("STREAM_MID", "1")        # from one query on
         for nq, k, nprobe in [(1, 10, 8), (3, 1, 12), (12, 10, 12), (41, 10, 5), (41, 70, 12)]:
             if metric != "l2" and nq * nprobe > 12 * 50:
                 continue
             check(nq, k, nprobe, "forced")
         for sl in ("1", "3", "64"):
-            monkeypatch.setenv("HNSWGPU_MID_SLICES", sl)
-            monkeypatch.setenv("HNSWGPU_FINISH_SLICES", sl)
+            tune.set("MID_SLICES", sl)
+            tune.set("FINISH_SLICES", sl)
             check(12, 10, 12, "slices " + sl)
-        monkeypatch.delenv("HNSWGPU_MID_SLICES")
-        monkeypatch.delenv("HNSWGPU_FINISH_SLICES")
-        monkeypatch.setenv("HNSWGPU_STREAM_CAP", "300")      # some survivor lists overflow: those queries take the fallback
+        tune.unset("MID_SLICES")
+        tune.unset("FINISH_SLICES")
+        tune.set("STREAM_CAP", "300")      # some survivor lists overflow: those queries take the fallback
         check(12, 10, 12, "mixed fallback", expect_few=False)
         # large batches give a query ONE workgroup per pass; the queries that is too little for (many survivors, or the
         # fallback's scan of every candidate) are listed and served by 64 slices each (ivf_heavy_kernel): forced here by
         # ordering from one query on (one workgroup per query) and a threshold of 8 / 100 survivors
-        monkeypatch.setenv("HNSWGPU_FINISH_ORDER", "1")
-        monkeypatch.setenv("HNSWGPU_FINISH_SLICES", "1")
-        monkeypatch.setenv("HNSWGPU_STREAM_HEAVY_MEAN", "0")  # (production: also at least four times the batch's mean)
+        tune.set("FINISH_ORDER", "1")
+        tune.set("FINISH_SLICES", "1")
+        tune.set("STREAM_HEAVY_MEAN", "0")  # (production: also at least four times the batch's mean)
         for thr in ("8", "100"):
-            monkeypatch.setenv("HNSWGPU_STREAM_HEAVY_MIN", thr)
+            tune.set("STREAM_HEAVY_MIN", thr)
             check(12, 10, 12, "heavy + fallback, threshold " + thr, expect_few=False)
             check(41, 33, 12 if metric == "l2" else 5, "heavy + fallback, threshold " + thr, expect_few=False)
-        monkeypatch.delenv("HNSWGPU_STREAM_CAP")
-        monkeypatch.setenv("HNSWGPU_STREAM_HEAVY_MIN", "8")
+        tune.unset("STREAM_CAP")
+        tune.set("STREAM_HEAVY_MIN", "8")
         check(41, 10, 5, "every query heavy", expect_few=False)
         check(3, 1, 12, "every query heavy", expect_few=False)
-        monkeypatch.setenv("HNSWGPU_STREAM_HEAVY_MEAN", "1")  # above the mean: about half of them
+        tune.set("STREAM_HEAVY_MEAN", "1")  # above the mean: about half of them
         check(41, 10, 5, "half the queries heavy", expect_few=False)
         idx.set_profiling(False)
 
@@ -1047,7 +1047,7 @@ def test_ivf_many_equal_distances(eng, oracle, metric):
 
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
 @pytest.mark.parametrize("dim", [5, 300, 768, 1000, 1536, 2048, 3072])
-def test_ivf_survivor_stream_every_row_width(eng, oracle, metric, dim, monkeypatch):
+def test_ivf_survivor_stream_every_row_width(eng, oracle, metric, dim, tune):
     """The survivor stream for every row-loader width (NCH = 1, 2, 3, 4, 6, 8, 12: 8 .. 96 MFMA steps per 32-row block, the
     operand pipeline with zero to eleven trips of its main loop), with both epilogues -- a handful of queries (one work item
     per pair), few queries per list (lane = row), many (lane = query) --, ragged lists over several tiles, exact ties and
@@ -1069,7 +1069,7 @@ def test_ivf_survivor_stream_every_row_width(eng, oracle, metric, dim, monkeypat
             assert metric == "l2" or nq * nprobe <= 12 * 7        # the GEMV-order side of the (pinned) boundary
             oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=code, mode=O.MODE_DEV)
             for mid in ("0", "1"):
-                monkeypatch.setenv("HNSWGPU_STREAM_MID", mid)
+                tune.set("STREAM_MID", mid)
                 idx.rejection_stats(reset=True)
                 ids, d = idx.ivf_search(Q[:nq], k, nprobe)
                 surv, cand = idx.rejection_stats(reset=True)
@@ -1079,7 +1079,7 @@ def test_ivf_survivor_stream_every_row_width(eng, oracle, metric, dim, monkeypat
 
 
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
-def test_ivf_routing_and_merge_break_ties_by_position(eng, oracle, metric, monkeypatch):
+def test_ivf_routing_and_merge_break_ties_by_position(eng, oracle, metric, tune):
     """The probed lists and the final k are picked by bisecting the KEY space (kernels.hpp: wave_topk_sorted): the
     distance words first, then -- only when equal distances straddle the k-th place -- the positions.  Centroids in
     identical groups of eight make the nprobe-th place fall inside a tie for every query (ivf_flat.clj:266-268 sorts
@@ -1100,9 +1100,9 @@ def test_ivf_routing_and_merge_break_ties_by_position(eng, oracle, metric, monke
     with eng.Index(base, metric) as idx:
         idx.set_rejection_test(2)
         idx.set_ivf(cen, off, lids)
-        monkeypatch.setenv("HNSWGPU_IVF_CODES", "1")
+        tune.set("IVF_CODES", "1")
         for mid in ("0", "1"):
-            monkeypatch.setenv("HNSWGPU_STREAM_MID", mid)
+            tune.set("STREAM_MID", mid)
             for nq, nprobe, k in [(1, 5, 10), (1, 64, 64), (3, 1, 1), (22, 12, 33), (22, 33, 10), (5, 60, 5)]:
                 if metric != "l2" and nq * nprobe > 12 * nlist:
                     continue

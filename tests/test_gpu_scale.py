@@ -107,7 +107,7 @@ def test_config3_ivf_per_gpu_shard(eng, oracle, shard3):
 
 
 @pytest.mark.parametrize("nq", [256, 1024, 4096])
-def test_config3_ivf_production_path_against_oracle(eng, oracle, shard3, nq, monkeypatch):
+def test_config3_ivf_production_path_against_oracle(eng, oracle, shard3, nq, tune):
     """The path a DEFAULT handle takes (what bench.py times and `profiles/` report): no pinned boundary, rejection mode 1
     with its first-search calibration -- int8 bounds on the matrix cores -> half-precision pass -> f32 finish, cosine --
     at 1.25M x 768 / nlist 1024 / nprobe 32 / k 10 and batches of 256 / 1024 / 4096 (ivf_flat.clj:217-294).  A 64-query
@@ -120,7 +120,7 @@ def test_config3_ivf_production_path_against_oracle(eng, oracle, shard3, nq, mon
     s = shard3
     idx, base, Q, qh, cent, off, lids, n = s["idx"], s["base"], s["Q"], s["qh"], s["cent"], s["off"], s["lids"], s["n"]
     nprobe, k = 32, 10
-    monkeypatch.delenv("HNSWGPU_TILE_PAIRS", raising=False)
+    tune.unset("TILE_PAIRS")
     idx.set_rejection_test(1)                 # the default mode: calibrates at the next IVF search
     try:
         Qb = Q[:nq].contiguous()

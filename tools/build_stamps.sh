@@ -1,9 +1,10 @@
 #!/bin/bash
-# Diagnostic build of the library with per-phase time stamps in the HNSW kernel and along an IVF search (never the product build).
+# Diagnostic build of the library with per-phase time stamps in the HNSW kernel and along an IVF search, and with the
+# ablation switches of the bounds pass / tile scan (-DHG_DIAG: hnswgpu_debug_set_ablation; results are wrong on purpose) -- never the product build.
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_dbg
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -DHG_HNSW_STAMPS -DHG_IVF_STAMPS"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -DHG_HNSW_STAMPS -DHG_IVF_STAMPS -DHG_DIAG"
 for f in engine ivf hnsw persist group; do
   /opt/rocm/bin/hipcc $FLAGS -c hnsw-clj_amd/csrc/$f.hip -o build_dbg/$f.o &
 done

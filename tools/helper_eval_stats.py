@@ -1,6 +1,6 @@
 """Developer tool: how many of the neighbours a small HNSW launch evaluates the traversal still has to gather itself when
 the helper workgroups evaluate the hinted nodes' neighbours and publish the distances (kernels.hpp: pf_res).
-usage: [HNSWGPU_PF_HINTS=n] [HNSWGPU_PREFETCH=groups] python tools/helper_eval_stats.py"""
+usage: [HNSWGPU_TUNE=PF_HINTS=n] [HNSWGPU_PREFETCH=groups] python tools/helper_eval_stats.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -40,5 +40,5 @@ else:
     for nw in (None, "1", "2", "4"):
         env = dict(os.environ)
         if nw:
-            env["HNSWGPU_HNSW_NW"] = nw
+            env["HNSWGPU_TUNE"] = "HNSW_NW=%s" % nw
         subprocess.run([sys.executable, os.path.abspath(__file__), "--child", ef], env=env, check=False)

@@ -1,5 +1,5 @@
 """Developer tool: list-scan kernel time and end-to-end time of batched IVF searches on the bench index
-(1M x 768, k-means lists, nprobe 32).  usage: [METRIC=l2] [HNSWGPU_TILE_DBG=1] python tools/ivf_batch_time.py [nq ...]"""
+(1M x 768, k-means lists, nprobe 32).  usage: [METRIC=l2] [HG_DIAG build + hnswgpu_debug_set_ablation(1, 1] python tools/ivf_batch_time.py [nq ...]"""
 import os
 import sys
 import time

@@ -1,5 +1,5 @@
 """Developer tool: single-query (and small-batch) IVF search latency on the bench index (1M x 768, nlist 1024, nprobe 32).
-usage: [HNSWGPU_IVF_FUSED=0] python tools/ivf_latency.py"""
+usage: [HNSWGPU_TUNE=IVF_FUSED=0] python tools/ivf_latency.py"""
 import os
 import sys
 import time

@@ -1,5 +1,5 @@
 """Developer tool: survivors of the bounds pass (candidates that reach the exact f32 pass) and the search time on the
-bench index.  usage: [HNSWGPU_STREAM_DBG=2] python tools/ivf_survivors.py <metric> [nq ...]"""
+bench index.  usage: [HG_DIAG build + hnswgpu_debug_set_ablation(0, 2] python tools/ivf_survivors.py <metric> [nq ...]"""
 import os
 import sys
 import time

@@ -1,5 +1,5 @@
 """Developer tool: single-query latency of the synchronous host entry points against the kernel time.
-usage: [HNSWGPU_ZEROCOPY=0] python tools/latency_probe.py [ef]"""
+usage: [HNSWGPU_TUNE=ZEROCOPY=0] python tools/latency_probe.py [ef]"""
 import os
 import sys
 import time

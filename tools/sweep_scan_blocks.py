@@ -36,7 +36,7 @@ for nq in (8, 16, 24, 32):
     res = {}
     for rep in range(4):
         for blocks in (1024, 2048, 3072, 4096, 6144, 8192, 16384, 32768, 65536):
-            os.environ["HNSWGPU_SCAN_BLOCKS"] = str(blocks)
+            engine.set_tuning("SCAN_BLOCKS", blocks)
             idx.ivf_search_dev(Q, K, nprobe)
             idx.get_profile(engine.PROF_IVF_SCAN, reset=True)
             for _ in range(10):

@@ -1,11 +1,11 @@
 """Developer tool: what does a work item of the batched IVF tile scan cost by the size of its query group?
 Diagnostic stamps of tile_scan_kernel ({start, end, hw id, tiles | cnt << 32} per workgroup), one workgroup per item
-(HNSWGPU_TILE_PERSIST=0 is forced).  usage: python tools/tile_item_cost.py [nq]"""
+(HNSWGPU_TUNE=TILE_PERSIST=0 is forced).  usage: python tools/tile_item_cost.py [nq]"""
 import ctypes
 import os
 import sys
 
-os.environ["HNSWGPU_TILE_PERSIST"] = "0"
+os.environ["HNSWGPU_TUNE"] = "TILE_PERSIST=0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

@@ -1,5 +1,5 @@
 """Developer tool: time the HNSW traversal kernel on the bench workload (31,173 x 768 manifold data).
-usage: HNSWGPU_HNSW_NW=1 python tools/tune_hnsw.py [nq] [ef]"""
+usage: HNSWGPU_TUNE=HNSW_NW=1 python tools/tune_hnsw.py [nq] [ef]"""
 import os
 import sys
 import time

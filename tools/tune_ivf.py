@@ -1,5 +1,5 @@
 """Developer tool: time the IVF list scan (1M x 768, nlist 1024, nprobe 32) at several batch sizes.
-usage: [HNSWGPU_SCAN_BLOCKS=N] python tools/tune_ivf.py"""
+usage: [HNSWGPU_TUNE=SCAN_BLOCKS=N] python tools/tune_ivf.py"""
 import os
 import sys
 import time
