@@ -50,6 +50,7 @@ _SIGS = {
     "hnswgpu_exact_knn_dev": ["p", "p", "i32", "i32", "p", "p", "p"],
     "hnswgpu_set_graph": ["p", "p", "p", "i32", "p", "p", "i32", "i32", "i32"],
     "hnswgpu_hnsw_build": ["p", "i32", "i32", "i64"],
+    "hnswgpu_hnsw_build_ex": ["p", "i32", "i32", "i64", "i32"],
     "hnswgpu_hnsw_add": ["p", "p", "i64", "i32", "i64"],
     "hnswgpu_graph_sizes": ["p", "p", "p", "p", "p", "p"],
     "hnswgpu_get_graph": ["p", "p", "p", "p", "p"],

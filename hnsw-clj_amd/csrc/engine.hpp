@@ -158,6 +158,7 @@ struct hnswgpu_index {
     uint64_t graph_gen = 0;  // bumped whenever the graph is replaced: a search in flight on a slot stream notices
 
     int M = 0, M0 = 0, entry = -1, max_level = 0;
+    int build_flags = 0;  // HNSWGPU_BUILD_* the graph was built with (hnswgpu_hnsw_add inserts the same way); 0 for an installed graph
     int64_t up_blocks = 0;
     int32_t *d_levels = nullptr, *d_l0 = nullptr, *d_upadj = nullptr;
     int64_t *d_upoff = nullptr;

@@ -12,6 +12,7 @@
 #include <thread>
 #include <vector>
 
+#include "build_kernels.hpp"
 #include "engine.hpp"
 #include "javarandom.hpp"
 
@@ -409,6 +410,54 @@ struct HostGraph {
             *cnt = m;
             srt = 1;
         }
+    }
+
+    // graph.clj's builder: an edge is appended while the list has room; into a full list it is PENDING until the list is
+    // re-selected by the heuristic (prune-connections, graph.clj:208-232) -- returns false then
+    bool append_edge(int32_t from, int32_t to, int lc, float dist, Dirty &out) {
+        float *d;
+        int32_t *cnt;
+        int m;
+        int32_t *a = adj(from, lc, &d, &cnt, &m);
+        for (int i = 0; i < *cnt; i++)
+            if (a[i] == to) return true;
+        if (*cnt >= m) return false;
+        a[*cnt] = to;
+        d[*cnt] = dist;
+        (*cnt)++;
+        mark(from, lc, out);
+        return true;
+    }
+    void set_list(int32_t node, int lc, const int32_t *ids, const float *ds, int n, Dirty &out) {
+        float *d;
+        int32_t *cnt;
+        int m;
+        int32_t *a = adj(node, lc, &d, &cnt, &m);
+        for (int i = 0; i < n; i++) {
+            a[i] = ids[i];
+            d[i] = ds[i];
+        }
+        for (int i = n; i <= m; i++) a[i] = -1;
+        *cnt = n;
+        mark(node, lc, out);
+    }
+    // one side of a symmetric removal (graph.clj:226-231); true if the edge was there
+    bool remove_edge(int32_t from, int32_t to, int lc, Dirty &out) {
+        float *d;
+        int32_t *cnt;
+        int m;
+        int32_t *a = adj(from, lc, &d, &cnt, &m);
+        for (int i = 0; i < *cnt; i++)
+            if (a[i] == to) {
+                for (int t = i; t + 1 < *cnt; t++) {
+                    a[t] = a[t + 1];
+                    d[t] = d[t + 1];
+                }
+                a[--(*cnt)] = -1;
+                mark(from, lc, out);
+                return true;
+            }
+        return false;
     }
 };
 
@@ -882,25 +931,247 @@ static int launch_edge_dist(hnswgpu_index *idx, const int32_t *d_owner, const in
     return 0;
 }
 
+// RAII for the builder's own device buffers
+struct OwnedBuf : DevBuf {
+    ~OwnedBuf() { release(); }
+};
+
+static int launch_heur(hnswgpu_index *idx, HeurArgs a, hipStream_t st) {
+    if (a.ntasks <= 0) return 0;
+    a.rows = idx->d_base;
+    a.row_norms = idx->d_norms;
+    a.ld = idx->ld;
+    a.dim = idx->dim;
+    a.metric = idx->metric;
+    const bool l2 = idx->metric == METRIC_L2;
+#define CALL(N, R, L) hipLaunchKernelGGL((heuristic_select_kernel<N, R, L>), dim3(a.ntasks), dim3(kWG), 0, st, a)
+    HG_DISPATCH(idx->nch, l2, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+// A pending reverse edge of graph.clj's builder: `id` wants into the FULL list of `target` on layer `lc`.
+struct PendingEdge {
+    int32_t target, lc, id;
+    float dist;
+    int64_t seq;  // position in the batch's sequential order of reverse edges
+};
+
+// The re-selection of the over-full lists of one batch (prune-connections, graph.clj:208-232): per (target, layer) the
+// candidates are its m present edges plus the pending ones, ascending by (distance, id); heuristic_select_kernel keeps
+// at most m of them (extend-candidates? false); with `sym` every dropped edge leaves the other node's list as well
+// (:226-231).  Batched: every task sees the lists as they stood when the batch's appends were done (the batched build's
+// own semantics); `seq_exact` (one insert per batch, the reference's order): a task whose list an earlier task of the
+// same insert has shortened is selected again from the list as it then stands -- the sequential loop's result.
+struct Pruner {
+    hnswgpu_index *idx;
+    HostGraph &g;
+    hipStream_t st;
+    bool sym, seq_exact;
+    OwnedBuf d_task, d_out;
+    std::vector<int64_t> off;
+    std::vector<int32_t> cid, tm, oid, ocnt;
+    std::vector<float> cd, od;
+    struct Task {
+        int32_t target, lc;
+        int64_t first;  // its pending edges: pend[first, first + npend)
+        int32_t npend;
+    };
+    std::vector<Task> tasks;
+    int64_t n_tasks = 0, n_removed = 0;
+
+    Pruner(hnswgpu_index *i, HostGraph &gr, hipStream_t s, bool sy, bool sq) : idx(i), g(gr), st(s), sym(sy), seq_exact(sq) {}
+
+    // candidates of task t from the CURRENT list + its pending edges, ascending by (distance, id)
+    void gather(const Task &t, const std::vector<PendingEdge> &pend, std::vector<std::pair<float, int32_t>> &c) {
+        float *d;
+        int32_t *cnt;
+        int m;
+        int32_t *a = g.adj(t.target, t.lc, &d, &cnt, &m);
+        c.clear();
+        for (int i = 0; i < *cnt; i++) c.emplace_back(d[i], a[i]);
+        for (int i = 0; i < t.npend; i++) c.emplace_back(pend[t.first + i].dist, pend[t.first + i].id);
+        std::sort(c.begin(), c.end());
+        if (c.size() > static_cast<size_t>(kSelMaxCand)) c.resize(kSelMaxCand);
+    }
+
+    int select(const std::vector<std::vector<std::pair<float, int32_t>>> &cands, const std::vector<int32_t> &ms) {
+        const int nt = static_cast<int>(cands.size());
+        off.assign(nt + 1, 0);
+        for (int i = 0; i < nt; i++) off[i + 1] = off[i] + static_cast<int64_t>(cands[i].size());
+        const int64_t tot = off[nt];
+        cid.resize(std::max<int64_t>(tot, 1));
+        cd.resize(std::max<int64_t>(tot, 1));
+        for (int i = 0; i < nt; i++)
+            for (size_t j = 0; j < cands[i].size(); j++) {
+                cid[off[i] + j] = cands[i][j].second;
+                cd[off[i] + j] = cands[i][j].first;
+            }
+        const int stride = g.M0;
+        const size_t b_off = sizeof(int64_t) * (nt + 1), b_id = sizeof(int32_t) * tot, b_d = sizeof(float) * tot, b_m = sizeof(int32_t) * nt;
+        HG_TRY(d_task.ensure(b_off + b_id + b_d + b_m + 64));
+        char *dp = static_cast<char *>(d_task.p);
+        HG_HIP(hipMemcpyAsync(dp, off.data(), b_off, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(dp + b_off, cid.data(), b_id, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(dp + b_off + b_id, cd.data(), b_d, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(dp + b_off + b_id + b_d, ms.data(), b_m, hipMemcpyHostToDevice, st));
+        const size_t o_id = sizeof(int32_t) * static_cast<size_t>(nt) * stride, o_d = sizeof(float) * static_cast<size_t>(nt) * stride,
+                     o_c = sizeof(int32_t) * nt;
+        HG_TRY(d_out.ensure(o_id + o_d + o_c + 64));
+        char *op = static_cast<char *>(d_out.p);
+        HeurArgs a;
+        memset(&a, 0, sizeof(a));
+        a.ntasks = nt;
+        a.off = reinterpret_cast<const int64_t *>(dp);
+        a.cand_id = reinterpret_cast<const int32_t *>(dp + b_off);
+        a.cand_d = reinterpret_cast<const float *>(dp + b_off + b_id);
+        a.m = reinterpret_cast<const int32_t *>(dp + b_off + b_id + b_d);
+        a.extend = 0;  // prune-connections passes extend-candidates? false (graph.clj:222)
+        a.out_stride = stride;
+        a.out_id = reinterpret_cast<int32_t *>(op);
+        a.out_d = reinterpret_cast<float *>(op + o_id);
+        a.out_cnt = reinterpret_cast<int32_t *>(op + o_id + o_d);
+        HG_TRY(launch_heur(idx, a, st));
+        oid.resize(static_cast<size_t>(nt) * stride);
+        od.resize(static_cast<size_t>(nt) * stride);
+        ocnt.resize(nt);
+        HG_HIP(hipMemcpyAsync(oid.data(), a.out_id, o_id, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipMemcpyAsync(od.data(), a.out_d, o_d, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipMemcpyAsync(ocnt.data(), a.out_cnt, o_c, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+
+    // pend: the batch's pending edges in sequential order (seq ascending)
+    int run(std::vector<PendingEdge> &pend, HostGraph::Dirty &dirty) {
+        if (pend.empty()) return 0;
+        // group by (target, lc), a group's edges in sequential order; the groups in the order of their first edge
+        std::stable_sort(pend.begin(), pend.end(), [](const PendingEdge &x, const PendingEdge &y) {
+            return x.target != y.target ? x.target < y.target : x.lc < y.lc;
+        });
+        tasks.clear();
+        for (size_t i = 0; i < pend.size();) {
+            size_t j = i;
+            while (j < pend.size() && pend[j].target == pend[i].target && pend[j].lc == pend[i].lc) j++;
+            tasks.push_back({pend[i].target, pend[i].lc, static_cast<int64_t>(i), static_cast<int32_t>(j - i)});
+            i = j;
+        }
+        std::sort(tasks.begin(), tasks.end(), [&](const Task &x, const Task &y) { return pend[x.first].seq < pend[y.first].seq; });
+        const int nt = static_cast<int>(tasks.size());
+        std::vector<std::vector<std::pair<float, int32_t>>> cands(nt);
+        std::vector<int32_t> ms(nt);
+        for (int i = 0; i < nt; i++) {
+            gather(tasks[i], pend, cands[i]);
+            ms[i] = tasks[i].lc == 0 ? g.M0 : g.M;
+        }
+        HG_TRY(select(cands, ms));
+        n_tasks += nt;
+        const int stride = g.M0;
+        // keep-lists of the launch above (select() is reused for the re-selections of the sequential mode)
+        std::vector<int32_t> kid(oid), kcnt(ocnt);
+        std::vector<float> kd(od);
+        std::vector<std::pair<int32_t, int32_t>> touched;  // (node, layer) lists shortened by a removal of this run
+        auto is_touched = [&](int32_t node, int32_t lc) {
+            for (auto &tl : touched)
+                if (tl.first == node && tl.second == lc) return true;
+            return false;
+        };
+        std::vector<std::pair<int32_t, std::pair<int32_t, int32_t>>> removals;  // batched: applied after every list is set
+        for (int i = 0; i < nt; i++) {
+            const Task &t = tasks[i];
+            const int32_t *keep = &kid[static_cast<size_t>(i) * stride];
+            const float *keepd = &kd[static_cast<size_t>(i) * stride];
+            int nk = kcnt[i];
+            std::vector<std::pair<float, int32_t>> *cv = &cands[i];
+            std::vector<std::vector<std::pair<float, int32_t>>> one(1);
+            if (seq_exact && is_touched(t.target, t.lc)) {
+                // an earlier pruning of this insert took an edge out of this list: the sequential loop meets it shorter
+                float *d;
+                int32_t *cnt;
+                int m;
+                (void)g.adj(t.target, t.lc, &d, &cnt, &m);
+                int used = 0;
+                while (used < t.npend && *cnt < m) {  // room again: plain appends
+                    g.append_edge(t.target, pend[t.first + used].id, t.lc, pend[t.first + used].dist, dirty);
+                    used++;
+                }
+                if (used == t.npend) continue;
+                Task rest = {t.target, t.lc, t.first + used, t.npend - used};
+                gather(rest, pend, one[0]);
+                std::vector<int32_t> m1(1, t.lc == 0 ? g.M0 : g.M);
+                HG_TRY(select(one, m1));
+                n_tasks++;
+                keep = oid.data();
+                keepd = od.data();
+                nk = ocnt[0];
+                cv = &one[0];
+            }
+            g.set_list(t.target, t.lc, keep, keepd, nk, dirty);
+            if (sym)
+                for (auto &c : *cv) {
+                    bool kept = false;
+                    for (int r = 0; r < nk; r++) kept |= keep[r] == c.second;
+                    if (kept) continue;
+                    if (seq_exact) {
+                        if (g.remove_edge(c.second, t.target, t.lc, dirty)) {
+                            n_removed++;
+                            touched.emplace_back(c.second, t.lc);
+                        }
+                    } else {
+                        removals.push_back({c.second, {t.target, t.lc}});
+                    }
+                }
+        }
+        for (auto &r : removals)
+            if (g.remove_edge(r.first, r.second.first, r.second.second, dirty)) n_removed++;
+        return 0;
+    }
+};
+
 // insert-batch (ultra_fast.clj:303-344) over rows [done, g.n): every node of a batch runs the reference's per-level
 // search (search-layer-ultra with ef-construction at layer 0 and 1 above, :250-251) on the GPU against the graph as it
 // stood when the batch started, then the host links the batch in row order (:255-266) and prunes over-full lists
 // (:279-299).  The device adjacency (idx->d_l0 / d_upadj, sized for g.n) holds the graph of rows [0, done) on entry and
 // of all rows on return; g.entry / g.top are updated (:271-273).
-static int insert_batches(hnswgpu_index *idx, HostGraph &g, int64_t done, int ef, hipStream_t st) {
+// `flags` (include/hnswgpu.h, HNSWGPU_BUILD_*): SEQUENTIAL = one insert per batch, the walk starting at
+// min(level, entry-level) with the entry point (:247-248) -- insert-single itself; HEURISTIC = links chosen by
+// get-neighbors-heuristic (graph.clj:162-198) on the device (heuristic_select_kernel) instead of the m closest, over-full
+// lists re-selected the same way (prune-connections, graph.clj:208-232); SYMMETRIC = a dropped edge leaves both lists
+// (:226-231); EXTEND = extend-candidates? for the new node's own selection (:191-195).
+static int insert_batches(hnswgpu_index *idx, HostGraph &g, int64_t done, int ef, hipStream_t st, int flags) {
+    const bool seq = flags & HNSWGPU_BUILD_SEQUENTIAL, heur = flags & HNSWGPU_BUILD_HEURISTIC;
+    const bool sym = heur && (flags & HNSWGPU_BUILD_SYMMETRIC), extend = flags & HNSWGPU_BUILD_EXTEND;
     const int64_t n = g.n;
     const int M0 = g.M0;
     const int64_t blocks = g.up_off[n];
     int maxlv = 1;
     for (int64_t i = done; i < n; i++) maxlv = std::max(maxlv, g.levels[i]);
-    const int64_t maxB = 16384;  // scratch sizing; the batch actually used grows with the graph (see below)
-    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * maxB * M0));
-    HG_TRY(idx->s_outd.ensure(sizeof(float) * maxB * M0));
+    const int64_t maxB = seq ? 1 : 16384;  // scratch sizing; the batch actually used grows with the graph (see below)
+    const int kk = heur ? ef : M0;         // layer-0 candidates a search hands back: all of them for the heuristic
+    HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * maxB * kk));
+    HG_TRY(idx->s_outd.ensure(sizeof(float) * maxB * kk));
     HG_TRY(idx->s_misc.ensure(sizeof(int32_t) * maxB * (2 + maxlv)));   // q_rows, q_levels, up_out_ids
     HG_TRY(idx->s_misc2.ensure(sizeof(float) * maxB * maxlv));           // up_out_dist
     int32_t *d_qrows = idx->s_misc.as<int32_t>();
     int32_t *d_qlev = d_qrows + maxB;
     int32_t *d_upids = d_qlev + maxB;
+    // the new nodes' own selections (heuristic mode): [maxB][M0] ids, distances, [maxB] counts, [maxB + 1] offsets
+    OwnedBuf d_sel;
+    int32_t *d_selid = nullptr, *d_selcnt = nullptr;
+    float *d_seld = nullptr;
+    int64_t *d_seloff = nullptr;
+    if (heur) {
+        HG_TRY(d_sel.ensure((sizeof(int32_t) + sizeof(float)) * maxB * M0 + sizeof(int32_t) * maxB + sizeof(int64_t) * (maxB + 1) + 64));
+        d_seloff = d_sel.as<int64_t>();
+        d_selid = reinterpret_cast<int32_t *>(d_seloff + maxB + 1);
+        d_seld = reinterpret_cast<float *>(d_selid + maxB * M0);
+        d_selcnt = reinterpret_cast<int32_t *>(d_seld + maxB * M0);
+        std::vector<int64_t> h_off(maxB + 1);
+        for (int64_t b = 0; b <= maxB; b++) h_off[b] = b * kk;
+        HG_HIP(hipMemcpyAsync(d_seloff, h_off.data(), sizeof(int64_t) * (maxB + 1), hipMemcpyHostToDevice, st));
+        HG_HIP(hipStreamSynchronize(st));
+    }
     std::vector<int32_t> h_ids(maxB * M0), h_up(maxB * maxlv), h_qrows(maxB), h_qlev(maxB);
     std::vector<float> h_d(maxB * M0), h_upd(maxB * maxlv);
     g.flag0.assign(n, 0);
@@ -908,12 +1179,15 @@ static int insert_batches(hnswgpu_index *idx, HostGraph &g, int64_t done, int ef
     // linker threads: at most 16 (a GPU box's CPU share per GPU), HNSWGPU_BUILD_THREADS overrides (1 = sequential)
     int nthreads = static_cast<int>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
     if (const int64_t e = tune(HNSWGPU_TUNE_BUILD_THREADS, 0)) nthreads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(64, e)));
-    if (n - done < 256) nthreads = 1;  // a handful of rows: no pool to start
+    if (n - done < 256 || seq) nthreads = 1;  // a handful of rows: no pool to start
     LinkPool pool(nthreads);
     std::vector<HostGraph::Dirty> dirties(pool.size());
+    std::vector<std::vector<PendingEdge>> pendings(pool.size());
+    std::vector<PendingEdge> pend;
+    Pruner pruner(idx, g, st, sym, seq);
     PinnedBuf pin;
     const bool timing = tune(HNSWGPU_TUNE_BUILD_TIMING, 0) != 0;  // developer switch: where a build spends its time
-    double t_gpu = 0.0, t_link = 0.0, t_up = 0.0;
+    double t_gpu = 0.0, t_link = 0.0, t_up = 0.0, t_prune = 0.0;
     int64_t nbatch = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (done < n) {
@@ -937,9 +1211,10 @@ static int insert_batches(hnswgpu_index *idx, HostGraph &g, int64_t done, int ef
         a.qld = idx->ld;
         a.q_rows = d_qrows;
         a.q_levels = d_qlev;
+        a.ref_start = seq ? 1 : 0;
         a.nq = static_cast<int32_t>(B);
         a.ef = ef;
-        a.k = M0;
+        a.k = kk;
         a.cap = ef + kGhost;
         a.out_ids = idx->s_ids.as<int32_t>();
         a.out_dist = idx->s_outd.as<float>();
@@ -948,8 +1223,32 @@ static int insert_batches(hnswgpu_index *idx, HostGraph &g, int64_t done, int ef
         a.up_out_dist = idx->s_misc2.as<float>();
         a.up_stride = maxlv;
         HG_TRY(launch_hnsw_idx(idx, a, st));
-        HG_HIP(hipMemcpyAsync(h_ids.data(), a.out_ids, sizeof(int32_t) * B * M0, hipMemcpyDeviceToHost, st));
-        HG_HIP(hipMemcpyAsync(h_d.data(), a.out_dist, sizeof(float) * B * M0, hipMemcpyDeviceToHost, st));
+        int32_t *h_cnt = nullptr;
+        std::vector<int32_t> h_selcnt;
+        if (heur) {  // the new nodes' own links: get-neighbors-heuristic over the search's ef candidates
+            HeurArgs ha;
+            memset(&ha, 0, sizeof(ha));
+            ha.ntasks = static_cast<int32_t>(B);
+            ha.off = d_seloff;
+            ha.cand_id = a.out_ids;
+            ha.cand_d = a.out_dist;
+            ha.m = nullptr;
+            ha.m_all = M0;
+            ha.extend = extend ? 1 : 0;
+            ha.out_stride = M0;
+            ha.out_id = d_selid;
+            ha.out_d = d_seld;
+            ha.out_cnt = d_selcnt;
+            HG_TRY(launch_heur(idx, ha, st));
+            h_selcnt.resize(B);
+            HG_HIP(hipMemcpyAsync(h_ids.data(), d_selid, sizeof(int32_t) * B * M0, hipMemcpyDeviceToHost, st));
+            HG_HIP(hipMemcpyAsync(h_d.data(), d_seld, sizeof(float) * B * M0, hipMemcpyDeviceToHost, st));
+            HG_HIP(hipMemcpyAsync(h_selcnt.data(), d_selcnt, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+            h_cnt = h_selcnt.data();
+        } else {
+            HG_HIP(hipMemcpyAsync(h_ids.data(), a.out_ids, sizeof(int32_t) * B * M0, hipMemcpyDeviceToHost, st));
+            HG_HIP(hipMemcpyAsync(h_d.data(), a.out_dist, sizeof(float) * B * M0, hipMemcpyDeviceToHost, st));
+        }
         HG_HIP(hipMemcpyAsync(h_up.data(), a.up_out_ids, sizeof(int32_t) * B * maxlv, hipMemcpyDeviceToHost, st));
         HG_HIP(hipMemcpyAsync(h_upd.data(), a.up_out_dist, sizeof(float) * B * maxlv, hipMemcpyDeviceToHost, st));
         HG_HIP(hipStreamSynchronize(st));
@@ -965,40 +1264,63 @@ static int insert_batches(hnswgpu_index *idx, HostGraph &g, int64_t done, int ef
                 if (nb < 0 || nb == id) continue;
                 g.add_edge(id, nb, lc, h_upd[b * maxlv + (lc - 1)], dirty);
             }
-            for (int t = 0; t < take; t++) {
+            const int mine = h_cnt ? h_cnt[b] : take;
+            for (int t = 0; t < mine; t++) {
                 const int32_t nb = h_ids[b * M0 + t];
                 if (nb < 0) break;
                 if (nb == id) continue;
                 g.add_edge(id, nb, 0, h_d[b * M0 + t], dirty);
             }
         };
-        auto link_reverse = [&](int64_t b, int me, int nt, HostGraph::Dirty &dirty) {
+        // the batch's reverse edges are numbered in the sequential loop's order: node by node, layers top down,
+        // a layer's links in selection order
+        auto link_reverse = [&](int64_t b, int me, int nt, HostGraph::Dirty &dirty, std::vector<PendingEdge> &pq) {
             const int32_t id = static_cast<int32_t>(done + b);
             const int L = g.levels[id];
-            for (int lc = std::min(L, top_at_start); lc >= 1; lc--) {
+            int64_t sq = b * (maxlv + M0);
+            auto rev = [&](int32_t nb, int lc, float dist) {
+                if (heur) {
+                    if (!g.append_edge(nb, id, lc, dist, dirty)) pq.push_back({nb, lc, id, dist, sq});
+                } else {
+                    g.add_edge(nb, id, lc, dist, dirty);
+                }
+            };
+            for (int lc = std::min(L, top_at_start); lc >= 1; lc--, sq++) {
                 const int32_t nb = h_up[b * maxlv + (lc - 1)];
                 if (nb < 0 || nb == id || nb % nt != me) continue;
-                g.add_edge(nb, id, lc, h_upd[b * maxlv + (lc - 1)], dirty);
+                rev(nb, lc, h_upd[b * maxlv + (lc - 1)]);
             }
-            for (int t = 0; t < take; t++) {
+            sq = b * (maxlv + M0) + maxlv;
+            const int mine = h_cnt ? h_cnt[b] : take;
+            for (int t = 0; t < mine; t++, sq++) {
                 const int32_t nb = h_ids[b * M0 + t];
                 if (nb < 0) break;
                 if (nb == id || nb % nt != me) continue;
-                g.add_edge(nb, id, 0, h_d[b * M0 + t], dirty);
+                rev(nb, 0, h_d[b * M0 + t]);
             }
         };
         const int nt = B >= 256 ? pool.size() : 1;  // small batches: the hand-over costs more than it saves
         if (nt == 1) {
             for (int64_t b = 0; b < B; b++) link_own(b, dirties[0]);
-            for (int64_t b = 0; b < B; b++) link_reverse(b, 0, 1, dirties[0]);
+            for (int64_t b = 0; b < B; b++) link_reverse(b, 0, 1, dirties[0], pendings[0]);
         } else {
             pool.run([&](int me) {
                 const int64_t lo = B * me / nt, hi = B * (me + 1) / nt;
                 for (int64_t b = lo; b < hi; b++) link_own(b, dirties[me]);
             });
             pool.run([&](int me) {
-                for (int64_t b = 0; b < B; b++) link_reverse(b, me, nt, dirties[me]);
+                for (int64_t b = 0; b < B; b++) link_reverse(b, me, nt, dirties[me], pendings[me]);
             });
+        }
+        const double tb2 = timing ? now() : 0.0;
+        if (heur) {  // the over-full lists of this batch: prune-connections (graph.clj:208-232) on the device
+            pend.clear();
+            for (auto &pq : pendings) {
+                pend.insert(pend.end(), pq.begin(), pq.end());
+                pq.clear();
+            }
+            std::sort(pend.begin(), pend.end(), [](const PendingEdge &x, const PendingEdge &y) { return x.seq < y.seq; });
+            HG_TRY(pruner.run(pend, dirties[0]));
         }
         for (auto &dd : dirties) {
             g.dirty0.insert(g.dirty0.end(), dd.d0.begin(), dd.d0.end());
@@ -1016,14 +1338,17 @@ static int insert_batches(hnswgpu_index *idx, HostGraph &g, int64_t done, int ef
         done += B;
         if (timing) {
             t_gpu += tb1 - tb0;
-            t_link += now() - tb1;
+            t_link += tb2 - tb1;
+            t_prune += now() - tb2;
             nbatch++;
         }
     }
     if (timing)
         fprintf(stderr, "hnsw build: %lld batches, %.2f s upload + search + download (%.2f s of it packing and uploading "
-                        "changed adjacency rows), %.2f s host linking\n",
-                static_cast<long long>(nbatch), t_gpu, t_up, t_link);
+                        "changed adjacency rows), %.2f s host linking, %.2f s re-selection of %lld over-full lists (%lld edges "
+                        "removed from the other side)\n",
+                static_cast<long long>(nbatch), t_gpu, t_up, t_link, t_prune, static_cast<long long>(pruner.n_tasks),
+                static_cast<long long>(pruner.n_removed));
     return 0;
 }
 
@@ -1063,13 +1388,22 @@ extern "C" {
 
 // build-index / insert-batch (ultra_fast.clj:303-344) as batched insertion (insert_batches above).
 // Level draw: floor(ml * -ln U), ml = 1/ln 2 (:133,:143-147), U from java.util.Random(seed).
-// Differences from the reference's sequential insert-single, stated in DESIGN.md: nodes of one
-// batch do not see each other (batches grow from 1 to at most 1/8 of the graph, capped); the walk
-// starts at the top layer with ef = 1 instead of at min(level, entry-level) (:247-248); each node
-// links to its m CLOSEST candidates (the reference's `(take m candidates)` takes PriorityQueue
-// array order, which is unspecified).
+// flags = 0, the fast default -- differences from the reference's sequential insert-single, stated in DESIGN.md: nodes
+// of one batch do not see each other (batches grow from 1 to at most 1/8 of the graph, capped); the walk starts at the
+// top layer with ef = 1 instead of at min(level, entry-level) (:247-248); each node links to its m CLOSEST candidates
+// (the reference's `(take m candidates)` takes PriorityQueue array order, which is unspecified).
+// HNSWGPU_BUILD_SEQUENTIAL removes the first two (insert-single itself: the graph equals oracle.c's orc_hnsw_build_ex
+// edge for edge); HNSWGPU_BUILD_HEURISTIC / _SYMMETRIC / _EXTEND select links as src/hnsw/graph.clj:162-232 does.
 int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, int64_t seed) {
+    return hnswgpu_hnsw_build_ex(idx, M, ef_construction, seed, 0);
+}
+
+int hnswgpu_hnsw_build_ex(hnswgpu_index *idx, int32_t M, int32_t ef_construction, int64_t seed, int32_t flags) {
     HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    HG_REQUIRE((flags & ~(HNSWGPU_BUILD_SEQUENTIAL | HNSWGPU_BUILD_HEURISTIC | HNSWGPU_BUILD_SYMMETRIC | HNSWGPU_BUILD_EXTEND)) == 0,
+               HNSWGPU_EINVAL, "unknown build flags 0x%x", flags);
+    HG_REQUIRE(!(flags & (HNSWGPU_BUILD_SYMMETRIC | HNSWGPU_BUILD_EXTEND)) || (flags & HNSWGPU_BUILD_HEURISTIC), HNSWGPU_EINVAL,
+               "HNSWGPU_BUILD_SYMMETRIC / _EXTEND qualify HNSWGPU_BUILD_HEURISTIC");
     HG_REQUIRE(M >= 1 && 2 * M <= kMaxDeg, HNSWGPU_ELIMIT, "need 1 <= M <= %d", kMaxDeg / 2);
     HG_REQUIRE(ef_construction >= 1 && ef_construction <= 4096, HNSWGPU_ELIMIT, "need 1 <= ef_construction <= 4096");
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -1113,7 +1447,8 @@ int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, i
     HG_HIP(hipMemsetAsync(idx->d_upadj, 0xff, sizeof(int32_t) * std::max<int64_t>(blocks, 1) * M, st));
     g.entry = 0;  // first element becomes the entry point (:229-231)
     g.top = g.levels[0];
-    HG_TRY(insert_batches(idx, g, 1, ef_construction, st));
+    idx->build_flags = flags;
+    HG_TRY(insert_batches(idx, g, 1, ef_construction, st, flags));
     return publish_graph(idx, g, st);
 }
 
@@ -1249,9 +1584,9 @@ int hnswgpu_hnsw_add(hnswgpu_index *idx, const float *rows, int64_t m, int32_t e
     if (n0 == 0) {  // an empty index with an (empty) graph: the first new row becomes the entry point (:229-231)
         g.entry = 0;
         g.top = g.levels[0];
-        HG_TRY(insert_batches(idx, g, 1, ef_construction, st));
+        HG_TRY(insert_batches(idx, g, 1, ef_construction, st, idx->build_flags));
     } else {
-        HG_TRY(insert_batches(idx, g, n0, ef_construction, st));
+        HG_TRY(insert_batches(idx, g, n0, ef_construction, st, idx->build_flags));
     }
     return publish_graph(idx, g, st);
 }

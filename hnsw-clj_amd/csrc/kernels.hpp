@@ -1079,6 +1079,8 @@ struct HnswArgs {
     int64_t qld;
     const int32_t *q_rows;    // build mode: query q is base row q_rows[q]
     const int32_t *q_levels;  // build mode: level of the node being inserted
+    int32_t ref_start;        // build mode: the walk starts at min(level, entry's level) with the entry point itself
+                              // (insert-single, ultra_fast.clj:247-248) instead of descending from the top layer
     int32_t nq;
     const int32_t *l0_adj;
     int32_t M0;
@@ -1368,7 +1370,8 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
             len = 1;
             n_eval = 1;
         }
-        for (int level = a.max_level; level >= 0; level--) {
+        const int top_l = (a.ref_start && qlevel >= 0 && qlevel < a.max_level) ? qlevel : a.max_level;
+        for (int level = top_l; level >= 0; level--) {
             int ef_l = level > 0 ? 1 : a.ef;
             // fresh visited set per layer (:156); entries carried from the level above are marked
             if (VG) {
@@ -1380,7 +1383,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
             if (len > ef_l) len = ef_l;
             // the reference re-evaluates its entry points at every layer (:162-167); the values are
             // reused here, but counted so that `evals` is the reference's number of distance calls
-            if (level != a.max_level) n_eval += len;
+            if (level != top_l) n_eval += len;
             for (int i = tid; i < len; i += kThreads) {
                 uint2 e = curA[i];
                 e.y &= ~kExpanded;

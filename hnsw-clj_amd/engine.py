@@ -12,6 +12,7 @@ from ._native import COSINE, DOT, L2, check, get_tuning, lib, set_tuning  # noqa
 
 METRICS = {"cosine": COSINE, "l2": L2, "euclidean": L2, "dot": DOT, COSINE: COSINE, L2: L2, DOT: DOT}
 PROF_IVF_SCAN, PROF_HNSW, PROF_ASSIGN = 0, 1, 2
+BUILD_SEQUENTIAL, BUILD_HEURISTIC, BUILD_SYMMETRIC, BUILD_EXTEND = 1, 2, 4, 8     # include/hnswgpu.h: HNSWGPU_BUILD_*
 
 
 def _p(a):
@@ -202,8 +203,14 @@ class Index:
         check(lib().hnswgpu_set_graph(self._h, _p(g.levels), _p(g.l0_adj), g.M0, _p(g.up_off), _p(g.up_adj), g.M,
                                       g.entry, g.max_level))
 
-    def hnsw_build(self, M=16, ef_construction=200, seed=42):
-        check(lib().hnswgpu_hnsw_build(self._h, M, ef_construction, seed))
+    def hnsw_build(self, M=16, ef_construction=200, seed=42, sequential=False, heuristic=False, symmetric=False,
+                   extend=False):
+        """hnswgpu_hnsw_build_ex: batched closest-m insertion by default (ultra_fast.clj:216-299); sequential = the
+        reference's insert-single order and start level (the CPU restatement's graph, oracle.c, edge for edge); heuristic / symmetric / extend =
+        neighbour selection of src/hnsw/graph.clj:162-232."""
+        flags = (BUILD_SEQUENTIAL if sequential else 0) | (BUILD_HEURISTIC if heuristic else 0) | \
+                (BUILD_SYMMETRIC if symmetric else 0) | (BUILD_EXTEND if extend else 0)
+        check(lib().hnswgpu_hnsw_build_ex(self._h, M, ef_construction, seed, flags))
 
     def hnsw_add(self, rows, ef_construction=200, seed=42):
         """insert-single on the live index (ultra_fast.clj:216-275): `rows` join the base and the installed graph; returns

@@ -109,6 +109,28 @@ int hnswgpu_exact_knn_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int3
 int hnswgpu_set_graph(hnswgpu_index *idx, const int32_t *levels, const int32_t *l0_adj, int32_t M0,
                       const int64_t *up_off, const int32_t *up_adj, int32_t M, int32_t entry, int32_t max_level);
 int hnswgpu_hnsw_build(hnswgpu_index *idx, int32_t M, int32_t ef_construction, int64_t seed);
+/* The same with build options.  flags = 0 is hnswgpu_hnsw_build: batched insertion, every node linked to its m closest
+ * candidates (insert-single / prune-connections-ultra, ultra_fast.clj:216-299).
+ *   HNSWGPU_BUILD_SEQUENTIAL  insert-single itself: one row at a time, the walk starting at min(level, entry-level) with the
+ *                             entry point (ultra_fast.clj:247-248), an over-full neighbour pruned at once (:264-266).  The
+ *                             graph equals the CPU restatement's (oracle/oracle.c: orc_hnsw_build_ex) edge for edge; one
+ *                             launch round trip per row -- the parity mode, not the fast one.
+ *   HNSWGPU_BUILD_HEURISTIC   links chosen by get-neighbors-heuristic (src/hnsw/graph.clj:162-198, the builder behind
+ *                             README's hnsw.hnsw-search): candidates ascending by (distance, id), one is taken unless it
+ *                             is closer to an already taken one than to the node itself -- for the new node's own links
+ *                             (from all its ef_construction candidates) and for an over-full neighbour list
+ *                             (prune-connections, graph.clj:208-232).  Clusters stay connected to each other: on the
+ *                             survey's clustered-normalised 31k x 768 set recall@10 goes from 0.02 (closest-m, at any ef)
+ *                             to 0.98.  The pair distances run on the device (heuristic_select_kernel).
+ *   HNSWGPU_BUILD_SYMMETRIC   with HEURISTIC: an edge a pruning drops is removed from the other node's list as well
+ *                             (graph.clj:226-231)
+ *   HNSWGPU_BUILD_EXTEND      with HEURISTIC: extend-candidates? for the new node's own selection (graph.clj:191-195)
+ * hnswgpu_hnsw_add inserts with the options the handle's graph was built with (batched). */
+#define HNSWGPU_BUILD_SEQUENTIAL 1
+#define HNSWGPU_BUILD_HEURISTIC 2
+#define HNSWGPU_BUILD_SYMMETRIC 4
+#define HNSWGPU_BUILD_EXTEND 8
+int hnswgpu_hnsw_build_ex(hnswgpu_index *idx, int32_t M, int32_t ef_construction, int64_t seed, int32_t flags);
 /* insert-single on a LIVE index (src/hnsw/ultra_fast.clj:216-275, reached by add-vector! src/hnsw/api.clj:30-33 and add!
  * src/hnsw/api/simple.clj:31-42): `m` more rows (m x dim floats) join the base matrix and the installed graph.  Their row
  * ids are n, n + 1, ...; their levels continue the seeded java.util.Random sequence (row i takes its i-th draw: the same

@@ -277,6 +277,90 @@ def test_hnsw_build_on_device(eng, oracle):
     assert rec_gpu_graph >= 0.9 and rec_gpu_graph >= rec_ref - 0.03, (rec_gpu_graph, rec_ref)
 
 
+def _same_graph(g, og, what):
+    """Edge for edge: levels, entry point, every adjacency row in its order."""
+    np.testing.assert_array_equal(g.levels, og.levels, err_msg=what + ": levels")
+    assert (g.entry, g.max_level, g.M, g.M0) == (og.entry, og.max_level, og.M, og.M0), what
+    np.testing.assert_array_equal(g.up_off, og.up_off, err_msg=what + ": up_off")
+    bad = np.nonzero((g.l0_adj.reshape(og.l0_adj.shape) != og.l0_adj).any(axis=1))[0]
+    assert bad.size == 0, "%s: layer-0 rows differ at nodes %s: device %s oracle %s" % (
+        what, bad[:5], g.l0_adj.reshape(og.l0_adj.shape)[bad[0]], og.l0_adj[bad[0]])
+    np.testing.assert_array_equal(g.up_adj.ravel(), og.up_adj.ravel(), err_msg=what + ": upper layers")
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
+def test_hnsw_build_equals_oracle_graph(eng, oracle, metric):
+    """HNSWGPU_BUILD_SEQUENTIAL is insert-single itself (ultra_fast.clj:216-275): one row at a time, the walk starting at
+    min(level, entry-level) with the entry point (:247-248), ef 1 above layer 0 (:250-251), links to the m closest, an
+    over-full neighbour list pruned at > m by a stable sort on the distance (:264-266, 279-299).  The exported adjacency
+    must equal the CPU restatement's (oracle.c: orc_hnsw_build_ex, device-order arithmetic) EDGE FOR EDGE -- with
+    duplicated rows (exact ties in every list they meet), a zero row, and clustered rows."""
+    O = oracle
+    code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
+    base = _data(O, 3000, 48, "clustered", num_clusters=12, noise_level=0.4, seed=7)
+    base[100:140] = base[60:100]          # 40 duplicated rows: exact distance ties
+    base[500] = base[499]
+    base[777] = 0.0
+    with eng.Index(base, metric) as idx:
+        idx.hnsw_build(8, 40, 42, sequential=True)
+        g = idx.get_graph()
+        og = O.hnsw_build_ex(base, code, 8, 40, 42, 0, mode=O.MODE_DEV)
+        _same_graph(g, og, "sequential closest-m build, %s" % metric)
+        Q = _data(O, 16, 48, seed=43)
+        ids, d, st = idx.hnsw_search(Q, 10, 60, want_stats=True)
+        oi, od, ost, _ = O.hnsw_search(base, og, Q, 10, ef=60, metric=code, mode=O.MODE_DEV)
+        assert_exact(ids, d, oi, od, "search on the sequentially built graph")
+        np.testing.assert_array_equal(st, ost)
+
+
+@pytest.mark.parametrize("flags", ["heuristic", "heuristic+symmetric", "heuristic+extend"])
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_hnsw_heuristic_build_equals_oracle_graph(eng, oracle, metric, flags):
+    """The neighbour selection of src/hnsw/graph.clj on the device: get-neighbors-heuristic (:162-198) for the new node's
+    links and for an over-full list (prune-connections :208-232), a dropped edge removed from both lists with SYMMETRIC
+    (:226-231), extend-candidates? with EXTEND (:191-195).  In the sequential order the graph must equal the oracle's
+    restatement edge for edge; the pair distances come from heuristic_select_kernel."""
+    O = oracle
+    code = {"cosine": O.COSINE, "l2": O.L2}[metric]
+    sym, ext = "symmetric" in flags, "extend" in flags
+    base = _data(O, 2500, 40, "clustered", num_clusters=10, noise_level=0.4, seed=17)
+    base[200:220] = base[100:120]         # duplicated rows: ties inside the (distance, id) order of the heuristic
+    with eng.Index(base, metric) as idx:
+        idx.hnsw_build(6, 48, 42, sequential=True, heuristic=True, symmetric=sym, extend=ext)
+        g = idx.get_graph()
+        of = O.BUILD_HEURISTIC | (O.BUILD_SYMMETRIC if sym else 0) | (O.BUILD_EXTEND if ext else 0)
+        og, cnt = O.hnsw_build_ex(base, code, 6, 48, 42, of, mode=O.MODE_DEV, want_counters=True)
+        assert cnt[3] > 100, "the data set must overflow lists: %s" % cnt
+        _same_graph(g, og, "sequential %s build, %s" % (flags, metric))
+
+
+def test_hnsw_heuristic_build_connects_clusters(eng, oracle):
+    """What the heuristic is for (missing 1): on well-separated clusters closest-m pruning
+    (ultra_fast.clj:279-299) leaves the clusters disconnected -- recall@10 stays near 0 at any ef --, the diversity
+    heuristic keeps links between them.  Batched device build, 20k x 96 clustered-normalised rows, held-out queries of
+    other clusters' directions (the survey's seed-43 recipe); search parity against the oracle on the exported graph."""
+    O = oracle
+    base = _data(O, 20000, 96, "clustered", num_clusters=160, noise_level=0.3, seed=42)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    Q = _data(O, 200, 96, "clustered", num_clusters=160, noise_level=0.3, seed=43)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    with eng.Index(base) as idx:
+        ex, _ = idx.exact_knn(Q, 10)
+        rec = {}
+        for name, kw in (("closest", {}), ("heuristic", dict(heuristic=True)), ("heuristic+symmetric", dict(heuristic=True, symmetric=True))):
+            idx.hnsw_build(16, 200, 42, **kw)
+            g = idx.get_graph()
+            deg = (g.l0_adj.reshape(len(base), -1) >= 0).sum(1)
+            assert deg.min() >= 1 and deg.max() <= 32
+            idx.set_graph(g)                # passes the validator
+            ids, d, st = idx.hnsw_search(Q, 10, 400, want_stats=True)
+            rec[name] = O.recall(ids, ex)
+            oi, od, ost, _ = O.hnsw_search(base, g, Q[:32], 10, ef=400, mode=O.MODE_DEV)
+            assert_exact(ids[:32], d[:32], oi, od, "search on the %s graph" % name)
+            np.testing.assert_array_equal(st[:32], ost)
+        assert rec["closest"] < 0.3 and rec["heuristic"] > 0.9 and rec["heuristic+symmetric"] > 0.9, rec
+
+
 @pytest.mark.parametrize("dim", [384, 768, 1536, 3072])
 def test_hnsw_embedding_dims(eng, oracle, dim):
     """The dimensions the reference's integration test walks (test/hnsw/integration_test.clj:91-118): every row-length
