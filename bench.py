@@ -43,7 +43,17 @@ M, EFC = 16, 200
 # the reference's own ef (max(k, 50), ultra_fast.clj:355) first, then steps of ~4 % so that the operating point is the
 # smallest ef that meets the recall bar, not the next power-of-two-ish value above it
 EF_SWEEP = [50, 56, 64, 72, 80, 88, 96, 100, 104, 108, 112, 116, 120, 128, 136, 144, 152, 160, 176, 192, 224, 256, 320, 384,
-            512, 768, 1024, 1536, 2048, 3072, 4096]
+            448, 512, 576, 640, 672, 704, 736, 768, 800, 832, 896, 1024, 1280, 1536, 2048, 3072, 4096]
+# The index builder (hnswgpu_hnsw_build_ex): "heuristic" = neighbour selection by hnsw.hnsw-search's
+# get-neighbors-heuristic (src/hnsw/graph.clj:162-198) for a node's links and for an over-full list, the dropped edge leaving
+# the pruned list only (as prune-connections-ultra, ultra_fast.clj:279-299, leaves the reverse edge); "graph.clj" = the
+# same with the dropped edge removed from BOTH lists (prune-connections, graph.clj:208-232); "ultra_fast.clj" = the m
+# closest (ultra_fast.clj:216-299).  Both namespaces search with the same search-layer / search-knn algorithm -- the
+# traversal kernel.  One-sided pruning keeps more ways INTO a cluster: on the 31k clustered set 0.98 at ef 704 against
+# 736 for graph.clj, on configs[4]'s 1.25M x 1536 clustered rows 0.991 at ef 256 against a plateau of 0.979
+# (profiles/r04_config5_hnsw_shard.txt); graph.clj is ahead on i.i.d. uniform rows (by_distribution).
+BUILDERS = {"heuristic": dict(heuristic=True), "graph.clj": dict(heuristic=True, symmetric=True), "ultra_fast.clj": {},
+            "heuristic+extend": dict(heuristic=True, extend=True)}
 
 
 def log(*a):
@@ -72,6 +82,14 @@ def make_31k(distribution, seed, n):
                                      dtype=np.float64)
         x /= np.linalg.norm(x, axis=1, keepdims=True)
         return x.astype(np.float32)
+    if distribution == "clustered_same_mixture":
+        # base AND held-out queries from ONE mixture (the generator draws its centres from the seed: seed-43 queries of
+        # 'clustered' point at other centres than the base's): rows [0, N31K) of the seed-42 stream are the base, the
+        # rows behind them the queries
+        x = datagen.generate_dataset(N31K + (0 if seed == 42 else n), DIM, "clustered", num_clusters=256, noise_level=0.3,
+                                     seed=42, dtype=np.float64)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        return (x[:n] if seed == 42 else x[N31K:N31K + n]).astype(np.float32)
     if distribution == "uniform01":
         # what the published run and the hnswlib script used: (rand) / np.random.rand, i.i.d. uniform on [0, 1)
         # (wip/ultra_optimized.clj:293-296, scripts/benchmark_python_hnswlib.py:31) -- here java.util.Random.nextDouble
@@ -126,7 +144,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nq", type=int, default=10000, help="queries per step per GPU")
     ap.add_argument("--ef", type=int, default=0, help="0 = first ef of the sweep with recall@10 >= 0.98")
-    ap.add_argument("--dist", default="manifold", choices=["manifold", "clustered", "gaussian", "uniform01", "uniform_pm1"])
+    ap.add_argument("--dist", default="clustered",
+                    choices=["clustered", "gaussian", "uniform01", "uniform_pm1", "clustered_same_mixture", "manifold"],
+                    help="31k x 768 data set; BASELINE.md section 3 names gaussian, clustered-normalised and uniform[0,1)")
+    ap.add_argument("--builder", default="heuristic", choices=sorted(BUILDERS),
+                    help="index builder: graph.clj's heuristic selection (one-sided pruning; 'graph.clj' = pruned on both "
+                         "sides) or hnsw.ultra-fast's closest-m")
     ap.add_argument("--no-ivf", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--ivf-n", type=int, default=1_000_000)
@@ -184,7 +207,7 @@ def main():
     log("[rank %d] data %.1fs" % (rank, time.time() - t0))
     idx = engine.Index(base, "cosine", dev.index)
     t0 = time.time()
-    idx.hnsw_build(M, EFC, 42)
+    idx.hnsw_build(M, EFC, 42, **BUILDERS[args.builder])
     build_s = time.time() - t0
     log("[rank %d] hnsw build on device %.2fs" % (rank, build_s))
     Q = torch.from_numpy(queries).to(dev)
@@ -291,8 +314,10 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "hnsw.ultra-optimized search-knn, 31,173 x 768 f32 (%s, java.util.Random seed 42), k=10, "
-                        "M=16 ef_construction=200, batched HIP traversal kernel" % args.dist,
+            "workload": "hnsw search-knn (ultra_fast.clj:346-374 = graph.clj:297-320), 31,173 x 768 f32 (%s, java.util.Random "
+                        "seed 42; queries: the same generator, seed 43), k=10, M=16 ef_construction=200, index built on the "
+                        "device by the %s builder, batched HIP traversal kernel" % (args.dist, args.builder),
+            "builder": args.builder,
             "queries_per_step_per_gpu": args.nq,
             "ef_search": ef,
             "recall_at_10": round(rec, 4),
@@ -381,23 +406,42 @@ def host_buffer_qps(idx, queries, ef, steps):
 
 
 def by_distribution(engine, dev, args, want_cpu):
-    """the generator's distributions beside the headline's manifold set -- gaussian (primary in the
-    survey), uniform01 = i.i.d. uniform on [0, 1) (what the published run and benchmark_python_hnswlib.py:31 used),
-    uniform_pm1 = the generator's own :uniform on [-1, 1), clustered-normalised.  Each: build on the device, ground truth by
-    GPU brute force over the full base, then the FIRST ef of the sweep whose recall@10 reaches 0.98 -- or the last point of
-    the sweep if none does (ef <= 4096 is the kernel's limit).  Beside every operating point the two numbers that say what
-    it is worth (bench.clj:72-92 defines both sides): exact_knn_qps = the same queries answered at recall 1.0 by the GPU's
-    exact scan (hnswgpu_exact_knn_dev), cpu_qps = the CPU oracle (f64 reference order) on the same graph at the same ef."""
+    """SURVEY 8(d) S1, every set beside the headline's: gaussian (primary in the survey), clustered-normalised (queries by
+    the same generator with seed 43: other centres than the base's), uniform01 = i.i.d. uniform on [0, 1) (what the
+    published run and benchmark_python_hnswlib.py:31 used), uniform_pm1 = the generator's own :uniform on [-1, 1), plus
+    clustered_same_mixture (held-out rows of the base's own mixture) and the latent-manifold set of rounds 1-3.  Each: build
+    on the device by the run's builder, ground truth by GPU brute force over the full base, then the FIRST ef of the sweep
+    whose recall@10 reaches 0.98 -- or the last point of the sweep if none does (ef <= 4096 is the kernel's limit).  Beside
+    every operating point the two numbers that say what it is worth (bench.clj:72-92 defines both sides): exact_knn_qps =
+    the same queries answered at recall 1.0 by the GPU's exact scan (hnswgpu_exact_knn_dev), cpu_qps = the CPU oracle (f64
+    reference order) on the same graph at the same ef; closest_m = the same sweep on hnsw.ultra-fast's closest-m graph."""
     out = {}
-    sweep = [50, 100, 200, 400, 800, 1600, 3200, 4096]
+    sweep = [50, 100, 200, 400, 600, 800, 1200, 1600, 2400, 3200, 4096]
     nq = min(args.nq, 4096)
-    for name in ("gaussian", "uniform01", "uniform_pm1", "clustered"):
+
+    def run_sweep(idx, Q, truth):
+        pts, hit = [], None
+        for e in sweep:
+            ids, _ = idx.hnsw_search_dev(Q, K, e)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                idx.hnsw_search_dev(Q, K, e)
+            torch.cuda.synchronize()
+            qps = 3 * nq / (time.perf_counter() - t1)
+            r = recall_at_k(ids, truth)
+            pts.append([e, round(r, 4), round(qps, 1)])
+            if r >= 0.98:
+                hit = pts[-1]
+                break
+        return pts, hit
+
+    for name in ("gaussian", "clustered", "uniform01", "uniform_pm1", "clustered_same_mixture", "manifold"):
         t0 = time.time()
         base = make_31k(name, 42, N31K)
         qh = make_31k(name, 43, nq)
         Q = torch.from_numpy(qh).to(dev)
         with engine.Index(base, "cosine", dev.index) as idx:
-            idx.hnsw_build(M, EFC, 42)
             truth, _ = idx.exact_knn_dev(Q, K)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -405,23 +449,23 @@ def by_distribution(engine, dev, args, want_cpu):
                 idx.exact_knn_dev(Q, K)
             torch.cuda.synchronize()
             exact_qps = 3 * nq / (time.perf_counter() - t1)
-            pts, hit = [], None
-            for e in sweep:
-                ids, _ = idx.hnsw_search_dev(Q, K, e)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(3):
-                    idx.hnsw_search_dev(Q, K, e)
-                torch.cuda.synchronize()
-                qps = 3 * nq / (time.perf_counter() - t1)
-                r = recall_at_k(ids, truth)
-                pts.append([e, round(r, 4), round(qps, 1)])
-                if r >= 0.98:
-                    hit = pts[-1]
-                    break
+            others = {}
+            for b in ("ultra_fast.clj", "graph.clj", "heuristic"):
+                if b == args.builder:
+                    continue
+                idx.hnsw_build(M, EFC, 42, **BUILDERS[b])
+                opts, ohit = run_sweep(idx, Q, truth)
+                of = ohit or opts[-1]
+                others[b] = {"ef": of[0], "recall_at_10": of[1], "qps": of[2], "reached_0.98": ohit is not None}
+            tb = time.time()
+            idx.hnsw_build(M, EFC, 42, **BUILDERS[args.builder])
+            tb = time.time() - tb
+            pts, hit = run_sweep(idx, Q, truth)
             first = hit or pts[-1]
-            out[name] = {"ef": first[0], "recall_at_10": first[1], "qps": first[2], "reached_0.98": hit is not None,
-                         "exact_knn_qps": round(exact_qps, 1), "sweep_ef_recall_qps": pts, "queries": nq}
+            out[name] = {"builder": args.builder, "ef": first[0], "recall_at_10": first[1], "qps": first[2],
+                         "reached_0.98": hit is not None, "build_s": round(tb, 2),
+                         "exact_knn_qps": round(exact_qps, 1), "sweep_ef_recall_qps": pts, "queries": nq,
+                         "other_builders": others}
             if want_cpu:
                 out[name].update(cpu_point(idx, base, qh, first[0]))
             o = out[name]
@@ -429,9 +473,9 @@ def by_distribution(engine, dev, args, want_cpu):
         log("by_distribution %s: %s (%.1fs)" % (name, out[name], time.time() - t0))
     out["note"] = ("i.i.d. gaussian / uniform 768-d have no neighbourhood structure: recall 0.98 needs ef in the thousands, where "
                    "the traversal evaluates most of the base per query -- on those sets the GPU's exact scan (recall 1.0) is the "
-                   "better answer by two orders of magnitude, and better_at_0.98 says so; clustered leaves the reference-style "
-                   "graph (closest-m pruning, no diversity heuristic, ultra_fast.clj:279-299) disconnected between clusters.  "
-                   "DESIGN.md section 6.")
+                   "better answer, and better_at_0.98 says so.  On well-separated clusters closest-m pruning "
+                   "(ultra_fast.clj:279-299) leaves the clusters disconnected (recall ~0.03 at every ef); the diversity heuristic "
+                   "of graph.clj:162-198 keeps them linked.  DESIGN.md section 6.")
     return out
 
 
@@ -855,31 +899,33 @@ def sharded_hnsw(engine, dev, rank, world, args):
     """BASELINE.json configs[4]: 1536-d cosine HNSW, row-sharded (1.25M rows per GPU = 10M x 1536 on 8), one
     independent sub-graph per GPU (= PartitionedHNSWIndex, partitioned_hnsw.clj:23-27, searched with the full k),
     ef_search = 256, batch = 1024 queries replicated on every rank, ONE all-gather of the per-shard top-k and a merge
-    kernel.  Weak scaling in rows.  Data: the latent-manifold generator of the 31k leg (r = 32; torch, on the device);
-    queries are held-out draws from the same manifold.  Recall against exact kNN over ALL shards (same gather/merge)."""
+    kernel.  Weak scaling in rows.  Data: SURVEY S4 -- clustered-normalised rows (1024 centres per shard's worth of rows,
+    noise 0.3; torch, on the device), queries held-out draws from the same mixture; the sub-graphs by the run's builder.
+    Recall against exact kNN over ALL shards (same gather/merge)."""
     from hnsw_clj_amd.sharded import ShardedSearcher
 
-    n, dim, r, ef, nq = args.hnsw_shard_rows, 1536, 32, 256, 1024
+    n, dim, ef, nq = args.hnsw_shard_rows, 1536, 256, 1024
+    ncen = 1024 * world
 
-    def manifold(gen, m, w):
+    def mixture(gen, m, cen):
         out = torch.empty(m, dim, device=dev)
         for i in range(0, m, 250_000):
             c = min(250_000, m - i)
-            x = torch.randn(c, r, generator=gen, device=dev) @ w / r ** 0.5 + 0.1 * torch.randn(c, dim, generator=gen, device=dev)
+            x = cen[torch.randint(0, ncen, (c,), generator=gen, device=dev)] + 0.3 * torch.randn(c, dim, generator=gen, device=dev)
             out[i:i + c] = x / x.norm(dim=1, keepdim=True)
         return out
 
     g = torch.Generator(device=dev)
-    g.manual_seed(11)                                  # the latent basis is global
-    w = torch.randn(r, dim, generator=g, device=dev)
+    g.manual_seed(11)                                  # the centres are global
+    cen = torch.randn(ncen, dim, generator=g, device=dev)
     g.manual_seed(2000 + rank)                         # every shard draws its own rows
-    x = manifold(g, n, w)
+    x = mixture(g, n, cen)
     g.manual_seed(43)                                  # the same query batch on every rank
-    Q = manifold(g, nq, w)
+    Q = mixture(g, nq, cen)
     idx = engine.Index(x, "cosine", dev.index)
     del x
     t0 = time.time()
-    idx.hnsw_build(M, EFC, 42)
+    idx.hnsw_build(M, EFC, 42, **BUILDERS[args.builder])
     build_s = time.time() - t0
     s = ShardedSearcher(lambda q, k: idx.hnsw_search_dev(q, k, ef), rank * n, always_collective=True)
     truth = ShardedSearcher(lambda q, k: idx.exact_knn_dev(q, k), rank * n, always_collective=True)
@@ -904,8 +950,9 @@ def sharded_hnsw(engine, dev, rank, world, args):
         el = float(t.item())
     ok = bool((ids >= 0).all() and (ids < world * n).all() and (d[:, 1:] >= d[:, :-1]).all())
     idx.close()
-    return {"workload": "hnsw (M=16, ef_construction=200) %d x 1536 cosine row-sharded over %d GPU(s) (%d rows, one sub-graph "
-                        "each), ef_search 256, batch 1024, all-gather of per-shard top-10 + merge" % (world * n, world, n),
+    return {"workload": "hnsw (M=16, ef_construction=200, %s builder) %d x 1536 cosine clustered-normalised, row-sharded over "
+                        "%d GPU(s) (%d rows, one sub-graph each), ef_search 256, batch 1024, all-gather of per-shard top-10 + merge"
+                        % (args.builder, world * n, world, n),
             "qps": round(nq * steps / el, 1), "ms_per_batch": round(el / steps * 1e3, 3), "recall_at_10": round(rec, 4),
             "valid": ok, "hnsw_build_s_per_shard": round(build_s, 1), "collective": "all_gather of %d B per rank" % (nq * K * 8)}
 

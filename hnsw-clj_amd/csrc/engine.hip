@@ -710,7 +710,7 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
         a.tau = rs->tau;
         a.surv_cnt = rs->surv_cnt;
         a.k = rs->k;
-        a.seed_rows = stream_seed_rows(nq, idx->n, idx->nlist);
+        a.seed_rows = stream_seed_rows(nq, idx->ivf_n_global > 0 ? idx->ivf_n_global : idx->n, idx->nlist);
         a.bk_cnt = rs->bk_cnt;
         a.bk_mem = rs->bk_mem;
         a.bk_cap = rs->bk_cap;

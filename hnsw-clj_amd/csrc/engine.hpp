@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -174,6 +175,10 @@ struct hnswgpu_index {
     // a SHARD of a larger IVF index (hnswgpu_set_ivf_shard): prefix sums of the list lengths of the WHOLE index, so
     // that every shard numbers its candidates as the unsharded search would; nullptr on an ordinary index
     int64_t *d_glistoff = nullptr;
+    // rows of the WHOLE index the lists belong to (= n on an ordinary index; the sum of the global list lengths on a shard):
+    // everything that chooses a kernel path or sizes a sample by the MEAN LIST LENGTH uses this, so that a shard decides
+    // what the unsharded index decides (a shard holds n / ndev rows over the same nlist)
+    int64_t ivf_n_global = 0;
     bool lrows_alias = false;  // lists are the base rows in place (list_ids = 0..n-1): d_lrows / d_lnorms alias d_base / d_norms
     std::vector<float> h_cent;
     std::vector<int64_t> h_listoff, h_glistlen;
@@ -197,6 +202,10 @@ struct hnswgpu_index {
 };
 
 namespace hg {
+
+inline int64_t ivf_mean_len(const hnswgpu_index *idx) {
+    return std::max<int64_t>(1, (idx->ivf_n_global > 0 ? idx->ivf_n_global : idx->n) / std::max(idx->nlist, 1));
+}
 
 int pick_nch(int64_t ld);  // 0 if unsupported
 // hipFuncSetAttribute is per device: true the first time a call site asks on the current device

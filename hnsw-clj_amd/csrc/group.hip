@@ -219,6 +219,14 @@ int hnswgpu_group_set_ivf(hnswgpu_group *g, const float *base, int64_t n, const 
             if (rn > 0) HG_HIP(hipMemcpy(mm.d_map, map.data(), sizeof(int32_t) * rn, hipMemcpyHostToDevice));
             mm.n = rn;
         }
+        // ONE verdict for the whole index (include/hnswgpu.h: hnswgpu_ivf_stream_state): off if any shard with rows says so
+        int32_t off_any = 0;
+        for (int r = 0; r < nd; r++) {
+            int32_t off = 0;
+            if (g->m[r].n > 0) HG_TRY(hnswgpu_ivf_stream_state(g->m[r].idx, &off));
+            off_any |= off;
+        }
+        for (int r = 0; r < nd; r++) HG_TRY(hnswgpu_ivf_set_stream_state(g->m[r].idx, off_any));
     } catch (const std::bad_alloc &) {
         group_clear_members(g);
         set_error("host allocation failed while dealing the lists");

@@ -64,6 +64,12 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     // with the rejection test (fewer f32 rows in flight, below) a CU holds 4 / 8 / 20 such workgroups up to dim 768:
     // 1,024 queries 0.60 / 0.68 / 0.96 ms with 4 / 2 / 1 waves, 2,048: 1.15 / 0.93 / 1.06, 3,072: 1.68 / 1.51 / 1.36
     if (hnsw_nw() == 0 && a.qrows && nch <= 3) nw = a.nq > 2048 ? 1 : (a.nq > 1024 ? 2 : 4);
+    // a long candidate list (large ef) bounds the queries a CU holds by its LDS, not by registers: fewer than ~13 waves per
+    // CU cannot hide the hop's dependent round trips, so the queries that fit get more waves each (the int8 and f32 steps
+    // of a hop then run side by side).  31k x 768 clustered, 10,000 queries, QPS with 1 / 2 / 4 waves: ef 400 729k / 784k /
+    // 513k, ef 800 250k / 343k / 258k, ef 1600 60k / 89k / 116k, ef 3200 10.8k / 17.7k / 25.6k (tools/large_ef_nw.py).
+    if (hnsw_nw() == 0)
+        while (nw < 4 && static_cast<int64_t>(kMaxLds / hnsw_lds_bytes(a.cap, vg ? 0 : a.nwords, nw)) * nw < 13) nw *= 2;
     int grid = a.nq;
     if (a.q_index) {  // repeat pass: few (usually no) work items, one large-list workgroup per CU at most
         nw = 4;
@@ -1147,7 +1153,8 @@ static int insert_batches(hnswgpu_index *idx, HostGraph &g, int64_t done, int ef
     const int64_t blocks = g.up_off[n];
     int maxlv = 1;
     for (int64_t i = done; i < n; i++) maxlv = std::max(maxlv, g.levels[i]);
-    const int64_t maxB = seq ? 1 : 16384;  // scratch sizing; the batch actually used grows with the graph (see below)
+    // scratch sizing; the batch actually used grows with the graph (see below)
+    const int64_t maxB = seq ? 1 : std::max<int64_t>(1, std::min<int64_t>(16384, tune(HNSWGPU_TUNE_BUILD_BATCH, 16384)));
     const int kk = heur ? ef : M0;         // layer-0 candidates a search hands back: all of them for the heuristic
     HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * maxB * kk));
     HG_TRY(idx->s_outd.ensure(sizeof(float) * maxB * kk));

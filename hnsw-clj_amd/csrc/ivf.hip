@@ -417,6 +417,7 @@ static void free_ivf(hnswgpu_index *idx) {
     idx->d_listids = nullptr;
     idx->lrows_alias = false;
     idx->h_glistlen.clear();
+    idx->ivf_n_global = 0;
     idx->nlist = 0;
 }
 
@@ -794,7 +795,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     const int32_t *qorder = nullptr;  // large batches: the queries in the order of their nearest list (below)
     const int64_t stride = (static_cast<int64_t>(nprobe) * idx->max_list_len + 3) / 4 * 4;
     // rows per workgroup: whole tiles; enough working workgroups to fill the chip a few times over
-    const int64_t mean = std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1));
+    const int64_t mean = ivf_mean_len(idx);
     const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows, max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows;
     const int64_t tgt = tune(HNSWGPU_TUNE_STREAM_WGS, 2048);
     const bool grouped = sc.bk_cnt != nullptr;
@@ -953,7 +954,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     f.out_ids = d_out_ids;
     f.out_dist = d_out_dist;
     f.out_gord = d_out_gord;
-    f.stats = idx->prof ? idx->d_rej_stats : nullptr;
+    f.stats = (idx->prof || idx->ivf_calibrating) ? idx->d_rej_stats : nullptr;
     f.qorder = f.slices == 1 ? qorder : nullptr;
     f.main_blocks = static_cast<int32_t>(f.qorder ? (static_cast<int64_t>(nq) + 7) / 8 * 8 : static_cast<int64_t>(nq) * f.slices);
     if (mid) {
@@ -1011,7 +1012,7 @@ constexpr int32_t kStreamMaxK = 256;  // largest k the bounds pass serves (large
 // foreign cluster, every survivor list overflows and the search is the f32 scan behind a wasted bounds pass (1M rows in 128
 // lists, k = 100, batch 1024: 147 ms against 25): such searches take the f32 paths.
 static int32_t ivf_stream_max_k(const hnswgpu_index *idx) {
-    const int64_t mean = idx->n / std::max(idx->nlist, 1);
+    const int64_t mean = ivf_mean_len(idx);  // of the WHOLE index: a shard must take the path the unsharded index takes
     const int64_t scale = std::max<int64_t>(1, std::min<int64_t>(8, mean / 1024));
     return static_cast<int32_t>(kStreamMaxK / scale);
 }
@@ -1042,51 +1043,54 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
 // alone; more than a quarter of the candidates fetched in f32 switches the stream off for the handle (mode 2 forces it,
 // mode 0 never builds it).  The decision depends on the rows and the lists only: the same handle always takes the same path.
 static int ivf_calibrate(hnswgpu_index *idx, hipStream_t st) {
-    idx->ivf_calibrated = true;
-    if (idx->rejection_mode != 1 || !idx->d_lctile || idx->dim < 128 || idx->n < 4096 || tune(HNSWGPU_TUNE_IVF_CALIBRATE, 1) == 0) return 0;
+    if (idx->rejection_mode != 1 || !idx->d_lctile || idx->dim < 128 || idx->n < 4096 || tune(HNSWGPU_TUNE_IVF_CALIBRATE, 1) == 0) {
+        idx->ivf_calibrated = true;  // nothing to measure in this mode
+        return 0;
+    }
+    // one allocation [queries | ids | distances | counters], freed on every path; the handle counts as calibrated only
+    // once the measurement has succeeded (a transient failure is retried by the next search); the user's profiling state
+    // and events are not touched (the counters go through ivf_calibrating, not through idx->prof).  The first search of a
+    // mode-1 handle is therefore synchronous once -- also through the *_dev entry points.
     const int32_t cq = 32, ck = 10, cp = std::min(32, idx->nlist);
-    float *d_q = nullptr;
-    int32_t *d_i = nullptr;
-    float *d_d = nullptr;
-    unsigned long long *d_st = nullptr, saved[2] = {0, 0}, got[2] = {0, 0};
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&d_q), sizeof(float) * cq * idx->dim));
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&d_i), sizeof(int32_t) * cq * ck));
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&d_d), sizeof(float) * cq * ck));
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&d_st), sizeof(saved)));
-    const int64_t step = idx->n / cq;
-    for (int i = 0; i < cq; i++)  // evenly spaced list rows as queries
-        HG_HIP(hipMemcpyAsync(d_q + static_cast<int64_t>(i) * idx->dim, idx->d_lrows + (static_cast<int64_t>(i) * step + step / 2) * idx->ld,
-                              sizeof(float) * idx->dim, hipMemcpyDeviceToDevice, st));
-    HG_HIP(hipMemsetAsync(d_st, 0, sizeof(saved), st));
+    const size_t b_q = sizeof(float) * cq * idx->dim, b_i = sizeof(int32_t) * cq * ck, b_d = sizeof(float) * cq * ck;
+    char *buf = nullptr;
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&buf), b_q + b_i + b_d + 2 * sizeof(unsigned long long)));
+    float *d_q = reinterpret_cast<float *>(buf);
+    int32_t *d_i = reinterpret_cast<int32_t *>(buf + b_q);
+    float *d_d = reinterpret_cast<float *>(buf + b_q + b_i);
+    unsigned long long *d_st = reinterpret_cast<unsigned long long *>(buf + b_q + b_i + b_d), got[2] = {0, 0};
     unsigned long long *const old_stats = idx->d_rej_stats;
-    const bool old_prof = idx->prof;
-    idx->d_rej_stats = d_st;
-    idx->prof = true;
-    idx->ivf_calibrating = true;
-    const int rc = ivf_search_enqueue(idx, d_q, cq, ck, cp, d_i, d_d, nullptr, st);
-    idx->ivf_calibrating = false;
-    idx->prof = old_prof;
-    idx->d_rej_stats = old_stats;
-    if (rc == 0) {
+    const int rc = [&]() -> int {
+        const int64_t step = idx->n / cq;
+        for (int i = 0; i < cq; i++)  // evenly spaced list rows as queries
+            HG_HIP(hipMemcpyAsync(d_q + static_cast<int64_t>(i) * idx->dim, idx->d_lrows + (static_cast<int64_t>(i) * step + step / 2) * idx->ld,
+                                  sizeof(float) * idx->dim, hipMemcpyDeviceToDevice, st));
+        HG_HIP(hipMemsetAsync(d_st, 0, sizeof(got), st));
+        idx->d_rej_stats = d_st;
+        idx->ivf_calibrating = true;
+        const int r = ivf_search_enqueue(idx, d_q, cq, ck, cp, d_i, d_d, nullptr, st);
+        idx->ivf_calibrating = false;
+        idx->d_rej_stats = old_stats;
+        HG_TRY(r);
         HG_HIP(hipMemcpyAsync(got, d_st, sizeof(got), hipMemcpyDeviceToHost, st));
         HG_HIP(hipStreamSynchronize(st));
-        // [0] = f32 rows fetched, [1] = candidates
-        if (got[1] >= static_cast<unsigned long long>(cq) * 256 && got[0] * 4 > got[1]) idx->ivf_stream_off = true;
-    } else {
-        (void)hipStreamSynchronize(st);
-    }
-    (void)saved;
-    (void)hipFree(d_q);
-    (void)hipFree(d_i);
-    (void)hipFree(d_d);
-    (void)hipFree(d_st);
-    return rc;
+        return 0;
+    }();
+    idx->ivf_calibrating = false;
+    idx->d_rej_stats = old_stats;
+    if (rc != 0) (void)hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    if (rc != 0) return rc;
+    // [0] = f32 rows fetched, [1] = candidates
+    idx->ivf_stream_off = got[1] >= static_cast<unsigned long long>(cq) * 256 && got[0] * 4 > got[1];
+    idx->ivf_calibrated = true;
+    return 0;
 }
 
 static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
                               int32_t *d_out_ids, float *d_out_dist, int32_t *d_out_probes, hipStream_t st,
                               const int32_t *d_given_probes, uint32_t *d_out_gord) {
-    if (!idx->ivf_calibrated) HG_TRY(ivf_calibrate(idx, st));
+    if (!idx->ivf_calibrated && !idx->ivf_calibrating) HG_TRY(ivf_calibrate(idx, st));
     const int64_t *glistoff = idx->d_glistoff ? idx->d_glistoff : idx->d_listoff;
     if (nprobe > idx->nlist && !d_given_probes) nprobe = idx->nlist;
     // 1. centroid routing (:261-269): top-nprobe of the centroid table, stable on the centroid index
@@ -1222,7 +1226,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
             pa.nq = nq;
             pa.nprobe = nprobe;
             pa.k = k;
-            pa.seed_rows = stream_seed_rows(nq, idx->n, idx->nlist);
+            pa.seed_rows = stream_seed_rows(nq, idx->ivf_n_global > 0 ? idx->ivf_n_global : idx->n, idx->nlist);
             pa.pairs = idx->s_pairs.as<Pair>();
             pa.qcnt = qcnt_buf;
             pa.rows = idx->d_lrows;
@@ -1274,11 +1278,11 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
             a.out_ids = d_out_ids;
             a.out_dist = d_out_dist;
             a.out_gord = d_out_gord;
-            return scan_fused(idx, a, nq, nprobe, idx->max_list_len, std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1)), st,
+            return scan_fused(idx, a, nq, nprobe, idx->max_list_len, ivf_mean_len(idx), st,
                               PROF_IVF_SCAN);
         }
         HG_TRY(scan_topk(idx, a, nq, nprobe, idx->max_list_len, st, PROF_IVF_SCAN,
-                         std::max<int64_t>(1, idx->n / std::max(idx->nlist, 1))));
+                         ivf_mean_len(idx)));
     }
     int64_t cnt = static_cast<int64_t>(nq) * k;
     hipLaunchKernelGGL(ivf_decode_kernel, dim3(static_cast<unsigned>((cnt + 255) / 256)), dim3(256), 0, st,
@@ -1329,7 +1333,11 @@ static int set_ivf_impl(hnswgpu_index *idx, const float *centroids, int32_t nlis
         HG_HIP(hipMemcpyAsync(idx->d_glistoff, goff.data(), sizeof(int64_t) * (nlist + 1), hipMemcpyHostToDevice, st));
     }
     HG_TRY(install_lists(idx, nlist, list_off, list_ids, st));  // synchronises: goff may go out of scope
-    if (global_len) idx->h_glistlen.assign(global_len, global_len + nlist);
+    idx->ivf_n_global = idx->n;
+    if (global_len) {
+        idx->h_glistlen.assign(global_len, global_len + nlist);
+        idx->ivf_n_global = goff[nlist];
+    }
     idx->h_cent.assign(centroids, centroids + static_cast<size_t>(nlist) * idx->dim);
     return 0;
 }
@@ -1584,6 +1592,29 @@ static int ivf_search_batch(hnswgpu_index *idx, const std::vector<hnswgpu_index:
     return 0;
 }
 
+int hnswgpu_ivf_stream_state(hnswgpu_index *idx, int32_t *off) {
+    HG_REQUIRE(idx && off, HNSWGPU_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_REQUIRE(idx->nlist > 0, HNSWGPU_ESTATE, "index has no IVF lists");
+    if (!idx->ivf_calibrated) {
+        HG_HIP(hipSetDevice(idx->device));
+        HG_TRY(begin_call(idx, idx->stream));
+        HG_TRY(ivf_calibrate(idx, idx->stream));
+        HG_TRY(end_call(idx, idx->stream));
+    }
+    *off = idx->ivf_stream_off ? 1 : 0;
+    return 0;
+}
+
+int hnswgpu_ivf_set_stream_state(hnswgpu_index *idx, int32_t off) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_REQUIRE(idx->nlist > 0, HNSWGPU_ESTATE, "index has no IVF lists");
+    idx->ivf_stream_off = off != 0;
+    idx->ivf_calibrated = true;
+    return 0;
+}
+
 int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k, int32_t nprobe,
                        int32_t *out_ids, float *out_dist, int32_t *out_probes) {
     HG_TRY(check_ivf_args(idx, Q, nq, k, nprobe, out_ids, out_dist));
@@ -1601,6 +1632,18 @@ int hnswgpu_ivf_search(hnswgpu_index *idx, const float *Q, int32_t nq, int32_t k
         me.out_ids = out_ids;
         me.out_dist = out_dist;
         me.stats = nullptr;
+        // (the handle's one-off measurement of what the int8 bounds separate decides ivf_tile_pairs: it runs here, under
+        // the index lock, before the predicate is built -- concurrent first calls would otherwise combine by the
+        // pre-calibration boundary and run on the post-calibration kernel)
+        {
+            std::lock_guard<std::mutex> lk(idx->mu);
+            if (!idx->ivf_calibrated && idx->nlist > 0) {
+                HG_HIP(hipSetDevice(idx->device));
+                HG_TRY(begin_call(idx, idx->stream));
+                HG_TRY(ivf_calibrate(idx, idx->stream));
+                HG_TRY(end_call(idx, idx->stream));
+            }
+        }
         const bool one_arith = idx->metric == METRIC_L2 || !tile_path_ok(idx) || tile_mode() == 0;
         // the kernel a batch of `total` queries gets: ivf_search_enqueue's own predicate, on the BATCH's nprobe (the
         // leader that evaluates this may have asked for another one)

@@ -251,6 +251,16 @@ class Index:
         ids = np.ascontiguousarray(list_ids, np.int32)
         check(lib().hnswgpu_set_ivf(self._h, _p(cen), cen.shape[0], _p(off), _p(ids)))
 
+    def ivf_stream_state(self):
+        """1 if this handle's first-search measurement switched the survivor stream off (measures now if it has not yet)."""
+        off = C.c_int32(0)
+        check(lib().hnswgpu_ivf_stream_state(self._h, C.byref(off)))
+        return off.value
+
+    def ivf_set_stream_state(self, off):
+        """Install a verdict without measuring: the shards of one index share one (see include/hnswgpu.h)."""
+        check(lib().hnswgpu_ivf_set_stream_state(self._h, 1 if off else 0))
+
     def set_ivf_shard(self, centroids, list_off, list_ids, global_list_len):
         """This handle holds some of the inverted lists of a larger index (see include/hnswgpu.h)."""
         cen = _f32(centroids)

@@ -5,7 +5,14 @@ Modes (:136-140): turbo 50 / fast 100 / balanced 200 / accurate 300 / precise 50
 values are written into ``[:params :ef]`` but ``graph/search-knn`` never reads them (it uses (max k 50),
 graph.clj:304 -- SURVEY fact 9), so every mode searches with the same breadth.  The default reproduces what the
 reference DOES (``honour_modes=False``: ef = (max k 50) whatever the mode -- a drop-in must return the reference's
-results); ``honour_modes=True`` opts in to what the presets' doc-string promises."""
+results); ``honour_modes=True`` opts in to what the presets' doc-string promises.
+
+The build is ``graph/insert`` (src/hnsw/graph.clj:239-295) as far as an adjacency row of at most 2M / M ids allows: links
+chosen by ``get-neighbors-heuristic`` (:162-198) on the device, an over-full neighbour list re-selected by it and the
+dropped edges removed from both lists (``prune-connections``, :208-232) -- ``hnswgpu_hnsw_build_ex`` with
+HNSWGPU_BUILD_HEURISTIC | HNSWGPU_BUILD_SYMMETRIC.  (The reference links a new node to EVERY candidate of its second
+search, :280-287, and only prunes the neighbours; include/hnswgpu.h says why this build selects the node's own links by
+the same heuristic.)  ``closest_m=True`` gives ``hnsw.ultra-fast``'s plain closest-m lists instead."""
 from . import ultra_fast
 from .ultra_fast import cosine_distance_ultra
 
@@ -22,8 +29,11 @@ class PureHNSWIndex:
 
 
 def build_pure_hnsw_index(data, M=16, ef_construction=200, ef=200, distance_fn=cosine_distance_ultra,
-                          show_progress=True, **kw):
-    """pure_hnsw.clj:38-123"""
+                          show_progress=True, closest_m=False, **kw):
+    """pure_hnsw.clj:38-123 over graph/insert (graph.clj:239-295)"""
+    if not closest_m and kw.get("graph") is None:
+        kw.setdefault("heuristic", True)
+        kw.setdefault("symmetric", True)
     g = ultra_fast.build_index(data, M=M, ef_construction=ef_construction, distance_fn=distance_fn,
                                show_progress=show_progress, **kw)
     return PureHNSWIndex(g, {"M": M, "ef-construction": ef_construction, "ef": ef})

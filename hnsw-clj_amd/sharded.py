@@ -250,6 +250,12 @@ class ShardedIVF:
         lens_local[mine] = llen.sum(axis=0)
         list_off[1:] = np.cumsum(lens_local)
         shard = ops.open_shard(rows, metric, cen, list_off, glen)
+        # ONE verdict of the first-search calibration for the whole index (include/hnswgpu.h: hnswgpu_ivf_stream_state):
+        # every rank measures on its rows, the index takes the survivor stream off if any rank would
+        if hasattr(shard, "ivf_stream_state"):
+            off = int(shard.ivf_stream_state()) if shard.n > 0 else 0
+            off = int(comm.all_reduce_sum(np.array([off], np.int64))[0] > 0)
+            shard.ivf_set_stream_state(off)
         return cls(comm, ops, shard, gid, cen, list_off, glen, owner, assign, row_base)
 
     def search(self, Q, k, nprobe):

@@ -73,9 +73,11 @@ def _split(data):
 
 
 def build_index(data, M=16, ef_construction=200, distance_fn=cosine_distance_ultra, show_progress=True, seed=42,
-                device=0, graph=None):
+                device=0, graph=None, sequential=False, heuristic=False, symmetric=False, extend=False):
     """ultra_fast.clj:334-344.  ``graph`` (an engine.Graph) uploads an adjacency built elsewhere instead
-    of building one on the device."""
+    of building one on the device.  ``sequential`` = insert-single's own order and start level (:216-275; slow, the
+    parity mode); ``heuristic`` / ``symmetric`` / ``extend`` = the neighbour selection of src/hnsw/graph.clj:162-232
+    (what ``pure_hnsw.build_index`` asks for)."""
     metric = _metric_of(distance_fn)
     ids, base = _split(data)
     if show_progress:
@@ -84,7 +86,7 @@ def build_index(data, M=16, ef_construction=200, distance_fn=cosine_distance_ult
     if graph is not None:
         idx.set_graph(graph)
     else:
-        idx.hnsw_build(M, ef_construction, seed)
+        idx.hnsw_build(M, ef_construction, seed, sequential=sequential, heuristic=heuristic, symmetric=symmetric, extend=extend)
     return UltraGraph(idx, ids, M, ef_construction, distance_fn)
 
 

@@ -210,6 +210,15 @@ int hnswgpu_ivf_search_lists(hnswgpu_index *idx, const float *Q, int32_t nq, int
  *   added, e.g. by an RCCL all-reduce, then divided by the global member count).  out_sums: nlist x dim doubles. */
 int hnswgpu_set_ivf_shard(hnswgpu_index *idx, const float *centroids, int32_t nlist, const int64_t *list_off,
                           const int32_t *list_ids, const int64_t *global_list_len);
+/* Mode-1 handles measure, at their first IVF search, what the int8 bounds separate on their rows, and keep the survivor
+ * stream only where it helps (the verdict chooses the kernel path, hence -- for cosine / dot batches past the tile
+ * boundary -- the summation order).  The shards of ONE index must share ONE verdict: hnswgpu_ivf_stream_state measures
+ * now (if it has not yet) and reports it (1 = stream off), hnswgpu_ivf_set_stream_state installs a verdict without
+ * measuring.  hnswgpu_group_set_ivf and sharded.ShardedIVF take the OR over the shards and push it to every member.
+ * A shard also decides everything that depends on the mean list length (largest k the stream serves, sample sizes) from
+ * the WHOLE index's list lengths (global_list_len), not from the rows it holds. */
+int hnswgpu_ivf_stream_state(hnswgpu_index *idx, int32_t *off);
+int hnswgpu_ivf_set_stream_state(hnswgpu_index *idx, int32_t off);
 int hnswgpu_ivf_search_shard_dev(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t k, int32_t nprobe,
                                  int32_t *d_out_ids, float *d_out_dist, uint32_t *d_out_order, void *stream);
 int hnswgpu_merge_keyed_dev(int32_t device, const int32_t *d_ids, const float *d_dist, const uint32_t *d_order,
@@ -349,7 +358,8 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_PF_EVAL 40 /* 0 = the helpers only warm the L2 (A/B) */
 #define HNSWGPU_TUNE_ZEROCOPY 41 /* 0 = small synchronous HNSW calls stage through copies instead of mapped pinned memory (A/B) */
 #define HNSWGPU_TUNE_BUILD_TIMING 42 /* 1 = hnswgpu_hnsw_build prints where its time went to stderr */
-#define HNSWGPU_TUNE_COUNT 43
+#define HNSWGPU_TUNE_BUILD_BATCH 43 /* largest insertion batch of hnswgpu_hnsw_build (default 16384; a batch never exceeds 1/8 of the graph it is searched against) */
+#define HNSWGPU_TUNE_COUNT 44
 int hnswgpu_set_tuning(int32_t key, int64_t value);
 int hnswgpu_get_tuning(int32_t key, int64_t *value, int32_t *is_set);
 

@@ -59,6 +59,38 @@ def test_group_ivf_equals_unsharded_and_oracle(eng, oracle, metric, ndev):
                 g.hnsw_search(Q[:2], k, 50)
 
 
+def test_group_shards_take_the_path_of_the_whole_index(eng, oracle):
+    """A shard holds n / ndev rows over the SAME nlist: what depends on the mean list length (the largest k the survivor
+    stream serves, hence -- past the tile boundary -- the summation order) and the first-search calibration verdict must be
+    decided for the WHOLE index, or shards and unsharded handle compute different distance bits.  40,000 rows
+    in 8 lists (mean 5,000: the stream serves k <= 64), k = 100, 64 queries x 4 probes (32 pairs per list: past the
+    boundary of 12): the unsharded handle takes the f32 MFMA tile scan, and so must four shards of 10,000 rows each
+    (whose own mean of 1,250 would let the stream serve k = 256)."""
+    O = oracle
+    n, dim, nlist, nprobe, k = 40_000, 136, 8, 4, 100
+    base = O.generate_dataset(n, dim, "clustered", num_clusters=8, noise_level=0.5).astype(np.float32)
+    Q = O.generate_dataset(64, dim, "clustered", num_clusters=8, noise_level=0.5, seed=43).astype(np.float32)
+    with eng.Index(base, "cosine") as full:
+        full.ivf_build(nlist, 4, 42)
+        cen, off, lids = full.get_ivf()
+        assert np.diff(off).mean() >= 4096
+        ui, ud = full.ivf_search(Q, k, nprobe)
+        oi, od, _ = O.ivf_search(base, cen, off, lids, Q, k, nprobe, mode=O.MODE_MFMA)
+        assert_exact(ui, ud, oi, od, "unsharded, k beyond the stream's range: tile scan")
+        for _ in range(1):
+            with eng.Group([0] * 4, dim, "cosine") as g:
+                g.set_ivf(base, cen, off, lids)
+                gi, gd = g.ivf_search(Q, k, nprobe)
+                np.testing.assert_array_equal(gi, ui)
+                np.testing.assert_array_equal(gd.view(np.uint32), ud.view(np.uint32))
+        # the verdict API: measuring on a member reports, installing overrides without measuring
+        full.set_rejection_test(1)
+        assert full.ivf_stream_state() in (0, 1)
+        full.ivf_set_stream_state(1)
+        assert full.ivf_stream_state() == 1
+        full.set_rejection_test(2)
+
+
 @pytest.mark.parametrize("metric", ["cosine", "l2"])
 def test_group_hnsw_equals_oracle_merge(eng, oracle, metric):
     """One HNSW sub-graph per handle over contiguous row ranges, each searched with the full k, merged by distance with

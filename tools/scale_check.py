@@ -1,5 +1,8 @@
 """Developer tool: BASELINE.json configs[3]/[4] at their per-GPU size on ONE MI355X.
-  python tools/scale_check.py hnsw   -> 1.25M x 1536 cosine HNSW (one GPU's shard of 10M x 1536), ef_search 256
+  python tools/scale_check.py hnsw [clustered|manifold] [graph.clj|ultra_fast.clj]
+                                     -> 1.25M x 1536 cosine HNSW (one GPU's shard of 10M x 1536), ef_search 256 and the
+                                        first ef with recall@10 >= 0.98; clustered = SURVEY S4 (clustered-normalised,
+                                        1024 centres per shard, noise 0.3; queries from the same mixture)
   python tools/scale_check.py ivf    -> 10M x 768 IVF-FLAT nlist 1024 nprobe 32, batch 1024"""
 import os
 import sys
@@ -28,16 +31,30 @@ def manifold(n, dim, r=48, noise=0.1, chunk=250_000):
 
 if sys.argv[1] == "hnsw":
     n, dim = 1_250_000, 1536
-    x, w = manifold(n, dim)
+    data = sys.argv[2] if len(sys.argv) > 2 else "clustered"
+    builder = sys.argv[3] if len(sys.argv) > 3 else "graph.clj"
+    if data == "manifold":
+        x, w = manifold(n, dim)
+        Q = x[:4096] + 0.02 * torch.randn(4096, dim, generator=g, device=dev)
+    else:
+        cen = torch.randn(1024, dim, generator=g, device=dev)
+        x = torch.empty(n, dim, device=dev)
+        for i in range(0, n, 250_000):
+            y = cen[torch.randint(0, 1024, (250_000,), generator=g, device=dev)] + 0.3 * torch.randn(250_000, dim, generator=g, device=dev)
+            x[i:i + 250_000] = y / y.norm(dim=1, keepdim=True)
+        g.manual_seed(43)
+        Q = cen[torch.randint(0, 1024, (4096,), generator=g, device=dev)] + 0.3 * torch.randn(4096, dim, generator=g, device=dev)
+    Q = (Q / Q.norm(dim=1, keepdim=True)).contiguous()
     idx = engine.Index(x, "cosine", 0)
     t = time.time()
-    idx.hnsw_build(16, 200, 42)
-    print("HNSW build %d x %d: %.1f s (%.0f vectors/s)" % (n, dim, time.time() - t, n / (time.time() - t)), flush=True)
-    Q = x[:4096] + 0.02 * torch.randn(4096, dim, generator=g, device=dev)
-    Q = (Q / Q.norm(dim=1, keepdim=True)).contiguous()
+    idx.hnsw_build(16, 200, 42, **bench.BUILDERS[builder])
+    print("HNSW build %d x %d (%s rows, %s builder): %.1f s (%.0f vectors/s)" % (n, dim, data, builder, time.time() - t, n / (time.time() - t)), flush=True)
     ti, _ = idx.exact_knn_dev(Q[:512], 10)
     stats = torch.zeros((len(Q), 2), dtype=torch.int64, device=dev)
-    for ef in (64, 128, 256):
+    reached = False
+    for ef in (64, 128, 256, 384, 512, 768, 1024, 1536, 2048):
+        if reached and ef > 256:
+            break
         ids, _ = idx.hnsw_search_dev(Q, 10, ef, stats=stats)
         torch.cuda.synchronize()
         ev, hp = float(stats[:, 0].double().mean()), float(stats[:, 1].double().mean())
@@ -56,9 +73,11 @@ if sys.argv[1] == "hnsw":
         tested = f32_rows < 0.98 * nb
         gb = ((nb * code_row if tested else 0) + f32_rows * (4 * dim + 4) + hp * len(Q) * 4 * 32) / 1e9
         alg = (ev * 4 * dim + hp * 4 * 32) * len(Q) / 1e9
+        rec = bench.recall_at_k(ids[:512], ti)
+        reached = reached or rec >= 0.98
         print("  ef %3d  recall@10 %.4f  %d queries in %.2f ms = %.0f QPS; E %.0f H %.0f, f32 rows fetched %.0f per query -> %.2f GB "
               "requested = %.0f GB/s (%.2f of 8 TB/s); the reference algorithm's bytes: %.2f GB"
-              % (ef, bench.recall_at_k(ids[:512], ti), len(Q), dt * 1e3, len(Q) / dt, ev, hp, f32_rows / len(Q), gb, gb / dt,
+              % (ef, rec, len(Q), dt * 1e3, len(Q) / dt, ev, hp, f32_rows / len(Q), gb, gb / dt,
                  gb / dt / 8000, alg), flush=True)
 else:
     n, dim, nlist = 10_000_000, 768, 1024
