@@ -54,7 +54,7 @@ int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, 
 }
 
 // int8 codes + per-row bound terms of `n` rows (kernels.hpp: quantize_rows_kernel)
-static int quantize_rows(hnswgpu_index *idx, const float *rows, int64_t n, uint32_t **crows, float4 **cmeta, hipStream_t st) {
+int quantize_rows(hnswgpu_index *idx, const float *rows, int64_t n, uint32_t **crows, float4 **cmeta, hipStream_t st) {
     HG_HIP(hipMalloc(reinterpret_cast<void **>(crows), sizeof(uint32_t) * kWave * idx->nch * n));
     HG_HIP(hipMalloc(reinterpret_cast<void **>(cmeta), sizeof(float4) * n));
     unsigned grid = static_cast<unsigned>((n + kNWave - 1) / kNWave);

@@ -242,6 +242,8 @@ bool attr_needed(bool (&done)[64]);
 
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);
 int ensure_qrows(hnswgpu_index *idx, hipStream_t st);
+// int8 codes + per-row bound terms of `n` rows into freshly allocated *crows / *cmeta (the caller owns them)
+int quantize_rows(hnswgpu_index *idx, const float *rows, int64_t n, uint32_t **crows, float4 **cmeta, hipStream_t st);
 int ensure_list_codes(hnswgpu_index *idx, hipStream_t st);
 int ensure_list_half(hnswgpu_index *idx, hipStream_t st);
 int launch_scan(int nch, const ScanArgs &a, hipStream_t st);

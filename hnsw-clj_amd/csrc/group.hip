@@ -105,7 +105,11 @@ int hnswgpu_group_create(const int32_t *devices, int32_t ndev, int32_t dim, int3
     int count = 0;
     HG_HIP(hipGetDeviceCount(&count));
     for (int i = 0; i < ndev; i++) HG_REQUIRE(devices[i] >= 0 && devices[i] < count, HNSWGPU_EINVAL, "device %d does not exist", devices[i]);
-    std::unique_ptr<hnswgpu_group> g(new (std::nothrow) hnswgpu_group);
+    // (a failure below goes through hnswgpu_group_destroy: the streams and events made so far are released with the struct)
+    struct Deleter {
+        void operator()(hnswgpu_group *p) const { (void)hnswgpu_group_destroy(p); }
+    };
+    std::unique_ptr<hnswgpu_group, Deleter> g(new (std::nothrow) hnswgpu_group);
     HG_REQUIRE(g, HNSWGPU_ENOMEM, "host allocation failed");
     g->dim = dim;
     g->metric = metric;
@@ -261,7 +265,7 @@ int hnswgpu_group_hnsw_build(hnswgpu_group *g, const float *base, int64_t n, int
 }
 
 // per-device results -> devices[0] -> merged -> host
-static int group_search(hnswgpu_group *g, const float *Q, int32_t nq, int32_t k, int32_t param, int32_t *out_ids,
+static int group_search_impl(hnswgpu_group *g, const float *Q, int32_t nq, int32_t k, int32_t param, int32_t *out_ids,
                         float *out_dist) {
     const int nd = static_cast<int>(g->devices.size());
     const size_t cnt = static_cast<size_t>(nq) * k;
@@ -320,6 +324,22 @@ static int group_search(hnswgpu_group *g, const float *Q, int32_t nq, int32_t k,
     HG_HIP(hipMemcpyAsync(out_dist, g->o_dist.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, g->st0));
     HG_HIP(hipStreamSynchronize(g->st0));
     return 0;
+}
+
+// An error part-way must not return while other members' copies from the caller's (pageable) Q or into its outputs are
+// still in flight: every stream of the group is drained first.
+static int group_search(hnswgpu_group *g, const float *Q, int32_t nq, int32_t k, int32_t param, int32_t *out_ids,
+                        float *out_dist) {
+    const int rc = group_search_impl(g, Q, nq, k, param, out_ids, out_dist);
+    if (rc != 0) {
+        for (size_t r = 0; r < g->m.size(); r++) {
+            (void)hipSetDevice(g->devices[r]);
+            if (g->m[r].st) (void)hipStreamSynchronize(g->m[r].st);
+        }
+        (void)hipSetDevice(g->devices[0]);
+        if (g->st0) (void)hipStreamSynchronize(g->st0);
+    }
+    return rc;
 }
 
 int hnswgpu_group_ivf_search(hnswgpu_group *g, const float *Q, int32_t nq, int32_t k, int32_t nprobe, int32_t *out_ids,

@@ -1483,119 +1483,159 @@ int hnswgpu_hnsw_add(hnswgpu_index *idx, const float *rows, int64_t m, int32_t e
     HG_TRY(quiesce(idx, st));
     const int M = idx->M, M0 = idx->M0;
     const int64_t ld = idx->ld;
-    // ---- 1. the base matrix, its norms and int8 rows grow
-    {
-        float *nb = nullptr, *nn = nullptr;
-        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nb), sizeof(float) * static_cast<size_t>(n1) * ld));
-        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nn), sizeof(float) * static_cast<size_t>(n1)));
-        if (n0 > 0) {
-            HG_HIP(hipMemcpyAsync(nb, idx->d_base, sizeof(float) * static_cast<size_t>(n0) * ld, hipMemcpyDeviceToDevice, st));
-            HG_HIP(hipMemcpyAsync(nn, idx->d_norms, sizeof(float) * static_cast<size_t>(n0), hipMemcpyDeviceToDevice, st));
-        }
-        if (ld != idx->dim) HG_HIP(hipMemsetAsync(nb + n0 * ld, 0, sizeof(float) * static_cast<size_t>(m) * ld, st));
-        HG_HIP(hipMemcpy2DAsync(nb + n0 * ld, sizeof(float) * ld, rows, sizeof(float) * idx->dim, sizeof(float) * idx->dim,
-                                static_cast<size_t>(m), hipMemcpyHostToDevice, st));
-        HG_TRY(launch_norms(idx->nch, nb + n0 * ld, ld, m, nn + n0, st));
-        HG_HIP(hipStreamSynchronize(st));
-        if (idx->d_base) (void)hipFree(idx->d_base);
-        if (idx->d_norms) (void)hipFree(idx->d_norms);
-        idx->d_base = nb;
-        idx->d_norms = nn;
-        if (idx->d_qrows) (void)hipFree(idx->d_qrows);
-        if (idx->d_qmeta) (void)hipFree(idx->d_qmeta);
-        idx->d_qrows = nullptr;
-        idx->d_qmeta = nullptr;
-        idx->n = n1;
-        HG_TRY(ensure_qrows(idx, st));  // (all rows again: one pass over the base, 0.7 ms per million 768-d rows)
-    }
-    // ---- 2. the host graph: the installed adjacency + its edge distances, then room for the new rows
+    // Failure-atomic: everything the call makes -- the grown base, norms, int8 rows, device graph -- is STAGED; the handle's
+    // fields point at the staged arrays while the insertion searches run against them (idx->mu is held and the streams are
+    // quiesced: no caller can see the intermediate state) and are restored, the staged arrays freed, if any step fails: the
+    // index then is exactly what it was (n, graph, host mirrors).  On success the old arrays are freed.
+    // Cost: O(n) per call, not per row (the base is copied, every row re-quantised, the installed edges' distances
+    // recomputed: ~1 ms per million 768-d rows each) -- add rows in batches.
+    struct Staged {
+        float *base = nullptr, *norms = nullptr;
+        uint32_t *qrows = nullptr;
+        float4 *qmeta = nullptr;
+        int32_t *levels = nullptr, *l0 = nullptr, *upadj = nullptr;
+        int64_t *upoff = nullptr;
+    } nw, old;
+    old.base = idx->d_base;
+    old.norms = idx->d_norms;
+    old.qrows = idx->d_qrows;
+    old.qmeta = idx->d_qmeta;
+    old.levels = idx->d_levels;
+    old.l0 = idx->d_l0;
+    old.upadj = idx->d_upadj;
+    old.upoff = idx->d_upoff;
+    const int64_t old_blocks = idx->up_blocks;
+    bool installed = false;
+    auto free_staged = [](Staged &sg) {
+        void *ptrs[] = {sg.base, sg.norms, sg.qrows, sg.qmeta, sg.levels, sg.l0, sg.upadj, sg.upoff};
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+        sg = Staged();
+    };
     HostGraph g;
-    g.n = n1;
-    g.M = M;
-    g.M0 = M0;
-    g.levels = idx->h_levels;
-    g.levels.resize(n1, 0);
-    g.up_off = idx->h_upoff;
-    g.up_off.resize(n1 + 1, 0);
-    draw_levels(seed, n0, n1, g.levels, g.up_off);
-    const int64_t blocks0 = idx->h_upoff[n0], blocks1 = g.up_off[n1];
-    g.l0.assign(static_cast<size_t>(n1) * (M0 + 1), -1);
-    g.l0_d.assign(static_cast<size_t>(n1) * (M0 + 1), 0.f);
-    g.l0_cnt.assign(n1, 0);
-    g.up.assign(static_cast<size_t>(std::max<int64_t>(blocks1, 1)) * (M + 1), -1);
-    g.up_d.assign(static_cast<size_t>(std::max<int64_t>(blocks1, 1)) * (M + 1), 0.f);
-    g.up_cnt.assign(std::max<int64_t>(blocks1, 1), 0);
-    g.sorted0.assign(n1, 0);
-    g.sortedu.assign(std::max<int64_t>(blocks1, 1), 0);
-    {
-        // edge distances of the installed graph, by the traversal's arithmetic (the old device adjacency is still in place)
-        std::vector<float> d0(static_cast<size_t>(n0) * M0), du(static_cast<size_t>(std::max<int64_t>(blocks0, 1)) * M);
-        std::vector<int32_t> owner(static_cast<size_t>(std::max<int64_t>(blocks0, 1)));
-        for (int64_t i = 0; i < n0; i++)
-            for (int64_t b = idx->h_upoff[i]; b < idx->h_upoff[i + 1]; b++) owner[b] = static_cast<int32_t>(i);
-        HG_TRY(idx->s_outd.ensure(sizeof(float) * (d0.size() + du.size())));
-        HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * owner.size()));
-        float *dd0 = idx->s_outd.as<float>(), *ddu = dd0 + d0.size();
-        HG_HIP(hipMemcpyAsync(idx->s_ids.p, owner.data(), sizeof(int32_t) * owner.size(), hipMemcpyHostToDevice, st));
-        HG_TRY(launch_edge_dist(idx, nullptr, idx->d_l0, M0, n0, dd0, st));
-        HG_TRY(launch_edge_dist(idx, idx->s_ids.as<int32_t>(), idx->d_upadj, M, blocks0, ddu, st));
-        HG_HIP(hipMemcpyAsync(d0.data(), dd0, sizeof(float) * d0.size(), hipMemcpyDeviceToHost, st));
-        if (blocks0 > 0) HG_HIP(hipMemcpyAsync(du.data(), ddu, sizeof(float) * static_cast<size_t>(blocks0) * M, hipMemcpyDeviceToHost, st));
+    const int rc = [&]() -> int {
+        // ---- 1. the base matrix, its norms and int8 rows grow (staged)
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nw.base), sizeof(float) * static_cast<size_t>(n1) * ld));
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nw.norms), sizeof(float) * static_cast<size_t>(n1)));
+        if (n0 > 0) {
+            HG_HIP(hipMemcpyAsync(nw.base, idx->d_base, sizeof(float) * static_cast<size_t>(n0) * ld, hipMemcpyDeviceToDevice, st));
+            HG_HIP(hipMemcpyAsync(nw.norms, idx->d_norms, sizeof(float) * static_cast<size_t>(n0), hipMemcpyDeviceToDevice, st));
+        }
+        if (ld != idx->dim) HG_HIP(hipMemsetAsync(nw.base + n0 * ld, 0, sizeof(float) * static_cast<size_t>(m) * ld, st));
+        HG_HIP(hipMemcpy2DAsync(nw.base + n0 * ld, sizeof(float) * ld, rows, sizeof(float) * idx->dim, sizeof(float) * idx->dim,
+                                static_cast<size_t>(m), hipMemcpyHostToDevice, st));
+        HG_TRY(launch_norms(idx->nch, nw.base + n0 * ld, ld, m, nw.norms + n0, st));
+        if (old.qrows) HG_TRY(quantize_rows(idx, nw.base, n1, &nw.qrows, &nw.qmeta, st));  // (all rows again: one pass over the base)
+        // ---- 2. the host graph: the installed adjacency + its edge distances, then room for the new rows
+        g.n = n1;
+        g.M = M;
+        g.M0 = M0;
+        g.levels = idx->h_levels;
+        g.levels.resize(n1, 0);
+        g.up_off = idx->h_upoff;
+        g.up_off.resize(n1 + 1, 0);
+        draw_levels(seed, n0, n1, g.levels, g.up_off);
+        const int64_t blocks0 = idx->h_upoff[n0], blocks1 = g.up_off[n1];
+        g.l0.assign(static_cast<size_t>(n1) * (M0 + 1), -1);
+        g.l0_d.assign(static_cast<size_t>(n1) * (M0 + 1), 0.f);
+        g.l0_cnt.assign(n1, 0);
+        g.up.assign(static_cast<size_t>(std::max<int64_t>(blocks1, 1)) * (M + 1), -1);
+        g.up_d.assign(static_cast<size_t>(std::max<int64_t>(blocks1, 1)) * (M + 1), 0.f);
+        g.up_cnt.assign(std::max<int64_t>(blocks1, 1), 0);
+        g.sorted0.assign(n1, 0);
+        g.sortedu.assign(std::max<int64_t>(blocks1, 1), 0);
+        {
+            // edge distances of the installed graph, by the traversal's arithmetic (rows [0, n0) of the old base: still in place)
+            std::vector<float> d0(static_cast<size_t>(n0) * M0), du(static_cast<size_t>(std::max<int64_t>(blocks0, 1)) * M);
+            std::vector<int32_t> owner(static_cast<size_t>(std::max<int64_t>(blocks0, 1)));
+            for (int64_t i = 0; i < n0; i++)
+                for (int64_t b = idx->h_upoff[i]; b < idx->h_upoff[i + 1]; b++) owner[b] = static_cast<int32_t>(i);
+            HG_TRY(idx->s_outd.ensure(sizeof(float) * (d0.size() + du.size())));
+            HG_TRY(idx->s_ids.ensure(sizeof(int32_t) * owner.size()));
+            float *dd0 = idx->s_outd.as<float>(), *ddu = dd0 + d0.size();
+            HG_HIP(hipMemcpyAsync(idx->s_ids.p, owner.data(), sizeof(int32_t) * owner.size(), hipMemcpyHostToDevice, st));
+            HG_TRY(launch_edge_dist(idx, nullptr, idx->d_l0, M0, n0, dd0, st));
+            HG_TRY(launch_edge_dist(idx, idx->s_ids.as<int32_t>(), idx->d_upadj, M, blocks0, ddu, st));
+            HG_HIP(hipMemcpyAsync(d0.data(), dd0, sizeof(float) * d0.size(), hipMemcpyDeviceToHost, st));
+            if (blocks0 > 0) HG_HIP(hipMemcpyAsync(du.data(), ddu, sizeof(float) * static_cast<size_t>(blocks0) * M, hipMemcpyDeviceToHost, st));
+            HG_HIP(hipStreamSynchronize(st));
+            // a full list whose distances ascend IS the pruned order (prune-connections-ultra's stable sort is the identity on
+            // it); any other list is still in insertion order and gets its first sort when it overflows
+            auto adopt = [](const int32_t *src, const float *dsrc, int width, int32_t *dst, float *ddst, int32_t &cnt, uint8_t &srt) {
+                int c = 0;
+                while (c < width && src[c] >= 0) c++;
+                bool asc = true;
+                for (int j = 0; j < c; j++) {
+                    dst[j] = src[j];
+                    ddst[j] = dsrc[j];
+                    if (j > 0 && dsrc[j] < dsrc[j - 1]) asc = false;
+                }
+                cnt = c;
+                srt = (c == width && asc) ? 1 : 0;
+            };
+            for (int64_t i = 0; i < n0; i++)
+                adopt(&idx->h_l0[static_cast<size_t>(i) * M0], &d0[static_cast<size_t>(i) * M0], M0, &g.l0[static_cast<size_t>(i) * (M0 + 1)],
+                      &g.l0_d[static_cast<size_t>(i) * (M0 + 1)], g.l0_cnt[i], g.sorted0[i]);
+            for (int64_t b = 0; b < blocks0; b++)
+                adopt(&idx->h_upadj[static_cast<size_t>(b) * M], &du[static_cast<size_t>(b) * M], M, &g.up[static_cast<size_t>(b) * (M + 1)],
+                      &g.up_d[static_cast<size_t>(b) * (M + 1)], g.up_cnt[b], g.sortedu[b]);
+        }
+        g.entry = idx->entry;
+        g.top = idx->max_level;
+        // ---- 3. the device graph grows: old rows copied, new rows empty (staged)
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nw.levels), sizeof(int32_t) * n1));
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nw.l0), sizeof(int32_t) * n1 * M0));
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nw.upoff), sizeof(int64_t) * (n1 + 1)));
+        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nw.upadj), sizeof(int32_t) * std::max<int64_t>(blocks1, 1) * M));
+        HG_HIP(hipMemcpyAsync(nw.levels, g.levels.data(), sizeof(int32_t) * n1, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(nw.upoff, g.up_off.data(), sizeof(int64_t) * (n1 + 1), hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemsetAsync(nw.l0, 0xff, sizeof(int32_t) * n1 * M0, st));
+        HG_HIP(hipMemsetAsync(nw.upadj, 0xff, sizeof(int32_t) * std::max<int64_t>(blocks1, 1) * M, st));
+        if (n0 > 0) HG_HIP(hipMemcpyAsync(nw.l0, idx->d_l0, sizeof(int32_t) * n0 * M0, hipMemcpyDeviceToDevice, st));
+        if (blocks0 > 0) HG_HIP(hipMemcpyAsync(nw.upadj, idx->d_upadj, sizeof(int32_t) * blocks0 * M, hipMemcpyDeviceToDevice, st));
         HG_HIP(hipStreamSynchronize(st));
-        // a full list whose distances ascend IS the pruned order (prune-connections-ultra's stable sort is the identity on
-        // it); any other list is still in insertion order and gets its first sort when it overflows
-        auto adopt = [](const int32_t *src, const float *dsrc, int width, int32_t *dst, float *ddst, int32_t &cnt, uint8_t &srt) {
-            int c = 0;
-            while (c < width && src[c] >= 0) c++;
-            bool asc = true;
-            for (int j = 0; j < c; j++) {
-                dst[j] = src[j];
-                ddst[j] = dsrc[j];
-                if (j > 0 && dsrc[j] < dsrc[j - 1]) asc = false;
-            }
-            cnt = c;
-            srt = (c == width && asc) ? 1 : 0;
-        };
-        for (int64_t i = 0; i < n0; i++)
-            adopt(&idx->h_l0[static_cast<size_t>(i) * M0], &d0[static_cast<size_t>(i) * M0], M0, &g.l0[static_cast<size_t>(i) * (M0 + 1)],
-                  &g.l0_d[static_cast<size_t>(i) * (M0 + 1)], g.l0_cnt[i], g.sorted0[i]);
-        for (int64_t b = 0; b < blocks0; b++)
-            adopt(&idx->h_upadj[static_cast<size_t>(b) * M], &du[static_cast<size_t>(b) * M], M, &g.up[static_cast<size_t>(b) * (M + 1)],
-                  &g.up_d[static_cast<size_t>(b) * (M + 1)], g.up_cnt[b], g.sortedu[b]);
-    }
-    g.entry = idx->entry;
-    g.top = idx->max_level;
-    // ---- 3. the device graph grows: old rows copied, new rows empty
-    {
-        int32_t *nl = nullptr, *n0adj = nullptr, *nu = nullptr;
-        int64_t *no = nullptr;
-        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nl), sizeof(int32_t) * n1));
-        HG_HIP(hipMalloc(reinterpret_cast<void **>(&n0adj), sizeof(int32_t) * n1 * M0));
-        HG_HIP(hipMalloc(reinterpret_cast<void **>(&no), sizeof(int64_t) * (n1 + 1)));
-        HG_HIP(hipMalloc(reinterpret_cast<void **>(&nu), sizeof(int32_t) * std::max<int64_t>(blocks1, 1) * M));
-        HG_HIP(hipMemcpyAsync(nl, g.levels.data(), sizeof(int32_t) * n1, hipMemcpyHostToDevice, st));
-        HG_HIP(hipMemcpyAsync(no, g.up_off.data(), sizeof(int64_t) * (n1 + 1), hipMemcpyHostToDevice, st));
-        HG_HIP(hipMemsetAsync(n0adj, 0xff, sizeof(int32_t) * n1 * M0, st));
-        HG_HIP(hipMemsetAsync(nu, 0xff, sizeof(int32_t) * std::max<int64_t>(blocks1, 1) * M, st));
-        if (n0 > 0) HG_HIP(hipMemcpyAsync(n0adj, idx->d_l0, sizeof(int32_t) * n0 * M0, hipMemcpyDeviceToDevice, st));
-        if (blocks0 > 0) HG_HIP(hipMemcpyAsync(nu, idx->d_upadj, sizeof(int32_t) * blocks0 * M, hipMemcpyDeviceToDevice, st));
-        HG_HIP(hipStreamSynchronize(st));
-        free_graph(idx);
-        idx->d_levels = nl;
-        idx->d_l0 = n0adj;
-        idx->d_upoff = no;
-        idx->d_upadj = nu;
+        // ---- 4. the insertion searches run against the staged arrays
+        idx->d_base = nw.base;
+        idx->d_norms = nw.norms;
+        idx->d_qrows = nw.qrows;
+        idx->d_qmeta = nw.qmeta;
+        idx->d_levels = nw.levels;
+        idx->d_l0 = nw.l0;
+        idx->d_upoff = nw.upoff;
+        idx->d_upadj = nw.upadj;
         idx->up_blocks = blocks1;
-        idx->has_graph = true;  // (the searches of insert_batches run against it; no caller can: idx->mu is held)
+        idx->n = n1;
+        idx->graph_gen++;
+        installed = true;
+        if (n0 == 0) {  // an empty index with an (empty) graph: the first new row becomes the entry point (:229-231)
+            g.entry = 0;
+            g.top = g.levels[0];
+            HG_TRY(insert_batches(idx, g, 1, ef_construction, st, idx->build_flags & ~HNSWGPU_BUILD_SEQUENTIAL));
+        } else {
+            HG_TRY(insert_batches(idx, g, n0, ef_construction, st, idx->build_flags & ~HNSWGPU_BUILD_SEQUENTIAL));
+        }
+        return publish_graph(idx, g, st);  // (host mirrors, entry, max_level: assigned only once the uploads succeeded)
+    }();
+    if (rc != 0) {
+        (void)hipStreamSynchronize(st);
+        if (installed) {
+            idx->d_base = old.base;
+            idx->d_norms = old.norms;
+            idx->d_qrows = old.qrows;
+            idx->d_qmeta = old.qmeta;
+            idx->d_levels = old.levels;
+            idx->d_l0 = old.l0;
+            idx->d_upoff = old.upoff;
+            idx->d_upadj = old.upadj;
+            idx->up_blocks = old_blocks;
+            idx->n = n0;
+            idx->graph_gen++;
+        }
+        free_staged(nw);
+        return rc;
     }
-    if (n0 == 0) {  // an empty index with an (empty) graph: the first new row becomes the entry point (:229-231)
-        g.entry = 0;
-        g.top = g.levels[0];
-        HG_TRY(insert_batches(idx, g, 1, ef_construction, st, idx->build_flags));
-    } else {
-        HG_TRY(insert_batches(idx, g, n0, ef_construction, st, idx->build_flags));
-    }
-    return publish_graph(idx, g, st);
+    free_staged(old);
+    return 0;
 }
 
 }  // extern "C"

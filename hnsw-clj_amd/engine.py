@@ -528,9 +528,10 @@ class Group:
         ix = Index.__new__(Index)
         ix._h = C.c_void_p(h)
         ix._borrowed = True
-        nn, dim, metric, hg, nl = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        check(lib().hnswgpu_info(ix._h, C.byref(nn), C.byref(dim), C.byref(metric), C.byref(hg), C.byref(nl)))
-        ix.n, ix.dim, ix.metric, ix.device = nn.value, dim.value, metric.value, int(self.devices[i])
-        g = ix.get_graph()
-        ix._h = C.c_void_p(None)   # borrowed: never destroyed from here
-        return g
+        try:
+            nn, dim, metric, hg, nl = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            check(lib().hnswgpu_info(ix._h, C.byref(nn), C.byref(dim), C.byref(metric), C.byref(hg), C.byref(nl)))
+            ix.n, ix.dim, ix.metric, ix.device = nn.value, dim.value, metric.value, int(self.devices[i])
+            return ix.get_graph()
+        finally:
+            ix._h = C.c_void_p(None)   # borrowed: never destroyed from here, whatever get_graph did

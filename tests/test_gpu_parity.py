@@ -1415,6 +1415,33 @@ def test_timed_launch_configurations_against_oracle(eng, oracle, dist, ef, nsub)
         assert_topk_parity(ids[sub[:16]], d[sub[:16]], fi, fd, "%s ef %d vs oracle (f64 reference order)" % (dist, ef))
 
 
+def test_hnsw_add_keeps_the_builder_of_the_graph(eng, oracle):
+    """hnswgpu_hnsw_add inserts with the options the handle's graph was built with: rows added to a graph built by the
+    heuristic builder (graph.clj:162-232) are linked by the heuristic too -- the grown graph passes the validator, its
+    search equals the oracle's on the export, and clustered rows stay reachable (closest-m links would not reach them)."""
+    O = oracle
+    n0, n1, dim = 6000, 7000, 64
+    base = O.generate_dataset(n1, dim, "clustered", num_clusters=40, noise_level=0.3).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    Q = base[n0:n0 + 200] + 0.01
+    with eng.Index(base[:n0]) as idx:
+        idx.hnsw_build(16, 100, 42, heuristic=True)
+        idx.hnsw_add(base[n0:n0 + 300], 100, 42)
+        idx.hnsw_add(base[n0 + 300:], 100, 42)
+        assert idx.n == n1
+        g = idx.get_graph()
+        deg = (g.l0_adj.reshape(n1, -1) >= 0).sum(1)
+        assert deg.min() >= 1 and deg.mean() < 31, "heuristic lists are not full: mean degree %.1f" % deg.mean()
+        ids, d, st = idx.hnsw_search(Q, 10, 200, want_stats=True)
+        oi, od, ost, _ = O.hnsw_search(base, g, Q, 10, ef=200, mode=O.MODE_DEV)
+        assert_exact(ids, d, oi, od, "search of the grown heuristic graph vs oracle")
+        np.testing.assert_array_equal(st, ost)
+        ex, _ = idx.exact_knn(Q, 10)
+        assert O.recall(ids, ex) > 0.9
+        with eng.Index(base) as chk:
+            chk.set_graph(g)
+
+
 @pytest.mark.parametrize("metric", ["cosine", "l2"])
 def test_hnsw_add_to_a_live_index(eng, oracle, metric):
     """insert-single on a live index (ultra_fast.clj:216-275; add-vector!, api.clj:30-33): a graph built over 20,000 rows
