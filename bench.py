@@ -105,6 +105,26 @@ def recall_at_k(ids, truth):
     return float((hit / truth.shape[1]).mean())
 
 
+def find_ef(idx, Q, truth, ef_arg):
+    """The operating point: the first ef of EF_SWEEP whose recall@10 against `truth` reaches 0.98 (or --ef)."""
+    sweep = []
+    ef, rec = ef_arg, None
+    if ef <= 0:
+        for e in EF_SWEEP:
+            ids, _ = idx.hnsw_search_dev(Q, K, e)
+            r = recall_at_k(ids, truth)
+            sweep.append([e, round(r, 4)])
+            if r >= 0.98:
+                ef, rec = e, r
+                break
+        if ef <= 0:
+            ef, rec = EF_SWEEP[-1], sweep[-1][1]
+    else:
+        ids, _ = idx.hnsw_search_dev(Q, K, ef)
+        rec = recall_at_k(ids, truth)
+    return ef, rec, sweep
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: N child processes, one rank per GPU.  This process has not
     touched the GPU (importing torch does not) and never will: it waits, relays rank 0's JSON line and returns the
@@ -213,22 +233,7 @@ def main():
     Q = torch.from_numpy(queries).to(dev)
     n_eval = args.nq                                              # recall is measured on the whole timed batch
     truth, _ = idx.exact_knn_dev(Q[:n_eval], K)                   # ground truth over the FULL base (bench.clj:72-84)
-    sweep = []
-    ef = args.ef
-    rec = None
-    if ef <= 0:
-        for e in EF_SWEEP:
-            ids, _ = idx.hnsw_search_dev(Q[:n_eval], K, e)
-            r = recall_at_k(ids, truth)
-            sweep.append([e, round(r, 4)])
-            if r >= 0.98:
-                ef, rec = e, r
-                break
-        if ef <= 0:
-            ef, rec = EF_SWEEP[-1], sweep[-1][1]
-    else:
-        ids, _ = idx.hnsw_search_dev(Q[:n_eval], K, ef)
-        rec = recall_at_k(ids, truth)
+    ef, rec, sweep = find_ef(idx, Q[:n_eval], truth, args.ef)
     if world > 1:  # every rank times the same ef (rank 0's)
         t = torch.tensor([ef], device=dev)
         dist.broadcast(t, 0)
@@ -336,7 +341,16 @@ def main():
                                             "path": "hnswgpu_hnsw_search_dev on torch's stream + torch.cuda.synchronize()"},
         },
         "roofline_hnsw": {"bound": "infinity-cache gather", "achieved": round(hnsw_gbs, 1), "peak": IC_GATHER_GBS[1],
-                          "unit": "GB/s", "frac": round(hnsw_gbs / IC_GATHER_GBS[1], 4), "traffic": None,
+                          "unit": "GB/s", "frac": round(hnsw_gbs / IC_GATHER_GBS[1], 4),
+                          "traffic": (traffic or {}).get("hnsw", None) and traffic["hnsw"]["traffic"],
+                          "traffic_GBs": (traffic or {}).get("hnsw", None) and round(traffic["hnsw"]["traffic"] / 1e9 / (hnsw_avg_ms * 1e-3), 1),
+                          "traffic_note": "fabric-side bytes of one timed launch (the traversal + its repeat pass): 2 x FETCH_SIZE "
+                                          "+ WRITE_SIZE from rocprofv3 --pmc passes of a child process that builds the same index and "
+                                          "issues the same launch (the factor 2 is the guide's gfx950 correction, calibrated for "
+                                          "16-B-per-lane reads -- the f32 rows; the int8 rows are read 12 B per lane, uncalibrated: "
+                                          "raw_fetch_size_bytes is beside it); below the requested bytes where the XCD L2s serve "
+                                          "re-reads",
+                          "raw_fetch_size_bytes": (traffic or {}).get("hnsw", None) and traffic["hnsw"]["raw_fetch_size_bytes"],
                           "peak_range": list(IC_GATHER_GBS), "frac_of_hbm_spec": round(hnsw_gbs / HBM_PEAK_GBS, 4),
                           "kernel": "hnsw_search_kernel", "avg_launch_ms": round(hnsw_avg_ms, 4),
                           "algorithmic_bytes_per_query": int(hnsw_bytes_q),
@@ -604,6 +618,10 @@ def ivf_roofline(engine, dev, args, traffic):
            "achieved_from": "PMC traffic / kernel time" if tr else "requested bytes / kernel time (no PMC pass in this run: "
                             "--no-pmc, N > 1 or rocprofv3 unavailable; a lower bound of the traffic; profiles/ holds a PMC run)",
            "frac_of_copy_ceiling": round(achieved / 6290.0, 4),
+           "frac_like_for_like": round(ach_f / HBM_PEAK_GBS, 4),
+           "frac_like_for_like_note": "the kernel that does the REFERENCE's work per candidate (f32 list scan, one GEMV per (query, "
+                                      "list) pair, bounds pass off: roofline.f32_scan) as traffic / time / 8 TB/s -- frac itself "
+                                      "is the int8 bounds kernel's, which decides ~97 % of the candidates without their f32 row",
            "kernel": "stream_bounds_kernel<3, true, false> (v_mfma_i32_32x32x32_i8; 1.6 queries per probed list at this batch: the "
                      "lane = row epilogue)",
            "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch: bounds of every candidate "
@@ -748,6 +766,22 @@ def pmc_child(args):
             idx.ivf_search_dev(Q, K, 32)
         torch.cuda.synchronize()
     idx.close()
+    # ... and the timed HNSW launch (roofline_hnsw.traffic): the same index, builder, queries and operating point as main()
+    base = make_31k(args.dist, 42, N31K)
+    Q = torch.from_numpy(make_31k(args.dist, 43, args.nq)).to(dev)
+    idx = engine.Index(base, "cosine", 0)
+    idx.hnsw_build(M, EFC, 42, **BUILDERS[args.builder])
+    truth, _ = idx.exact_knn_dev(Q, K)
+    ef, _, _ = find_ef(idx, Q, truth, args.ef)
+    out = (torch.empty((args.nq, K), dtype=torch.int32, device=dev), torch.empty((args.nq, K), dtype=torch.float32, device=dev))
+    torch.cuda.synchronize()
+    for _ in range(PMC_HNSW_LAUNCHES):                 # the LAST dispatches of hnsw_search_kernel in the counter file
+        idx.hnsw_search_dev(Q, K, ef, out=out)
+    torch.cuda.synchronize()
+    idx.close()
+
+
+PMC_HNSW_LAUNCHES = 3
 
 
 def pmc_traffic(args):
@@ -766,21 +800,24 @@ def pmc_traffic(args):
     if exe is None:
         log("pmc: rocprofv3 not found, roofline.traffic stays null")
         return None
-    got, search = {}, {}
+    got, search, hn = {}, {}, {}
     env = dict(os.environ, TMPDIR="/tmp")
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="hnswgpu_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--",
-               sys.executable, os.path.abspath(__file__), "--pmc-child", "--ivf-n", str(args.ivf_n)]
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--ivf-n", str(args.ivf_n), "--dist", args.dist,
+               "--builder", args.builder, "--nq", str(args.nq), "--ef", str(args.ef)]
         t0 = time.time()
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-            vals, vals_f = [], []
+            vals, vals_f, vals_h = [], [], []
             per_k = {}
             for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f)):
                     if row["Counter_Name"] != ctr:
                         continue
+                    if "hg::hnsw_search_kernel<" in row["Kernel_Name"]:      # (dispatch id, bytes): the timed launches are the last
+                        vals_h.append((int(row.get("Dispatch_Id", len(vals_h))), float(row["Counter_Value"]) * 1024.0))
                     if PMC_SCAN_KERNEL in row["Kernel_Name"]:
                         vals.append(float(row["Counter_Value"]))
                     elif PMC_F32_KERNEL in row["Kernel_Name"]:
@@ -789,6 +826,9 @@ def pmc_traffic(args):
                         if ("hg::" + kn + "<") in row["Kernel_Name"] or ("hg::" + kn + "(") in row["Kernel_Name"]:
                             per_k[kn] = per_k.get(kn, 0.0) + float(row["Counter_Value"]) * 1024.0 / PMC_CHILD_SEARCHES
             search[ctr] = per_k
+            # a search is two dispatches (the traversal + its repeat pass for queries with hundreds of tied candidates)
+            vals_h.sort()
+            hn[ctr] = sum(v for _, v in vals_h[-2 * PMC_HNSW_LAUNCHES:]) / PMC_HNSW_LAUNCHES if len(vals_h) >= 2 * PMC_HNSW_LAUNCHES else None
             if r.returncode != 0 or not vals or not vals_f:
                 log("pmc: %s pass failed (rc %d, %d + %d rows): %s" % (ctr, r.returncode, len(vals), len(vals_f), r.stderr.decode()[-300:]))
                 return None
@@ -807,7 +847,11 @@ def pmc_traffic(args):
     rd_f, wr_f = 2.0 * got["FETCH_SIZE"][2], got["WRITE_SIZE"][2]
     per_kernel = {kn: int(2.0 * search["FETCH_SIZE"].get(kn, 0.0) + search["WRITE_SIZE"].get(kn, 0.0))
                   for kn in PMC_SEARCH_KERNELS if kn in search["FETCH_SIZE"] or kn in search["WRITE_SIZE"]}
-    return {"traffic": int(rd + wr), "traffic_f32_scan": int(rd_f + wr_f),
+    hnsw_tr = None
+    if hn.get("FETCH_SIZE") is not None and hn.get("WRITE_SIZE") is not None:
+        hnsw_tr = {"traffic": int(2.0 * hn["FETCH_SIZE"] + hn["WRITE_SIZE"]), "raw_fetch_size_bytes": int(hn["FETCH_SIZE"]),
+                   "write_size_bytes": int(hn["WRITE_SIZE"])}
+    return {"hnsw": hnsw_tr, "traffic": int(rd + wr), "traffic_f32_scan": int(rd_f + wr_f),
             "traffic_search": int(sum(per_kernel.values())), "per_kernel": per_kernel,
             "raw_fetch_size_bytes": int(got["FETCH_SIZE"][0]), "raw_fetch_size_bytes_f32_scan": int(got["FETCH_SIZE"][2]),
             "traffic_note": "HBM bytes per launch at batch 32: 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE, each "

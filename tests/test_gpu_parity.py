@@ -913,6 +913,61 @@ def test_half_precision_bounds_hold_and_are_tight(eng, metric, dim):
                 assert ((d[blk] - lb[blk]) / scale).max() < 1e-3 and ((ub[blk] - d[blk]) / scale).max() < 1e-3
 
 
+@pytest.mark.parametrize("dim", [128, 768, 3072])
+@pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
+def test_bounds_randomised_soak(eng, metric, dim):
+    """Every bit-exact result of the int8 / half-precision paths hangs on lb <= d <= ub against the distance the exact path
+    computes (kernels.hpp: code_bounds; stream_kernels.hpp: the half-precision bounds): a randomised check over (query,
+    row) pairs built to stress the slack constants -- per-row scales e^+-12 (f32 rounding of sums of very different
+    magnitude), rows that are near-duplicates of the query (distance ~ 0: cancellation in 1 - dot / (|q||v|) and in
+    |q - v|), rows whose dot with the query cancels to ~0 by construction (sign-alternating copies), sparse rows with one
+    dominant component, and queries of the same families.  2e4 pairs per (metric, dim) in the suite; HNSWGPU_SOAK=<n> runs
+    n times as many with fresh seeds (1e5 and more per (metric, dim))."""
+    reps = 1 + int(os.environ.get("HNSWGPU_SOAK", "0")) * 5
+    n = 2000
+    for rep in range(reps):
+        rs = np.random.RandomState(1000 * rep + dim + {"cosine": 0, "l2": 1, "dot": 2}[metric])
+        scale = np.exp(rs.uniform(-12, 12, (n, 1)))
+        base = (rs.randn(n, dim) * scale).astype(np.float32)
+        qs = [rs.randn(dim).astype(np.float32) * np.float32(np.exp(rs.uniform(-12, 12))) for _ in range(6)]
+        # near-duplicates of query 0 at relative distances 1e-7 .. 1e-2, and exact copies at other scales
+        for j in range(200):
+            base[j] = (qs[0] * (1.0 + 0.0 * j) + rs.randn(dim).astype(np.float32) * np.linalg.norm(qs[0]) / np.sqrt(dim) * 10.0 ** rs.uniform(-7, -2)).astype(np.float32)
+        for j in range(200, 260):
+            base[j] = (qs[0] * np.float32(np.exp(rs.uniform(-10, 10)))).astype(np.float32)
+        # rows orthogonal to query 1 by construction: its elements with alternating signs and pairwise swapped
+        q1 = qs[1]
+        orth = np.empty(dim, np.float32)
+        orth[0::2], orth[1::2] = q1[1::2], -q1[0::2]
+        for j in range(260, 330):
+            base[j] = (orth * np.float32(np.exp(rs.uniform(-6, 6))) + rs.randn(dim).astype(np.float32) * np.float32(np.linalg.norm(q1) / np.sqrt(dim) * 10.0 ** rs.uniform(-8, -3))).astype(np.float32)
+        # sparse rows: one dominant component over a tiny tail
+        for j in range(330, 400):
+            base[j] = (rs.randn(dim) * 1e-6).astype(np.float32)
+            base[j, rs.randint(dim)] = np.float32(rs.randn() * np.exp(rs.uniform(-3, 8)))
+        qs.append(base[331].copy())
+        qs.append((orth * 3.0).astype(np.float32))
+        ids = np.arange(n, dtype=np.int32)
+        lids = np.concatenate([np.arange(l, n, 2) for l in range(2)]).astype(np.int32)
+        off = np.array([0, len(np.arange(0, n, 2)), n], np.int64)
+        with eng.Index(base, metric) as idx:
+            idx.set_rejection_test(2)
+            idx.set_ivf(base[:2].copy(), off, lids)
+            for qi, q in enumerate(qs):
+                d = idx.batch_distances(q, ids)
+                lb, ub = idx.distance_bounds(q, ids)                                      # int8, base order
+                ok = ~np.isnan(lb) & ~np.isnan(d)
+                assert np.all(lb[ok] <= d[ok]), "int8 lb > d: %s dim %d rep %d query %d rows %s" % (metric, dim, rep, qi, np.nonzero(ok & ~(lb <= d))[0][:6])
+                oku = ~np.isnan(ub) & ~np.isnan(d)
+                assert np.all(d[oku] <= ub[oku]), "int8 ub < d: %s dim %d rep %d query %d rows %s" % (metric, dim, rep, qi, np.nonzero(oku & ~(d <= ub))[0][:6])
+                hl, hu = idx.ivf_half_bounds(q, ids)                                      # fp16, list order
+                dl = d[lids]
+                ok = ~np.isnan(hl) & ~np.isnan(dl)
+                assert np.all(hl[ok] <= dl[ok]), "fp16 lb > d: %s dim %d rep %d query %d list rows %s" % (metric, dim, rep, qi, np.nonzero(ok & ~(hl <= dl))[0][:6])
+                oku = ~np.isnan(hu) & ~np.isnan(dl)
+                assert np.all(dl[oku] <= hu[oku]), "fp16 ub < d: %s dim %d rep %d query %d list rows %s" % (metric, dim, rep, qi, np.nonzero(oku & ~(dl <= hu))[0][:6])
+
+
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
 def test_ivf_half_precision_pass(eng, oracle, metric, tune):
     """The half-precision pass between the int8 bounds and the f32 rows (production: batches with 1.5 M candidates and
