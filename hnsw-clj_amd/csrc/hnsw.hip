@@ -19,8 +19,9 @@
 namespace hg {
 
 static size_t hnsw_lds_bytes(int cap, int nwords, int nw) {
-    return sizeof(uint2) * 2 * cap + sizeof(int32_t) * 3 * kMaxDeg + sizeof(int32_t) * 16 + sizeof(int32_t) * nw * kWave +
-           sizeof(int32_t) * cap + sizeof(uint2) * kPfRing + sizeof(uint32_t) * nwords;
+    // kernels.hpp: hnsw_search_kernel's layout -- ONE list of 8-byte entries + a 16-bit merged position per slot
+    return sizeof(uint2) * cap + sizeof(int32_t) * 3 * kMaxDeg + sizeof(int32_t) * 16 + sizeof(int32_t) * nw * kWave +
+           sizeof(uint2) * kPfRing + sizeof(uint32_t) * nwords + sizeof(uint16_t) * cap + 16;
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
@@ -301,7 +302,7 @@ static int search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, int3
     // finds no work item on ordinary data (a few microseconds).
     const int vgw = (force_vg() || idx->n > kLdsVisitedMaxRows) ? 0 : static_cast<int>((idx->n + 31) / 32);
     const size_t fixed = hnsw_lds_bytes(0, vgw, 4);
-    const int64_t cap_max = static_cast<int64_t>((kMaxLds - fixed) / (2 * sizeof(uint2) + sizeof(int32_t)));
+    const int64_t cap_max = std::min<int64_t>(65000, static_cast<int64_t>((kMaxLds - fixed) / (sizeof(uint2) + sizeof(uint16_t))));
     const int32_t big = static_cast<int32_t>(std::min<int64_t>(cap_max - ef, idx->n));
     if (big > kGhost) {
         a.cap = ef + big;

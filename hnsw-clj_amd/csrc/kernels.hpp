@@ -1311,16 +1311,19 @@ template <int NCH, int RB, bool L2, int NW, bool VG, bool PF = false>
 __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
     constexpr int kThreads = NW * kWave;
     extern __shared__ __align__(16) unsigned char smem[];
+    // LDS: [list: cap x (distance bits, node | expanded flag)] [cand_id | cand_d | cand_P: kMaxDeg each] [sc: 16] [part: NW x 64]
+    //      [hint_s: kPfRing x 8 B] [bits: nwords] [posA: cap x 16 bit].  ONE list: the merge moves entries in place (they only
+    //      ever move towards the tail), so a query costs 10 bytes of LDS per list slot instead of the 20 of a double buffer --
+    //      at large ef the list is what bounds the queries a CU holds (ef 704: 12 instead of 7).
     uint2 *listA = reinterpret_cast<uint2 *>(smem);
-    uint2 *listB = listA + a.cap;
-    int32_t *cand_id = reinterpret_cast<int32_t *>(listB + a.cap);
+    int32_t *cand_id = reinterpret_cast<int32_t *>(listA + a.cap);
     float *cand_d = reinterpret_cast<float *>(cand_id + kMaxDeg);
     int32_t *cand_P = reinterpret_cast<int32_t *>(cand_d + kMaxDeg);
     int32_t *sc = cand_P + kMaxDeg;  // scalars
     int32_t *part = sc + 16;         // [NW][64] per-wave partial counts of the merge
-    int32_t *posA = part + NW * kWave;  // [cap] merged position of every list entry
-    uint2 *hint_s = reinterpret_cast<uint2 *>(posA + a.cap);  // [kPfRing] (node, ring entry) of the hints posted (PF)
+    uint2 *hint_s = reinterpret_cast<uint2 *>(part + NW * kWave);  // [kPfRing] (node, ring entry) of the hints posted (PF)
     uint32_t *bits = reinterpret_cast<uint32_t *>(hint_s + kPfRing);
+    uint16_t *posA = reinterpret_cast<uint16_t *>(bits + a.nwords);  // [cap] merged position of every list entry (cap < 65536)
     uint32_t *stamps = VG ? a.vis + static_cast<int64_t>(blockIdx.x) * a.vis_stride : nullptr;
     // sc[0]=cursor sc[1]=ncand sc[2]=nadmit sc[3]=minP sc[4]=worst bits sc[5]=nghost sc[6]=ghost overflow (per query)
     const int tid = threadIdx.x;
@@ -1340,7 +1343,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
     }
     for (int wi = wi0; wi < nq_eff; wi += wi_step) {
         const int qi = a.q_index ? a.q_index[wi] : wi;  // the query this work item serves
-        uint2 *curA = listA, *curB = listB;
+        uint2 *const curA = listA;
         uint32_t pf_head = 0, pf_recent = 0xffffffffu;  // wave 1: entries posted so far; lane l: the l-th recent node
         const float *qptr = a.q_rows ? a.rows + static_cast<int64_t>(a.q_rows[qi]) * a.ld : a.Q + qi * a.qld;
         float4 q[NCH];
@@ -1596,7 +1599,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                     }
                     if (valid) {
                         const int P = i + sh;
-                        posA[i] = P;
+                        posA[i] = static_cast<uint16_t>(P < 65535 ? P : 65535);
                         if (P == ef_l - 1) sc[4] = static_cast<int32_t>(curA[i].x);
                     }
                 }
@@ -1643,30 +1646,43 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                     cur_start = c + 1;
                     continue;
                 }
-                // ---- merge, step 3 (all waves): scatter to the merged positions; entries pushed past ef whose
-                //      distance ties the new worst stay as ghosts
+                // ---- merge, step 3 (all waves): the entries move to their merged positions IN PLACE -- every entry moves
+                //      towards the tail (by the number of admitted candidates that go before it), so the list is walked
+                //      from its last block of kThreads entries down to the block of the first admitted position: a block is
+                //      read, then (all waves have read their share) written; its writes land at or behind its own start,
+                //      never on an entry that is still to be read.  Entries before the first admitted position stay where
+                //      they are.  Entries pushed past ef whose distance ties the new worst stay as ghosts.
                 const int total = len + nadm;
                 const bool full = total > ef_l;
                 const uint32_t wbits = static_cast<uint32_t>(sc[4]);
+                const int minP = sc[3];
                 int ghosts = 0;
-                for (int base = 0; base < len; base += kThreads) {
+                for (int base = ((len - 1) / kThreads) * kThreads; base >= 0 && base + kThreads > minP; base -= kThreads) {
                     const int i = base + tid;
+                    const bool valid = i < len;
+                    uint2 e = make_uint2(0u, 0u);
+                    int P = 0;
+                    if (valid) {
+                        e = curA[i];
+                        P = posA[i];
+                    }
+                    if (NW > 1) __syncthreads();  // (one wave: its LDS reads and writes are in program order)
                     bool gh = false;
-                    if (i < len) {
-                        const uint2 e = curA[i];
-                        const int P = posA[i];
-                        if (P < a.cap) curB[P] = e;
+                    if (valid) {
+                        if (P < a.cap && P != i) curA[P] = e;
                         gh = full && P >= ef_l && P < a.cap && e.x == wbits;
                         if (full && P >= a.cap && e.x == wbits && !(e.y & kExpanded)) sc[6] = 1;  // a tie with no slot left
                     }
                     ghosts += __popcll(__ballot(gh));
                 }
                 {
+                    // the admitted candidates into the gaps (every entry of the blocks above has been read: the loop's
+                    // barriers; a candidate's position is at or behind minP, i.e. inside those blocks or behind the list)
                     bool gh = false;
                     if (tid < nc) {
                         const int P = cand_P[tid];
                         if (P >= 0) {
-                            if (P < a.cap) curB[P] = make_uint2(static_cast<uint32_t>(cbits), static_cast<uint32_t>(cand_id[tid]));
+                            if (P < a.cap) curA[P] = make_uint2(static_cast<uint32_t>(cbits), static_cast<uint32_t>(cand_id[tid]));
                             gh = full && P >= ef_l && P < a.cap && static_cast<uint32_t>(cbits) == wbits;
                             if (full && P >= a.cap && static_cast<uint32_t>(cbits) == wbits) sc[6] = 1;
                         }
@@ -1677,13 +1693,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                 __syncthreads();
                 HG_STAMP(5);  // merge step 3
                 const int newlen = full ? ef_l + sc[5] : total;
-                {
-                    uint2 *t = curA;
-                    curA = curB;
-                    curB = t;
-                }
                 len = newlen;
-                const int minP = sc[3];
                 cur_start = minP < c + 1 ? minP : c + 1;
             }
             // ---- level done
