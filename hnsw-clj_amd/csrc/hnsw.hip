@@ -1015,6 +1015,12 @@ struct Pruner {
                 cid[off[i] + j] = cands[i][j].second;
                 cd[off[i] + j] = cands[i][j].first;
             }
+        return select_flat(nt, ms);
+    }
+
+    // off / cid / cd hold `nt` tasks; ms their m.  Results in oid / od / ocnt (stride M0).
+    int select_flat(int nt, const std::vector<int32_t> &ms) {
+        const int64_t tot = off[nt];
         const int stride = g.M0;
         const size_t b_off = sizeof(int64_t) * (nt + 1), b_id = sizeof(int32_t) * tot, b_d = sizeof(float) * tot, b_m = sizeof(int32_t) * nt;
         HG_TRY(d_task.ensure(b_off + b_id + b_d + b_m + 64));
@@ -1047,6 +1053,71 @@ struct Pruner {
         HG_HIP(hipMemcpyAsync(od.data(), a.out_d, o_d, hipMemcpyDeviceToHost, st));
         HG_HIP(hipMemcpyAsync(ocnt.data(), a.out_cnt, o_c, hipMemcpyDeviceToHost, st));
         HG_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+
+    // The batched build's form of run(): every task sees the lists as they stood when the batch's appends were done, so
+    // the tasks are independent -- candidates gathered and sorted, lists replaced and (SYMMETRIC) removals collected by the
+    // linker's threads, flat arrays throughout (a 1.25M-row build has millions of tasks of ~33 candidates).
+    int run_batched(std::vector<PendingEdge> &pend, LinkPool &pool, std::vector<HostGraph::Dirty> &dirties) {
+        if (pend.empty()) return 0;
+        std::sort(pend.begin(), pend.end(), [](const PendingEdge &x, const PendingEdge &y) {
+            return x.target != y.target ? x.target < y.target : (x.lc != y.lc ? x.lc < y.lc : x.seq < y.seq);
+        });
+        tasks.clear();
+        for (size_t i = 0; i < pend.size();) {
+            size_t j = i;
+            while (j < pend.size() && pend[j].target == pend[i].target && pend[j].lc == pend[i].lc) j++;
+            tasks.push_back({pend[i].target, pend[i].lc, static_cast<int64_t>(i), static_cast<int32_t>(j - i)});
+            i = j;
+        }
+        const int nt = static_cast<int>(tasks.size());
+        off.assign(nt + 1, 0);
+        std::vector<int32_t> ms(nt);
+        for (int i = 0; i < nt; i++) {
+            const Task &t = tasks[i];
+            const int have = t.lc == 0 ? g.l0_cnt[t.target] : g.up_cnt[g.up_off[t.target] + (t.lc - 1)];
+            off[i + 1] = off[i] + std::min<int64_t>(kSelMaxCand, static_cast<int64_t>(have) + t.npend);
+            ms[i] = t.lc == 0 ? g.M0 : g.M;
+        }
+        cid.resize(std::max<int64_t>(off[nt], 1));
+        cd.resize(std::max<int64_t>(off[nt], 1));
+        const int nth = nt >= 1024 ? pool.size() : 1;
+        auto fill = [&](int me) {
+            std::vector<std::pair<float, int32_t>> c;
+            for (int i = static_cast<int>(static_cast<int64_t>(nt) * me / nth); i < static_cast<int>(static_cast<int64_t>(nt) * (me + 1) / nth); i++) {
+                gather(tasks[i], pend, c);
+                for (size_t j = 0; j < c.size(); j++) {
+                    cid[off[i] + j] = c[j].second;
+                    cd[off[i] + j] = c[j].first;
+                }
+            }
+        };
+        if (nth == 1) fill(0);
+        else pool.run(fill);
+        HG_TRY(select_flat(nt, ms));
+        n_tasks += nt;
+        const int stride = g.M0;
+        std::vector<std::vector<std::pair<int32_t, std::pair<int32_t, int32_t>>>> removals(nth);
+        auto apply = [&](int me) {
+            for (int i = static_cast<int>(static_cast<int64_t>(nt) * me / nth); i < static_cast<int>(static_cast<int64_t>(nt) * (me + 1) / nth); i++) {
+                const Task &t = tasks[i];
+                const int32_t *keep = &oid[static_cast<size_t>(i) * stride];
+                const int nk = ocnt[i];
+                if (sym)  // (before the list is replaced: the candidates are the present edges + the parked ones)
+                    for (int64_t j = off[i]; j < off[i + 1]; j++) {
+                        bool kept = false;
+                        for (int r = 0; r < nk; r++) kept |= keep[r] == cid[j];
+                        if (!kept) removals[me].push_back({cid[j], {t.target, t.lc}});
+                    }
+                g.set_list(t.target, t.lc, keep, &od[static_cast<size_t>(i) * stride], nk, dirties[me]);
+            }
+        };
+        if (nth == 1) apply(0);
+        else pool.run(apply);
+        for (auto &rv : removals)  // (a removal touches another node's list: serial, and commutative -- the order does not matter)
+            for (auto &r : rv)
+                if (g.remove_edge(r.first, r.second.first, r.second.second, dirties[0])) n_removed++;
         return 0;
     }
 
@@ -1328,7 +1399,8 @@ static int insert_batches(hnswgpu_index *idx, HostGraph &g, int64_t done, int ef
                 pq.clear();
             }
             std::sort(pend.begin(), pend.end(), [](const PendingEdge &x, const PendingEdge &y) { return x.seq < y.seq; });
-            HG_TRY(pruner.run(pend, dirties[0]));
+            if (seq) HG_TRY(pruner.run(pend, dirties[0]));
+            else HG_TRY(pruner.run_batched(pend, pool, dirties));
         }
         for (auto &dd : dirties) {
             g.dirty0.insert(g.dirty0.end(), dd.d0.begin(), dd.d0.end());
