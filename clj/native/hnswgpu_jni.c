@@ -40,6 +40,13 @@ JNIEXPORT jint JNICALL Java_hnsw_gpu_Native_hnswBuild(JNIEnv *env, jclass c, jlo
     return rc;
 }
 
+/* build options: include/hnswgpu.h HNSWGPU_BUILD_* (1 sequential, 2 heuristic, 4 symmetric, 8 extend) */
+JNIEXPORT jint JNICALL Java_hnsw_gpu_Native_hnswBuildEx(JNIEnv *env, jclass c, jlong h, jint M, jint efc, jlong seed, jint flags) {
+    int rc = hnswgpu_hnsw_build_ex((hnswgpu_index *)(intptr_t)h, M, efc, seed, flags);
+    if (rc != 0) throw_last(env);
+    return rc;
+}
+
 JNIEXPORT jint JNICALL Java_hnsw_gpu_Native_hnswSearch(JNIEnv *env, jclass c, jlong h, jfloatArray q, jint nq, jint k,
                                                        jint ef, jintArray ids, jfloatArray dist) {
     jfloat *pq = (*env)->GetFloatArrayElements(env, q, NULL);

@@ -39,7 +39,7 @@
 
 (def ^:private h-create   (delay (fn-handle "hnswgpu_create" (FunctionDescriptor/of I (into-array [P L I I I P])))))
 (def ^:private h-destroy  (delay (fn-handle "hnswgpu_destroy" (FunctionDescriptor/of I (into-array [P])))))
-(def ^:private h-build    (delay (fn-handle "hnswgpu_hnsw_build" (FunctionDescriptor/of I (into-array [P I I L])))))
+(def ^:private h-build    (delay (fn-handle "hnswgpu_hnsw_build_ex" (FunctionDescriptor/of I (into-array [P I I L I])))))
 (def ^:private h-search   (delay (fn-handle "hnswgpu_hnsw_search" (FunctionDescriptor/of I (into-array [P P I I I P P P])))))
 (def ^:private h-ivfbuild (delay (fn-handle "hnswgpu_ivf_build" (FunctionDescriptor/of I (into-array [P I I L])))))
 (def ^:private h-ivfsearch (delay (fn-handle "hnswgpu_ivf_search" (FunctionDescriptor/of I (into-array [P P I I I P P P])))))
@@ -83,11 +83,22 @@
                                    [base (long (count ids)) (int dim) (int (metric-of metric 0)) (int 0) out]))
       (->GpuIndex (.get out P 0) ids dim kind))))
 
+(def ^:private build-flag {:sequential 1 :heuristic 2 :symmetric 4 :extend 8})   ; include/hnswgpu.h: HNSWGPU_BUILD_*
+
 (defn build-index
-  "hnsw.ultra-fast/build-index (src/hnsw/ultra_fast.clj:334-344): data = seq of [id ^doubles vector]."
-  [data & {:keys [M ef-construction metric seed] :or {M 16 ef-construction 200 metric :cosine seed 42}}]
-  (let [idx (create data metric :hnsw)]
-    (check (.invokeWithArguments ^MethodHandle @h-build [(:handle idx) (int M) (int ef-construction) (long seed)]))
+  "hnsw.ultra-fast/build-index (src/hnsw/ultra_fast.clj:334-344): data = seq of [id ^doubles vector].
+   :select :closest   the m closest candidates (insert-single / prune-connections-ultra, ultra_fast.clj:216-299; default)
+           :heuristic get-neighbors-heuristic for a node's links and for an over-full list (src/hnsw/graph.clj:162-232),
+                      the dropped edge leaving the pruned list only
+           :graph-clj the same, the dropped edge removed from both lists (prune-connections, graph.clj:226-231): what
+                      hnsw.ann.graph.pure-hnsw/build-index builds
+   :sequential? true  insert-single's own order and start level (slow: one launch round trip per row)."
+  [data & {:keys [M ef-construction metric seed select sequential?]
+           :or {M 16 ef-construction 200 metric :cosine seed 42 select :closest sequential? false}}]
+  (let [idx (create data metric :hnsw)
+        flags (bit-or (case select :closest 0 :heuristic 2 :graph-clj 6)
+                      (if sequential? (build-flag :sequential) 0))]
+    (check (.invokeWithArguments ^MethodHandle @h-build [(:handle idx) (int M) (int ef-construction) (long seed) (int flags)]))
     idx))
 
 (def ^:private h-add (delay (fn-handle "hnswgpu_hnsw_add" (FunctionDescriptor/of I (into-array [P P L I L])))))

@@ -1439,12 +1439,14 @@ def test_full_size_31k_properties(eng, oracle):
         assert_topk_parity(ii, dd, ei, ed, "ivf(all lists) vs exact")
 
 
-@pytest.mark.parametrize("dist,ef,nsub", [("manifold", 100, 64), ("gaussian", 3200, 24)])
-def test_timed_launch_configurations_against_oracle(eng, oracle, dist, ef, nsub):
+@pytest.mark.parametrize("dist,builder,ef,nsub", [("clustered", "heuristic", 640, 48), ("manifold", "ultra_fast.clj", 100, 64),
+                                                  ("gaussian", "graph.clj", 2400, 24), ("uniform01", "heuristic", 3200, 16)])
+def test_timed_launch_configurations_against_oracle(eng, oracle, dist, builder, ef, nsub):
     """The launches bench.py times, under the oracle: bench.make_31k's 31,173 x 768 sets, the graph built on the
-    device, 4,096 held-out queries in ONE launch with the DEFAULT rejection mode -- one wave per query, two f32 rows in
-    flight, the int8 rejection test on (hnsw_search_kernel<3, 2, false, 1, false, false>, the instantiation of the
-    headline) -- at the headline's ef (manifold, 100) and at the ef the gaussian set needs (3200: the large-ef merge).
+    device by bench.py's builders, 4,096 held-out queries in ONE launch with the DEFAULT rejection mode -- the int8
+    rejection test on, waves per query by the LDS residency rule, the in-place merge of a long list -- at the headline's
+    operating point (S1's clustered set, heuristic builder, ef 640), at round 3's (manifold, closest-m, ef 100) and at the ef
+    the i.i.d. sets need (2400 / 3200: lists of thousands of entries, two and four waves per query).
     A subsample of the batch: ids, distance bits and both traversal counters equal the oracle's device-order mode; ids and
     distances agree with its f64 reference-order mode within the north_star's tolerance (ultra_fast.clj:151-212, 346-374)."""
     import bench
@@ -1454,14 +1456,15 @@ def test_timed_launch_configurations_against_oracle(eng, oracle, dist, ef, nsub)
     Q = bench.make_31k(dist, 43, 4096)
     with eng.Index(base, "cosine") as idx:
         idx.set_rejection_test(1)                 # the default of a new handle outside the test processes
-        idx.hnsw_build(bench.M, bench.EFC, 42)
+        idx.hnsw_build(bench.M, bench.EFC, 42, **bench.BUILDERS[builder])
         g = idx.get_graph()
         idx.set_profiling(True)
         idx.rejection_stats(reset=True)
         ids, d, st = idx.hnsw_search(Q, 10, ef, want_stats=True)
         f32_rows, neighbours = idx.rejection_stats(reset=True)
         idx.set_profiling(False)
-        assert 0 < f32_rows < 0.6 * neighbours, "the rejection test did not run on the timed configuration"
+        # (on the clustered set's seed-43 queries the bounds reject about half of the neighbours, on the others 80 - 85 %)
+        assert 0 < f32_rows < 0.7 * neighbours, "the rejection test did not run on the timed configuration"
         sub = np.linspace(0, len(Q) - 1, nsub).astype(np.int64)
         oi, od, ost, _ = O.hnsw_search(base, g, Q[sub], 10, ef=ef, mode=O.MODE_DEV, nthreads=8)
         assert_exact(ids[sub], d[sub], oi, od, "%s ef %d vs oracle (device order)" % (dist, ef))

@@ -154,35 +154,36 @@ def test_config3_ivf_production_path_against_oracle(eng, oracle, shard3, nq, tun
 
 
 def test_config4_hnsw_per_gpu_shard(eng, oracle):
-    """1.25M x 1536 cosine (rows on a 32-dimensional manifold, as bench.py's sharded_hnsw leg), graph built on the device
-    (M 16, ef_construction 200), 1024 queries at ef_search 256: the traversal is HBM-resident (7.7 GB of rows) and
-    keeps its visited stamps in HBM."""
+    """1.25M x 1536 cosine, clustered-normalised rows (1024 centres, noise 0.3; queries held out of the same
+    mixture -- bench.py's sharded_hnsw leg), graph built on the device by the heuristic builder (M 16, ef_construction 200,
+    graph.clj:162-232 selection; closest-m lists reach recall 0.09 on these rows), 1024 queries at ef_search 256: the
+    traversal is HBM-resident (7.7 GB of rows) and keeps its visited stamps in HBM."""
     import torch
 
     O = oracle
     dev = torch.device("cuda", 0)
-    n, dim, r, ef, nq, k = N_SHARD, 1536, 32, 256, 1024, 10
+    n, dim, ef, nq, k = N_SHARD, 1536, 256, 1024, 10
     g = torch.Generator(device=dev)
     g.manual_seed(11)
-    w = torch.randn(r, dim, generator=g, device=dev)
+    cen = torch.randn(1024, dim, generator=g, device=dev)
 
-    def manifold(m):
+    def mixture(m):
         out = torch.empty(m, dim, device=dev)
         for i in range(0, m, 250_000):
             c = min(250_000, m - i)
-            y = torch.randn(c, r, generator=g, device=dev) @ w / r ** 0.5 + 0.1 * torch.randn(c, dim, generator=g, device=dev)
+            y = cen[torch.randint(0, 1024, (c,), generator=g, device=dev)] + 0.3 * torch.randn(c, dim, generator=g, device=dev)
             out[i:i + c] = y / y.norm(dim=1, keepdim=True)
         return out
 
     g.manual_seed(2000)
-    x = manifold(n)
+    x = mixture(n)
     g.manual_seed(43)
-    Q = manifold(nq)
+    Q = mixture(nq)
     base = x.cpu().numpy()
     qh = Q.cpu().numpy()
     with eng.Index(x, "cosine") as idx:
         del x
-        idx.hnsw_build(16, 200, 42)
+        idx.hnsw_build(16, 200, 42, heuristic=True)
         stats = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
         i1, d1 = idx.hnsw_search_dev(Q, k, ef, stats=stats)
         i2, d2 = idx.hnsw_search_dev(Q, k, ef)
@@ -197,7 +198,7 @@ def test_config4_hnsw_per_gpu_shard(eng, oracle):
         torch.cuda.synchronize()
         ei = ei.cpu().numpy()
         rec = np.mean([len(set(ids[q]) & set(ei[q])) / k for q in range(256)])
-        assert rec >= 0.9, rec
+        assert rec >= 0.97, rec
         # the oracle on the SAME graph, 64-query subsample: ids, distance bits, both traversal counters
         gr = idx.get_graph()
         og = O.Graph(gr.levels, gr.l0_adj, gr.up_off, gr.up_adj, gr.M, gr.entry, gr.max_level)

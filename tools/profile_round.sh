@@ -3,7 +3,7 @@
 # counters in passes of their own, as MI355X_MICROARCH.md prescribes), condensed by profiles/summarize.py.
 #   usage (on the GPU box): bash tools/profile_round.sh r01      -> gpurun_out/prof_r01/{summary.txt,...}
 set -e
-TAG=${1:-r01}
+TAG=${1:-r04}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
