@@ -108,10 +108,8 @@ __global__ __launch_bounds__(kWG) void heuristic_select_kernel(HeurArgs a) {
                 }
                 float s[RB];
 #pragma unroll
-                for (int b = 0; b < RB; b++) s[b] = wave_sum(lane_partial<NCH, L2>(q, r[b]));
-                float sm = 0.0f;
-#pragma unroll
-                for (int b = 0; b < RB; b++) sm = lane == b ? s[b] : sm;
+                for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2>(q, r[b]);
+                const float sm = rows_sum_to_lane<RB>(s, lane);
                 if (lane < RB && r0 + lane < nres) mine = mine || (finish_dist(a.metric, sm, qn, rn) < dc);
             }
             if (__ballot(mine) && lane == 0) atomicOr(&sflag[1], 1);

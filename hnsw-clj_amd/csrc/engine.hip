@@ -596,16 +596,10 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
             float sm[RB];
 #pragma unroll
             for (int b = 0; b < RB; b++) sm[b] = lane_partial<NCH, L2>(q, r[b]);
-#pragma unroll
-            for (int b = 0; b < RB; b++) sm[b] = wave_sum(sm[b]);
-#pragma unroll
-            for (int b = 0; b < RB; b++) {
-                const int64_t row = base + b;
-                if (row < r1 && lane == 0) {
-                    const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), b));
-                    coherent_store(a.dense + static_cast<int64_t>(qi) * a.nlist + row, finish_dist(a.metric, sm[b], qn, rn));
-                }
-            }
+            // lane b: row b's sum and (above) its norm: the distance is finished and stored by the lane that holds both
+            const float mine = rows_sum_to_lane<RB>(sm, lane);
+            if (lane < RB && base + lane < r1)
+                coherent_store(a.dense + static_cast<int64_t>(qi) * a.nlist + base + lane, finish_dist(a.metric, mine, qn, myrn));
         }
     }
     wait_stores_acked();  // the slice of distances is at the point of coherence before this workgroup counts itself
@@ -666,12 +660,8 @@ __global__ __launch_bounds__(kWG) void ivf_route_dist_kernel(RouteArgs a) {
             float sm[RB];
 #pragma unroll
             for (int b = 0; b < RB; b++) sm[b] = lane_partial<NCH, L2>(q, r[b]);
-#pragma unroll
-            for (int b = 0; b < RB; b++) sm[b] = wave_sum(sm[b]);
             // lane b takes row b's distance: RB consecutive floats of the query's row of the matrix
-            float mine = 0.0f;
-#pragma unroll
-            for (int b = 0; b < RB; b++) mine = lane == b ? sm[b] : mine;
+            const float mine = rows_sum_to_lane<RB>(sm, lane);  // (eight rows: one halving exchange, the butterflies' bits)
             if (lane < RB && base + lane < r1)
                 a.dense[static_cast<int64_t>(qi) * a.nlist + base + lane] = finish_dist(a.metric, mine, qn, myrn);
         }

@@ -42,6 +42,52 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// Eight rows' lane sums reduced TOGETHER, with the association of wave_sum (the xor butterfly 1, 2, 4, 8, 16, 32): at the
+// first three levels a lane keeps one of two rows and hands the other to its partner (halving exchange: 8 -> 4 -> 2 -> 1
+// values per lane, each level adding exactly the pair x[l] + x[l ^ off] the butterfly adds), then the single value goes
+// through the last three levels -- 28 operations and two LDS-crossbar shuffles instead of eight six-step butterflies and
+// sixteen.  Lane l ends with the total of row (l & 7): bit for bit wave_sum(x[l & 7]).
+__device__ __forceinline__ float wave_sum8(const float (&x)[8], int lane) {
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+    float y[4], z[2];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {  // xor 1: even lanes keep rows 0 2 4 6, odd lanes rows 1 3 5 7
+        const float keep = b0 ? x[2 * p + 1] : x[2 * p], send = b0 ? x[2 * p] : x[2 * p + 1];
+        y[p] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {  // xor 2: lanes with bit 1 clear keep y[0] / y[2] (rows 0|1, 4|5), the others y[1] / y[3]
+        const float keep = b1 ? y[2 * p + 1] : y[2 * p], send = b1 ? y[2 * p] : y[2 * p + 1];
+        z[p] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    }
+    // xor 4: row_shl:4 into banks 0 and 2 (lanes 0-3, 8-11 read lane + 4), row_shr:4 into banks 1 and 3
+    const float keep = b2 ? z[1] : z[0], send = b2 ? z[0] : z[1];
+    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x104, 0xF, 0x5, false);
+    r = __builtin_amdgcn_update_dpp(r, __float_as_int(send), 0x114, 0xF, 0xA, false);
+    float v = keep + __int_as_float(r);
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));  // row_ror:8 = lane ^ 8
+    v = v + __shfl_xor(v, 16, kWave);
+    v = v + __shfl_xor(v, 32, kWave);
+    return v;
+}
+
+// RB rows' lane sums -> lane b holds the total of row b (lanes >= RB: unspecified).  Eight rows go through wave_sum8, other
+// counts through RB butterflies: the same bits either way.
+template <int RB>
+__device__ __forceinline__ float rows_sum_to_lane(float (&s)[RB], int lane) {
+    if constexpr (RB == 8) {
+        return wave_sum8(s, lane);
+    } else {
+        float mine = 0.0f;
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            const float t = wave_sum(s[b]);
+            mine = lane == b ? t : mine;
+        }
+        return mine;
+    }
+}
+
 template <int NCH>
 __device__ __forceinline__ void load_query(float4 (&q)[NCH], const float *Q, int dim, int lane) {
 #pragma unroll
@@ -631,14 +677,13 @@ __global__ __launch_bounds__(kWG) void scan_kernel(ScanArgs a) {
             float s[RB];
 #pragma unroll
             for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2>(q, r[b]);
-#pragma unroll
-            for (int b = 0; b < RB; b++) s[b] = wave_sum(s[b]);
+            const float tot = rows_sum_to_lane<RB>(s, lane);  // lane b: row b's sum (eight rows: one halving exchange)
 #pragma unroll
             for (int b = 0; b < RB; b++) {
                 int64_t row = base + b;
                 if (row < r1) {  // wave-uniform
                     float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), b));
-                    float d = finish_dist(a.metric, s[b], qn, rn);
+                    float d = finish_dist(a.metric, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), b)), qn, rn);
                     if (a.mode == MODE_TOPK) {
                         uint64_t key = make_key(d, ord_base + static_cast<uint32_t>(row - rb0));
                         if (key < thr) {
@@ -1239,11 +1284,7 @@ __device__ __forceinline__ void pf_helper(const HnswArgs &a, uint32_t *mail, int
                             float sums[RB];
 #pragma unroll
                             for (int b = 0; b < RB; b++) sums[b] = lane_partial<NCH, L2>(hq, r[b]);
-#pragma unroll
-                            for (int b = 0; b < RB; b++) sums[b] = wave_sum(sums[b]);
-                            float mine = 0.0f;
-#pragma unroll
-                            for (int b = 0; b < RB; b++) mine = lane == b ? sums[b] : mine;
+                            const float mine = rows_sum_to_lane<RB>(sums, lane);
                             if (lane < RB && myid >= 0) {
                                 const float dv = finish_dist(a.metric, mine, hqn, myrn) + 0.0f;
                                 coherent_store(res + (j0 + lane), tagw | __float_as_uint(dv));
@@ -1560,11 +1601,7 @@ __global__ __launch_bounds__(NW * kWave) void hnsw_search_kernel(HnswArgs a) {
                     float s[RB];
 #pragma unroll
                     for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2>(q, r[b]);
-#pragma unroll
-                    for (int b = 0; b < RB; b++) s[b] = wave_sum(s[b]);
-                    float mine = 0.0f;  // lane b keeps candidate b's reduced sum
-#pragma unroll
-                    for (int b = 0; b < RB; b++) mine = lane == b ? s[b] : mine;
+                    const float mine = rows_sum_to_lane<RB>(s, lane);  // lane b keeps candidate b's reduced sum
                     if (myj >= 0) cand_d[myj] = finish_dist(a.metric, mine, qn, myrn) + 0.0f;
                 }
                 __syncthreads();

@@ -131,23 +131,21 @@ __global__ __launch_bounds__(kTileThreads) void l2_group_kernel(TileArgs a) {
             float s[RB];
 #pragma unroll
             for (int b = 0; b < RB; b++) s[b] = lane_partial<NCH, L2M>(qv, r[b]);
-#pragma unroll
-            for (int b = 0; b < RB; b++) s[b] = wave_sum(s[b]);
+            const float mine = rows_sum_to_lane<RB>(s, lane);  // lane b: row b's sum (eight rows: one halving exchange)
             if (a.out_key) {  // first minimum wins (strict <, ivf_flat.clj:86-89) = smallest (distance, row)
                 uint64_t kmin = ~0ull;
 #pragma unroll
                 for (int b = 0; b < RB; b++) {
                     const int64_t row = base + b;
+                    const float sb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), b));
                     const float rn = L2M ? 0.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), b));
-                    const float dv = L2M ? __builtin_sqrtf(s[b]) : finish_dist(a.metric, s[b], qn, rn);
+                    const float dv = L2M ? __builtin_sqrtf(sb) : finish_dist(a.metric, sb, qn, rn);
                     const uint64_t key = row < r1 ? make_key(dv, static_cast<uint32_t>(row - rb0)) : ~0ull;
                     kmin = key < kmin ? key : kmin;
                 }
                 if (lane == q) best = kmin < best ? kmin : best;
             } else {
-                float mine = 0.0f;  // lane b takes row b's distance: RB consecutive floats of the query's array
-#pragma unroll
-                for (int b = 0; b < RB; b++) mine = lane == b ? s[b] : mine;
+                // lane b takes row b's distance: RB consecutive floats of the query's array
                 // lane b holds row b's norm already: the distance is finished where it is stored
                 if (lane < RB && base + lane < r1)
                     a.out[ob_s[q] + (base + lane - rb0)] = L2M ? __builtin_sqrtf(mine) : finish_dist(a.metric, mine, qn, myrn);

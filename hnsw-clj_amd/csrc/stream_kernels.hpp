@@ -137,9 +137,13 @@ __device__ __forceinline__ void seed_tau_wg(const float4 (&q)[NCH], float qn, in
                                 static_cast<uint32_t>(__builtin_amdgcn_readlane(rlo, b));
             load_row<NCH>(r[b], rows + row * ld, nvec, lane, j0 + b < m);
         }
+        float sm[RB];
+#pragma unroll
+        for (int b = 0; b < RB; b++) sm[b] = lane_partial<NCH, L2>(q, r[b]);
+        const float tot = rows_sum_to_lane<RB>(sm, lane);  // lane b: row b's sum (eight rows: one halving exchange)
 #pragma unroll
         for (int b = 0; b < RB; b++) {
-            const float sum = wave_sum(lane_partial<NCH, L2>(q, r[b]));
+            const float sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), b));
             const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), b));
             const float d = finish_dist(metric, sum, qn, rn);
             if (lane == 0 && j0 + b < m) dist_s[j0 + b] = d == d ? d : __builtin_inff();
@@ -1106,6 +1110,7 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
 #pragma unroll
                 for (int c = 0; c < NCH; c++) w[b][c] = has && c * kWave + lane < nvec ? rp[c * kWave + lane] : make_uint2(0u, 0u);
             }
+            float accs[RB];
 #pragma unroll
             for (int b = 0; b < RB; b++) {
                 float acc = 0.0f;
@@ -1124,7 +1129,12 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
                         }
                     }
                 }
-                const float sum = wave_sum(acc);
+                accs[b] = acc;
+            }
+            const float tot = rows_sum_to_lane<RB>(accs, lane);  // lane b: row b's sum (eight rows: one halving exchange)
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                const float sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), b));
                 mysum = lane == js[b] ? sum : mysum;
             }
         }
