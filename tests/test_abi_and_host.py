@@ -43,6 +43,47 @@ def test_no_torch_types_or_oracle_in_product():
     assert "torch" not in hdr.replace("torch tensor's", "") and "at::" not in hdr
 
 
+def test_library_reads_no_environment_on_search_paths(native_lib):
+    """The switches of rounds 1-3 were 45 HNSWGPU_* environment names, 20 of them read by getenv on every IVF search and two
+    that made results wrong on purpose.  Now: hnswgpu_set_tuning for all of them, six documented names read once when the
+    library is loaded, the ablation switches in -DHG_DIAG builds only (<= 10 strings, no getenv on the search
+    path)."""
+    import re
+    import subprocess
+
+    blob = open(native_lib.SO, "rb").read()
+    names = sorted(set(m.decode() for m in re.findall(rb"HNSWGPU_[A-Z0-9_]+", blob)))
+    env = {"HNSWGPU_BUILD_THREADS", "HNSWGPU_IVF_CALIBRATE", "HNSWGPU_IVF_HALF", "HNSWGPU_PREFETCH", "HNSWGPU_PREFILTER",
+           "HNSWGPU_TILE_PAIRS"}
+    api_constants_in_messages = {"HNSWGPU_BUILD_HEURISTIC", "HNSWGPU_BUILD_SYMMETRIC"}   # an error text names the flags
+    assert env <= set(names) and set(names) <= env | api_constants_in_messages and len(names) <= 10, names
+    assert b"STREAM_DBG" not in blob and b"TILE_DBG" not in blob and b"hnswgpu_debug_set_ablation" not in blob
+    src = "".join(open(os.path.join(ROOT, "hnsw-clj_amd", "csrc", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "hnsw-clj_amd", "csrc")) if f.endswith((".hip", ".hpp")))
+    assert src.count("getenv(") == 1, "getenv belongs in engine.hip's load-time TuneInit only"
+    nm = subprocess.run(["nm", "-D", "--defined-only", native_lib.SO], capture_output=True, text=True).stdout
+    assert "hnswgpu_set_tuning" in nm and "hnswgpu_get_tuning" in nm
+
+
+def test_tuning_table_roundtrip(native_lib):
+    """hnswgpu_set_tuning / hnswgpu_get_tuning need no GPU: set, read back, restore the default, reject unknown keys; the
+    header's key numbers are the wrapper's."""
+    import re
+
+    N = native_lib
+    hdr = open(os.path.join(ROOT, "include", "hnswgpu.h")).read()
+    keys = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"#define HNSWGPU_TUNE_([A-Z0-9_]+) (\d+) ", hdr))
+    count = keys.pop("COUNT") if "COUNT" in keys else int(re.search(r"#define HNSWGPU_TUNE_COUNT (\d+)", hdr).group(1))
+    assert [k for k, _ in sorted(keys.items(), key=lambda kv: kv[1])] == N.TUNE_KEYS and count == len(N.TUNE_KEYS)
+    was = N.get_tuning("STREAM_CAP")
+    N.set_tuning("stream_cap", 7)
+    assert N.get_tuning("STREAM_CAP") == 7
+    N.set_tuning("STREAM_CAP", None)
+    assert N.get_tuning("STREAM_CAP") is None
+    N.set_tuning("STREAM_CAP", was)
+    assert N.lib().hnswgpu_set_tuning(count, 1) == -1 and N.lib().hnswgpu_set_tuning(-1, 1) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch, native_lib):
     monkeypatch.setattr(native_lib, "SO", "/nonexistent/libhnswgpu.so")
     monkeypatch.setattr(native_lib, "_lib", None)
