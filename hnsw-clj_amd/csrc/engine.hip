@@ -136,6 +136,22 @@ int launch_heavy(const HeavyArgs &a, hipStream_t st) {
     return 0;
 }
 
+// the home lists through the matrix cores in half precision (stream_kernels.hpp, step 1a): `blocks` bounds the work list
+int launch_home(const HomeArgs &a, int64_t blocks, int nch, hipStream_t st) {
+    if (blocks <= 0) return 0;
+    HG_REQUIRE(a.ld % 128 == 0 && a.metric != METRIC_L2, HNSWGPU_EINVAL, "home-list pass: cosine / dot rows of whole 128-element steps only");
+    const bool pf8 = (a.ld / 32) % 8 == 0;  // eight operand loads in flight per wave where the steps of a row divide by eight
+#define CALL(N, R, L)                                                                                              \
+    do {                                                                                                           \
+        if (pf8) hipLaunchKernelGGL((ivf_home_kernel<N, 8>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), 0, st, a); \
+        else hipLaunchKernelGGL((ivf_home_kernel<N, 4>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), 0, st, a);     \
+    } while (0)
+    HG_DISPATCH(nch, false, CALL);
+#undef CALL
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_mid(const MidArgs &a, int nch, hipStream_t st) {
     int64_t blocks = static_cast<int64_t>(a.nq) * a.slices;
     if (a.qorder) blocks = (static_cast<int64_t>(a.nq) + 7) / 8 * 8;  // ordered queries: whole rounds over the eight XCDs
@@ -1508,7 +1524,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf *bufs[] = {&idx->s_q,   &idx->s_partial, &idx->s_ord,   &idx->s_dist, &idx->s_pairs, &idx->s_ids,
-                      &idx->s_outd, &idx->s_probes,  &idx->s_stats, &idx->s_misc, &idx->s_misc2, &idx->s_vis, &idx->s_qp, &idx->s_qn, &idx->s_tile, &idx->s_grp, &idx->s_done, &idx->s_pf, &idx->s_bk, &idx->s_heavy};
+                      &idx->s_outd, &idx->s_probes,  &idx->s_stats, &idx->s_misc, &idx->s_misc2, &idx->s_vis, &idx->s_qp, &idx->s_qn, &idx->s_tile, &idx->s_grp, &idx->s_done, &idx->s_pf, &idx->s_bk, &idx->s_heavy, &idx->s_home, &idx->s_dh};
     for (DevBuf *b : bufs) b->release();
     for (int s = 0; s < PROF_N; s++)
         for (auto &pr : idx->prof_ev[s]) {
@@ -1979,6 +1995,73 @@ int hnswgpu_ivf_half_bounds(hnswgpu_index *idx, const float *q, const int32_t *l
         memcpy(out_lb + i, &ent[i].z, sizeof(float));
         memcpy(out_ub + i, &ent[i].w, sizeof(float));
     }
+    return 0;
+}
+
+// Diagnostic / test entry: the matrix-core half-precision bounds (stream_kernels.hpp, step 1a: ivf_home_kernel) of the
+// LIST rows [row_begin, row_end) -- positions in list order -- against `nq` queries, as if that range were the list all of
+// them are nearest to; out_lb / out_ub [nq][row_end - row_begin].
+int hnswgpu_ivf_home_bounds(hnswgpu_index *idx, const float *Q, int32_t nq, int64_t row_begin, int64_t row_end, float *out_lb,
+                            float *out_ub) {
+    HG_REQUIRE(idx && Q && out_lb && out_ub && nq >= 1, HNSWGPU_EINVAL, "null argument");
+    HG_REQUIRE(row_begin >= 0 && row_begin < row_end && row_end <= idx->n && row_end - row_begin < (1 << 24), HNSWGPU_EINVAL, "row range");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    HG_HIP(hipSetDevice(idx->device));
+    HG_REQUIRE(idx->d_lhalf, HNSWGPU_EINVAL, "this handle has no half-precision list rows (no lists, no int8 rows, or HNSWGPU_IVF_HALF=0)");
+    HG_REQUIRE(idx->metric != METRIC_L2 && idx->ld % 128 == 0, HNSWGPU_EINVAL, "the home-list pass serves cosine / dot rows of whole 128-element steps");
+    hipStream_t st = idx->stream;
+    HG_TRY(begin_call(idx, st));
+    HG_TRY(upload_queries(idx, Q, nq, st));
+    const int64_t len = row_end - row_begin, hstride = (len + 15) / 16 * 16;
+    const int gq = home_group(idx->nch);
+    std::vector<HomeDesc> items;
+    for (int64_t r0 = 0; r0 < len; r0 += 256)
+        for (int32_t q0 = 0; q0 < nq; q0 += gq) {
+            HomeDesc d;
+            d.rb0 = row_begin;
+            d.r0_off = static_cast<int32_t>(r0);
+            d.r1_off = static_cast<int32_t>(std::min<int64_t>(len, r0 + 256));
+            d.q0 = q0;
+            d.cnt = std::min<int32_t>(gq, nq - q0);
+            d.list = 0;
+            d.pad = 0;
+            items.push_back(d);
+        }
+    std::vector<int32_t> order(nq);
+    for (int32_t i = 0; i < nq; i++) order[i] = i;
+    const int32_t nit = static_cast<int32_t>(items.size());
+    HG_TRY(idx->s_home.ensure(sizeof(HomeDesc) * items.size() + 64 + sizeof(int32_t) * nq));
+    HG_TRY(idx->s_dh.ensure(sizeof(float2) * static_cast<size_t>(nq) * hstride));
+    HomeDesc *d_items = idx->s_home.as<HomeDesc>();
+    int32_t *d_nit = reinterpret_cast<int32_t *>(d_items + items.size());
+    int32_t *d_order = d_nit + 16;
+    HG_HIP(hipMemcpyAsync(d_items, items.data(), sizeof(HomeDesc) * items.size(), hipMemcpyHostToDevice, st));
+    HG_HIP(hipMemcpyAsync(d_nit, &nit, sizeof(nit), hipMemcpyHostToDevice, st));
+    HG_HIP(hipMemcpyAsync(d_order, order.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, st));
+    HomeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.items = d_items;
+    a.nitems = d_nit;
+    a.qorder = d_order;
+    a.half = idx->d_lhalf;
+    a.hmeta = idx->d_lhmeta;
+    a.ld = idx->ld;
+    a.Q = idx->s_q.as<float>();
+    a.qld = idx->dim;
+    a.dim = idx->dim;
+    a.metric = idx->metric;
+    a.dh = idx->s_dh.as<float2>();
+    a.hstride = hstride;
+    HG_TRY(launch_home(a, nit, idx->nch, st));
+    std::vector<float2> host(static_cast<size_t>(nq) * hstride);
+    HG_HIP(hipMemcpyAsync(host.data(), a.dh, sizeof(float2) * host.size(), hipMemcpyDeviceToHost, st));
+    HG_TRY(end_call(idx, st));
+    HG_HIP(hipStreamSynchronize(st));
+    for (int32_t i = 0; i < nq; i++)
+        for (int64_t r = 0; r < len; r++) {
+            out_lb[i * len + r] = host[i * hstride + r].x;
+            out_ub[i * len + r] = host[i * hstride + r].y;
+        }
     return 0;
 }
 

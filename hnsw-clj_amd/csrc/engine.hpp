@@ -185,7 +185,7 @@ struct hnswgpu_index {
     std::vector<int32_t> h_listids;
 
     // scratch (grown on demand, reused across calls; calls are serialised by `mu`)
-    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2, s_vis, s_qp, s_qn, s_tile, s_grp, s_done, s_pf, s_bk, s_heavy;
+    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2, s_vis, s_qp, s_qn, s_tile, s_grp, s_done, s_pf, s_bk, s_heavy, s_home, s_dh;
     // s_bk: the per-list pair counters of the IVF survivor stream -- zero between searches (the work-list kernel clears
     // them behind its last read); bk_dirty = a search was enqueued past the point that fills them but not past the
     // work-list kernel (an error in between): the next search clears them itself
@@ -282,8 +282,10 @@ int launch_query_prep(const PrepArgs &a, int nch, hipStream_t st);
 // narrow: the epilogue for few queries per probed list (lane = row); otherwise lane = query
 struct MidArgs;
 struct HeavyArgs;
+struct HomeArgs;
 int launch_mid(const MidArgs &a, int nch, hipStream_t st);
 int launch_heavy(const HeavyArgs &a, hipStream_t st);
+int launch_home(const HomeArgs &a, int64_t blocks, int nch, hipStream_t st);
 int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narrow, hipStream_t st);
 int launch_finish(const FinishArgs &a, int nch, hipStream_t st);
 // zero-initialised per-query counters of the fused tails (s_done: [n] scan / finish tails | [n] route tails)

@@ -122,9 +122,41 @@ __global__ __launch_bounds__(1024) void pair_order_kernel(const int32_t *probes,
 __global__ __launch_bounds__(1024) void ivf_worklist_kernel(uint32_t *bk_cnt, int32_t bk_cap, int nlist,
                                                             const int64_t *list_off, int64_t chunk_rows, int max_chunks,
                                                             WorkDesc *desc, int32_t *nitems, const int32_t *ord_probes,
-                                                            int ord_nq, int32_t *ord_out, int ord_stride) {
+                                                            int ord_nq, int32_t *ord_out, int ord_stride,
+                                                            HomeDesc *home_desc, int32_t *home_nitems, int home_gq,
+                                                            int home_chunk) {
     if (blockIdx.x == 1) {
         pair_order_wg(ord_probes, ord_nq, nlist, ord_out, ord_stride);
+        if (home_desc) {
+            // the work list of ivf_home_kernel: after the counting sort ocnt[l] is where list l's queries END in the order
+            // (they start where list l - 1's end); every list that is some query's nearest gives (groups of <= home_gq of
+            // them) x (chunks of home_chunk rows) items, in whatever order the threads reserve their ranges
+            extern __shared__ int32_t ocnt[];
+            __shared__ int32_t hn_s;
+            if (threadIdx.x == 0) hn_s = 0;
+            __syncthreads();
+            for (int l = threadIdx.x; l < nlist; l += 1024) {
+                const int end = ocnt[l], start = l > 0 ? ocnt[l - 1] : 0, c = end - start;
+                const int64_t rb0 = list_off[l], rows = list_off[l + 1] - rb0;
+                if (c <= 0 || rows <= 0) continue;
+                const int ng = (c + home_gq - 1) / home_gq, nch = static_cast<int>((rows + home_chunk - 1) / home_chunk);
+                int at = atomicAdd(&hn_s, ng * nch);
+                for (int ch = 0; ch < nch; ch++)
+                    for (int g = 0; g < ng; g++, at++) {
+                        HomeDesc d;
+                        d.rb0 = rb0;
+                        d.r0_off = ch * home_chunk;
+                        d.r1_off = static_cast<int32_t>(rows < static_cast<int64_t>(ch + 1) * home_chunk ? rows : static_cast<int64_t>(ch + 1) * home_chunk);
+                        d.q0 = start + g * home_gq;
+                        d.cnt = c - g * home_gq < home_gq ? c - g * home_gq : home_gq;
+                        d.list = l;
+                        d.pad = 0;
+                        home_desc[at] = d;
+                    }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) *home_nitems = hn_s;
+        }
         return;
     }
     __shared__ int32_t off_s[1025];  // exclusive offsets of this pass's lists
@@ -804,6 +836,40 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows, tpc = cr / kTileRows;
     b.chunk_rows = static_cast<int32_t>(cr);
     b.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
+    // Once the exact pass would be the largest kernel (its rows are 3 KB each and every query fetches its own) the survivors
+    // first meet their half-precision rows.  The survivors are a few per cent of the candidates: from ~1.5 M candidates per
+    // batch (48 queries x 32 lists x 977 rows; 5 queries at 10 M rows) the pass saves more than its launch costs -- measured
+    // at 1M x 768: batch 32 0.183 ms without vs 0.195 with, 64: 0.250 vs 0.243, 128: 0.298 vs 0.277.
+    // HNSWGPU_STREAM_MID=<queries> overrides (tests: 1 = always; 0 = never).
+    const int64_t mid_env = tune(HNSWGPU_TUNE_STREAM_MID, -1);
+    const int64_t cand = npairs * mean;
+    const bool mid = idx->d_lhalf != nullptr && !idx->ivf_calibrating && (mid_env >= 0 ? (mid_env > 0 && nq >= mid_env) : cand >= 1500000);
+    const int64_t order_min = tune(HNSWGPU_TUNE_FINISH_ORDER, 512);  // 0 = never (A/B)
+    const bool ordered = grouped && d_probes && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists;
+    // Batches in which the lists are home to about a query each or more: every home list once through the matrix cores in
+    // half precision for all of its queries (ivf_home_kernel) instead of a half row per (query, survivor).  cosine / dot,
+    // rows of whole 128-element steps; HNSWGPU_TUNE_STREAM_HOME: -1 this rule, 0 never, 1 whenever the queries are ordered.
+    const int64_t home_env = tune(HNSWGPU_TUNE_STREAM_HOME, -1);
+    const int64_t hstride = (idx->max_list_len + 15) / 16 * 16;
+    const int home_gq = home_group(idx->nch);
+    bool home = mid && ordered && idx->metric != METRIC_L2 && idx->ld % 128 == 0 && home_env != 0 && tune(HNSWGPU_TUNE_MID_SLICES, 0) <= 1 &&
+                (home_env > 0 || (nq >= 1024 && 2LL * nq >= idx->nlist)) &&
+                static_cast<int64_t>(nq) * hstride * 8 <= (2LL << 30);
+    int64_t home_chunk = 256, home_bound = 0;
+    if (home) {
+        const int64_t groups = nq / home_gq + std::min<int64_t>(nq, idx->nlist);
+        while (home_chunk < 4096 && groups * ((idx->max_list_len + home_chunk - 1) / home_chunk) > 16384) home_chunk *= 2;
+        home_bound = groups * ((idx->max_list_len + home_chunk - 1) / home_chunk);
+        if (home_bound >= 2147483647LL) home = false;
+    }
+    HomeDesc *home_desc = nullptr;
+    int32_t *home_nit = nullptr;
+    if (home) {
+        HG_TRY(idx->s_home.ensure(sizeof(HomeDesc) * static_cast<size_t>(home_bound) + 64));
+        HG_TRY(idx->s_dh.ensure(sizeof(float2) * static_cast<size_t>(nq) * hstride));
+        home_desc = idx->s_home.as<HomeDesc>();
+        home_nit = reinterpret_cast<int32_t *>(home_desc + home_bound);
+    }
     if (grouped) {
         // the work list: items <= sum over lists of ceil(members / 32) * chunks <= (npairs / 32 + nlist) * nchunks
         const int64_t wbound = (npairs / kTileQ + idx->nlist) * b.nchunks;
@@ -812,9 +878,8 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         WorkDesc *desc = idx->s_misc2.as<WorkDesc>();
         int32_t *nit = reinterpret_cast<int32_t *>(desc + wbound);
         // (large batches: the query order of the half-precision pass and the finish kernel by a second workgroup of this launch)
-        const int64_t order_min = tune(HNSWGPU_TUNE_FINISH_ORDER, 512);  // 0 = never (A/B)
         size_t olds = 0;
-        if (d_probes && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists) {
+        if (ordered) {
             HG_TRY(idx->s_stats.ensure(sizeof(int32_t) * static_cast<size_t>(nq)));  // (s_ids / s_outd may be the caller's outputs)
             olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);
             if (olds > 32 * 1024) {  // (+ the work list's static 4 KB)
@@ -826,7 +891,8 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
             qorder = idx->s_stats.as<int32_t>();
         }
         hipLaunchKernelGGL(ivf_worklist_kernel, dim3(qorder ? 2 : 1), dim3(1024), olds, st, sc.bk_cnt, sc.bk_cap, idx->nlist,
-                           idx->d_listoff, cr, b.nchunks, desc, nit, d_probes, nq, idx->s_stats.as<int32_t>(), nprobe);
+                           idx->d_listoff, cr, b.nchunks, desc, nit, d_probes, nq, idx->s_stats.as<int32_t>(), nprobe,
+                           home_desc, home_nit, home_gq, static_cast<int>(home_chunk));
         HG_HIP(hipGetLastError());
         idx->bk_dirty = false;  // (the kernel leaves the counters zero)
         b.wi_desc = desc;
@@ -861,15 +927,11 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     b.dbg = 0;
 #endif
     b.stamps = g_tile_dbg_buf;  // null outside diagnostic sessions
-    // Once the exact pass would be the largest kernel (its rows are 3 KB each and every query fetches its own) the survivors
-    // first meet their half-precision rows.  The survivors are a few per cent of the candidates: from ~1.5 M candidates per
-    // batch (48 queries x 32 lists x 977 rows; 5 queries at 10 M rows) the pass saves more than its launch costs -- measured
-    // at 1M x 768: batch 32 0.183 ms without vs 0.195 with, 64: 0.250 vs 0.243, 128: 0.298 vs 0.277.
-    // HNSWGPU_STREAM_MID=<queries> overrides (tests: 1 = always; 0 = never).
-    const int64_t mid_env = tune(HNSWGPU_TUNE_STREAM_MID, -1);
-    const int64_t cand = npairs * mean;
-    const bool mid = idx->d_lhalf != nullptr && !idx->ivf_calibrating && (mid_env >= 0 ? (mid_env > 0 && nq >= mid_env) : cand >= 1500000);
     b.defer = mid ? 1 : 0;
+    if (home) {
+        b.home_pairs = idx->s_pairs.as<Pair>();
+        b.home_nprobe = nprobe;
+    }
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);
     // which epilogue: few queries per probed list -> lane = row (a list probed by more takes several passes); many -> lane = query
@@ -880,7 +942,6 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     // Large batches: a query's survivors are, above all, its nearest list -- and several queries share one.  The queries are
     // taken in the order of their nearest list, a contiguous eighth of that order per XCD, so that the queries which read
     // the same rows run side by side on ONE L2 (each XCD otherwise fetches the list for itself).
-    const int64_t order_min = tune(HNSWGPU_TUNE_FINISH_ORDER, 512);  // 0 = never (A/B)
     if (!qorder && d_probes && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists) {  // (ungrouped launches)
         HG_TRY(idx->s_stats.ensure(sizeof(int32_t) * static_cast<size_t>(nq)));  // (s_ids / s_outd may be the caller's outputs)
         const size_t olds = sizeof(int32_t) * (idx->nlist + 1 + 1024);
@@ -933,7 +994,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     const size_t keys = static_cast<size_t>(nq) * (heavy ? std::max(f.slices, kHeavySlices) : f.slices) * (k <= kWave ? 1 : kNWave) * k;
     HG_TRY(idx->s_partial.ensure(sizeof(uint64_t) * keys));
     if (heavy) {
-        HG_TRY(idx->s_heavy.ensure(sizeof(int32_t) * (static_cast<size_t>(nq) + 4)));
+        HG_TRY(idx->s_heavy.ensure(sizeof(int32_t) * (2 * static_cast<size_t>(nq) + 4)));
         HeavyArgs ha;
         ha.surv_cnt = b.surv_cnt;
         ha.nq = nq;
@@ -942,6 +1003,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         ha.thr = static_cast<uint32_t>(std::min<int64_t>(cap, tune(HNSWGPU_TUNE_STREAM_HEAVY_MIN, 4096)));
         ha.cnt = idx->s_heavy.as<uint32_t>();
         ha.list = idx->s_heavy.as<int32_t>() + 4;
+        ha.nsv = home ? reinterpret_cast<uint32_t *>(ha.list + nq) : nullptr;
         HG_TRY(launch_heavy(ha, st));
         f.heavy_cnt = ha.cnt;
         f.heavy_list = ha.list;
@@ -984,6 +1046,29 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
             ma.heavy_list = f.heavy_list;
             ma.heavy_slices = kHeavySlices;
             ma.main_blocks = static_cast<int32_t>(ma.qorder ? (static_cast<int64_t>(nq) + 7) / 8 * 8 : static_cast<int64_t>(nq) * ma.slices);
+        }
+        if (home) {
+            HG_REQUIRE(ma.slices == 1 && ma.qorder, HNSWGPU_EINVAL, "home-list pass without the query order");
+            HomeArgs ho;
+            memset(&ho, 0, sizeof(ho));
+            ho.items = home_desc;
+            ho.nitems = home_nit;
+            ho.qorder = qorder;
+            ho.half = idx->d_lhalf;
+            ho.hmeta = idx->d_lhmeta;
+            ho.ld = idx->ld;
+            ho.Q = d_Q;
+            ho.qld = idx->dim;
+            ho.dim = idx->dim;
+            ho.metric = idx->metric;
+            ho.dh = idx->s_dh.as<float2>();
+            ho.hstride = hstride;
+            HG_TRY(launch_home(ho, home_bound, idx->nch, st));
+            ma.dh = ho.dh;
+            ma.hstride = hstride;
+            ma.pairs = idx->s_pairs.as<Pair>();
+            ma.nprobe = nprobe;
+            ma.heavy_nsv = heavy ? reinterpret_cast<const uint32_t *>(f.heavy_list + nq) : nullptr;
         }
         HG_TRY(launch_mid(ma, idx->nch, st));
     }

@@ -236,6 +236,8 @@ struct StreamArgs {
     int64_t cap;
     int32_t dbg;         // developer ablation switches (-DHG_DIAG builds: hnswgpu_debug_set_ablation); 0 in the product
     int32_t defer;       // the half-precision pass follows: the wide epilogue appends entries without bounds (template DEFER)
+    const Pair *home_pairs;  // optional [nq][home_nprobe]: ivf_home_kernel serves every row of a query's nearest list -- the
+    int32_t home_nprobe;     // pair (query, that list) appends nothing here
     unsigned long long *stamps;  // -DHG_IVF_STAMPS diagnostic builds only
 };
 
@@ -259,7 +261,8 @@ __host__ inline size_t stream_lds_bytes(int nch, bool narrow) {
            + sizeof(QueryScal) * kTileQ + sizeof(float4) * 32 * kTileWaves  // query scalars, per-wave row terms
            + sizeof(float4) * kTileQ                                        // query terms of the test
            + (sizeof(uint32_t) + sizeof(int32_t)) * kTileQ                  // order bases, query indices
-           + sizeof(int32_t) * stream_epilogue_words(narrow) * kTileWaves;  // per-wave tile of the epilogue
+           + sizeof(int32_t) * stream_epilogue_words(narrow) * kTileWaves   // per-wave tile of the epilogue
+           + 16;                                                            // the group's home-list mask
 }
 
 // The rejection test of one (query, row) in its cheapest form.  code_bounds' lower bound exceeds the threshold tau
@@ -312,6 +315,7 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
     uint32_t *ob_s = reinterpret_cast<uint32_t *>(qt_s + kTileQ);                 // [32]
     int32_t *qi_s = reinterpret_cast<int32_t *>(ob_s + kTileQ);                  // [32]
     int32_t *narrow_all = qi_s + kTileQ;                                          // [waves][stream_epilogue_words]
+    uint32_t &home_mask_s = *reinterpret_cast<uint32_t *>(narrow_all + kTileWaves * stream_epilogue_words(NARROW));  // slots of the group whose nearest list this is (served by ivf_home_kernel)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
@@ -388,6 +392,13 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
         }
         qi_s[tid] = qi;
         ob_s[tid] = ob;
+        bool home = false;
+        if (a.home_pairs && qi >= 0) {
+            const Pair hp = a.home_pairs[static_cast<int64_t>(qi) * a.home_nprobe];
+            home = hp.row_begin == rb0 && hp.row_end > hp.row_begin;
+        }
+        const uint64_t hb = __ballot(home);
+        if (tid == 0) home_mask_s = static_cast<uint32_t>(hb);
     }
     __syncthreads();
     // query codes: natural order in global memory (16-B chunk t of query q = step t / 2, half t & 1); empty slots are zero
@@ -407,7 +418,8 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
     }
     __syncthreads();
 
-    const bool live = col < cnt;
+    const uint32_t home_mask = home_mask_s;
+    const bool live = col < cnt && !((home_mask >> col) & 1u);
     const float4 myqt = qt_s[col];
     const v2f_t P2 = {myqt.x, myqt.x}, nQ2 = {-myqt.y, -myqt.y}, K2 = {myqt.z, myqt.z};
     const int myq = live ? qi_s[col] : 0;
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
                     const bool act = qx < cend;
                     const int qxc = act ? qx : q0;
                     const int dot = tile_w[(qxc - c0) * 33 + col];
-                    const bool pass = valid && act && !stream_reject(dot, mcur, qt_s[qxc]);  // NaN (no bound) survives
+                    const bool pass = valid && act && !((home_mask >> qxc) & 1u) && !stream_reject(dot, mcur, qt_s[qxc]);  // NaN (no bound) survives
                     const uint64_t pb = __ballot(pass);
                     if (pb) {  // (most blocks of most lists append nothing)
                         const uint32_t pm = half ? static_cast<uint32_t>(pb >> 32) : static_cast<uint32_t>(pb);
@@ -648,6 +660,200 @@ __device__ __forceinline__ void half_bounds(int metric, float sum, float qn, flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// Step 1a (large batches): the HOME LIST of a query -- its nearest list, where nearly all of its int8 survivors sit (its
+// cluster: ~970 of 977 rows on the bench index) -- against half-precision rows ON THE MATRIX CORES, once per list for all
+// the queries it is home to.
+//
+// ivf_mid_kernel fetches a half row per (query, survivor): at batch 4096 four queries on average share a home list and
+// each of them reads its ~970 rows for itself -- 6 GB requested, served by the L2s at their limit (591 of 1,337 us).  Here
+// a workgroup takes (list, group of <= GQ of the queries it is home to, chunk of rows): the queries' rows are split into
+// two fp16 planes (hi + 2^-12 lo: a 22-bit significand, the split's own residual measured) and staged in LDS as B operands,
+// the list rows stream from the row-major fp16 copy straight into A operands (lane = (row, 16-byte piece): 64 contiguous
+// bytes per row and instruction), v_mfma_f32_16x16x32_f16 does the reduction -- no cross-lane sum at all -- and the
+// epilogue writes the pair (lb, ub) of EVERY row of the list for every query of the group into a dense array
+// dh[query][row in list].  The bounds pass then appends nothing for a (query, home list) pair and the per-query pass reads
+// 8 bytes per home row instead of 1.5 KB.
+//
+//   q = s_q (hi + 2^-12 lo) + e_q,  v = s h + e_v:   |q.v - s_q s (hi + 2^-12 lo).h| <= (|q| + |e_q|) |e_v| + |e_q| |v|
+// and the matrix cores' f32 accumulation of the exact fp16 x fp16 products is within 1e-4 |q||v| of the exact sum (768 +
+// 48 roundings of 2^-23 -- twice the unit roundoff, whatever the order or the rounding mode of the adder tree -- times
+// sum |a_i b_i| <= |a||b|; measured: 3e-7).  So with the row's stored E (1.01 res / |v| + 4e-5 for the cosine):
+//   cosine   c = 1 - s_q s S / (|q||v|)     lb/ub = c -/+ (E + 1.01 |e_q| / |q| + 1.1e-4)
+//   dot      d = -s_q s S                   lb/ub = d -/+ (|q| E + 1.01 |e_q| |v| + 1.1e-4 |q||v|)
+// (Euclidean handles keep the per-query pass for every survivor.)  The distances, and with them every result bit, still
+// come from the f32 rows in the finish kernel.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef float v4f32_t __attribute__((ext_vector_type(4)));
+
+// queries per group: what keeps both planes of the group within 48 KB of LDS
+__host__ __device__ constexpr int home_group(int nch) { return nch <= 3 ? 16 : (nch <= 6 ? 8 : 4); }
+constexpr float kHomeAccum = 1.1e-4f;  // accumulation allowance, relative to |q||v|
+
+struct HomeDesc {  // rows [rb0 + r0_off, rb0 + r1_off) of the list that starts at rb0, queries order[q0 .. q0 + cnt)
+    int64_t rb0;
+    int32_t r0_off, r1_off;
+    int32_t q0, cnt;
+    int32_t list, pad;
+};
+
+struct HomeArgs {
+    const HomeDesc *items;   // written by ivf_worklist_kernel's second workgroup
+    const int32_t *nitems;
+    const int32_t *qorder;   // the queries in the order of their nearest list
+    const uint2 *half;       // [rows][ld / 4] four halves each (row-major)
+    const float4 *hmeta;     // (scale, E, 0, 1 / |v|)
+    int64_t ld;              // elements per row, a multiple of 128
+    const float *Q;
+    int64_t qld;
+    int32_t dim, metric;
+    float2 *dh;              // [nq][hstride] (lb, ub) of row r of the query's home list
+    int64_t hstride;
+};
+
+// bounds from the matrix cores' sum S (in units of s_q s): sq = s_q, eq = 1.01 |e_q|, qn = |q|
+__device__ __forceinline__ void home_bounds(int metric, float S, float sq, float eq, float qn, float4 mt, float &lb, float &ub) {
+    const float dh = (S * sq) * mt.x;
+    if (metric == METRIC_DOT) {
+        const float nv = 1.0f / mt.w;
+        const float W = __builtin_fmaf(qn, mt.y, __builtin_fmaf(eq, nv, kHomeAccum * (qn * nv))) * (1.0f + 1.0e-6f);
+        lb = -dh - W;
+        ub = -dh + W;
+        return;
+    }
+    const float c = 1.0f - dh * ((1.0f / qn) * mt.w);  // |q| or |v| zero: NaN, no bound
+    const float W = (mt.y + eq / qn + kHomeAccum) * (1.0f + 1.0e-6f);
+    lb = c - W;
+    ub = c + W;
+}
+
+template <int NCH, int PF>
+__global__ __launch_bounds__(kWG) void ivf_home_kernel(HomeArgs a) {
+    constexpr int GQ = home_group(NCH);
+    constexpr int SMAX = NCH * 8;  // steps of 32 elements
+    __shared__ __align__(16) h8_t qh_s[SMAX * 4 * GQ];  // [step][piece][query]: the B operand of (step, lane) is one 16-byte read
+    __shared__ __align__(16) h8_t ql_s[SMAX * 4 * GQ];
+    __shared__ float sq_s[16], eq_s[16], qn_s[16];
+    __shared__ int32_t qi_s[16];
+    const int item = blockIdx.x;
+    if (item >= *a.nitems) return;
+    const HomeDesc d = a.items[item];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const int S = static_cast<int>(a.ld >> 5);
+    const int m = lane & 15, kg = lane >> 4;
+    const int nrows = d.r1_off - d.r0_off;
+    const int nblk = (nrows + 15) >> 4;
+    if (nrows <= 0 || d.cnt <= 0) return;
+    const h8_t *hbase = reinterpret_cast<const h8_t *>(a.half);
+    const int64_t ld8 = a.ld >> 3;
+
+    // ---- the load stream of this wave: blocks wave, wave + 4, ... of 16 rows, S steps each, PF loads in flight
+    int ls = 0, lblk = wave;
+    auto rowptr = [&](int blk) {
+        int r = d.r0_off + blk * 16 + m;
+        r = r < d.r1_off ? r : d.r1_off - 1;  // rows past the chunk: the last row again (computed, not used)
+        return hbase + (d.rb0 + r) * ld8 + kg;
+    };
+    const h8_t *lp = rowptr(lblk < nblk ? lblk : 0);
+    h8_t av[PF];
+    auto issue = [&](h8_t &dst) {
+        if (lblk < nblk) dst = lp[ls * 4];
+        if (++ls == S) {
+            ls = 0;
+            lblk += kNWave;
+            if (lblk < nblk) lp = rowptr(lblk);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < PF; u++) issue(av[u]);  // on their way while the group is set up
+
+    // ---- the group's queries: two fp16 planes each, in B-operand order
+    for (int n = wave; n < GQ; n += kNWave) {
+        if (n >= d.cnt) {
+            if (lane == 0) qi_s[n] = -1;
+            continue;
+        }
+        const int qi = a.qorder[d.q0 + n];
+        float4 q[NCH];
+        load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+        bool bad;
+        const float mx = wave_absmax<NCH>(q, bad);
+        const float qn = query_norm<NCH>(q);
+        // s_q = 2^(e - 14): the scaled query fills fp16's range from the top (as the rows do)
+        int field = static_cast<int>((__float_as_uint(mx) >> 23) & 0xffu) - 14;
+        field = field < 1 ? 1 : (field > 253 ? 253 : field);
+        const float s = __uint_as_float(static_cast<uint32_t>(field) << 23), is = __uint_as_float(static_cast<uint32_t>(254 - field) << 23);
+        float res = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const float e[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+            _Float16 hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float x = e[j] * is;
+                hi[j] = static_cast<_Float16>(x);
+                const float r1 = x - static_cast<float>(hi[j]);
+                lo[j] = static_cast<_Float16>(r1 * 4096.0f);
+                const float back = (static_cast<float>(hi[j]) + static_cast<float>(lo[j]) * (1.0f / 4096.0f)) * s;
+                const float dd = e[j] - back;
+                res = __builtin_fmaf(dd, dd, res);
+            }
+            // element k = 256 c + 4 lane + j: step 8 c + (lane >> 3), piece (lane >> 1) & 3, halves 4 (lane & 1) + j
+            const int step = 8 * c + (lane >> 3);
+            if (step < S) {
+                const int at = ((step * 4 + ((lane >> 1) & 3)) * GQ + n) * 8 + 4 * (lane & 1);
+                typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<h4v *>(reinterpret_cast<_Float16 *>(qh_s) + at) = h4v{hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<h4v *>(reinterpret_cast<_Float16 *>(ql_s) + at) = h4v{lo[0], lo[1], lo[2], lo[3]};
+            }
+        }
+        res = __builtin_sqrtf(wave_sum(res));
+        if (lane == 0) {
+            const bool nob = bad || !(mx > 0.0f);
+            qi_s[n] = qi;
+            sq_s[n] = s;
+            eq_s[n] = nob ? __uint_as_float(0x7fc00000u) : 1.01f * res;  // NaN: no bound for this query
+            qn_s[n] = qn;
+        }
+    }
+    __syncthreads();
+
+    const int myq = m < GQ ? qi_s[m] : -1;  // C/D: lane & 15 is the column = the query
+    const float mysq = myq >= 0 ? sq_s[m] : 0.0f, myeq = myq >= 0 ? eq_s[m] : 0.0f, myqn = myq >= 0 ? qn_s[m] : 0.0f;
+    float2 *out = a.dh + static_cast<int64_t>(myq >= 0 ? myq : 0) * a.hstride;
+    const h8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int blk = wave; blk < nblk; blk += kNWave) {
+        const int rel = d.r0_off + blk * 16 + 4 * kg;  // this lane's four result rows, relative to the list
+        float4 mt[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = rel + j < d.r1_off ? rel + j : d.r1_off - 1;
+            mt[j] = a.hmeta[d.rb0 + r];
+        }
+        v4f32_t acch = {0.0f, 0.0f, 0.0f, 0.0f}, accl = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int s0 = 0; s0 < S; s0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const h8_t cur = av[u];
+                issue(av[u]);
+                const int at = ((s0 + u) * 4 + kg) * GQ + (m < GQ ? m : 0);
+                const h8_t bh = m < GQ ? qh_s[at] : zero8, bl = m < GQ ? ql_s[at] : zero8;
+                acch = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur, bh, acch, 0, 0, 0);
+                accl = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur, bl, accl, 0, 0, 0);
+            }
+        }
+        if (myq >= 0) {
+            float lb[4], ub[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) home_bounds(a.metric, __builtin_fmaf(accl[j], 1.0f / 4096.0f, acch[j]), mysq, myeq, myqn, mt[j], lb[j], ub[j]);
+            float4 *o = reinterpret_cast<float4 *>(out + rel);  // rel is a multiple of 4: 32-byte aligned
+            o[0] = make_float4(lb[0], ub[0], lb[1], ub[1]);
+            o[1] = make_float4(lb[2], ub[2], lb[3], ub[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Step 2: survivors -> f32 distances -> the k nearest -> results.
 // ------------------------------------------------------------------------------------------------
 // ---- queries that are too much for one workgroup -------------------------------------------------------------------
@@ -667,6 +873,7 @@ struct HeavyArgs {
     uint32_t times_mean;  // ... and at least this many times the batch's mean (4; tests: 0)
     uint32_t *cnt;     // [1]
     int32_t *list;     // [nq]
+    uint32_t *nsv;     // optional [nq]: the listed queries' survivor counts as they stood (the half-precision pass may append to a heavy list while its slices run)
 };
 static __global__ __launch_bounds__(1024) void ivf_heavy_kernel(HeavyArgs a) {
     __shared__ uint32_t n_s;
@@ -691,7 +898,9 @@ static __global__ __launch_bounds__(1024) void ivf_heavy_kernel(HeavyArgs a) {
     for (int i = threadIdx.x; i < a.nq; i += 1024) {
         const uint32_t raw = a.surv_cnt[i];
         if (raw > thr) {
-            a.list[atomicAdd(&n_s, 1u)] = i;
+            const uint32_t at = atomicAdd(&n_s, 1u);
+            a.list[at] = i;
+            if (a.nsv) a.nsv[at] = raw;
             a.surv_cnt[i] = raw | kHeavyBit;
         }
     }
@@ -1058,6 +1267,13 @@ struct MidArgs {
     const uint32_t *heavy_cnt;  // optional (ivf_heavy_kernel), as in FinishArgs
     const int32_t *heavy_list;
     int32_t heavy_slices, main_blocks;
+    // the home lists went through ivf_home_kernel: (lb, ub) of every row of a query's nearest list in dh[query][row]; the
+    // bounds pass appended nothing for them, this kernel's slice 0 brings them in
+    const float2 *dh;
+    int64_t hstride;
+    const Pair *pairs;          // [nq][nprobe]: pair 0 = the nearest list
+    int32_t nprobe;
+    const uint32_t *heavy_nsv;  // with dh: the heavy queries' counts before anything was appended
 };
 
 // NW waves per workgroup: 4, or 8 for the one-workgroup-per-query launches of batches that do not fill the chip otherwise
@@ -1069,16 +1285,30 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     if (nsv > a.cap) return;  // the list overflowed: the finish kernel walks the candidate stream instead
+    // the query's nearest list, if ivf_home_kernel has served it: its rows are not among the nsv entries (slice 0 brings them in)
+    int hlen = 0;
+    uint32_t hob = 0, hrb = 0;
+    const float2 *hd = nullptr;
+    if (a.dh && sl == 0) {
+        const Pair hp = a.pairs[static_cast<int64_t>(qi) * a.nprobe];
+        hlen = static_cast<int>(hp.row_end - hp.row_begin);
+        hob = hp.ord_base;
+        hrb = static_cast<uint32_t>(hp.row_begin);
+        hd = a.dh + static_cast<int64_t>(qi) * a.hstride;
+    }
     constexpr int gran = kT;
     int64_t per = (static_cast<int64_t>(nsv) + slices - 1) / slices;
     per = (per + gran - 1) / gran * gran;
     const int64_t i0 = static_cast<int64_t>(sl) * per;
     const int64_t i1 = i0 + per < nsv ? i0 + per : nsv;
-    if (i0 >= i1) return;
+    if (i0 >= i1 && hlen <= 0) return;
     const int nvec = static_cast<int>(a.ld / 4);
     float4 q[NCH];
-    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
-    const float qn = L2 ? 0.0f : query_norm<NCH>(q);
+    float qn = 0.0f;
+    if (i0 < i1) {
+        load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+        qn = L2 ? 0.0f : query_norm<NCH>(q);
+    }
     uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
     float *lb_s = reinterpret_cast<float *>(smem);  // [compact] the entries' new lower bounds
     const bool compact = may_compact && a.compact > 0 && nsv <= static_cast<uint32_t>(a.compact) && a.k <= kT;
@@ -1151,7 +1381,26 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
             }
         }
     }
-    if (!compact) return;
+    if (!compact) {
+        // the home rows join the list as entries of their own (a list too long to compact here, or a heavy query's slice 0:
+        // the other slices work on [0, nsv), which this does not touch); a list they do not fit sends the query through
+        // the finish kernel's walk of the candidate stream
+        if (hlen > 0) {
+            const bool fits = static_cast<int64_t>(nsv) + hlen <= a.cap;
+            if (fits)
+                for (int r = threadIdx.x; r < hlen; r += kT) {
+                    const float2 b = hd[r];
+                    sv[nsv + r] = make_uint4(hob + static_cast<uint32_t>(r), hrb + static_cast<uint32_t>(r), __float_as_uint(b.x), __float_as_uint(b.y));
+                }
+            if (threadIdx.x == 0)
+                a.surv_cnt[qi] = (fits ? nsv + static_cast<uint32_t>(hlen) : static_cast<uint32_t>(a.cap) + 1u) | (may_compact ? 0u : kHeavyBit);
+        }
+        return;
+    }
+    for (int r = threadIdx.x; r < hlen; r += kT) {  // the home rows' upper bounds count towards the threshold as well
+        const float u = hd[r].y;
+        ub_min = u < ub_min ? u : ub_min;
+    }
     // ---- the query's whole list went through this workgroup: the threshold the finish kernel would derive from the upper
     // bounds (the k-th smallest of the 256 threads' minima: k candidates at most that far) is applied here, and the list
     // shrinks to the entries it does not exclude -- little more than k -- before the finish kernel reads it
@@ -1198,8 +1447,32 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
         nout += tot;
         __syncthreads();
     }
+    for (int base = 0; base < hlen; base += kT) {  // ... and the rows of the home list the threshold does not exclude
+        const int r = base + static_cast<int>(threadIdx.x);
+        float lbr = 0.0f;
+        bool keep = r < hlen;
+        if (keep) {
+            lbr = hd[r].x;
+            keep = !(lbr > T);  // NaN (no bound) stays
+        }
+        const uint64_t m = __ballot(keep);
+        if (lane == 0) wcnt_s[wave] = static_cast<uint32_t>(__popcll(m));
+        __syncthreads();
+        uint32_t off = nout, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t c = wcnt_s[w];
+            off += w < wave ? c : 0u;
+            tot += c;
+        }
+        const uint32_t slot = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && slot < a.cap)
+            sv[slot] = make_uint4(hob + static_cast<uint32_t>(r), hrb + static_cast<uint32_t>(r), __float_as_uint(lbr), 0x7f800000u);
+        nout += tot;
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        a.surv_cnt[qi] = nout;
+        a.surv_cnt[qi] = nout <= a.cap ? nout : static_cast<uint32_t>(a.cap) + 1u;  // (more than fit: the walk of the candidate stream)
         if (T < __builtin_inff()) (void)__hip_atomic_fetch_min(a.tau + qi, tau_encode(T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // (Tried: finishing the query right here -- finish_wg on the ~15 entries left, no second launch for it.  The finish
@@ -1215,7 +1488,8 @@ __global__ __launch_bounds__(NW * kWave) void ivf_mid_kernel(MidArgs a) {
         const int n = static_cast<int>(*a.heavy_cnt);
         for (int t = slot; t < n; t += kHeavySlots) {
             const int hq = a.heavy_list[t];
-            mid_query_wg<NCH, RB, L2, NW>(a, hq, hsl, a.heavy_slices, a.surv_cnt[hq] & ~kHeavyBit, false, smem);
+            const uint32_t hn = a.heavy_nsv ? a.heavy_nsv[t] : (a.surv_cnt[hq] & ~kHeavyBit);  // (with home lists slice 0 appends: the count as it stood)
+            mid_query_wg<NCH, RB, L2, NW>(a, hq, hsl, a.heavy_slices, hn, false, smem);
         }
         return;
     }

@@ -168,6 +168,15 @@ class Index:
         check(lib().hnswgpu_ivf_half_bounds(self._h, _p(q), _p(rows), len(rows), _p(lb), _p(ub)))
         return lb, ub
 
+    def ivf_home_bounds(self, Q, row_begin, row_end):
+        """(lower, upper) bounds [nq][row_end - row_begin] of d(query, list row) from the matrix-core half-precision pass of
+        large batches (ivf_home_kernel); rows are positions in list order.  NaN = no bound."""
+        Q = _f32(Q).reshape(-1, self.dim)
+        m = int(row_end) - int(row_begin)
+        lb, ub = np.empty((len(Q), m), np.float32), np.empty((len(Q), m), np.float32)
+        check(lib().hnswgpu_ivf_home_bounds(self._h, _p(Q), len(Q), int(row_begin), int(row_end), _p(lb), _p(ub)))
+        return lb, ub
+
     def norms(self):
         out = np.empty(self.n, np.float32)
         check(lib().hnswgpu_norms(self._h, _p(out)))

@@ -299,6 +299,14 @@ int hnswgpu_distance_bounds(hnswgpu_index *idx, const float *q, const int32_t *i
  * query, by the kernel the searches run: out_lb[i] <= distance <= out_ub[i], NaN where a row or the query has no bound. */
 int hnswgpu_ivf_half_bounds(hnswgpu_index *idx, const float *q, const int32_t *list_rows, int32_t m, float *out_lb,
                             float *out_ub);
+/* Large batches (from 1024 queries and half a query per list; cosine / dot, rows of whole 128-element steps) put the
+ * half-precision rows of a query's NEAREST list -- where nearly all of its int8 survivors sit -- through the matrix
+ * cores, once per list for all the queries it is nearest to (v_mfma_f32_16x16x32_f16, the query split into two fp16
+ * planes), instead of fetching a half row per (query, survivor).  This entry reports those bounds for the list rows
+ * [row_begin, row_end) (positions in list order) against `nq` queries, by the kernel the searches run:
+ * out_lb[q * len + r] <= distance(q, row_begin + r) <= out_ub[q * len + r], NaN where a row or the query has no bound. */
+int hnswgpu_ivf_home_bounds(hnswgpu_index *idx, const float *Q, int32_t nq, int64_t row_begin, int64_t row_end,
+                            float *out_lb, float *out_ub);
 int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode);
 /* While profiling is on the traversal counts the neighbours it evaluated and the f32 rows it had to fetch for them
  * (everything with the test off): the bytes a search really moved = neighbours * (int8 row + 16 B) + f32_rows * 4 * dim. */
@@ -359,7 +367,8 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_ZEROCOPY 41 /* 0 = small synchronous HNSW calls stage through copies instead of mapped pinned memory (A/B) */
 #define HNSWGPU_TUNE_BUILD_TIMING 42 /* 1 = hnswgpu_hnsw_build prints where its time went to stderr */
 #define HNSWGPU_TUNE_BUILD_BATCH 43 /* largest insertion batch of hnswgpu_hnsw_build (default 16384; a batch never exceeds 1/8 of the graph it is searched against) */
-#define HNSWGPU_TUNE_COUNT 44
+#define HNSWGPU_TUNE_STREAM_HOME 44 /* the home-list pass of large IVF batches (every list once through the matrix cores in half precision for all the queries it is nearest to): -1 from 1024 queries and half a query per list, 0 never, 1 whenever the batch is served in the order of its nearest lists */
+#define HNSWGPU_TUNE_COUNT 45
 int hnswgpu_set_tuning(int32_t key, int64_t value);
 int hnswgpu_get_tuning(int32_t key, int64_t *value, int32_t *is_set);
 

@@ -913,6 +913,122 @@ def test_half_precision_bounds_hold_and_are_tight(eng, metric, dim):
                 assert ((d[blk] - lb[blk]) / scale).max() < 1e-3 and ((ub[blk] - d[blk]) / scale).max() < 1e-3
 
 
+@pytest.mark.parametrize("dim", [128, 384, 768, 1536, 3072])
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_home_list_bounds_hold_and_are_tight(eng, metric, dim):
+    """Large batches put the half-precision rows of a query's NEAREST list through the matrix cores once for all the
+    queries it is nearest to (stream_kernels.hpp step 1a, ivf_home_kernel: v_mfma_f32_16x16x32_f16, the query in two fp16
+    planes) and the bounds of every row of that list come from there.  Same obligations as the per-survivor pass: lb <= d
+    <= ub against the exact path for rows of very different scale, a zero row, a huge component, tiny and huge rows,
+    duplicates of the query, a zero query; non-finite rows and queries abstain; and tight -- within 1.5e-3 of the distance
+    scale.  More queries than one group holds (17 / 9 / 5 by row length), a row count that ends inside a 16-row block."""
+    rs = np.random.RandomState(dim + 7)
+    n = 603
+    base = rs.randn(n, dim).astype(np.float32) * np.exp(rs.uniform(-6, 6, (n, 1))).astype(np.float32)
+    base[:200] = rs.randn(200, dim).astype(np.float32)
+    base[200] = 0.0
+    base[201, 3] = 1.0e6
+    base[202] = base[5]
+    base[203, 1] = np.inf
+    base[204, 2] = np.nan
+    base[205] = (rs.randn(dim) * 1e-9).astype(np.float32)
+    base[206] = (rs.randn(dim) * 1e9).astype(np.float32)
+    lids = np.concatenate([np.arange(l, n, 3) for l in range(3)]).astype(np.int32)
+    off = np.cumsum([0] + [len(np.arange(l, n, 3)) for l in range(3)]).astype(np.int64)
+    pos = np.empty(n, np.int32)
+    pos[lids] = np.arange(n, dtype=np.int32)
+    queries = [rs.randn(dim).astype(np.float32), base[5].copy(), (base[7] * 1000).astype(np.float32),
+               np.zeros(dim, np.float32), base[201].copy(), base[205].copy(), base[206].copy()]
+    queries += [rs.randn(dim).astype(np.float32) * np.float32(np.exp(rs.uniform(-8, 8))) for _ in range(12)]
+    bad_q = rs.randn(dim).astype(np.float32)
+    bad_q[1] = np.inf
+    queries.append(bad_q)
+    Q = np.stack(queries)
+    with eng.Index(base, metric) as idx:
+        idx.set_rejection_test(2)
+        idx.set_ivf(base[:3].copy(), off, lids)
+        for (r0, r1) in ((0, n), (int(off[1]), int(off[2])), (5, 5 + 37)):
+            LB, UB = idx.ivf_home_bounds(Q, r0, r1)
+            for qi, q in enumerate(queries):
+                lb, ub = LB[qi], UB[qi]
+                if qi == len(queries) - 1:                       # a non-finite query has no bounds at all
+                    assert np.isnan(lb).all() and not (ub < np.inf).any()
+                    continue
+                d = idx.batch_distances(q, lids)[r0:r1]          # the exact path, list order
+                ok = ~np.isnan(lb) & ~np.isnan(d)
+                assert np.all(lb[ok] <= d[ok]), "metric %s dim %d query %d: lower bound above the distance at list rows %s" % (
+                    metric, dim, qi, r0 + np.nonzero(ok & ~(lb <= d))[0][:8])
+                oku = ~np.isnan(ub) & ~np.isnan(d)
+                assert np.all(d[oku] <= ub[oku]), "metric %s dim %d query %d: upper bound below the distance at list rows %s" % (
+                    metric, dim, qi, r0 + np.nonzero(oku & ~(d <= ub))[0][:8])
+                for bad in (203, 204):
+                    if r0 <= pos[bad] < r1:
+                        assert np.isnan(lb[pos[bad] - r0]) and not (ub[pos[bad] - r0] < np.inf)
+                if qi == 0 and r0 == 0:
+                    blk = pos[:200]
+                    qn, vn = np.linalg.norm(q), np.linalg.norm(base[:200], axis=1)
+                    scale = {"cosine": 1.0, "dot": qn * vn}[metric]
+                    assert ok[blk].all()
+                    assert ((d[blk] - lb[blk]) / scale).max() < 1.5e-3 and ((ub[blk] - d[blk]) / scale).max() < 1.5e-3
+                    # ... and the matrix cores' sum itself is far inside its allowance: the bounds' centre against f64
+                    c64 = (base[:200].astype(np.float64) @ q.astype(np.float64)) / (qn * vn.astype(np.float64))
+                    mid = 0.5 * (lb[blk].astype(np.float64) + ub[blk].astype(np.float64)) / scale
+                    ref = (1.0 - c64) if metric == "cosine" else -c64
+                    assert np.abs(mid - ref).max() < 3e-4, np.abs(mid - ref).max()
+
+
+@pytest.mark.parametrize("metric,dim", [("cosine", 128), ("dot", 128), ("cosine", 384), ("cosine", 768)])
+def test_ivf_home_list_pass(eng, oracle, metric, dim, tune):
+    """Large IVF batches with the home-list pass (production: from 1024 queries and half a query per list), bit-equal to
+    the oracle: forced on for small batches through the tuning table (queries ordered by nearest list from one query on),
+    lists that are home to more queries than one group holds, lists home to none, k of one / beyond a wave, exact ties,
+    survivor lists that overflow next to it, heavy queries (whose slice 0 appends the home rows), and the counters show
+    that f32 rows were fetched for little more than k candidates per query."""
+    O = oracle
+    code = {"cosine": O.COSINE, "dot": O.DOT}[metric]
+    base = _data(O, 9000, dim, "clustered", num_clusters=40, noise_level=0.25, seed=73)
+    base[4000:4030] = base[11]                               # exact ties
+    Q = np.concatenate([_data(O, 299, dim, "clustered", num_clusters=40, noise_level=0.25, seed=74), base[11:12]]).astype(np.float32)
+    with eng.Index(base, metric) as idx:
+        idx.ivf_build(50, 4, 42)
+        cen, off, lids = idx.get_ivf()
+        idx.set_rejection_test(2)
+        idx.set_profiling(True)
+        tune.set("TILE_PAIRS", str(1 << 40))   # the GEMV-order paths at every batch size (the production rule of such a handle)
+        tune.set("IVF_CODES", "1")
+        tune.set("STREAM_MID", "1")
+        tune.set("FINISH_ORDER", "1")
+        tune.set("STREAM_HOME", "1")
+
+        def check(nq, k, nprobe, what, expect_few=True):
+            idx.rejection_stats(reset=True)
+            ids, d = idx.ivf_search(Q[-nq:], k, nprobe)
+            surv, cand = idx.rejection_stats(reset=True)
+            oi, od, _ = O.ivf_search(base, cen, off, lids, Q[-nq:], k, nprobe, metric=code, mode=O.MODE_DEV)
+            assert_exact(ids, d, oi, od, "%s %s nq=%d k=%d nprobe=%d" % (what, metric, nq, k, nprobe))
+            if expect_few:
+                assert cand > 0 and surv <= nq * max(k + 40, 128), (what, surv, cand, nq, k)
+
+        for nq, k, nprobe in [(1, 10, 8), (3, 1, 12), (41, 10, 5), (41, 70, 12), (300, 10, 12), (300, 100, 50), (170, 10, 1)]:
+            check(nq, k, nprobe, "home forced")
+        tune.set("STREAM_HOME", "0")
+        check(300, 10, 12, "home off")
+        tune.set("STREAM_HOME", "1")
+        tune.set("MID_COMPACT", "0")       # the home rows join the list as entries, the finish kernel derives the threshold
+        check(300, 10, 12, "no compaction")
+        tune.unset("MID_COMPACT")
+        tune.set("STREAM_CAP", "300")      # some lists overflow (and home rows that do not fit send a query through the fallback)
+        check(300, 10, 12, "mixed fallback", expect_few=False)
+        tune.set("STREAM_HEAVY_MEAN", "0")
+        for thr in ("1", "8"):
+            tune.set("STREAM_HEAVY_MIN", thr)
+            check(41, 33, 5, "heavy + fallback, threshold " + thr, expect_few=False)
+        tune.unset("STREAM_CAP")
+        tune.set("STREAM_HEAVY_MIN", "1")
+        check(300, 10, 12, "every query with foreign survivors heavy", expect_few=False)
+        idx.set_profiling(False)
+
+
 @pytest.mark.parametrize("dim", [128, 768, 3072])
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
 def test_bounds_randomised_soak(eng, metric, dim):
@@ -966,6 +1082,14 @@ def test_bounds_randomised_soak(eng, metric, dim):
                 assert np.all(hl[ok] <= dl[ok]), "fp16 lb > d: %s dim %d rep %d query %d list rows %s" % (metric, dim, rep, qi, np.nonzero(ok & ~(hl <= dl))[0][:6])
                 oku = ~np.isnan(hu) & ~np.isnan(dl)
                 assert np.all(dl[oku] <= hu[oku]), "fp16 ub < d: %s dim %d rep %d query %d list rows %s" % (metric, dim, rep, qi, np.nonzero(oku & ~(dl <= hu))[0][:6])
+            if metric != "l2":                                                            # fp16 on the matrix cores (the home-list pass), list order
+                Ml, Mu = idx.ivf_home_bounds(np.stack(qs), 0, n)
+                for qi, q in enumerate(qs):
+                    dl = idx.batch_distances(q, ids)[lids]
+                    ok = ~np.isnan(Ml[qi]) & ~np.isnan(dl)
+                    assert np.all(Ml[qi][ok] <= dl[ok]), "mfma fp16 lb > d: %s dim %d rep %d query %d list rows %s" % (metric, dim, rep, qi, np.nonzero(ok & ~(Ml[qi] <= dl))[0][:6])
+                    oku = ~np.isnan(Mu[qi]) & ~np.isnan(dl)
+                    assert np.all(dl[oku] <= Mu[qi][oku]), "mfma fp16 ub < d: %s dim %d rep %d query %d list rows %s" % (metric, dim, rep, qi, np.nonzero(oku & ~(dl <= Mu[qi]))[0][:6])
 
 
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
