@@ -140,14 +140,26 @@ int launch_heavy(const HeavyArgs &a, hipStream_t st) {
 int launch_home(const HomeArgs &a, int64_t blocks, int nch, hipStream_t st) {
     if (blocks <= 0) return 0;
     HG_REQUIRE(a.ld % 128 == 0 && a.metric != METRIC_L2, HNSWGPU_EINVAL, "home-list pass: cosine / dot rows of whole 128-element steps only");
-    const bool pf8 = (a.ld / 32) % 8 == 0;  // eight operand loads in flight per wave where the steps of a row divide by eight
-#define CALL(N, R, L)                                                                                              \
-    do {                                                                                                           \
-        if (pf8) hipLaunchKernelGGL((ivf_home_kernel<N, 8>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), 0, st, a); \
-        else hipLaunchKernelGGL((ivf_home_kernel<N, 4>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), 0, st, a);     \
+    // operand loads in flight per wave: the kernel lives on them (one query group per 16-row block is 24 KB of rows and
+    // ~1.5 us of a CU's share of HBM); a depth has to divide the steps of a row
+    const int S = static_cast<int>(a.ld / 32), want = static_cast<int>(tune(HNSWGPU_TUNE_HOME_DEPTH, 12));
+    int pf = 4;
+    for (int c : {8, 12, 16, 24})
+        if (c <= want && S % c == 0) pf = c;
+#define CALLP(N, P) hipLaunchKernelGGL((ivf_home_kernel<N, P>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), 0, st, a)
+#define CALL(N, R, L)                  \
+    do {                               \
+        switch (pf) {                  \
+            case 24: CALLP(N, 24); break; \
+            case 16: CALLP(N, 16); break; \
+            case 12: CALLP(N, 12); break; \
+            case 8: CALLP(N, 8); break;   \
+            default: CALLP(N, 4); break;  \
+        }                              \
     } while (0)
     HG_DISPATCH(nch, false, CALL);
 #undef CALL
+#undef CALLP
     HG_HIP(hipGetLastError());
     return 0;
 }
@@ -463,6 +475,7 @@ struct RouteArgs {
     uint32_t *bk_cnt;        // [nlist] members filed per list (zeroed before the launch), or null
     uint2 *bk_mem;           // [nlist][bk_cap] (query, offset of the list in the query's candidate stream)
     int32_t bk_cap;
+    int32_t home;            // the home-list pass follows: no seed for a query whose nearest list holds k rows (its threshold comes from there)
     unsigned long long *dbg;  // -DHG_IVF_STAMPS diagnostic builds only
 };
 
@@ -569,6 +582,14 @@ __device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsign
     if (!a.tau) return;
     // survivor stream: the first threshold, from the head of the query's candidate stream
     __syncthreads();
+    if (a.home && head_s[0].row_end - head_s[0].row_begin >= a.k) {
+        // large batches: every row of the nearest list goes through the matrix cores in half precision next, and the k-th
+        // smallest upper bound found there -- over the whole list, not a sample of it -- is the query's threshold before the
+        // bounds pass reads it (ivf_home_kernel, then ivf_mid_kernel): 64 f32 rows per query are not fetched here (0.8 GB at
+        // batch 4096)
+        if (threadIdx.x == 0) a.tau[qi] = 0xffffffffu;
+        return;
+    }
     const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
     // the head's table entries are in LDS (no dependent global reads) when they cover the rows the seed looks at
     const bool head_ok = a.nprobe <= kHead || tail_cover >= static_cast<uint32_t>(kSeedMax);
@@ -720,6 +741,7 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
         a.bk_cnt = rs->bk_cnt;
         a.bk_mem = rs->bk_mem;
         a.bk_cap = rs->bk_cap;
+        a.home = rs->home;
     }
     a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions
     a.rows = idx->d_lrows;
@@ -2015,12 +2037,13 @@ int hnswgpu_ivf_home_bounds(hnswgpu_index *idx, const float *Q, int32_t nq, int6
     const int64_t len = row_end - row_begin, hstride = (len + 15) / 16 * 16;
     const int gq = home_group(idx->nch);
     std::vector<HomeDesc> items;
-    for (int64_t r0 = 0; r0 < len; r0 += 256)
+    const int64_t chunk = std::max<int64_t>(64, tune(HNSWGPU_TUNE_HOME_CHUNK, 256) / 64 * 64);
+    for (int64_t r0 = 0; r0 < len; r0 += chunk)
         for (int32_t q0 = 0; q0 < nq; q0 += gq) {
             HomeDesc d;
             d.rb0 = row_begin;
             d.r0_off = static_cast<int32_t>(r0);
-            d.r1_off = static_cast<int32_t>(std::min<int64_t>(len, r0 + 256));
+            d.r1_off = static_cast<int32_t>(std::min<int64_t>(len, r0 + chunk));
             d.q0 = q0;
             d.cnt = std::min<int32_t>(gq, nq - q0);
             d.list = 0;

@@ -814,6 +814,35 @@ static int stream_scratch(hnswgpu_index *idx, int32_t nq, StreamScratch &s) {
     return 0;
 }
 
+// The half-precision pass of a batch (stream_kernels.hpp, step 1b).  Once the exact pass would be the largest kernel (its
+// rows are 3 KB each and every query fetches its own) the survivors first meet their half-precision rows.  The survivors
+// are a few per cent of the candidates: from ~1.5 M candidates per batch (48 queries x 32 lists x 977 rows; 5 queries at 10 M
+// rows) the pass saves more than its launch costs -- measured at 1M x 768: batch 32 0.183 ms without vs 0.195 with, 64:
+// 0.250 vs 0.243, 128: 0.298 vs 0.277.  HNSWGPU_TUNE_STREAM_MID=<queries> overrides (tests: 1 = always; 0 = never).
+static bool ivf_mid_mode(const hnswgpu_index *idx, int32_t nq, int32_t nprobe) {
+    const int64_t mid_env = tune(HNSWGPU_TUNE_STREAM_MID, -1);
+    const int64_t cand = static_cast<int64_t>(nq) * nprobe * ivf_mean_len(idx);
+    return idx->d_lhalf != nullptr && !idx->ivf_calibrating && (mid_env >= 0 ? (mid_env > 0 && nq >= mid_env) : cand >= 1500000);
+}
+// are the queries of a batch served in the order of their nearest list (grouped bounds pass, large batches)?
+static bool ivf_ordered_mode(const hnswgpu_index *idx, int32_t nq, bool grouped) {
+    const int64_t order_min = tune(HNSWGPU_TUNE_FINISH_ORDER, 512);  // 0 = never (A/B)
+    return grouped && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists;
+}
+// The home-list pass (stream_kernels.hpp, step 1a): batches in which the lists are home to about a query each or more --
+// every home list once through the matrix cores in half precision for all of its queries (ivf_home_kernel) instead of a
+// half row per (query, survivor), and the queries' thresholds from there instead of from 64 sampled f32 rows.  cosine /
+// dot, rows of whole 128-element steps; HNSWGPU_TUNE_STREAM_HOME: -1 this rule, 0 never, 1 whenever the queries are
+// ordered.  Decided BEFORE the routing (whose tail then skips the threshold seed) and again by the scan: one rule.
+static bool ivf_home_mode(const hnswgpu_index *idx, int32_t nq, int32_t nprobe, bool grouped) {
+    const int64_t home_env = tune(HNSWGPU_TUNE_STREAM_HOME, -1);
+    const int64_t hstride = (idx->max_list_len + 15) / 16 * 16;
+    return ivf_mid_mode(idx, nq, nprobe) && ivf_ordered_mode(idx, nq, grouped) && idx->metric != METRIC_L2 && idx->ld % 128 == 0 &&
+           home_env != 0 && tune(HNSWGPU_TUNE_MID_SLICES, 0) <= 1 && tune(HNSWGPU_TUNE_MID_COMPACT, 1) != 0 &&
+           (home_env > 0 || (nq >= 1024 && 2LL * nq >= idx->nlist)) && static_cast<int64_t>(nq) * hstride * 8 <= (2LL << 30) &&
+           (static_cast<int64_t>(nq) / home_group(idx->nch) + std::min<int64_t>(nq, idx->nlist)) * ((idx->max_list_len + 4095) / 4096) < (1LL << 30);
+}
+
 // The list scan as a survivor stream (stream_kernels.hpp): int8 bounds with a running threshold -> compact survivor
 // lists -> f32 distances (GEMV order), top-k, ids and distances written by the finish kernel.  The query codes, tau = none
 // and empty survivor lists are set up by the routing step.
@@ -836,39 +865,29 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows, tpc = cr / kTileRows;
     b.chunk_rows = static_cast<int32_t>(cr);
     b.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
-    // Once the exact pass would be the largest kernel (its rows are 3 KB each and every query fetches its own) the survivors
-    // first meet their half-precision rows.  The survivors are a few per cent of the candidates: from ~1.5 M candidates per
-    // batch (48 queries x 32 lists x 977 rows; 5 queries at 10 M rows) the pass saves more than its launch costs -- measured
-    // at 1M x 768: batch 32 0.183 ms without vs 0.195 with, 64: 0.250 vs 0.243, 128: 0.298 vs 0.277.
-    // HNSWGPU_STREAM_MID=<queries> overrides (tests: 1 = always; 0 = never).
-    const int64_t mid_env = tune(HNSWGPU_TUNE_STREAM_MID, -1);
-    const int64_t cand = npairs * mean;
-    const bool mid = idx->d_lhalf != nullptr && !idx->ivf_calibrating && (mid_env >= 0 ? (mid_env > 0 && nq >= mid_env) : cand >= 1500000);
+    const bool mid = ivf_mid_mode(idx, nq, nprobe);
     const int64_t order_min = tune(HNSWGPU_TUNE_FINISH_ORDER, 512);  // 0 = never (A/B)
-    const bool ordered = grouped && d_probes && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists;
-    // Batches in which the lists are home to about a query each or more: every home list once through the matrix cores in
-    // half precision for all of its queries (ivf_home_kernel) instead of a half row per (query, survivor).  cosine / dot,
-    // rows of whole 128-element steps; HNSWGPU_TUNE_STREAM_HOME: -1 this rule, 0 never, 1 whenever the queries are ordered.
-    const int64_t home_env = tune(HNSWGPU_TUNE_STREAM_HOME, -1);
+    const bool ordered = d_probes != nullptr && ivf_ordered_mode(idx, nq, grouped);
     const int64_t hstride = (idx->max_list_len + 15) / 16 * 16;
     const int home_gq = home_group(idx->nch);
-    bool home = mid && ordered && idx->metric != METRIC_L2 && idx->ld % 128 == 0 && home_env != 0 && tune(HNSWGPU_TUNE_MID_SLICES, 0) <= 1 &&
-                (home_env > 0 || (nq >= 1024 && 2LL * nq >= idx->nlist)) &&
-                static_cast<int64_t>(nq) * hstride * 8 <= (2LL << 30);
+    bool home = d_probes != nullptr && ivf_home_mode(idx, nq, nprobe, grouped);  // (the routing took the same decision)
     int64_t home_chunk = 256, home_bound = 0;
+    if (const int64_t hc = tune(HNSWGPU_TUNE_HOME_CHUNK, 0); hc >= 64) home_chunk = hc / 64 * 64;
     if (home) {
         const int64_t groups = nq / home_gq + std::min<int64_t>(nq, idx->nlist);
         while (home_chunk < 4096 && groups * ((idx->max_list_len + home_chunk - 1) / home_chunk) > 16384) home_chunk *= 2;
         home_bound = groups * ((idx->max_list_len + home_chunk - 1) / home_chunk);
-        if (home_bound >= 2147483647LL) home = false;
+        HG_REQUIRE(home_bound < 2147483647LL, HNSWGPU_ELIMIT, "home-list pass: work list too large");
     }
     HomeDesc *home_desc = nullptr;
     int32_t *home_nit = nullptr;
+    uint32_t *home_first = nullptr;  // [nq] entries of a query's list behind the home-list launch
     if (home) {
-        HG_TRY(idx->s_home.ensure(sizeof(HomeDesc) * static_cast<size_t>(home_bound) + 64));
+        HG_TRY(idx->s_home.ensure(sizeof(HomeDesc) * static_cast<size_t>(home_bound) + 64 + sizeof(uint32_t) * static_cast<size_t>(nq)));
         HG_TRY(idx->s_dh.ensure(sizeof(float2) * static_cast<size_t>(nq) * hstride));
         home_desc = idx->s_home.as<HomeDesc>();
         home_nit = reinterpret_cast<int32_t *>(home_desc + home_bound);
+        home_first = reinterpret_cast<uint32_t *>(home_nit + 16);
     }
     if (grouped) {
         // the work list: items <= sum over lists of ceil(members / 32) * chunks <= (npairs / 32 + nlist) * nchunks
@@ -929,8 +948,54 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     b.stamps = g_tile_dbg_buf;  // null outside diagnostic sessions
     b.defer = mid ? 1 : 0;
     if (home) {
+        // the home lists first: every row of a query's nearest list through the matrix cores in half precision
+        // (ivf_home_kernel), then one workgroup per query takes the k-th smallest upper bound found there as the query's
+        // threshold and starts its survivor list with the rows it does not exclude (ivf_mid_kernel on an empty list).  The
+        // bounds pass below appends nothing for a (query, home list) pair and meets every other list with that threshold;
+        // what survives there (the part of a query's cluster that k-means put into a second list, above all) goes through the
+        // per-survivor half-precision pass behind it, held against the same threshold.
+        HG_REQUIRE(qorder != nullptr, HNSWGPU_EINVAL, "home-list pass without the query order");
         b.home_pairs = idx->s_pairs.as<Pair>();
         b.home_nprobe = nprobe;
+        HomeArgs ho;
+        memset(&ho, 0, sizeof(ho));
+        ho.items = home_desc;
+        ho.nitems = home_nit;
+        ho.qorder = qorder;
+        ho.half = idx->d_lhalf;
+        ho.hmeta = idx->d_lhmeta;
+        ho.ld = idx->ld;
+        ho.Q = d_Q;
+        ho.qld = idx->dim;
+        ho.dim = idx->dim;
+        ho.metric = idx->metric;
+        ho.dh = idx->s_dh.as<float2>();
+        ho.hstride = hstride;
+        HG_TRY(launch_home(ho, home_bound, idx->nch, st));
+        MidArgs ma;
+        memset(&ma, 0, sizeof(ma));
+        ma.surv = b.surv;
+        ma.surv_cnt = b.surv_cnt;
+        ma.cap = cap;
+        ma.nq = nq;
+        ma.slices = 1;
+        ma.qorder = qorder;
+        ma.tau = b.tau;
+        ma.k = k;
+        ma.compact = static_cast<int32_t>(std::min<int64_t>(cap, 4096));
+        ma.half = idx->d_lhalf;
+        ma.hmeta = idx->d_lhmeta;
+        ma.ld = idx->ld;
+        ma.Q = d_Q;
+        ma.qld = idx->dim;
+        ma.dim = idx->dim;
+        ma.metric = idx->metric;
+        ma.dh = ho.dh;
+        ma.hstride = hstride;
+        ma.pairs = idx->s_pairs.as<Pair>();
+        ma.nprobe = nprobe;
+        ma.first_out = home_first;
+        HG_TRY(launch_mid(ma, idx->nch, st));
     }
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);
@@ -957,7 +1022,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     }
     FinishArgs f;
     memset(&f, 0, sizeof(f));
-    f.prepass = mid ? 1 : 0;
+    f.prepass = mid && !home ? 1 : 0;
     f.adapt = static_cast<int32_t>(tune(HNSWGPU_TUNE_FINISH_ADAPT, 1));        // A/B
     f.bisect_min = static_cast<int32_t>(tune(HNSWGPU_TUNE_FINISH_BISECT, 1));  // A/B
     f.dbg = g_tile_dbg_buf;
@@ -1003,7 +1068,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         ha.thr = static_cast<uint32_t>(std::min<int64_t>(cap, tune(HNSWGPU_TUNE_STREAM_HEAVY_MIN, 4096)));
         ha.cnt = idx->s_heavy.as<uint32_t>();
         ha.list = idx->s_heavy.as<int32_t>() + 4;
-        ha.nsv = home ? reinterpret_cast<uint32_t *>(ha.list + nq) : nullptr;
+        ha.nsv = nullptr;
         HG_TRY(launch_heavy(ha, st));
         f.heavy_cnt = ha.cnt;
         f.heavy_list = ha.list;
@@ -1047,29 +1112,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
             ma.heavy_slices = kHeavySlices;
             ma.main_blocks = static_cast<int32_t>(ma.qorder ? (static_cast<int64_t>(nq) + 7) / 8 * 8 : static_cast<int64_t>(nq) * ma.slices);
         }
-        if (home) {
-            HG_REQUIRE(ma.slices == 1 && ma.qorder, HNSWGPU_EINVAL, "home-list pass without the query order");
-            HomeArgs ho;
-            memset(&ho, 0, sizeof(ho));
-            ho.items = home_desc;
-            ho.nitems = home_nit;
-            ho.qorder = qorder;
-            ho.half = idx->d_lhalf;
-            ho.hmeta = idx->d_lhmeta;
-            ho.ld = idx->ld;
-            ho.Q = d_Q;
-            ho.qld = idx->dim;
-            ho.dim = idx->dim;
-            ho.metric = idx->metric;
-            ho.dh = idx->s_dh.as<float2>();
-            ho.hstride = hstride;
-            HG_TRY(launch_home(ho, home_bound, idx->nch, st));
-            ma.dh = ho.dh;
-            ma.hstride = hstride;
-            ma.pairs = idx->s_pairs.as<Pair>();
-            ma.nprobe = nprobe;
-            ma.heavy_nsv = heavy ? reinterpret_cast<const uint32_t *>(f.heavy_list + nq) : nullptr;
-        }
+        ma.first = home_first;  // (home-list batches: only what the bounds pass appended, against the threshold as it stands)
         HG_TRY(launch_mid(ma, idx->nch, st));
     }
     return launch_finish(f, idx->nch, st);
@@ -1245,6 +1288,8 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
         if (nq >= stream_group_min) HG_TRY(stream_buckets(idx, nq, nprobe, sc, st));  // (zeroes the per-list counters)
     }
     bool codes_done = false;
+    // the home-list pass of large batches (ivf_home_mode): the routing's tail leaves the thresholds to it
+    const bool home_mode = use_code && sc.bk_cnt != nullptr && probes_buf != nullptr && ivf_home_mode(idx, nq, nprobe, true);
     // queries from which a GEMV-order batch routes through the group kernel
     // (Euclidean 1M x 768: 512 queries 0.85 vs 0.87 ms (GEMV vs group), 1024: 1.50 vs 1.43, 4096: 5.08 vs 4.70)
     const int route_group_min = static_cast<int>(tune(HNSWGPU_TUNE_ROUTE_GROUP, 1024));
@@ -1267,14 +1312,14 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     if (!use_tile && (fused_mode || (use_code && nq <= stream_route_max)) && static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20)) {
         // small batches: distances to the centroids, the choice of the nprobe nearest and the probe table in ONE launch
         // (for the survivor stream also the query codes, tau = none and the empty survivor lists)
-        RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap};
+        RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap, home_mode ? 1 : 0};
         HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, use_code ? &rs : nullptr));
         codes_done = use_code;
     } else if (use_code && static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20)) {
         // survivor stream, larger batches: the centroid distances by a pass that serves a group of queries per fetch of a
         // centroid row (the GEMV order, same bits), then ONE launch for everything else of the routing -- select, probe
         // table, pairs filed by list, query codes, first thresholds
-        RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap};
+        RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap, home_mode ? 1 : 0};
         HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, &rs, true));
         codes_done = true;
     } else {
@@ -1312,6 +1357,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
             pa.nprobe = nprobe;
             pa.k = k;
             pa.seed_rows = stream_seed_rows(nq, idx->ivf_n_global > 0 ? idx->ivf_n_global : idx->n, idx->nlist);
+            pa.home = home_mode ? 1 : 0;
             pa.pairs = idx->s_pairs.as<Pair>();
             pa.qcnt = qcnt_buf;
             pa.rows = idx->d_lrows;

@@ -177,6 +177,7 @@ struct PrepArgs {
     int64_t qld;
     int32_t dim, metric, nq, nprobe, k;
     int32_t seed_rows;  // stream_seed_rows
+    int32_t home;       // the home-list pass follows: no seed for a query whose nearest list holds k rows
     const Pair *pairs;
     const int32_t *qcnt;
     const float *rows;
@@ -201,6 +202,13 @@ __global__ __launch_bounds__(kWG) void ivf_query_prep_kernel(PrepArgs a) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) a.qcodes[(static_cast<int64_t>(qi) * NCH + c) * kWave + lane] = qc.a[c];
         if (lane == 0) a.qscal[qi] = qc.sc;
+    }
+    if (a.home) {
+        const Pair hp = a.pairs[static_cast<int64_t>(qi) * a.nprobe];
+        if (hp.row_end - hp.row_begin >= a.k) {  // (as route_tail_wg: the threshold comes from the home-list pass)
+            if (threadIdx.x == 0) a.tau[qi] = 0xffffffffu;
+            return;
+        }
     }
     seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, a.pairs + static_cast<int64_t>(qi) * a.nprobe, a.nprobe, a.qcnt[qi], a.k, a.rows,
                              a.row_norms, a.ld, dist_s, a.tau + qi, a.seed_rows);
@@ -1274,6 +1282,10 @@ struct MidArgs {
     const Pair *pairs;          // [nq][nprobe]: pair 0 = the nearest list
     int32_t nprobe;
     const uint32_t *heavy_nsv;  // with dh: the heavy queries' counts before anything was appended
+    uint32_t *first_out;        // optional [nq]: the entries this launch leaves in a query's list (the home-list launch: what a later
+                                // launch over the same lists need not look at again)
+    const uint32_t *first;      // optional [nq]: the launch behind the bounds pass of a home-list batch -- entries [0, first) are what the
+                                // home-list launch left (their bounds stand), [first, nsv) what the bounds pass appended
 };
 
 // NW waves per workgroup: 4, or 8 for the one-workgroup-per-query launches of batches that do not fill the chip otherwise
@@ -1296,6 +1308,10 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
         hrb = static_cast<uint32_t>(hp.row_begin);
         hd = a.dh + static_cast<int64_t>(qi) * a.hstride;
     }
+    // (the launch behind the bounds pass of a home-list batch: entries [0, f0) are what the home-list launch left -- their
+    // bounds stand, no half row is fetched for them; a query the bounds pass appended nothing to is done)
+    const uint32_t f0 = a.first ? a.first[qi] : 0u;
+    if (a.first && nsv <= f0) return;
     constexpr int gran = kT;
     int64_t per = (static_cast<int64_t>(nsv) + slices - 1) / slices;
     per = (per + gran - 1) / gran * gran;
@@ -1322,7 +1338,7 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
             e = sv[i];
             mt = a.hmeta[e.y];
         }
-        uint64_t m = __ballot(in);
+        uint64_t m = __ballot(in && i >= f0);
         float mysum = 0.0f;
         while (m) {
             uint2 w[RB][NCH];
@@ -1369,12 +1385,14 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
             }
         }
         if (in) {
-            float lb, ub;
-            half_bounds(a.metric, mysum, qn, mt, lb, ub);
-            // (both pairs hold: the tighter of each -- v_max / v_min return the other operand for a NaN)
-            lb = __builtin_fmaxf(lb, __uint_as_float(e.z));
-            ub = __builtin_fminf(ub, __uint_as_float(e.w));
-            *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(sv + i) + 2) = make_uint2(__float_as_uint(lb), __float_as_uint(ub));
+            float lb = __uint_as_float(e.z), ub = __uint_as_float(e.w);
+            if (i >= f0) {
+                half_bounds(a.metric, mysum, qn, mt, lb, ub);
+                // (both pairs hold: the tighter of each -- v_max / v_min return the other operand for a NaN)
+                lb = __builtin_fmaxf(lb, __uint_as_float(e.z));
+                ub = __builtin_fminf(ub, __uint_as_float(e.w));
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(sv + i) + 2) = make_uint2(__float_as_uint(lb), __float_as_uint(ub));
+            }
             if (compact) {
                 lb_s[i] = lb;
                 ub_min = ub < ub_min ? ub : ub_min;  // (NaN: no upper bound, not counted)
@@ -1449,10 +1467,12 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
     }
     for (int base = 0; base < hlen; base += kT) {  // ... and the rows of the home list the threshold does not exclude
         const int r = base + static_cast<int>(threadIdx.x);
-        float lbr = 0.0f;
+        float lbr = 0.0f, ubr = __builtin_inff();
         bool keep = r < hlen;
         if (keep) {
-            lbr = hd[r].x;
+            const float2 b = hd[r];
+            lbr = b.x;
+            if (a.first_out) ubr = b.y;  // (a launch behind the bounds pass ranks the upper bounds once more, with what was appended)
             keep = !(lbr > T);  // NaN (no bound) stays
         }
         const uint64_t m = __ballot(keep);
@@ -1467,12 +1487,13 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
         }
         const uint32_t slot = off + __popcll(m & ((1ull << lane) - 1ull));
         if (keep && slot < a.cap)
-            sv[slot] = make_uint4(hob + static_cast<uint32_t>(r), hrb + static_cast<uint32_t>(r), __float_as_uint(lbr), 0x7f800000u);
+            sv[slot] = make_uint4(hob + static_cast<uint32_t>(r), hrb + static_cast<uint32_t>(r), __float_as_uint(lbr), __float_as_uint(ubr));
         nout += tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         a.surv_cnt[qi] = nout <= a.cap ? nout : static_cast<uint32_t>(a.cap) + 1u;  // (more than fit: the walk of the candidate stream)
+        if (a.first_out) a.first_out[qi] = nout <= a.cap ? nout : 0u;
         if (T < __builtin_inff()) (void)__hip_atomic_fetch_min(a.tau + qi, tau_encode(T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // (Tried: finishing the query right here -- finish_wg on the ~15 entries left, no second launch for it.  The finish
@@ -1503,6 +1524,7 @@ __global__ __launch_bounds__(NW * kWave) void ivf_mid_kernel(MidArgs a) {
     }
     const uint32_t nsv = a.surv_cnt[qi];
     if (a.heavy_cnt && (nsv & kHeavyBit)) return;  // served by the workgroups above
+    if (a.first_out && sl == 0 && threadIdx.x == 0) a.first_out[qi] = 0u;  // (unless the workgroup below leaves a compacted list)
     mid_query_wg<NCH, RB, L2, NW>(a, qi, sl, a.slices, nsv, true, smem);
 }
 
