@@ -950,7 +950,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     if (home) {
         // the home lists first: every row of a query's nearest list through the matrix cores in half precision
         // (ivf_home_kernel), then one workgroup per query takes the k-th smallest upper bound found there as the query's
-        // threshold and starts its survivor list with the rows it does not exclude (ivf_mid_kernel on an empty list).  The
+        // threshold and starts its survivor list with the rows it does not exclude (ivf_home_select_kernel).  The
         // bounds pass below appends nothing for a (query, home list) pair and meets every other list with that threshold;
         // what survives there (the part of a query's cluster that k-means put into a second list, above all) goes through the
         // per-survivor half-precision pass behind it, held against the same threshold.
@@ -972,30 +972,21 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         ho.dh = idx->s_dh.as<float2>();
         ho.hstride = hstride;
         HG_TRY(launch_home(ho, home_bound, idx->nch, st));
-        MidArgs ma;
-        memset(&ma, 0, sizeof(ma));
-        ma.surv = b.surv;
-        ma.surv_cnt = b.surv_cnt;
-        ma.cap = cap;
-        ma.nq = nq;
-        ma.slices = 1;
-        ma.qorder = qorder;
-        ma.tau = b.tau;
-        ma.k = k;
-        ma.compact = static_cast<int32_t>(std::min<int64_t>(cap, 4096));
-        ma.half = idx->d_lhalf;
-        ma.hmeta = idx->d_lhmeta;
-        ma.ld = idx->ld;
-        ma.Q = d_Q;
-        ma.qld = idx->dim;
-        ma.dim = idx->dim;
-        ma.metric = idx->metric;
-        ma.dh = ho.dh;
-        ma.hstride = hstride;
-        ma.pairs = idx->s_pairs.as<Pair>();
-        ma.nprobe = nprobe;
-        ma.first_out = home_first;
-        HG_TRY(launch_mid(ma, idx->nch, st));
+        HomeSelectArgs hs;
+        memset(&hs, 0, sizeof(hs));
+        hs.dh = ho.dh;
+        hs.hstride = hstride;
+        hs.pairs = idx->s_pairs.as<Pair>();
+        hs.nq = nq;
+        hs.nprobe = nprobe;
+        hs.k = k;
+        hs.surv = b.surv;
+        hs.cap = cap;
+        hs.surv_cnt = b.surv_cnt;
+        hs.first = home_first;
+        hs.tau = b.tau;
+        hipLaunchKernelGGL(ivf_home_select_kernel, dim3(nq), dim3(kWG), 0, st, hs);
+        HG_HIP(hipGetLastError());
     }
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);
@@ -1068,7 +1059,6 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         ha.thr = static_cast<uint32_t>(std::min<int64_t>(cap, tune(HNSWGPU_TUNE_STREAM_HEAVY_MIN, 4096)));
         ha.cnt = idx->s_heavy.as<uint32_t>();
         ha.list = idx->s_heavy.as<int32_t>() + 4;
-        ha.nsv = nullptr;
         HG_TRY(launch_heavy(ha, st));
         f.heavy_cnt = ha.cnt;
         f.heavy_list = ha.list;
@@ -1112,7 +1102,8 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
             ma.heavy_slices = kHeavySlices;
             ma.main_blocks = static_cast<int32_t>(ma.qorder ? (static_cast<int64_t>(nq) + 7) / 8 * 8 : static_cast<int64_t>(nq) * ma.slices);
         }
-        ma.first = home_first;  // (home-list batches: only what the bounds pass appended, against the threshold as it stands)
+        ma.first = home_first;  // (home-list batches: half rows only for what the bounds pass appended)
+        ma.first_few = static_cast<int32_t>(tune(HNSWGPU_TUNE_HOME_STRAYS, 32));
         HG_TRY(launch_mid(ma, idx->nch, st));
     }
     return launch_finish(f, idx->nch, st);

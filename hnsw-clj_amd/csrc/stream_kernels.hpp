@@ -861,6 +861,108 @@ __global__ __launch_bounds__(kWG) void ivf_home_kernel(HomeArgs a) {
     }
 }
 
+// One workgroup per query behind ivf_home_kernel: the k-th smallest upper bound over the rows of the query's home list -- k
+// candidates are at most that far -- becomes its threshold (tau, which the bounds pass then meets every other list with), and
+// the rows that threshold does not exclude (little more than k) start the query's survivor list.  The bounds of up to
+// kHomeKeep x 256 rows stay in registers between the two passes (a longer list is read again); the kept rows are placed by
+// one block-wide scan of the threads' counts.
+constexpr int kHomeKeep = 8;
+struct HomeSelectArgs {
+    const float2 *dh;
+    int64_t hstride;
+    const Pair *pairs;  // [nq][nprobe]: pair 0 = the nearest list
+    int32_t nq, nprobe, k;
+    uint4 *surv;        // [nq][cap]
+    int64_t cap;
+    uint32_t *surv_cnt; // 0 (or the routing's overflow mark: such a query is left alone) -> entries written
+    uint32_t *first;    // [nq] the same count: what a later pass over the list need not look at again
+    uint32_t *tau;
+};
+static __global__ __launch_bounds__(kWG) void ivf_home_select_kernel(HomeSelectArgs a) {
+    __shared__ __align__(16) uint32_t ubv_s[kWG];
+    __shared__ uint32_t kth_s, wsum_s[kNWave];
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const uint32_t nsv0 = a.surv_cnt[qi];
+    const Pair hp = a.pairs[static_cast<int64_t>(qi) * a.nprobe];
+    if (tid == 0) a.first[qi] = 0u;
+    if (nsv0 > a.cap) return;  // (a bucket overflowed in the routing: the finish kernel walks the candidate stream)
+    const int hlen = static_cast<int>(hp.row_end - hp.row_begin);
+    if (hlen <= 0) return;
+    const float2 *hd = a.dh + static_cast<int64_t>(qi) * a.hstride;
+    const float inf = __builtin_inff();
+    float2 b[kHomeKeep];
+#pragma unroll
+    for (int j = 0; j < kHomeKeep; j++) {
+        const int r = tid + j * kWG;
+        b[j] = r < hlen ? hd[r] : make_float2(inf, inf);
+    }
+    float ub_min = inf;
+#pragma unroll
+    for (int j = 0; j < kHomeKeep; j++) ub_min = b[j].y < ub_min ? b[j].y : ub_min;  // (NaN: no upper bound, not counted)
+    for (int r = tid + kHomeKeep * kWG; r < hlen; r += kWG) {
+        const float u = hd[r].y;
+        ub_min = u < ub_min ? u : ub_min;
+    }
+    const uint32_t v = tau_encode(ub_min);
+    ubv_s[tid] = v;
+    __syncthreads();
+    {
+        int rank = 0;
+        for (int j = 0; j < kWG; j += 4) {
+            const uint4 o = *reinterpret_cast<const uint4 *>(ubv_s + j);  // uniform address: an LDS broadcast
+            rank += (o.x < v || (o.x == v && j < tid)) ? 1 : 0;
+            rank += (o.y < v || (o.y == v && j + 1 < tid)) ? 1 : 0;
+            rank += (o.z < v || (o.z == v && j + 2 < tid)) ? 1 : 0;
+            rank += (o.w < v || (o.w == v && j + 3 < tid)) ? 1 : 0;
+        }
+        if (rank == a.k - 1) kth_s = v;  // ranks are a permutation of 0..255: exactly one thread (k <= 256)
+    }
+    __syncthreads();
+    const float T = tau_decode(kth_s);
+    // rows this thread keeps: NaN (no bound) stays
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kHomeKeep; j++) cnt += (tid + j * kWG < hlen && !(b[j].x > T)) ? 1u : 0u;
+    for (int r = tid + kHomeKeep * kWG; r < hlen; r += kWG) cnt += !(hd[r].x > T) ? 1u : 0u;
+    uint32_t incl = cnt;
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += u;
+    }
+    if (lane == kWave - 1) wsum_s[wave] = incl;
+    __syncthreads();
+    uint32_t at = incl - cnt, total = 0;
+#pragma unroll
+    for (int w = 0; w < kNWave; w++) {
+        const uint32_t c = wsum_s[w];
+        at += w < wave ? c : 0u;
+        total += c;
+    }
+    uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
+    const uint32_t hob = hp.ord_base, hrb = static_cast<uint32_t>(hp.row_begin);
+#pragma unroll
+    for (int j = 0; j < kHomeKeep; j++) {
+        const int r = tid + j * kWG;
+        if (r < hlen && !(b[j].x > T)) {
+            if (at < a.cap) sv[at] = make_uint4(hob + static_cast<uint32_t>(r), hrb + static_cast<uint32_t>(r), __float_as_uint(b[j].x), __float_as_uint(b[j].y));
+            at++;
+        }
+    }
+    for (int r = tid + kHomeKeep * kWG; r < hlen; r += kWG) {
+        const float2 e = hd[r];
+        if (!(e.x > T)) {
+            if (at < a.cap) sv[at] = make_uint4(hob + static_cast<uint32_t>(r), hrb + static_cast<uint32_t>(r), __float_as_uint(e.x), __float_as_uint(e.y));
+            at++;
+        }
+    }
+    if (tid == 0) {
+        const bool fits = total <= a.cap;
+        a.surv_cnt[qi] = fits ? total : static_cast<uint32_t>(a.cap) + 1u;  // (more than fit: the walk of the candidate stream)
+        a.first[qi] = fits ? total : 0u;
+        if (T < inf) (void)__hip_atomic_fetch_min(a.tau + qi, tau_encode(T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Step 2: survivors -> f32 distances -> the k nearest -> results.
 // ------------------------------------------------------------------------------------------------
@@ -881,7 +983,6 @@ struct HeavyArgs {
     uint32_t times_mean;  // ... and at least this many times the batch's mean (4; tests: 0)
     uint32_t *cnt;     // [1]
     int32_t *list;     // [nq]
-    uint32_t *nsv;     // optional [nq]: the listed queries' survivor counts as they stood (the half-precision pass may append to a heavy list while its slices run)
 };
 static __global__ __launch_bounds__(1024) void ivf_heavy_kernel(HeavyArgs a) {
     __shared__ uint32_t n_s;
@@ -906,9 +1007,7 @@ static __global__ __launch_bounds__(1024) void ivf_heavy_kernel(HeavyArgs a) {
     for (int i = threadIdx.x; i < a.nq; i += 1024) {
         const uint32_t raw = a.surv_cnt[i];
         if (raw > thr) {
-            const uint32_t at = atomicAdd(&n_s, 1u);
-            a.list[at] = i;
-            if (a.nsv) a.nsv[at] = raw;
+            a.list[atomicAdd(&n_s, 1u)] = i;
             a.surv_cnt[i] = raw | kHeavyBit;
         }
     }
@@ -1275,17 +1374,9 @@ struct MidArgs {
     const uint32_t *heavy_cnt;  // optional (ivf_heavy_kernel), as in FinishArgs
     const int32_t *heavy_list;
     int32_t heavy_slices, main_blocks;
-    // the home lists went through ivf_home_kernel: (lb, ub) of every row of a query's nearest list in dh[query][row]; the
-    // bounds pass appended nothing for them, this kernel's slice 0 brings them in
-    const float2 *dh;
-    int64_t hstride;
-    const Pair *pairs;          // [nq][nprobe]: pair 0 = the nearest list
-    int32_t nprobe;
-    const uint32_t *heavy_nsv;  // with dh: the heavy queries' counts before anything was appended
-    uint32_t *first_out;        // optional [nq]: the entries this launch leaves in a query's list (the home-list launch: what a later
-                                // launch over the same lists need not look at again)
-    const uint32_t *first;      // optional [nq]: the launch behind the bounds pass of a home-list batch -- entries [0, first) are what the
-                                // home-list launch left (their bounds stand), [first, nsv) what the bounds pass appended
+    const uint32_t *first;      // optional [nq]: the launch behind the bounds pass of a home-list batch -- entries [0, first) are what
+                                // ivf_home_select_kernel left (their bounds stand), [first, nsv) what the bounds pass appended
+    int32_t first_few;          // ... and a query it appended no more than this many entries to is left to the finish kernel as it is
 };
 
 // NW waves per workgroup: 4, or 8 for the one-workgroup-per-query launches of batches that do not fill the chip otherwise
@@ -1297,34 +1388,20 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     if (nsv > a.cap) return;  // the list overflowed: the finish kernel walks the candidate stream instead
-    // the query's nearest list, if ivf_home_kernel has served it: its rows are not among the nsv entries (slice 0 brings them in)
-    int hlen = 0;
-    uint32_t hob = 0, hrb = 0;
-    const float2 *hd = nullptr;
-    if (a.dh && sl == 0) {
-        const Pair hp = a.pairs[static_cast<int64_t>(qi) * a.nprobe];
-        hlen = static_cast<int>(hp.row_end - hp.row_begin);
-        hob = hp.ord_base;
-        hrb = static_cast<uint32_t>(hp.row_begin);
-        hd = a.dh + static_cast<int64_t>(qi) * a.hstride;
-    }
     // (the launch behind the bounds pass of a home-list batch: entries [0, f0) are what the home-list launch left -- their
     // bounds stand, no half row is fetched for them; a query the bounds pass appended nothing to is done)
     const uint32_t f0 = a.first ? a.first[qi] : 0u;
-    if (a.first && nsv <= f0) return;
+    if (a.first && nsv <= f0 + static_cast<uint32_t>(a.first_few)) return;  // (a few strays: the finish kernel fetches their f32 rows outright)
     constexpr int gran = kT;
     int64_t per = (static_cast<int64_t>(nsv) + slices - 1) / slices;
     per = (per + gran - 1) / gran * gran;
     const int64_t i0 = static_cast<int64_t>(sl) * per;
     const int64_t i1 = i0 + per < nsv ? i0 + per : nsv;
-    if (i0 >= i1 && hlen <= 0) return;
+    if (i0 >= i1) return;
     const int nvec = static_cast<int>(a.ld / 4);
     float4 q[NCH];
-    float qn = 0.0f;
-    if (i0 < i1) {
-        load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
-        qn = L2 ? 0.0f : query_norm<NCH>(q);
-    }
+    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+    const float qn = L2 ? 0.0f : query_norm<NCH>(q);
     uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
     float *lb_s = reinterpret_cast<float *>(smem);  // [compact] the entries' new lower bounds
     const bool compact = may_compact && a.compact > 0 && nsv <= static_cast<uint32_t>(a.compact) && a.k <= kT;
@@ -1399,26 +1476,7 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
             }
         }
     }
-    if (!compact) {
-        // the home rows join the list as entries of their own (a list too long to compact here, or a heavy query's slice 0:
-        // the other slices work on [0, nsv), which this does not touch); a list they do not fit sends the query through
-        // the finish kernel's walk of the candidate stream
-        if (hlen > 0) {
-            const bool fits = static_cast<int64_t>(nsv) + hlen <= a.cap;
-            if (fits)
-                for (int r = threadIdx.x; r < hlen; r += kT) {
-                    const float2 b = hd[r];
-                    sv[nsv + r] = make_uint4(hob + static_cast<uint32_t>(r), hrb + static_cast<uint32_t>(r), __float_as_uint(b.x), __float_as_uint(b.y));
-                }
-            if (threadIdx.x == 0)
-                a.surv_cnt[qi] = (fits ? nsv + static_cast<uint32_t>(hlen) : static_cast<uint32_t>(a.cap) + 1u) | (may_compact ? 0u : kHeavyBit);
-        }
-        return;
-    }
-    for (int r = threadIdx.x; r < hlen; r += kT) {  // the home rows' upper bounds count towards the threshold as well
-        const float u = hd[r].y;
-        ub_min = u < ub_min ? u : ub_min;
-    }
+    if (!compact) return;
     // ---- the query's whole list went through this workgroup: the threshold the finish kernel would derive from the upper
     // bounds (the k-th smallest of the 256 threads' minima: k candidates at most that far) is applied here, and the list
     // shrinks to the entries it does not exclude -- little more than k -- before the finish kernel reads it
@@ -1465,35 +1523,8 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
         nout += tot;
         __syncthreads();
     }
-    for (int base = 0; base < hlen; base += kT) {  // ... and the rows of the home list the threshold does not exclude
-        const int r = base + static_cast<int>(threadIdx.x);
-        float lbr = 0.0f, ubr = __builtin_inff();
-        bool keep = r < hlen;
-        if (keep) {
-            const float2 b = hd[r];
-            lbr = b.x;
-            if (a.first_out) ubr = b.y;  // (a launch behind the bounds pass ranks the upper bounds once more, with what was appended)
-            keep = !(lbr > T);  // NaN (no bound) stays
-        }
-        const uint64_t m = __ballot(keep);
-        if (lane == 0) wcnt_s[wave] = static_cast<uint32_t>(__popcll(m));
-        __syncthreads();
-        uint32_t off = nout, tot = 0;
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-            const uint32_t c = wcnt_s[w];
-            off += w < wave ? c : 0u;
-            tot += c;
-        }
-        const uint32_t slot = off + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep && slot < a.cap)
-            sv[slot] = make_uint4(hob + static_cast<uint32_t>(r), hrb + static_cast<uint32_t>(r), __float_as_uint(lbr), __float_as_uint(ubr));
-        nout += tot;
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        a.surv_cnt[qi] = nout <= a.cap ? nout : static_cast<uint32_t>(a.cap) + 1u;  // (more than fit: the walk of the candidate stream)
-        if (a.first_out) a.first_out[qi] = nout <= a.cap ? nout : 0u;
+        a.surv_cnt[qi] = nout;
         if (T < __builtin_inff()) (void)__hip_atomic_fetch_min(a.tau + qi, tau_encode(T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // (Tried: finishing the query right here -- finish_wg on the ~15 entries left, no second launch for it.  The finish
@@ -1509,8 +1540,7 @@ __global__ __launch_bounds__(NW * kWave) void ivf_mid_kernel(MidArgs a) {
         const int n = static_cast<int>(*a.heavy_cnt);
         for (int t = slot; t < n; t += kHeavySlots) {
             const int hq = a.heavy_list[t];
-            const uint32_t hn = a.heavy_nsv ? a.heavy_nsv[t] : (a.surv_cnt[hq] & ~kHeavyBit);  // (with home lists slice 0 appends: the count as it stood)
-            mid_query_wg<NCH, RB, L2, NW>(a, hq, hsl, a.heavy_slices, hn, false, smem);
+            mid_query_wg<NCH, RB, L2, NW>(a, hq, hsl, a.heavy_slices, a.surv_cnt[hq] & ~kHeavyBit, false, smem);
         }
         return;
     }
@@ -1524,7 +1554,6 @@ __global__ __launch_bounds__(NW * kWave) void ivf_mid_kernel(MidArgs a) {
     }
     const uint32_t nsv = a.surv_cnt[qi];
     if (a.heavy_cnt && (nsv & kHeavyBit)) return;  // served by the workgroups above
-    if (a.first_out && sl == 0 && threadIdx.x == 0) a.first_out[qi] = 0u;  // (unless the workgroup below leaves a compacted list)
     mid_query_wg<NCH, RB, L2, NW>(a, qi, sl, a.slices, nsv, true, smem);
 }
 

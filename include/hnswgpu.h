@@ -370,7 +370,8 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_STREAM_HOME 44 /* the home-list pass of large IVF batches (every list once through the matrix cores in half precision for all the queries it is nearest to): -1 from 1024 queries and half a query per list, 0 never, 1 whenever the batch is served in the order of its nearest lists */
 #define HNSWGPU_TUNE_HOME_CHUNK 45 /* rows per work item of the home-list pass (a multiple of 64; 0 = auto) */
 #define HNSWGPU_TUNE_HOME_DEPTH 46 /* operand loads in flight per wave of the home-list pass: 4 / 8 / 12 / 16 / 24, the largest that divides the 32-element steps of a row and does not exceed this (default 12) */
-#define HNSWGPU_TUNE_COUNT 47
+#define HNSWGPU_TUNE_HOME_STRAYS 47 /* home-list batches: a query the bounds pass appended no more than this many candidates to skips the per-survivor half-precision pass (the finish kernel fetches their f32 rows; default 32) */
+#define HNSWGPU_TUNE_COUNT 48
 int hnswgpu_set_tuning(int32_t key, int64_t value);
 int hnswgpu_get_tuning(int32_t key, int64_t *value, int32_t *is_set);
 
