@@ -164,14 +164,15 @@ int launch_home(const HomeArgs &a, int64_t blocks, int nch, hipStream_t st) {
     return 0;
 }
 
-int launch_mid(const MidArgs &a, int nch, hipStream_t st) {
+int launch_mid(const MidArgs &a0, int nch, hipStream_t st) {
+    MidArgs a = a0;
     int64_t blocks = static_cast<int64_t>(a.nq) * a.slices;
     if (a.qorder) blocks = (static_cast<int64_t>(a.nq) + 7) / 8 * 8;  // ordered queries: whole rounds over the eight XCDs
+    if (a.todo) blocks = static_cast<int64_t>(std::min(a.nq, 1024)) * a.todo_slices;  // (slots that walk the list of queries with work)
     if (blocks <= 0) return 0;
-    if (a.heavy_cnt) {  // + the workgroups that walk the list of heavy queries
-        HG_REQUIRE(a.main_blocks == blocks, HNSWGPU_EINVAL, "half-precision pass: main_blocks does not match the grid");
+    a.main_blocks = static_cast<int32_t>(blocks);
+    if (a.heavy_cnt)  // + the workgroups that walk the list of heavy queries
         blocks += static_cast<int64_t>(kHeavySlots) * a.heavy_slices;
-    }
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "half-precision pass grid too large");
     const bool l2 = a.metric == METRIC_L2;
     const size_t lds = sizeof(float) * static_cast<size_t>(std::max(a.compact, 0));
@@ -179,7 +180,7 @@ int launch_mid(const MidArgs &a, int nch, hipStream_t st) {
     const bool wide_env = tune(HNSWGPU_TUNE_MID_WIDE, 1) != 0;  // 0 = never (A/B)
     // eight waves per query where the grid alone does not fill the chip (cosine batch 1024: 235 -> 216 us; the Euclidean kernel,
     // heavier per element, measured 2 - 3 % slower with them and keeps four)
-    const bool wide = wide_env && a.slices == 1 && a.nq < 2048 && a.k <= 8 * kWave && a.metric != METRIC_L2;
+    const bool wide = wide_env && a.slices == 1 && !a.todo && a.nq < 2048 && a.k <= 8 * kWave && a.metric != METRIC_L2;
 #define CALL(N, R, L)                                                                                                             \
     do {                                                                                                                          \
         if (wide) hipLaunchKernelGGL((ivf_mid_kernel<N, R, L, 8>), dim3(static_cast<unsigned>(blocks)), dim3(8 * kWave), lds, st, a); \

@@ -1013,7 +1013,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     }
     FinishArgs f;
     memset(&f, 0, sizeof(f));
-    f.prepass = mid && !home ? 1 : 0;
+    f.prepass = mid ? 1 : 0;  // (lists of more than 128 entries only: what a compacting pass has left is evaluated in one step)
     f.adapt = static_cast<int32_t>(tune(HNSWGPU_TUNE_FINISH_ADAPT, 1));        // A/B
     f.bisect_min = static_cast<int32_t>(tune(HNSWGPU_TUNE_FINISH_BISECT, 1));  // A/B
     f.dbg = g_tile_dbg_buf;
@@ -1052,6 +1052,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     if (heavy) {
         HG_TRY(idx->s_heavy.ensure(sizeof(int32_t) * (2 * static_cast<size_t>(nq) + 4)));
         HeavyArgs ha;
+        memset(&ha, 0, sizeof(ha));
         ha.surv_cnt = b.surv_cnt;
         ha.nq = nq;
         ha.cap = static_cast<uint32_t>(cap);
@@ -1059,6 +1060,12 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         ha.thr = static_cast<uint32_t>(std::min<int64_t>(cap, tune(HNSWGPU_TUNE_STREAM_HEAVY_MIN, 4096)));
         ha.cnt = idx->s_heavy.as<uint32_t>();
         ha.list = idx->s_heavy.as<int32_t>() + 4;
+        if (home) {  // ... and the queries the bounds pass appended more than a few candidates to
+            ha.first = home_first;
+            ha.few = static_cast<uint32_t>(std::max<int64_t>(0, tune(HNSWGPU_TUNE_HOME_STRAYS, 32)));
+            ha.todo_cnt = idx->s_heavy.as<uint32_t>() + 1;
+            ha.todo = ha.list + nq;
+        }
         HG_TRY(launch_heavy(ha, st));
         f.heavy_cnt = ha.cnt;
         f.heavy_list = ha.list;
@@ -1103,6 +1110,11 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
             ma.main_blocks = static_cast<int32_t>(ma.qorder ? (static_cast<int64_t>(nq) + 7) / 8 * 8 : static_cast<int64_t>(nq) * ma.slices);
         }
         ma.first = home_first;  // (home-list batches: half rows only for what the bounds pass appended)
+        if (home && heavy) {
+            ma.todo_cnt = idx->s_heavy.as<uint32_t>() + 1;
+            ma.todo = f.heavy_list + nq;
+            ma.todo_slices = 8;
+        }
         ma.first_few = static_cast<int32_t>(tune(HNSWGPU_TUNE_HOME_STRAYS, 32));
         HG_TRY(launch_mid(ma, idx->nch, st));
     }

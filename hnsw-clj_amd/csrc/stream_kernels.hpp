@@ -983,12 +983,19 @@ struct HeavyArgs {
     uint32_t times_mean;  // ... and at least this many times the batch's mean (4; tests: 0)
     uint32_t *cnt;     // [1]
     int32_t *list;     // [nq]
+    // home-list batches: the queries the bounds pass appended more than `few` candidates to (and that are not heavy) are listed
+    // as well -- the only ones the per-survivor half-precision pass behind it has work for (a few per cent of a batch)
+    const uint32_t *first;  // optional [nq] entries the home-list launch left
+    uint32_t few;
+    uint32_t *todo_cnt;     // [1]
+    int32_t *todo;          // [nq]
 };
 static __global__ __launch_bounds__(1024) void ivf_heavy_kernel(HeavyArgs a) {
-    __shared__ uint32_t n_s;
+    __shared__ uint32_t n_s, t_s;
     __shared__ unsigned long long sum_s;
     if (threadIdx.x == 0) {
         n_s = 0;
+        t_s = 0;
         sum_s = 0;
     }
     __syncthreads();
@@ -1009,10 +1016,15 @@ static __global__ __launch_bounds__(1024) void ivf_heavy_kernel(HeavyArgs a) {
         if (raw > thr) {
             a.list[atomicAdd(&n_s, 1u)] = i;
             a.surv_cnt[i] = raw | kHeavyBit;
+        } else if (a.first && raw <= a.cap && raw > a.first[i] + a.few) {
+            a.todo[atomicAdd(&t_s, 1u)] = i;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) *a.cnt = n_s;
+    if (threadIdx.x == 0) {
+        *a.cnt = n_s;
+        if (a.first) *a.todo_cnt = t_s;
+    }
 }
 
 struct FinishArgs {
@@ -1377,6 +1389,9 @@ struct MidArgs {
     const uint32_t *first;      // optional [nq]: the launch behind the bounds pass of a home-list batch -- entries [0, first) are what
                                 // ivf_home_select_kernel left (their bounds stand), [first, nsv) what the bounds pass appended
     int32_t first_few;          // ... and a query it appended no more than this many entries to is left to the finish kernel as it is
+    const uint32_t *todo_cnt;   // with first: the queries that have such work, listed by ivf_heavy_kernel: todo_slices workgroups
+    const int32_t *todo;        // each, sixteen entries per wave and step (one WORKGROUP walking a few hundred entries is ~45 us of
+    int32_t todo_slices;        // dependent gathers); their lists are not compacted -- the finish kernel ranks the upper bounds
 };
 
 // NW waves per workgroup: 4, or 8 for the one-workgroup-per-query launches of batches that do not fill the chip otherwise
@@ -1392,7 +1407,8 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
     // bounds stand, no half row is fetched for them; a query the bounds pass appended nothing to is done)
     const uint32_t f0 = a.first ? a.first[qi] : 0u;
     if (a.first && nsv <= f0 + static_cast<uint32_t>(a.first_few)) return;  // (a few strays: the finish kernel fetches their f32 rows outright)
-    constexpr int gran = kT;
+    const int span = a.todo ? 16 : kWave;  // entries a wave looks at per step
+    const int gran = NW * span;
     int64_t per = (static_cast<int64_t>(nsv) + slices - 1) / slices;
     per = (per + gran - 1) / gran * gran;
     const int64_t i0 = static_cast<int64_t>(sl) * per;
@@ -1406,9 +1422,9 @@ __device__ __forceinline__ void mid_query_wg(const MidArgs &a, int qi, int sl, i
     float *lb_s = reinterpret_cast<float *>(smem);  // [compact] the entries' new lower bounds
     const bool compact = may_compact && a.compact > 0 && nsv <= static_cast<uint32_t>(a.compact) && a.k <= kT;
     float ub_min = __builtin_inff();                // over this thread's entries
-    for (int64_t base = i0 + wave * kWave; base < i1; base += gran) {
+    for (int64_t base = i0 + wave * span; base < i1; base += gran) {
         const int64_t i = base + lane;
-        const bool in = i < i1;
+        const bool in = lane < span && i < i1;
         uint4 e = make_uint4(0u, 0u, 0u, 0u);
         float4 mt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (in) {
@@ -1546,6 +1562,15 @@ __global__ __launch_bounds__(NW * kWave) void ivf_mid_kernel(MidArgs a) {
     }
     int qi = blockIdx.x % a.nq;
     const int sl = a.qorder ? 0 : blockIdx.x / a.nq;
+    if (a.todo) {  // home-list batches: only the listed queries have work
+        const int n = static_cast<int>(*a.todo_cnt), ts = a.todo_slices;
+        const int slot = static_cast<int>(blockIdx.x) / ts, tsl = static_cast<int>(blockIdx.x) % ts, nslots = a.main_blocks / ts;
+        for (int t = slot; t < n; t += nslots) {
+            const int tq = a.todo[t];
+            mid_query_wg<NCH, RB, L2, NW>(a, tq, tsl, ts, a.surv_cnt[tq], false, smem);
+        }
+        return;
+    }
     if (a.qorder) {  // workgroup b runs on XCD b % 8: XCD x takes a contiguous eighth of the ordered queries
         const int per = (a.nq + 7) >> 3;
         const int pos = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
