@@ -299,7 +299,7 @@ int hnswgpu_distance_bounds(hnswgpu_index *idx, const float *q, const int32_t *i
  * query, by the kernel the searches run: out_lb[i] <= distance <= out_ub[i], NaN where a row or the query has no bound. */
 int hnswgpu_ivf_half_bounds(hnswgpu_index *idx, const float *q, const int32_t *list_rows, int32_t m, float *out_lb,
                             float *out_ub);
-/* Large batches (from 1024 queries and half a query per list; cosine / dot, rows of whole 128-element steps) put the
+/* Large batches (from 512 queries and half a query per list; cosine / dot, rows of whole 128-element steps) put the
  * half-precision rows of a query's NEAREST list -- where nearly all of its int8 survivors sit -- through the matrix
  * cores, once per list for all the queries it is nearest to (v_mfma_f32_16x16x32_f16, the query split into two fp16
  * planes), instead of fetching a half row per (query, survivor).  This entry reports those bounds for the list rows
@@ -367,11 +367,12 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_ZEROCOPY 41 /* 0 = small synchronous HNSW calls stage through copies instead of mapped pinned memory (A/B) */
 #define HNSWGPU_TUNE_BUILD_TIMING 42 /* 1 = hnswgpu_hnsw_build prints where its time went to stderr */
 #define HNSWGPU_TUNE_BUILD_BATCH 43 /* largest insertion batch of hnswgpu_hnsw_build (default 16384; a batch never exceeds 1/8 of the graph it is searched against) */
-#define HNSWGPU_TUNE_STREAM_HOME 44 /* the home-list pass of large IVF batches (every list once through the matrix cores in half precision for all the queries it is nearest to): -1 from 1024 queries and half a query per list, 0 never, 1 whenever the batch is served in the order of its nearest lists */
+#define HNSWGPU_TUNE_STREAM_HOME 44 /* the home-list pass of large IVF batches (every list once through the matrix cores in half precision for all the queries it is nearest to): -1 from 512 queries and half a query per list, 0 never, 1 whenever the batch is served in the order of its nearest lists */
 #define HNSWGPU_TUNE_HOME_CHUNK 45 /* rows per work item of the home-list pass (a multiple of 64; 0 = auto) */
 #define HNSWGPU_TUNE_HOME_DEPTH 46 /* operand loads in flight per wave of the home-list pass: 4 / 8 / 12 / 16 / 24, the largest that divides the 32-element steps of a row and does not exceed this (default 12) */
 #define HNSWGPU_TUNE_HOME_STRAYS 47 /* home-list batches: a query the bounds pass appended no more than this many candidates to skips the per-survivor half-precision pass (the finish kernel fetches their f32 rows; default 32) */
-#define HNSWGPU_TUNE_COUNT 48
+#define HNSWGPU_TUNE_ROUTE_MFMA 48 /* centroid distances of IVF batches on the f32 matrix cores in the GEMV order (the same bits): -1 from 512 queries (cosine / dot, rows of 256 / 512 / 768 elements), 0 never, 1 whenever possible, > 1 that many slices of the table per group of 32 queries */
+#define HNSWGPU_TUNE_COUNT 49
 int hnswgpu_set_tuning(int32_t key, int64_t value);
 int hnswgpu_get_tuning(int32_t key, int64_t *value, int32_t *is_set);
 

@@ -1032,6 +1032,41 @@ def test_ivf_home_list_pass(eng, oracle, metric, dim, tune):
         idx.set_profiling(False)
 
 
+@pytest.mark.parametrize("metric,dim,nlist", [("cosine", 256, 50), ("dot", 256, 77), ("cosine", 512, 33), ("cosine", 768, 130), ("dot", 768, 64)])
+def test_ivf_routing_on_the_matrix_cores(eng, oracle, metric, dim, nlist, tune):
+    """The centroid distances of large batches come from the f32 matrix cores IN THE GEMV ORDER (ivf_route_mfma_kernel: one
+    v_mfma_f32_32x32x2_f32 chain per lane partial, the 64 partial tiles added in the butterfly's tree): the probed lists, their
+    order, and with them every id and distance bit must be what the VALU routing gives and what the oracle's device order
+    gives -- rows of very different scale, a zero query, a zero centroid row's worth of duplicates, table sizes that end inside
+    a 32-centroid tile, batches that end inside a 32-query group, every slicing of the table."""
+    O = oracle
+    code = {"cosine": O.COSINE, "dot": O.DOT}[metric]
+    rs = np.random.RandomState(dim + nlist)
+    base = _data(O, 6000, dim, "clustered", num_clusters=nlist, noise_level=0.3, seed=91)
+    base *= np.exp(rs.uniform(-3, 3, (len(base), 1))).astype(np.float32)      # (row norms of very different size)
+    base[100:140] = base[7]                                                    # duplicates: ties between candidates
+    Q = _data(O, 170, dim, "clustered", num_clusters=nlist, noise_level=0.3, seed=92).astype(np.float32)
+    if metric == "cosine":                                                     # (dot: -0 against the engine's canonical +0, whatever the routing)
+        Q[5] = 0.0
+    Q[6] = base[7]
+    with eng.Index(base, metric) as idx:
+        idx.ivf_build(nlist, 3, 42)
+        cen, off, lids = idx.get_ivf()
+        idx.set_rejection_test(2)
+        tune.set("TILE_PAIRS", str(1 << 40))
+        tune.set("IVF_CODES", "1")
+        for nq, k, nprobe in [(170, 10, 8), (33, 5, nlist), (64, 10, 1)]:
+            oi, od, _ = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=code, mode=O.MODE_DEV)
+            tune.set("ROUTE_MFMA", "0")
+            ids0, d0, pr0 = idx.ivf_search(Q[:nq], k, nprobe, want_probes=True)
+            assert_exact(ids0, d0, oi, od, "VALU routing %s dim %d nq=%d" % (metric, dim, nq))
+            for sl in (1, 2, 3, 64):                                           # auto, and explicit slicings of the table
+                tune.set("ROUTE_MFMA", str(sl))
+                ids, d, pr = idx.ivf_search(Q[:nq], k, nprobe, want_probes=True)
+                np.testing.assert_array_equal(pr, pr0, err_msg="probed lists %s dim %d nq=%d slices %d" % (metric, dim, nq, sl))
+                assert_exact(ids, d, oi, od, "matrix-core routing %s dim %d nq=%d slices %d" % (metric, dim, nq, sl))
+
+
 @pytest.mark.parametrize("dim", [128, 768, 3072])
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
 def test_bounds_randomised_soak(eng, metric, dim):
