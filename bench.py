@@ -535,10 +535,12 @@ def ivf_roofline(engine, dev, args, traffic):
     cent_h, off, lids_h = idx.get_ivf()
     lens = np.diff(off)
     out = {}
-    for nq in (1, 32, 256, 1024, 4096, "32_f32", "4096_f32"):
-        f32_only = isinstance(nq, str)                 # the same batch with the int8 / half-precision rows switched off
-        key, nq = nq, int(nq.split("_")[0]) if f32_only else nq
+    for nq in (1, 32, 256, 1024, 2048, 4096, "4096_nohome", "32_f32", "4096_f32"):
+        f32_only = isinstance(nq, str) and nq.endswith("_f32")   # the same batch with the int8 / half-precision rows switched off
+        no_home = isinstance(nq, str) and nq.endswith("_nohome")  # ... with the home-list pass of large batches switched off (A/B, same box)
+        key, nq = nq, int(nq.split("_")[0]) if isinstance(nq, str) else nq
         idx.set_rejection_test(0 if f32_only else 1)
+        engine.set_tuning("STREAM_HOME", 0 if no_home else None)
         Q = Qa[:nq].contiguous()
         _, _, probes = idx.ivf_search(Q.cpu().numpy(), K, nprobe, want_probes=True)
         rows = int(lens[probes.ravel()].sum())
@@ -571,6 +573,7 @@ def ivf_roofline(engine, dev, args, traffic):
         if base_h is not None:
             out[key]["parity_checked"] = ivf_parity_check(idx, base_h, cent_h, off, lids_h, Q, nprobe, surv / max(steps * nq, 1))
     idx.set_rejection_test(1)
+    engine.set_tuning("STREAM_HOME", None)
     # single query, true latency: one call, one sync, host timer
     lat = []
     o1 = (torch.empty((1, K), dtype=torch.int32, device=dev), torch.empty((1, K), dtype=torch.float32, device=dev))
@@ -650,10 +653,17 @@ def ivf_roofline(engine, dev, args, traffic):
            "batch_32": r,
            "batch_256": m,
            "batch_1024": out[1024],
+           "batch_2048": out[2048],
            "batch_4096": out[4096],
+           "batch_4096_home_list_pass_off": out["4096_nohome"],
            "stream_note": "batches of 1.5 M candidates and more (48 queries here) pass the int8 survivors (survivors_per_query of batch_32: ~3 % of the "
                           "candidates) through half-precision list rows before any f32 row is fetched: survivors_per_query "
-                          "of batch_256 / 1024 / 4096 counts the f32 rows that remain",
+                          "of batch_256 / 1024 / 2048 / 4096 counts the f32 rows that remain.  From 512 queries (and half a query per list) "
+                          "the half-precision rows of every query's NEAREST list go once through the matrix cores for all the queries "
+                          "it is nearest to (ivf_home_kernel, v_mfma_f32_16x16x32_f16), the queries' thresholds come from there "
+                          "(ivf_home_select_kernel) and the centroid distances from the f32 matrix cores in the GEMV order "
+                          "(ivf_route_mfma_kernel); avg_scan_ms stays the int8 bounds kernel.  batch_4096_home_list_pass_off: the same "
+                          "batch with that pass switched off (hnswgpu_set_tuning STREAM_HOME 0), same run",
            "batch_1": {"kernel_ms": o["avg_scan_ms"], "algorithmic_bytes": int(o["algorithmic_GB"] * 1e9),
                        "int8_bytes": int(o["unique_rows"] * code_row), "survivors": o["survivors_per_query"],
                        "achieved": round(o["unique_rows"] * code_row / 1e9 / (o["avg_scan_ms"] * 1e-3), 1), "unit": "GB/s",
