@@ -106,6 +106,19 @@ else:
         torch.cuda.synchronize()
         dt = (time.time() - t) / 5
         print("  batch %4d: %.3f ms per batch = %.0f QPS" % (nq, dt * 1e3, nq / dt), flush=True)
+    engine.set_tuning("STREAM_HOME", 0)                # the same batch without the home-list pass of large batches (A/B)
+    ref_ids, ref_d = idx.ivf_search_dev(Q, 10, 32)
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(5):
+        idx.ivf_search_dev(Q, 10, 32)
+    torch.cuda.synchronize()
+    print("  batch 1024, home-list pass off: %.3f ms per batch" % ((time.time() - t) / 5 * 1e3), flush=True)
+    engine.set_tuning("STREAM_HOME", None)
+    ids, d = idx.ivf_search_dev(Q, 10, 32)
+    torch.cuda.synchronize()
+    print("  ids / distance bits equal with the pass on and off: %s / %s" % (
+        bool((ids == ref_ids).all()), bool((d.view(torch.int32) == ref_d.view(torch.int32)).all())), flush=True)
     ti, _ = idx.exact_knn_dev(Q[:64].contiguous(), 10)
     ids, _ = idx.ivf_search_dev(Q[:64].contiguous(), 10, 32)
     torch.cuda.synchronize()
