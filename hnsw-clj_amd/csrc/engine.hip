@@ -714,52 +714,55 @@ __global__ __launch_bounds__(kWG) void ivf_route_dist_kernel(RouteArgs a) {
 
 // The same distances ON THE F32 MATRIX CORES, in the GEMV order, bit for bit (cosine / dot, rows of 256 / 512 / 768 elements).
 // The GEMV order is 64 independent chains -- lane l accumulates elements 256 c + 4 l + j, one fmaf each -- whose results are
-// added in the xor butterfly's tree.  v_mfma_f32_32x32x2_f32 IS an f32 fmaf chain over its two k-slots, so one chain of
-// 2 NCH of them computes lane partial l of a whole 32-centroid x 32-query tile at once (slot h = element 2 p + h of the
-// lane's four), and the 64 partial tiles are added pairwise in the butterfly's association: tile l joins the pending tile of
-// its level like a carry in a binary counter (at most six pending: 112 registers).  tools/micro/mfma_gemv_order.hip checks
-// the scheme against lane_partial + wave_sum on the hardware -- rows of scales e^+-12, denormal products, signed zeros: equal
-// in every bit.  The VALU form is bound by its issue rate (4096 x 1024 x 768: 150 us); this one by the f32 matrix rate.
-// A workgroup keeps 32 queries in LDS (all of K, rows padded by four floats: conflict-free 16-byte reads) and its four waves
-// take the 32-centroid tiles of a slice of the table, the A operands straight from the (L2-resident) table: lane (i, h) reads
-// the float4 of centroid i that holds its k-slots and picks by h.
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-constexpr int kRouteTileQ = 32;
-__host__ __device__ constexpr int route_mfma_ldq(int nch) { return 256 * nch + 4; }
-__host__ __device__ constexpr int route_mfma_astr(int nch) { return 32 * nch + 4; }
-__host__ __device__ constexpr size_t route_mfma_lds(int nch) { return sizeof(float) * (kRouteTileQ * route_mfma_ldq(nch) + kNWave * 32 * route_mfma_astr(nch)); }
+// added in the xor butterfly's tree.  An f32 matrix instruction IS an fmaf chain over its k-slots (v_mfma_f32_32x32x2_f32:
+// slot 0, 1; v_mfma_f32_16x16x4_f32: slot 0, 1, 2, 3 -- tools/micro/mfma16_order.hip), so a chain of them over the elements of
+// lane partial l computes that partial for a whole tile of (centroid, query) pairs at once, and the 64 partial tiles are added
+// pairwise in the butterfly's association: tile l joins the pending tile of its level like a carry in a binary counter (at
+// most six pending).  tools/micro/mfma_gemv_order.hip checks the scheme against lane_partial + wave_sum on the hardware --
+// rows of scales e^+-12, denormal products, signed zeros: equal in every bit.  The VALU form is bound by its issue rate (4096 x
+// 1024 x 768: 150 us); this one by the f32 matrix rate.
+//
+// First built on v_mfma_f32_32x32x2_f32 (32 queries per workgroup in 99 KB of LDS: one wave per SIMD, 2 NCH instructions and
+// four operand selects per lane partial, 16-register tiles): 127 us at 4096 queries -- the tree's additions and the matrix
+// instructions took turns instead of overlapping.  Lessons that stay: a conditional load becomes a branch and every wait a
+// vmcnt(0); the compiler re-loads "prefetched" operands in the iteration that uses them unless a memory clobber pins them;
+// operand arrays behind such a clobber go to scratch memory, named registers do not; lane (i, h) fetching its own 16 bytes of
+// 32 rows per instruction makes the CU's address unit the bound (eight rows x 128 B per instruction into an LDS slab instead).
+__host__ __device__ constexpr int route_mfma_ldq(int nch) { return 256 * nch + 4; }   // floats per staged query (conflict-free reads)
+__host__ __device__ constexpr int route_mfma_astr(int nch) { return 32 * nch + 4; }   // floats per row of a wave's operand slab
+
+// On v_mfma_f32_16x16x4_f32 the four k-slots are exactly the four elements 256 c + 4 l + 0..3 of a lane partial: ONE
+// instruction per (lane partial, chunk), operands one float per lane (lane (i, s) reads element s of row i's four: no
+// selects), tiles of 16 centroids x 16 queries in four registers (the tree's additions cost a quarter), 16 queries per
+// workgroup = 49 KB of LDS + a 6 KB operand slab per wave (eight lane partials of 16 centroids, fetched eight rows x 128 B per
+// instruction, the next block on its way under this one's matrix work): two workgroups per CU, two waves per SIMD, and one's
+// additions run under the other's matrix instructions.  4096 x 1024 x 768: 99 us (65 TFLOP/s), 1024: 33, 256: 13.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kRoute16Q = 16;
+__host__ __device__ constexpr size_t route_mfma16_lds(int nch) {
+    return sizeof(float) * (kRoute16Q * route_mfma_ldq(nch) + kNWave * 16 * route_mfma_astr(nch));
+}
 
 template <int NCH>
-__global__ __launch_bounds__(kWG) void ivf_route_mfma_kernel(RouteArgs a) {
+__global__ __launch_bounds__(kWG) void ivf_route_mfma16_kernel(RouteArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int LDQ = route_mfma_ldq(NCH);
-    constexpr int ASTR = route_mfma_astr(NCH);  // floats per row of a wave's operand slab: NCH x 32 + 4 (conflict-free 16-byte reads)
-    float *qs = reinterpret_cast<float *>(smem);  // [32][LDQ]
-    float *as_all = qs + kRouteTileQ * LDQ;       // [waves][32][ASTR]: the A operands of one block of eight lane partials
-    __shared__ float qn_s[kRouteTileQ];
+    constexpr int ASTR = route_mfma_astr(NCH);
+    float *qs = reinterpret_cast<float *>(smem);  // [16][LDQ]
+    float *as_all = qs + kRoute16Q * LDQ;         // [waves][16][ASTR]: the A operands of one block of eight lane partials
+    __shared__ float qn_s[kRoute16Q];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int grp = blockIdx.x / a.blocks_per_query, bx = blockIdx.x % a.blocks_per_query;
-    const int q0 = grp * kRouteTileQ;
-    const int i = lane & 31, kh = lane >> 5;
+    const int q0 = grp * kRoute16Q;
+    const int i = lane & 15, ks = lane >> 4;
     const int64_t r0 = static_cast<int64_t>(bx) * a.rows_per_block;
     const int64_t r1 = r0 + a.rows_per_block < a.nlist ? r0 + a.rows_per_block : a.nlist;
-    // A operands: a block of eight lane partials of the wave's 32 centroids is NCH x 128 contiguous bytes per row -- fetched
-    // eight rows x 128 B per instruction (lane -> (row lane / 8 + 8 k, piece lane % 8)), parked in the wave's LDS slab and
-    // read from there in operand order.  (Straight from the table in operand order -- lane (i, h) its own 16 bytes, 32 rows per
-    // instruction -- the CU's one address unit was the bound: 37 us per tile against 10 of matrix work.)
-    float *aslab = as_all + wave * 32 * ASTR;
+    float *aslab = as_all + wave * 16 * ASTR;
     const int prow = lane >> 3, ppiece = lane & 7;
-    // (the operands of a block in NAMED registers, by macro: as arrays -- whatever the unrolling -- they ended up in scratch memory)
-#define RM_FOR12(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
-#define RM_ROWPTR(k, tb_)                                                                                  \
-    (a.cent + ((tb_) + ((k) & 3) * 8 + prow < a.nlist ? (tb_) + ((k) & 3) * 8 + prow : a.nlist - 1) * a.ld + 256 * ((k) >> 2) + 4 * ppiece)
-    int64_t tb = r0 + 32 * wave;
-    // ---- the group's queries (zero rows behind the batch's end) and their norms (query_norm: the GEMV order's): a wave's eight
-    // queries all in flight before the first is touched
     {
-        float4 qq[kRouteTileQ / kNWave][NCH];
+        float4 qq[kRoute16Q / kNWave][NCH];
 #pragma unroll
-        for (int t = 0; t < kRouteTileQ / kNWave; t++) {
+        for (int t = 0; t < kRoute16Q / kNWave; t++) {
             const int g = wave + t * kNWave;
             if (q0 + g < a.nq && a.dim == 256 * NCH && (a.qld & 3) == 0) {  // whole 16-byte pieces (load_query checks every element)
 #pragma unroll
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(kWG) void ivf_route_mfma_kernel(RouteArgs a) {
             }
         }
 #pragma unroll
-        for (int t = 0; t < kRouteTileQ / kNWave; t++) {
+        for (int t = 0; t < kRoute16Q / kNWave; t++) {
             const int g = wave + t * kNWave;
 #pragma unroll
             for (int c = 0; c < NCH; c++) *reinterpret_cast<float4 *>(qs + g * LDQ + 256 * c + 4 * lane) = qq[t][c];
@@ -780,94 +783,48 @@ __global__ __launch_bounds__(kWG) void ivf_route_mfma_kernel(RouteArgs a) {
         }
     }
     __syncthreads();
-    const float *qrow = qs + i * LDQ;      // B operand: lane (j = i, h) reads query j
-    const float *arow = aslab + i * ASTR;  // A operand: lane (i, h) reads centroid i of the tile
-    for (; tb < r1; tb += 32 * kNWave) {
-        // (rows behind the table's end: the last row again, computed and not stored)
-#define RM_DECL(k) float4 ac##k = make_float4(0.0f, 0.0f, 0.0f, 0.0f), an##k = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        RM_FOR12(RM_DECL)
-#undef RM_DECL
-#define RM_FIRST(k) \
-    if constexpr (k < 4 * NCH) ac##k = *reinterpret_cast<const float4 *>(RM_ROWPTR(k, tb));
-        RM_FOR12(RM_FIRST)
-#undef RM_FIRST
-        f32x16_t s3, s4, s5, fin;  // pending tiles of levels 3, 4, 5 of the tree (blocks of 8, 16, 32 lane partials); the sum
+    const float *qrow = qs + i * LDQ + ks;      // B operand: lane (j = i, s) reads element s of query j's four
+    const float *arow = aslab + i * ASTR + ks;  // A operand: lane (i, s) of centroid i's
+#define R16_FOR6(M) M(0) M(1) M(2) M(3) M(4) M(5)
+#define R16_ROWPTR(k, tb_)                                                                                 \
+    (a.cent + ((tb_) + ((k) & 1) * 8 + prow < a.nlist ? (tb_) + ((k) & 1) * 8 + prow : a.nlist - 1) * a.ld + 256 * ((k) >> 1) + 4 * ppiece)
+    for (int64_t tb = r0 + 16 * wave; tb < r1; tb += 16 * kNWave) {
+#define R16_DECL(k) float4 ac##k = make_float4(0.0f, 0.0f, 0.0f, 0.0f), an##k = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        R16_FOR6(R16_DECL)
+#undef R16_DECL
+#define R16_FIRST(k) \
+    if constexpr (k < 2 * NCH) ac##k = *reinterpret_cast<const float4 *>(R16_ROWPTR(k, tb));
+        R16_FOR6(R16_FIRST)
+#undef R16_FIRST
+        f32x4_t s3, s4, s5, fin;  // pending tiles of levels 3, 4, 5 of the tree; the sum
 #pragma unroll 1
         for (int lb = 0; lb < 8; lb++) {
-            // this block's operands into the slab (the reads of the previous block are ahead of these writes in the wave's LDS
-            // queue), the next block's on their way under this block's matrix work
-#define RM_PARK(k) \
-    if constexpr (k < 4 * NCH) *reinterpret_cast<float4 *>(aslab + ((k & 3) * 8 + prow) * ASTR + (k >> 2) * 32 + 4 * ppiece) = ac##k;
-            RM_FOR12(RM_PARK)
-#undef RM_PARK
+#define R16_PARK(k) \
+    if constexpr (k < 2 * NCH) *reinterpret_cast<float4 *>(aslab + ((k & 1) * 8 + prow) * ASTR + (k >> 1) * 32 + 4 * ppiece) = ac##k;
+            R16_FOR6(R16_PARK)
+#undef R16_PARK
             const int nlb = lb + 1 < 8 ? lb + 1 : 7;  // (no branch around the loads: their wait counts stay exact)
-#define RM_NEXT(k) \
-    if constexpr (k < 4 * NCH) an##k = *reinterpret_cast<const float4 *>(RM_ROWPTR(k, tb) + 32 * nlb);
-            RM_FOR12(RM_NEXT)
-#undef RM_NEXT
-            asm volatile("" ::: "memory");  // (or the compiler forgets the prefetch: it re-loads the operands in the iteration that uses them)
-            f32x16_t st[3], T;
+#define R16_NEXT(k) \
+    if constexpr (k < 2 * NCH) an##k = *reinterpret_cast<const float4 *>(R16_ROWPTR(k, tb) + 32 * nlb);
+            R16_FOR6(R16_NEXT)
+#undef R16_NEXT
+            asm volatile("" ::: "memory");  // (or the compiler forgets the prefetch)
+            f32x4_t st[3], T;
             const float *qb = qrow + 32 * lb;
-            // Two lane partials at a time: their chains alternate on the matrix cores (a dependent v_mfma_f32_32x32x2_f32 waits
-            // out its predecessor -- one chain alone ran at a third of the matrix rate), and the operands of the NEXT pair leave LDS
-            // while this one is computed (one wave per SIMD has nobody else to hide an LDS round trip behind; the compiler keeps
-            // that order only behind a barrier).
-            const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#define RM_DECL6(P) float4 P##A0 = z4, P##A1 = z4, P##A2 = z4, P##B0 = z4, P##B1 = z4, P##B2 = z4;
-            RM_DECL6(x) RM_DECL6(y) RM_DECL6(nx) RM_DECL6(ny)
-#undef RM_DECL6
-#define RM_OPERANDS(P, u_)                                                             \
-    do {                                                                               \
-        P##A0 = *reinterpret_cast<const float4 *>(arow + 4 * (u_));                      \
-        P##B0 = *reinterpret_cast<const float4 *>(qb + 4 * (u_));                        \
-        if constexpr (NCH > 1) {                                                       \
-            P##A1 = *reinterpret_cast<const float4 *>(arow + 32 + 4 * (u_));             \
-            P##B1 = *reinterpret_cast<const float4 *>(qb + 256 + 4 * (u_));              \
-        }                                                                              \
-        if constexpr (NCH > 2) {                                                       \
-            P##A2 = *reinterpret_cast<const float4 *>(arow + 64 + 4 * (u_));             \
-            P##B2 = *reinterpret_cast<const float4 *>(qb + 512 + 4 * (u_));              \
-        }                                                                              \
-    } while (0)
-#define RM_CHAIN2(c_)                                                                                                   \
-    do {                                                                                                                \
-        P0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kh ? xA##c_.y : xA##c_.x, kh ? xB##c_.y : xB##c_.x, P0, 0, 0, 0);       \
-        P1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kh ? yA##c_.y : yA##c_.x, kh ? yB##c_.y : yB##c_.x, P1, 0, 0, 0);       \
-        P0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kh ? xA##c_.w : xA##c_.z, kh ? xB##c_.w : xB##c_.z, P0, 0, 0, 0);       \
-        P1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kh ? yA##c_.w : yA##c_.z, kh ? yB##c_.w : yB##c_.z, P1, 0, 0, 0);       \
-    } while (0)
-#define RM_ROLL6(D, S) D##A0 = S##A0, D##A1 = S##A1, D##A2 = S##A2, D##B0 = S##B0, D##B1 = S##B1, D##B2 = S##B2
-            RM_OPERANDS(x, 0);
-            RM_OPERANDS(y, 1);
 #pragma unroll
-            for (int up = 0; up < 4; up++) {
-                if (up + 1 < 4) {
-                    RM_OPERANDS(nx, 2 * up + 2);
-                    RM_OPERANDS(ny, 2 * up + 3);
-                }
-                asm volatile("" ::: "memory");
-                f32x16_t P0, P1;
+            for (int u = 0; u < 8; u++) {
+                f32x4_t P = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int g = 0; g < 16; g++) P0[g] = P1[g] = 0.0f;
-                RM_CHAIN2(0);
-                if constexpr (NCH > 1) RM_CHAIN2(1);
-                if constexpr (NCH > 2) RM_CHAIN2(2);
-                RM_ROLL6(x, nx);
-                RM_ROLL6(y, ny);
-                // the butterfly's tree: lane partial 2 up waits at level 0 for 2 up + 1; their sum climbs while the levels are taken
-#pragma unroll
-                for (int g = 0; g < 16; g++) P1[g] = P0[g] + P1[g];
-                int t = up, lvl = 1;
+                for (int c = 0; c < NCH; c++) P = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[32 * c + 4 * u], qb[256 * c + 4 * u], P, 0, 0, 0);
+                int t = u, lvl = 0;
                 while (t & 1) {  // (compile-time after unrolling)
-#pragma unroll
-                    for (int g = 0; g < 16; g++) P1[g] = st[lvl][g] + P1[g];
+                    P = st[lvl] + P;
                     t >>= 1;
                     lvl++;
                 }
-                if (lvl < 3) st[lvl] = P1;
-                else T = P1;
+                if (lvl < 3) st[lvl] = P;
+                else T = P;
             }
-            // the block's tile joins the pending tiles of the levels above (uniform branches: lb is a scalar)
             if (lb & 1) {
                 T = s3 + T;
                 if (lb & 2) {
@@ -880,35 +837,31 @@ __global__ __launch_bounds__(kWG) void ivf_route_mfma_kernel(RouteArgs a) {
             } else {
                 s3 = T;
             }
-#define RM_ROLL(k) ac##k = an##k;
-            RM_FOR12(RM_ROLL)
-#undef RM_ROLL
+#define R16_ROLL(k) ac##k = an##k;
+            R16_FOR6(R16_ROLL)
+#undef R16_ROLL
         }
-        // C/D: lane holds column j = i (the query); register g is row (g & 3) + 8 (g >> 2) + 4 kh of the tile
+        // C/D: lane holds column j = i (the query); register g is row 4 s + g of the tile
         const int qi = q0 + i;
         if (qi < a.nq) {
             const float qn = qn_s[i];
             float *orow = a.dense + static_cast<int64_t>(qi) * a.nlist;
-            float rn[16];  // the tile's norms first, all in flight (a load per result in front of its divide was a round trip each)
+            float rn[4];
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-                const int64_t cc = tb + 8 * (g >> 2) + 4 * kh + (g & 3);
+            for (int g = 0; g < 4; g++) {
+                const int64_t cc = tb + 4 * ks + g;
                 rn[g] = (a.metric == METRIC_COS && cc < r1) ? a.cnorms[cc] : 0.0f;
             }
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-                const int64_t cc = tb + 8 * (g >> 2) + 4 * kh + (g & 3);
+            for (int g = 0; g < 4; g++) {
+                const int64_t cc = tb + 4 * ks + g;
                 if (cc < r1) orow[cc] = finish_dist(a.metric, fin[g], qn, rn[g]);
             }
         }
     }
+#undef R16_ROWPTR
+#undef R16_FOR6
 }
-
-#undef RM_ROWPTR
-#undef RM_FOR12
-#undef RM_OPERANDS
-#undef RM_CHAIN2
-#undef RM_ROLL6
 
 // The same tail as a launch of its own, one workgroup per query, behind a distance pass that serves many queries per
 // centroid row (large batches): select, probe table, pairs filed by list, query codes, first threshold.
@@ -979,27 +932,26 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
         // larger batches: the distances by workgroups that share their centroid rows among a group of queries, then the tail
         // as a launch of its own (plain loads: the distances come from an earlier launch)
         // (the group's queries are staged in LDS: 1 KB x NCH each, 48 KB at most)
-        // cosine / dot, rows of 256 / 512 / 768 elements, from 512 queries: the GEMV-order distances on the f32 matrix cores
-        // (1M x 768 / 1024 centroids, VALU vs matrix cores: 256 queries 20 vs 36 us, 1024: 54 vs 35, 4096: 150 vs 127; a tile of
-        // 32 x 32 distances takes a wave 23 us -- 2.3 x its matrix time --, staging a group's queries 12: what is left to gain)
+        // cosine / dot, rows of 256 / 512 / 768 elements, from 256 queries: the GEMV-order distances on the f32 matrix cores
+        // (1M x 768 / 1024 centroids, VALU vs matrix cores: 32 queries 6.7 vs 11.8 us, 64: 8.6 vs 11.8, 128: 12.4 vs 11.9, 256:
+        // 20 vs 13, 1024: 54 vs 33, 4096: 150 vs 99)
         const int64_t rm = tune(HNSWGPU_TUNE_ROUTE_MFMA, -1);  // -1 that rule, 0 never, 1 whenever possible, > 1: slices per query group
-        if (!l2 && idx->nch <= 3 && idx->ld == 256 * idx->nch && rm != 0 && (rm > 0 || nq >= 512)) {
-            const int64_t ngroups = (nq + kRouteTileQ - 1) / kRouteTileQ, tiles = (idx->nlist + 31) / 32;
-            // slices of the table per query group: 256 workgroups and more where the table allows (a wave takes whole tiles)
-            int64_t split = std::max<int64_t>(1, std::min<int64_t>((tiles + kNWave - 1) / kNWave, (512 + ngroups - 1) / ngroups));
+        if (!l2 && idx->nch <= 3 && idx->ld == 256 * idx->nch && rm != 0 && (rm > 0 || nq >= 256)) {
+            const int64_t ngroups = (nq + kRoute16Q - 1) / kRoute16Q, tiles = (idx->nlist + 15) / 16;
+            int64_t split = std::max<int64_t>(1, std::min<int64_t>((tiles + kNWave - 1) / kNWave, (1024 + ngroups - 1) / ngroups));
             if (rm > 1) split = std::max<int64_t>(1, std::min<int64_t>(rm, tiles));  // (tuning: slices per query group)
-            const int64_t tps = (tiles + split - 1) / split;  // tiles per slice
-            a.rows_per_block = static_cast<int32_t>(tps * 32);
+            const int64_t tps = (tiles + split - 1) / split;
+            a.rows_per_block = static_cast<int32_t>(tps * 16);
             a.blocks_per_query = static_cast<int32_t>((tiles + tps - 1) / tps);
-            const size_t mlds = route_mfma_lds(idx->nch);
-#define CALLM(N)                                                                                                                          \
-    do {                                                                                                                                  \
-        static bool attr_done[64] = {};                                                                                                   \
-        if (mlds > 48 * 1024 && attr_needed(attr_done))                                                                                   \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_route_mfma_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       static_cast<int>(route_mfma_lds(N))));                              \
-        hipLaunchKernelGGL((ivf_route_mfma_kernel<N>), dim3(static_cast<unsigned>(ngroups * a.blocks_per_query)), dim3(kWG), mlds, st, a); \
-    } while (0)
+            const size_t mlds = route_mfma16_lds(idx->nch);
+#define CALLM(N)                                                                                                                            \
+do {                                                                                                                                    \
+    static bool attr_done[64] = {};                                                                                                     \
+    if (mlds > 48 * 1024 && attr_needed(attr_done))                                                                                     \
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_route_mfma16_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   static_cast<int>(route_mfma16_lds(N))));                                                            \
+    hipLaunchKernelGGL((ivf_route_mfma16_kernel<N>), dim3(static_cast<unsigned>(ngroups * a.blocks_per_query)), dim3(kWG), mlds, st, a); \
+} while (0)
             switch (idx->nch) {
                 case 1: CALLM(1); break;
                 case 2: CALLM(2); break;

@@ -1,6 +1,7 @@
 // Developer micro-test: the GEMV summation order of kernels.hpp (lane l accumulates elements 256 c + 4 l + j with one fmaf
 // each, the 64 lane partials are added in the xor butterfly's tree) reproduced bit for bit on the f32 matrix cores: one
-// v_mfma_f32_32x32x2_f32 chain per LANE PARTIAL (K = 2 per instruction: 2 NCH instructions per partial), the 64 partial
+// v_mfma_f32_32x32x2_f32 chain per LANE PARTIAL (K = 2 per instruction: 2 NCH instructions per partial; or v_mfma_f32_16x16x4_f32:
+// K = 4, NCH instructions -- the production kernel's form, ivf_route_mfma16_kernel), the 64 partial
 // tiles added pairwise in the butterfly's association (a binary counter of pending tiles).  32 rows x 32 queries x 768,
 // random data, rows of very different scale, denormal products.
 // build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I hnsw-clj_amd/csrc tools/micro/mfma_gemv_order.hip -o /tmp/mfma_gemv_order
@@ -54,6 +55,27 @@ __global__ void k_mfma(const float *A, const float *B, float *out) {
     for (int g = 0; g < 16; g++) out[((g & 3) + 8 * (g >> 2) + 4 * kh) * 32 + i] = st[6][g];
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void k_mfma16(const float *A, const float *B, float *out) {  // rows 0..15 x queries 0..15: the production form
+    const int lane = threadIdx.x, i = lane & 15, ks = lane >> 4;
+    f32x4 st[7];
+#pragma unroll
+    for (int l = 0; l < 64; l++) {
+        f32x4 P = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+            P = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i * D + 256 * c + 4 * l + ks], B[i * D + 256 * c + 4 * l + ks], P, 0, 0, 0);
+        int t = l, lvl = 0;
+        while (t & 1) {
+            P = st[lvl] + P;
+            t >>= 1;
+            lvl++;
+        }
+        st[lvl] = P;
+    }
+    for (int g = 0; g < 4; g++) out[(4 * ks + g) * 32 + i] = st[6][g];
+}
+
 int main() {
     static float hA[32 * D], hB[32 * D], h1[32 * 32], h2[32 * 32];
     srand(11);
@@ -85,6 +107,16 @@ int main() {
                 if (r == 5 || q == 6) badden++;
                 else if (bad++ < 8) printf("differs at row %d query %d: valu %.9g mfma %.9g\n", r, q, h1[r * 32 + q], h2[r * 32 + q]);
             }
+    static float h3[32 * 32];
+    (void)hipMemset(O2, 0, sizeof(h2));
+    k_mfma16<<<1, 64>>>(A, B, O2);
+    (void)hipMemcpy(h3, O2, sizeof(h3), hipMemcpyDeviceToHost);
+    int bad16 = 0;
+    for (int r = 0; r < 16; r++)
+        for (int q = 0; q < 16; q++)
+            if (memcmp(&h1[r * 32 + q], &h3[r * 32 + q], 4)) bad16++;
+    printf("v_mfma_f32_16x16x4_f32 form (rows / queries 0..15, denormal row 5 and query 6 included): %d of 256 differ\n", bad16);
+    bad += bad16;
     printf("GEMV order on the matrix cores: %d of 1024 differ outside the denormal row / query; %d of 63 differ on them (valu[5][6] = %g, mfma = %g)\n",
            bad, badden, h1[5 * 32 + 6], h2[5 * 32 + 6]);
     return bad ? 1 : 0;
