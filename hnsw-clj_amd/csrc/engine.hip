@@ -139,7 +139,7 @@ int launch_heavy(const HeavyArgs &a, hipStream_t st) {
 // the home lists through the matrix cores in half precision (stream_kernels.hpp, step 1a): `blocks` bounds the work list
 int launch_home(const HomeArgs &a, int64_t blocks, int nch, hipStream_t st) {
     if (blocks <= 0) return 0;
-    HG_REQUIRE(a.ld % 128 == 0 && a.metric != METRIC_L2, HNSWGPU_EINVAL, "home-list pass: cosine / dot rows of whole 128-element steps only");
+    HG_REQUIRE(a.ld % 128 == 0, HNSWGPU_EINVAL, "home-list pass: rows of whole 128-element steps only");
     // operand loads in flight per wave: the kernel lives on them (one query group per 16-row block is 24 KB of rows and
     // ~1.5 us of a CU's share of HBM); a depth has to divide the steps of a row
     const int S = static_cast<int>(a.ld / 32), want = static_cast<int>(tune(HNSWGPU_TUNE_HOME_DEPTH, 12));
@@ -2215,7 +2215,7 @@ int hnswgpu_ivf_home_bounds(hnswgpu_index *idx, const float *Q, int32_t nq, int6
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     HG_REQUIRE(idx->d_lhalf, HNSWGPU_EINVAL, "this handle has no half-precision list rows (no lists, no int8 rows, or HNSWGPU_IVF_HALF=0)");
-    HG_REQUIRE(idx->metric != METRIC_L2 && idx->ld % 128 == 0, HNSWGPU_EINVAL, "the home-list pass serves cosine / dot rows of whole 128-element steps");
+    HG_REQUIRE(idx->ld % 128 == 0, HNSWGPU_EINVAL, "the home-list pass serves rows of whole 128-element steps");
     hipStream_t st = idx->stream;
     HG_TRY(begin_call(idx, st));
     HG_TRY(upload_queries(idx, Q, nq, st));

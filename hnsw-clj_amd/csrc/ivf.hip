@@ -831,14 +831,14 @@ static bool ivf_ordered_mode(const hnswgpu_index *idx, int32_t nq, bool grouped)
 }
 // The home-list pass (stream_kernels.hpp, step 1a): batches in which the lists are home to about a query each or more --
 // every home list once through the matrix cores in half precision for all of its queries (ivf_home_kernel) instead of a
-// half row per (query, survivor), and the queries' thresholds from there instead of from 64 sampled f32 rows.  cosine /
-// dot, rows of whole 128-element steps; from 512 queries and half a query per list (measured on the bench index, on / off: batch
+// half row per (query, survivor), and the queries' thresholds from there instead of from 64 sampled f32 rows.  Rows of whole
+// 128-element steps; from 512 queries and half a query per list (measured on the bench index, on / off: batch
 // 128 0.265 / 0.266 ms, 256 0.321 / 0.318, 512 0.383 / 0.399, 1024 0.480 / 0.558); HNSWGPU_TUNE_STREAM_HOME: -1 this rule, 0
 // never, 1 whenever the queries are ordered.  Decided BEFORE the routing (whose tail then skips the threshold seed) and again by the scan: one rule.
 static bool ivf_home_mode(const hnswgpu_index *idx, int32_t nq, int32_t nprobe, bool grouped) {
     const int64_t home_env = tune(HNSWGPU_TUNE_STREAM_HOME, -1);
     const int64_t hstride = (idx->max_list_len + 15) / 16 * 16;
-    return ivf_mid_mode(idx, nq, nprobe) && ivf_ordered_mode(idx, nq, grouped) && idx->metric != METRIC_L2 && idx->ld % 128 == 0 &&
+    return ivf_mid_mode(idx, nq, nprobe) && ivf_ordered_mode(idx, nq, grouped) && idx->ld % 128 == 0 &&
            home_env != 0 && tune(HNSWGPU_TUNE_MID_SLICES, 0) <= 1 && tune(HNSWGPU_TUNE_MID_COMPACT, 1) != 0 &&
            (home_env > 0 || (nq >= 512 && 2LL * nq >= idx->nlist)) && static_cast<int64_t>(nq) * hstride * 8 <= (2LL << 30) &&
            (static_cast<int64_t>(nq) / home_group(idx->nch) + std::min<int64_t>(nq, idx->nlist)) * ((idx->max_list_len + 4095) / 4096) < (1LL << 30);

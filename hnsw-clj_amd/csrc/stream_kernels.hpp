@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kWG) void quantize_rows_half_kernel(const float *ro
     int field = static_cast<int>((__float_as_uint(mx) >> 23) & 0xffu) - 14;
     field = field < 1 ? 1 : (field > 253 ? 253 : field);
     const float s = __uint_as_float(static_cast<uint32_t>(field) << 23), is = __uint_as_float(static_cast<uint32_t>(254 - field) << 23);
-    float res = 0.0f;
+    float res = 0.0f, v2 = 0.0f;
     uint2 *dst = half + row * nvec;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
@@ -633,8 +633,10 @@ __global__ __launch_bounds__(kWG) void quantize_rows_half_kernel(const float *ro
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             h[j] = static_cast<_Float16>(e[j] * is);
-            const float d = e[j] - static_cast<float>(h[j]) * s;
+            const float back = static_cast<float>(h[j]) * s;  // (a power-of-two scale: exact)
+            const float d = e[j] - back;
             res = __builtin_fmaf(d, d, res);
+            v2 = __builtin_fmaf(back, back, v2);
         }
         if (c * kWave + lane < nvec) dst[c * kWave + lane] = __builtin_bit_cast(uint2, h);
     }
@@ -645,7 +647,8 @@ __global__ __launch_bounds__(kWG) void quantize_rows_half_kernel(const float *ro
     else if (metric == METRIC_DOT) E = 1.01f * res + 2.0e-5f * nv;
     else E = 1.01f * res;
     if (bad || !(E >= 0.0f)) E = __uint_as_float(0x7fc00000u);  // NaN: no bound, the exact path
-    if (lane == 0) meta[row] = make_float4(s, E, 0.0f, 1.0f / nv);
+    v2 = wave_sum(v2);  // |v'|^2 of the row as stored (the Euclidean home-list bounds: |q - v'|^2 = |q|^2 - 2 q.v' + |v'|^2)
+    if (lane == 0) meta[row] = make_float4(s, E, v2, 1.0f / nv);
 }
 
 __device__ __forceinline__ void half_bounds(int metric, float sum, float qn, float4 mt, float &lb, float &ub) {
@@ -688,8 +691,9 @@ __device__ __forceinline__ void half_bounds(int metric, float sum, float qn, flo
 // sum |a_i b_i| <= |a||b|; measured: 3e-7).  So with the row's stored E (1.01 res / |v| + 4e-5 for the cosine):
 //   cosine   c = 1 - s_q s S / (|q||v|)     lb/ub = c -/+ (E + 1.01 |e_q| / |q| + 1.1e-4)
 //   dot      d = -s_q s S                   lb/ub = d -/+ (|q| E + 1.01 |e_q| |v| + 1.1e-4 |q||v|)
-// (Euclidean handles keep the per-query pass for every survivor.)  The distances, and with them every result bit, still
-// come from the f32 rows in the finish kernel.
+//   L2       d2 = |q|^2 - 2 s_q s S + |v'|^2        lb/ub = sqrt(d2 -/+ eps) (1 -/+ 8e-6) -/+ E,  eps = 2 (1.1e-4 |q| + 1.01 |e_q|) |v'| + 4e-6 (...)
+// (|v'|^2 of the stored row sits in the row's meta word; E = 1.01 res: the triangle inequality on |v - v'|.)  The distances,
+// and with them every result bit, still come from the f32 rows in the finish kernel.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef float v4f32_t __attribute__((ext_vector_type(4)));
@@ -722,6 +726,18 @@ struct HomeArgs {
 // bounds from the matrix cores' sum S (in units of s_q s): sq = s_q, eq = 1.01 |e_q|, qn = |q|
 __device__ __forceinline__ void home_bounds(int metric, float S, float sq, float eq, float qn, float4 mt, float &lb, float &ub) {
     const float dh = (S * sq) * mt.x;
+    if (metric == METRIC_L2) {
+        // |q - v'|^2 = |q|^2 - 2 q.v' + |v'|^2 with the dot product from the matrix cores: within 2 (1.1e-4 |q| + |e_q|) |v'| of
+        // it, + the f32 rounding of the three terms (4e-6 of their magnitudes); then the triangle inequality on |v - v'| = res
+        const float q2 = qn * qn, nv = __builtin_sqrtf(mt.z);
+        const float d2 = (q2 - 2.0f * dh) + mt.z;
+        const float eps = 2.0f * __builtin_fmaf(kHomeAccum, qn, eq) * nv * (1.0f + 1.0e-6f) + 4.0e-6f * ((q2 + mt.z) + 2.0f * __builtin_fabsf(dh));
+        const float lo2 = d2 - eps, hi2 = d2 + eps;
+        lb = __builtin_sqrtf(lo2 > 0.0f ? lo2 : 0.0f) * (1.0f - 8.0e-6f) - mt.y;  // (NaN anywhere: a bound that excludes nothing, or NaN)
+        ub = __builtin_sqrtf(hi2) * (1.0f + 8.0e-6f) + mt.y;
+        if (!(eps >= 0.0f)) lb = ub = __uint_as_float(0x7fc00000u);
+        return;
+    }
     if (metric == METRIC_DOT) {
         const float nv = 1.0f / mt.w;
         const float W = __builtin_fmaf(qn, mt.y, __builtin_fmaf(eq, nv, kHomeAccum * (qn * nv))) * (1.0f + 1.0e-6f);
@@ -786,7 +802,7 @@ __global__ __launch_bounds__(kWG) void ivf_home_kernel(HomeArgs a) {
         load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
         bool bad;
         const float mx = wave_absmax<NCH>(q, bad);
-        const float qn = query_norm<NCH>(q);
+        const float qn = query_norm<NCH>(q);  // (|q| in the GEMV order's arithmetic: cosine and dot scale by it, Euclidean squares it)
         // s_q = 2^(e - 14): the scaled query fills fp16's range from the top (as the rows do)
         int field = static_cast<int>((__float_as_uint(mx) >> 23) & 0xffu) - 14;
         field = field < 1 ? 1 : (field > 253 ? 253 : field);

@@ -299,7 +299,7 @@ int hnswgpu_distance_bounds(hnswgpu_index *idx, const float *q, const int32_t *i
  * query, by the kernel the searches run: out_lb[i] <= distance <= out_ub[i], NaN where a row or the query has no bound. */
 int hnswgpu_ivf_half_bounds(hnswgpu_index *idx, const float *q, const int32_t *list_rows, int32_t m, float *out_lb,
                             float *out_ub);
-/* Large batches (from 512 queries and half a query per list; cosine / dot, rows of whole 128-element steps) put the
+/* Large batches (from 512 queries and half a query per list; rows of whole 128-element steps) put the
  * half-precision rows of a query's NEAREST list -- where nearly all of its int8 survivors sit -- through the matrix
  * cores, once per list for all the queries it is nearest to (v_mfma_f32_16x16x32_f16, the query split into two fp16
  * planes), instead of fetching a half row per (query, survivor).  This entry reports those bounds for the list rows

@@ -914,7 +914,7 @@ def test_half_precision_bounds_hold_and_are_tight(eng, metric, dim):
 
 
 @pytest.mark.parametrize("dim", [128, 384, 768, 1536, 3072])
-@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
 def test_home_list_bounds_hold_and_are_tight(eng, metric, dim):
     """Large batches put the half-precision rows of a query's NEAREST list through the matrix cores once for all the
     queries it is nearest to (stream_kernels.hpp step 1a, ivf_home_kernel: v_mfma_f32_16x16x32_f16, the query in two fp16
@@ -967,17 +967,18 @@ def test_home_list_bounds_hold_and_are_tight(eng, metric, dim):
                 if qi == 0 and r0 == 0:
                     blk = pos[:200]
                     qn, vn = np.linalg.norm(q), np.linalg.norm(base[:200], axis=1)
-                    scale = {"cosine": 1.0, "dot": qn * vn}[metric]
+                    scale = {"cosine": 1.0, "dot": qn * vn, "l2": qn + vn}[metric]
                     assert ok[blk].all()
                     assert ((d[blk] - lb[blk]) / scale).max() < 1.5e-3 and ((ub[blk] - d[blk]) / scale).max() < 1.5e-3
-                    # ... and the matrix cores' sum itself is far inside its allowance: the bounds' centre against f64
-                    c64 = (base[:200].astype(np.float64) @ q.astype(np.float64)) / (qn * vn.astype(np.float64))
-                    mid = 0.5 * (lb[blk].astype(np.float64) + ub[blk].astype(np.float64)) / scale
-                    ref = (1.0 - c64) if metric == "cosine" else -c64
-                    assert np.abs(mid - ref).max() < 3e-4, np.abs(mid - ref).max()
+                    if metric != "l2":
+                        # ... and the matrix cores' sum itself is far inside its allowance: the bounds' centre against f64
+                        c64 = (base[:200].astype(np.float64) @ q.astype(np.float64)) / (qn * vn.astype(np.float64))
+                        mid = 0.5 * (lb[blk].astype(np.float64) + ub[blk].astype(np.float64)) / scale
+                        ref = (1.0 - c64) if metric == "cosine" else -c64
+                        assert np.abs(mid - ref).max() < 3e-4, np.abs(mid - ref).max()
 
 
-@pytest.mark.parametrize("metric,dim", [("cosine", 128), ("dot", 128), ("cosine", 384), ("cosine", 768)])
+@pytest.mark.parametrize("metric,dim", [("cosine", 128), ("dot", 128), ("l2", 128), ("cosine", 384), ("cosine", 768), ("l2", 768)])
 def test_ivf_home_list_pass(eng, oracle, metric, dim, tune):
     """Large IVF batches with the home-list pass (production: from 1024 queries and half a query per list), bit-equal to
     the oracle: forced on for small batches through the tuning table (queries ordered by nearest list from one query on),
@@ -985,7 +986,7 @@ def test_ivf_home_list_pass(eng, oracle, metric, dim, tune):
     survivor lists that overflow next to it, heavy queries (whose slice 0 appends the home rows), and the counters show
     that f32 rows were fetched for little more than k candidates per query."""
     O = oracle
-    code = {"cosine": O.COSINE, "dot": O.DOT}[metric]
+    code = {"cosine": O.COSINE, "dot": O.DOT, "l2": O.L2}[metric]
     base = _data(O, 9000, dim, "clustered", num_clusters=40, noise_level=0.25, seed=73)
     base[4000:4030] = base[11]                               # exact ties
     Q = np.concatenate([_data(O, 299, dim, "clustered", num_clusters=40, noise_level=0.25, seed=74), base[11:12]]).astype(np.float32)
@@ -1120,7 +1121,7 @@ def test_bounds_randomised_soak(eng, metric, dim):
                 assert np.all(hl[ok] <= dl[ok]), "fp16 lb > d: %s dim %d rep %d query %d list rows %s" % (metric, dim, rep, qi, np.nonzero(ok & ~(hl <= dl))[0][:6])
                 oku = ~np.isnan(hu) & ~np.isnan(dl)
                 assert np.all(dl[oku] <= hu[oku]), "fp16 ub < d: %s dim %d rep %d query %d list rows %s" % (metric, dim, rep, qi, np.nonzero(oku & ~(dl <= hu))[0][:6])
-            if metric != "l2":                                                            # fp16 on the matrix cores (the home-list pass), list order
+            if True:                                                                      # fp16 on the matrix cores (the home-list pass), list order
                 Ml, Mu = idx.ivf_home_bounds(np.stack(qs), 0, n)
                 for qi, q in enumerate(qs):
                     dl = idx.batch_distances(q, ids)[lids]
