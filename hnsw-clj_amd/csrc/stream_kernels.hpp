@@ -688,7 +688,7 @@ __device__ __forceinline__ void half_bounds(int metric, float sum, float qn, flo
 //   q = s_q (hi + 2^-12 lo) + e_q,  v = s h + e_v:   |q.v - s_q s (hi + 2^-12 lo).h| <= (|q| + |e_q|) |e_v| + |e_q| |v|
 // and the matrix cores' f32 accumulation of the exact fp16 x fp16 products is within 1e-4 |q||v| of the exact sum (768 +
 // 48 roundings of 2^-23 -- twice the unit roundoff, whatever the order or the rounding mode of the adder tree -- times
-// sum |a_i b_i| <= |a||b|; measured: 3e-7).  So with the row's stored E (1.01 res / |v| + 4e-5 for the cosine):
+// sum |a_i b_i| <= |a||b|; measured: 7e-8, test_home_list_bounds_hold_and_are_tight).  So with the row's stored E (1.01 res / |v| + 4e-5 for the cosine):
 //   cosine   c = 1 - s_q s S / (|q||v|)     lb/ub = c -/+ (E + 1.01 |e_q| / |q| + 1.1e-4)
 //   dot      d = -s_q s S                   lb/ub = d -/+ (|q| E + 1.01 |e_q| |v| + 1.1e-4 |q||v|)
 //   L2       d2 = |q|^2 - 2 s_q s S + |v'|^2        lb/ub = sqrt(d2 -/+ eps) (1 -/+ 8e-6) -/+ E,  eps = 2 (1.1e-4 |q| + 1.01 |e_q|) |v'| + 4e-6 (...)

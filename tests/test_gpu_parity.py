@@ -971,11 +971,27 @@ def test_home_list_bounds_hold_and_are_tight(eng, metric, dim):
                     assert ok[blk].all()
                     assert ((d[blk] - lb[blk]) / scale).max() < 1.5e-3 and ((ub[blk] - d[blk]) / scale).max() < 1.5e-3
                     if metric != "l2":
-                        # ... and the matrix cores' sum itself is far inside its allowance: the bounds' centre against f64
+                        # ... and the bounds' centre against f64: within the half-precision copy's own error
                         c64 = (base[:200].astype(np.float64) @ q.astype(np.float64)) / (qn * vn.astype(np.float64))
                         mid = 0.5 * (lb[blk].astype(np.float64) + ub[blk].astype(np.float64)) / scale
                         ref = (1.0 - c64) if metric == "cosine" else -c64
                         assert np.abs(mid - ref).max() < 3e-4, np.abs(mid - ref).max()
+                    if metric == "cosine":
+                        # ... and the matrix cores' ACCUMULATION alone (the kernel allows 1.1e-4 |q||v| for it): the same fp16
+                        # planes built here -- rows h = fp16(v / s), s = 2^(e - 14); the query as hi + 2^-12 lo -- and summed in f64
+                        def pow2_scale(x):
+                            return np.float32(2.0) ** (np.floor(np.log2(np.abs(x).max(axis=-1, keepdims=True))) - 14)
+                        rows = base[:200]
+                        sv = pow2_scale(rows)
+                        h = (rows / sv).astype(np.float16).astype(np.float64)
+                        sq_ = pow2_scale(q)
+                        x = (q / sq_).astype(np.float32)
+                        hi = x.astype(np.float16).astype(np.float32)
+                        lo = ((x - hi) * np.float32(4096.0)).astype(np.float16).astype(np.float64)
+                        exact = (h @ (hi.astype(np.float64) + lo / 4096.0)) * (sv[:, 0].astype(np.float64) * float(sq_[0])) / (qn * vn.astype(np.float64))
+                        acc_err = np.abs((1.0 - exact) - mid).max()
+                        print("matrix-core accumulation error, dim %d: %.2e of |q||v| (allowance 1.1e-4)" % (dim, acc_err))
+                        assert acc_err < 2e-5, acc_err
 
 
 @pytest.mark.parametrize("metric,dim", [("cosine", 128), ("dot", 128), ("l2", 128), ("cosine", 384), ("cosine", 768), ("l2", 768)])
