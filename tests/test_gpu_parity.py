@@ -994,7 +994,8 @@ def test_home_list_bounds_hold_and_are_tight(eng, metric, dim):
                         assert acc_err < 2e-5, acc_err
 
 
-@pytest.mark.parametrize("metric,dim", [("cosine", 128), ("dot", 128), ("l2", 128), ("cosine", 384), ("cosine", 768), ("l2", 768)])
+@pytest.mark.parametrize("metric,dim", [("cosine", 128), ("dot", 128), ("l2", 128), ("cosine", 384), ("cosine", 768), ("l2", 768),
+                                        ("cosine", 1536), ("dot", 3072)])   # (groups of 16 / 8 / 4 queries by row length)
 def test_ivf_home_list_pass(eng, oracle, metric, dim, tune):
     """Large IVF batches with the home-list pass (production: from 1024 queries and half a query per list), bit-equal to
     the oracle: forced on for small batches through the tuning table (queries ordered by nearest list from one query on),
@@ -1003,7 +1004,8 @@ def test_ivf_home_list_pass(eng, oracle, metric, dim, tune):
     that f32 rows were fetched for little more than k candidates per query."""
     O = oracle
     code = {"cosine": O.COSINE, "dot": O.DOT, "l2": O.L2}[metric]
-    base = _data(O, 9000, dim, "clustered", num_clusters=40, noise_level=0.25, seed=73)
+    n = 9000 if dim <= 768 else 4500
+    base = _data(O, n, dim, "clustered", num_clusters=40, noise_level=0.25, seed=73)
     base[4000:4030] = base[11]                               # exact ties
     Q = np.concatenate([_data(O, 299, dim, "clustered", num_clusters=40, noise_level=0.25, seed=74), base[11:12]]).astype(np.float32)
     with eng.Index(base, metric) as idx:
