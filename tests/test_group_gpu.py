@@ -59,6 +59,34 @@ def test_group_ivf_equals_unsharded_and_oracle(eng, oracle, metric, ndev):
                 g.hnsw_search(Q[:2], k, 50)
 
 
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_group_ivf_with_the_home_list_pass_on_shards(eng, oracle, metric, tune):
+    """Large batches send every row of a query's NEAREST list through the matrix cores in half precision and take the query's
+    threshold from there (stream_kernels.hpp, step 1a) -- on a shard the nearest list of most queries lives elsewhere: those
+    keep the sampled threshold, their home pair has no rows here, and the shard's answer must still merge into the unsharded
+    one bit for bit.  Forced on for a batch of 150 through the tuning table (production: from 512 queries)."""
+    O = oracle
+    m = O.METRICS[metric]
+    n, dim, nlist, nprobe, k = 30_000, 128, 64, 6, 10
+    base = O.generate_dataset(n, dim, "clustered", num_clusters=20, noise_level=0.5).astype(np.float32)
+    base[5000:5040] = base[3]
+    Q = np.concatenate([O.generate_dataset(149, dim, "clustered", num_clusters=20, noise_level=0.5, seed=43), base[3:4]]).astype(np.float32)
+    for key, v in (("TILE_PAIRS", 1 << 40), ("IVF_CODES", 1), ("STREAM_MID", 1), ("FINISH_ORDER", 1), ("STREAM_HOME", 1), ("ROUTE_MFMA", 1)):
+        tune.set(key, str(v))
+    with eng.Index(base, metric) as full:
+        full.set_rejection_test(2)
+        full.ivf_build(nlist, 4, 42)
+        cen, off, lids = full.get_ivf()
+        oi, od, _ = O.ivf_search(base, cen, off, lids, Q, k, nprobe, metric=m, mode=O.MODE_DEV)
+        ui, ud = full.ivf_search(Q, k, nprobe)
+        assert_exact(ui, ud, oi, od, "unsharded, home-list pass forced, %s" % metric)
+        for ndev in (2, 5):
+            with eng.Group([0] * ndev, dim, metric) as g:
+                g.set_ivf(base, cen, off, lids)
+                gi, gd = g.ivf_search(Q, k, nprobe)
+                assert_exact(gi, gd, oi, od, "group of %d, home-list pass forced, %s" % (ndev, metric))
+
+
 def test_group_shards_take_the_path_of_the_whole_index(eng, oracle):
     """A shard holds n / ndev rows over the SAME nlist: what depends on the mean list length (the largest k the survivor
     stream serves, hence -- past the tile boundary -- the summation order) and the first-search calibration verdict must be
