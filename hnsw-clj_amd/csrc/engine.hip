@@ -192,23 +192,27 @@ int launch_mid(const MidArgs &a0, int nch, hipStream_t st) {
     return 0;
 }
 
-int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narrow, hipStream_t st) {
+int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narrow, hipStream_t st, int qblocks) {
     if (blocks <= 0) return 0;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "bounds pass grid too large");
-    const size_t lds = stream_lds_bytes(nch, narrow);
-#define CALLV(N, NARROW, DEFER)                                                                                        \
+    const bool two = qblocks == 2 && !narrow && a.defer;  // two 32-query column blocks per group (the work list was built for them)
+    HG_REQUIRE(qblocks == 1 || two, HNSWGPU_EINVAL, "bounds pass: two column blocks need the wide deferring epilogue");
+    const size_t lds = stream_lds_bytes(nch, narrow, two ? 2 : 1, two ? 4 : kTileWaves);
+#define CALLV(N, NARROW, DEFER, QB)                                                                                    \
     do {                                                                                                               \
         static bool attr_done[64] = {};                                                                                \
         if (lds > 48 * 1024 && attr_needed(attr_done))                                                                 \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_bounds_kernel<N, NARROW, DEFER>),        \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_bounds_kernel<N, NARROW, DEFER, QB>),    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
-        hipLaunchKernelGGL((stream_bounds_kernel<N, NARROW, DEFER>), dim3(static_cast<unsigned>(blocks)), dim3(kTileThreads), lds, st, a); \
+        hipLaunchKernelGGL((stream_bounds_kernel<N, NARROW, DEFER, QB>), dim3(static_cast<unsigned>(blocks)),          \
+                           dim3(QB == 1 ? kTileThreads : 256), lds, st, a);                                            \
     } while (0)
 #define CALL(N, R, L)                         \
     do {                                      \
-        if (narrow) CALLV(N, true, false);    \
-        else if (a.defer) CALLV(N, false, true); \
-        else CALLV(N, false, false);          \
+        if (narrow) CALLV(N, true, false, 1); \
+        else if (two) CALLV(N, false, true, 2); \
+        else if (a.defer) CALLV(N, false, true, 1); \
+        else CALLV(N, false, false, 1);       \
     } while (0)
     HG_DISPATCH(nch, false, CALL);
 #undef CALL

@@ -287,7 +287,7 @@ struct HomeArgs;
 int launch_mid(const MidArgs &a, int nch, hipStream_t st);
 int launch_heavy(const HeavyArgs &a, hipStream_t st);
 int launch_home(const HomeArgs &a, int64_t blocks, int nch, hipStream_t st);
-int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narrow, hipStream_t st);
+int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narrow, hipStream_t st, int qblocks = 1);
 int launch_finish(const FinishArgs &a, int nch, hipStream_t st);
 // zero-initialised per-query counters of the fused tails (s_done: [n] scan / finish tails | [n] route tails)
 int ensure_counters(hnswgpu_index *idx, size_t n, hipStream_t st);

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(1024) void ivf_worklist_kernel(uint32_t *bk_cnt, in
                                                             WorkDesc *desc, int32_t *nitems, const int32_t *ord_probes,
                                                             int ord_nq, int32_t *ord_out, int ord_stride,
                                                             HomeDesc *home_desc, int32_t *home_nitems, int home_gq,
-                                                            int home_chunk) {
+                                                            int home_chunk, int tq) {  // tq: members per group (32, or 64: two column blocks)
     if (blockIdx.x == 1) {
         pair_order_wg(ord_probes, ord_nq, nlist, ord_out, ord_stride);
         if (home_desc) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(1024) void ivf_worklist_kernel(uint32_t *bk_cnt, in
             rows = list_off[l + 1] - list_off[l];
             nch = (c > 0 && rows > 0) ? static_cast<int>(tile_nchunks(rows, chunk_rows, max_chunks)) : 0;
         }
-        const int ng = (c + kTileQ - 1) / kTileQ;
+        const int ng = (c + tq - 1) / tq;
         const int nw = ng * nch;
         // inclusive scan: within the wave, then across the 16 waves
         int incl = nw;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024) void ivf_worklist_kernel(uint32_t *bk_cnt, in
             const int ll = l0 + lo, k = w - off_s[lo];
             const uint32_t filed = bk_cnt[ll];
             const int cc = filed < static_cast<uint32_t>(bk_cap) ? static_cast<int>(filed) : bk_cap;
-            const int ngl = (cc + kTileQ - 1) / kTileQ;
+            const int ngl = (cc + tq - 1) / tq;
             const int ch = k / ngl, g = k - ch * ngl;  // chunk-major
             const int64_t rb0 = list_off[ll], rws = list_off[ll + 1] - rb0;
             const int64_t tiles = (rws + kTileRows - 1) / kTileRows;
@@ -214,8 +214,8 @@ __global__ __launch_bounds__(1024) void ivf_worklist_kernel(uint32_t *bk_cnt, in
             d.r0_off = static_cast<int32_t>(a0);
             d.r1_off = static_cast<int32_t>(a1 > a0 ? a1 : a0);
             d.list = ll;
-            d.mem0 = g * kTileQ;
-            d.cnt = cc - g * kTileQ < kTileQ ? cc - g * kTileQ : kTileQ;
+            d.mem0 = g * tq;
+            d.cnt = cc - g * tq < tq ? cc - g * tq : tq;
             d.pad = 0;
             desc[base + w] = d;
         }
@@ -890,6 +890,15 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         home_nit = reinterpret_cast<int32_t *>(home_desc + home_bound);
         home_first = reinterpret_cast<uint32_t *>(home_nit + 16);
     }
+    // The largest batches (a list probed by 256 queries and more on average, entries appended without bounds): two 32-query
+    // column blocks per group -- every staged row operand meets 64 queries, the lists leave L2 half as often
+    const int64_t wide2 = tune(HNSWGPU_TUNE_STREAM_WIDE2, -1);  // -1 that rule, 0 never, 1 whenever the epilogue allows
+    const int64_t narrow_env = tune(HNSWGPU_TUNE_STREAM_NARROW, -1);  // A/B: 0 / 1 force
+    const bool narrow = narrow_env >= 0 ? narrow_env != 0 : npairs < 6LL * idx->nlist;
+    const int qblocks = grouped && mid && !narrow && idx->nch <= 4 /* (64 queries' codes: two workgroups per CU still fit) */ &&
+                                wide2 != 0 && (wide2 > 0 || npairs >= 256LL * idx->nlist)
+                            ? 2
+                            : 1;
     if (grouped) {
         // the work list: items <= sum over lists of ceil(members / 32) * chunks <= (npairs / 32 + nlist) * nchunks
         const int64_t wbound = (npairs / kTileQ + idx->nlist) * b.nchunks;
@@ -912,7 +921,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         }
         hipLaunchKernelGGL(ivf_worklist_kernel, dim3(qorder ? 2 : 1), dim3(1024), olds, st, sc.bk_cnt, sc.bk_cap, idx->nlist,
                            idx->d_listoff, cr, b.nchunks, desc, nit, d_probes, nq, idx->s_stats.as<int32_t>(), nprobe,
-                           home_desc, home_nit, home_gq, static_cast<int>(home_chunk));
+                           home_desc, home_nit, home_gq, static_cast<int>(home_chunk), kTileQ * qblocks);
         HG_HIP(hipGetLastError());
         idx->bk_dirty = false;  // (the kernel leaves the counters zero)
         b.wi_desc = desc;
@@ -992,9 +1001,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     hipEvent_t e0;
     prof_begin(idx, PROF_IVF_SCAN, st, &e0);
     // which epilogue: few queries per probed list -> lane = row (a list probed by more takes several passes); many -> lane = query
-    const int64_t narrow_env = tune(HNSWGPU_TUNE_STREAM_NARROW, -1);  // A/B: 0 / 1 force
-    const bool narrow = narrow_env >= 0 ? narrow_env != 0 : npairs < 6LL * idx->nlist;
-    HG_TRY(launch_stream_bounds(b, blocks, idx->nch, narrow, st));
+    HG_TRY(launch_stream_bounds(b, blocks, idx->nch, narrow, st, qblocks));
     prof_end(idx, PROF_IVF_SCAN, st, e0);
     // Large batches: a query's survivors are, above all, its nearest list -- and several queries share one.  The queries are
     // taken in the order of their nearest list, a contiguous eighth of that order per XCD, so that the queries which read

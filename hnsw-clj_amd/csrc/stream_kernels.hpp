@@ -264,12 +264,13 @@ struct StreamArgs {
 constexpr int kNarrow = 8;
 
 __host__ __device__ constexpr int stream_epilogue_words(bool narrow) { return narrow ? kNarrow * 33 : 16 * kWave; }
-__host__ inline size_t stream_lds_bytes(int nch, bool narrow) {
-    return static_cast<size_t>(nch) * 256 * kTileQ                          // query codes [step][half][query][16 B]
-           + sizeof(QueryScal) * kTileQ + sizeof(float4) * 32 * kTileWaves  // query scalars, per-wave row terms
-           + sizeof(float4) * kTileQ                                        // query terms of the test
-           + (sizeof(uint32_t) + sizeof(int32_t)) * kTileQ                  // order bases, query indices
-           + sizeof(int32_t) * stream_epilogue_words(narrow) * kTileWaves   // per-wave tile of the epilogue
+__host__ inline size_t stream_lds_bytes(int nch, bool narrow, int qb = 1, int waves = kTileWaves) {  // qb: 32-query column blocks per group
+    const size_t tq = static_cast<size_t>(kTileQ) * qb;
+    return static_cast<size_t>(nch) * 256 * tq                              // query codes [block][step][half][query][16 B]
+           + sizeof(QueryScal) * tq + sizeof(float4) * 32 * waves           // query scalars, per-wave row terms
+           + sizeof(float4) * tq                                            // query terms of the test
+           + (sizeof(uint32_t) + sizeof(int32_t)) * tq                      // order bases, query indices
+           + (qb > 1 ? 0 : sizeof(int32_t) * stream_epilogue_words(narrow) * waves)  // per-wave tile of the epilogue (two column blocks: entries without bounds, no tile)
            + 16;                                                            // the group's home-list mask
 }
 
@@ -311,24 +312,33 @@ __device__ __forceinline__ bool stream_reject(int dot, float4 r, float4 qt) {
     return static_cast<float>(dot) * r.x < __builtin_fmaf(-qt.y, r.y, __builtin_fmaf(r.z, qt.z, qt.x));
 }
 
-template <int NCH, bool NARROW, bool DEFER>
-__global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs a) {
+// QB = 2 (wide deferring launches of the largest batches): TWO 32-query column blocks per group -- a staged row operand meets
+// 64 queries (two matrix instructions), so a list probed by 512 queries leaves L2 eight times instead of sixteen: there the
+// kernel is bound by the L2s, not by HBM.  Two accumulators are ~150 registers: four-wave workgroups, three per CU (eight-wave
+// ones fit once: 358 us against 283 at batch 4096).  At batch 2048 / 4096 it is no faster than one block (194 vs 189, 280 vs 284
+// us: what the L2s are spared the lower occupancy takes back), so only batches with 256 and more pairs per list take it.
+template <int NCH, bool NARROW, bool DEFER, int QB = 1>
+__global__ __launch_bounds__(QB == 1 ? kTileThreads : 256) void stream_bounds_kernel(StreamArgs a) {
+    static_assert(QB == 1 || (QB == 2 && !NARROW && DEFER), "two column blocks: the wide deferring epilogue only");
     constexpr int S = NCH * 8;  // steps of 32 bytes
     constexpr int PF = 8;       // operand loads in flight per wave
+    constexpr int TQ = kTileQ * QB;                     // queries per group
+    constexpr int NWV = QB == 1 ? kTileWaves : 4;       // waves per workgroup
+    constexpr int NTHR = NWV * kWave;
     extern __shared__ __align__(16) unsigned char smem[];
-    v4i_t *qb_s = reinterpret_cast<v4i_t *>(smem);                               // [S][2][32]
-    QueryScal *qs_s = reinterpret_cast<QueryScal *>(qb_s + S * 64);              // [32]
-    float4 *meta_all = reinterpret_cast<float4 *>(qs_s + kTileQ);                // [waves][32] row terms
-    float4 *qt_s = meta_all + 32 * kTileWaves;                                    // [32] query terms
-    uint32_t *ob_s = reinterpret_cast<uint32_t *>(qt_s + kTileQ);                 // [32]
-    int32_t *qi_s = reinterpret_cast<int32_t *>(ob_s + kTileQ);                  // [32]
-    int32_t *narrow_all = qi_s + kTileQ;                                          // [waves][stream_epilogue_words]
-    uint32_t &home_mask_s = *reinterpret_cast<uint32_t *>(narrow_all + kTileWaves * stream_epilogue_words(NARROW));  // slots of the group whose nearest list this is (served by ivf_home_kernel)
+    v4i_t *qb_s = reinterpret_cast<v4i_t *>(smem);                               // [QB][S][2][32]
+    QueryScal *qs_s = reinterpret_cast<QueryScal *>(qb_s + S * 64 * QB);         // [TQ]
+    float4 *meta_all = reinterpret_cast<float4 *>(qs_s + TQ);                    // [waves][32] row terms
+    float4 *qt_s = meta_all + 32 * NWV;                                           // [TQ] query terms
+    uint32_t *ob_s = reinterpret_cast<uint32_t *>(qt_s + TQ);                     // [TQ]
+    int32_t *qi_s = reinterpret_cast<int32_t *>(ob_s + TQ);                      // [TQ]
+    int32_t *narrow_all = qi_s + TQ;                                              // [waves][stream_epilogue_words] (QB == 1)
+    uint32_t *home_mask_s = reinterpret_cast<uint32_t *>(narrow_all + (QB > 1 ? 0 : kTileWaves * stream_epilogue_words(NARROW)));  // [QB] slots of the group whose nearest list this is (served by ivf_home_kernel)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
     float *terms_w = reinterpret_cast<float *>(meta_all + wave * 32);
-    int32_t *tile_w = narrow_all + wave * stream_epilogue_words(NARROW);          // narrow: [kNarrow][33] dot products; wide: [16][64]
+    int32_t *tile_w = narrow_all + (QB > 1 ? 0 : wave * stream_epilogue_words(NARROW));  // narrow: [kNarrow][33] dot products; wide: [16][64] (QB == 1)
 
     const int col = lane & 31, half = lane >> 5;
     constexpr bool narrow = NARROW;
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
         if (row >= r0 && row < r1) metar = a.cmeta[row];
     }
 
-    if (tid < kTileQ) {
+    if (tid < TQ) {
         int qi = -1;
         uint32_t ob = 0;
         if (tid < cnt) {
@@ -406,36 +416,40 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
             home = hp.row_begin == rb0 && hp.row_end > hp.row_begin;
         }
         const uint64_t hb = __ballot(home);
-        if (tid == 0) home_mask_s = static_cast<uint32_t>(hb);
+        if (tid == 0) {
+            home_mask_s[0] = static_cast<uint32_t>(hb);
+            if (QB > 1) home_mask_s[1] = static_cast<uint32_t>(hb >> 32);
+        }
     }
     __syncthreads();
     // query codes: natural order in global memory (16-B chunk t of query q = step t / 2, half t & 1); empty slots are zero
     if (tid < cnt) qs_s[tid] = a.qscal[qi_s[tid]];
-    for (int f = tid; f < kTileQ * S * 2; f += kTileThreads) {
+    for (int f = tid; f < TQ * S * 2; f += NTHR) {
         const int q = f / (S * 2), t = f - q * (S * 2);
         v4i_t v = {0, 0, 0, 0};
         if (q < cnt) v = reinterpret_cast<const v4i_t *>(a.qcodes + static_cast<int64_t>(qi_s[q]) * NCH * kWave)[t];
-        qb_s[t * 32 + q] = v;
+        qb_s[(q >> 5) * S * 64 + t * 32 + (q & 31)] = v;
     }
     // the query's side of the test (lane = slot of the group): P, Q, K of stream_query_terms, once per workgroup -- the
     // threshold of a query does not move while this kernel runs (it falls again in the finish kernel)
-    if (tid < kTileQ) {
+    if (tid < TQ) {
         float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (tid < cnt) t = stream_query_terms(a.metric, qs_s[tid], tau_decode(a.tau[qi_s[tid]]));
         qt_s[tid] = t;
     }
     __syncthreads();
 
-    const uint32_t home_mask = home_mask_s;
+    const uint32_t home_mask = home_mask_s[0];
     const bool live = col < cnt && !((home_mask >> col) & 1u);
     const float4 myqt = qt_s[col];
     const v2f_t P2 = {myqt.x, myqt.x}, nQ2 = {-myqt.y, -myqt.y}, K2 = {myqt.z, myqt.z};
     const int myq = live ? qi_s[col] : 0;
     const uint32_t myob = live ? ob_s[col] : 0;
     uint4 *dst = a.surv + static_cast<int64_t>(myq) * a.cap;
+    const bool live1 = QB > 1 && col + 32 < cnt && !((home_mask_s[QB - 1] >> col) & 1u);  // (second column block: queries 32 .. 63)
     const v4i_t *ap = tile + (b * S) * 64 + lane;  // this wave's current block
     const v4i_t *qb_mine = qb_s + half * 32 + col;   // B operand of step s: qb_mine[s * 64]
-    for (; b < b1; b += kTileWaves, ap += static_cast<int64_t>(kTileWaves) * S * 64) {
+    for (; b < b1; b += NWV, ap += static_cast<int64_t>(NWV) * S * 64) {
         // the row's side of the test: lane & 31 is the row whose terms these are (rows outside the chunk: zeros)
         const float4 mraw = narrow ? metar : make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // (narrow epilogue: an appended row's bounds come from these)
         const float4 mcur = stream_row_terms(a.metric, metar);
@@ -445,6 +459,7 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
             terms_w[64 + lane] = mcur.z;
         }
         v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        v16i_t acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (QB == 2: the second column block)
         {
             const v4i_t *p = ap;
             const v4i_t *qp = qb_mine;
@@ -455,19 +470,23 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
                     const v4i_t cur = av[u];
                     av[u] = p[(PF + u) * 64];
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur, qp[u * 64], acc, 0, 0, 0);
+                    if (QB > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur, qp[u * 64 + S * 64], acc1, 0, 0, 0);
                 }
                 p += PF * 64;
                 qp += PF * 64;
             }
 #pragma unroll
-            for (int u = 0; u < PF; u++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[u], qp[u * 64], acc, 0, 0, 0);
+            for (int u = 0; u < PF; u++) {
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[u], qp[u * 64], acc, 0, 0, 0);
+                if (QB > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[u], qp[u * 64 + S * 64], acc1, 0, 0, 0);
+            }
         }
         metar = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (b + kTileWaves < b1) {  // the next block's first operands and row terms, before this block's epilogue
-            const v4i_t *np = ap + static_cast<int64_t>(kTileWaves) * S * 64;
+        if (b + NWV < b1) {  // the next block's first operands and row terms, before this block's epilogue
+            const v4i_t *np = ap + static_cast<int64_t>(NWV) * S * 64;
 #pragma unroll
             for (int u = 0; u < PF; u++) av[u] = np[u * 64];
-            const int64_t row = (b + kTileWaves) * 32 + (lane & 31);
+            const int64_t row = (b + NWV) * 32 + (lane & 31);
             if (row >= r0 && row < r1) metar = a.cmeta[row];
         }
         if (a.dbg & 1) {  // ablation: no epilogue (results are wrong)
@@ -583,6 +602,51 @@ __global__ __launch_bounds__(kTileThreads) void stream_bounds_kernel(StreamArgs 
                             dst[base] = make_uint4(myob + r, static_cast<uint32_t>(rb0) + r, __float_as_uint(lb), __float_as_uint(ub));
                         }
                     }
+                }
+            }
+        }
+        if (QB > 1) {  // ---- the second column block of the group: the same test on its accumulator, entries without bounds
+            const float4 myqt1 = qt_s[col + 32];  // (from LDS per block: held in registers they cost the kernel a workgroup per CU)
+            const v2f_t P21 = {myqt1.x, myqt1.x}, nQ21 = {-myqt1.y, -myqt1.y}, K21 = {myqt1.z, myqt1.z};
+            uint32_t pm1 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const v4f_t X = *reinterpret_cast<const v4f_t *>(terms_w + 8 * j + 4 * half);
+                const v4f_t Y = *reinterpret_cast<const v4f_t *>(terms_w + 32 + 8 * j + 4 * half);
+                const v4f_t Z = *reinterpret_cast<const v4f_t *>(terms_w + 64 + 8 * j + 4 * half);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const v2f_t d = {static_cast<float>(acc1[4 * j + 2 * h]), static_cast<float>(acc1[4 * j + 2 * h + 1])};
+                    const v2f_t x = {X[2 * h], X[2 * h + 1]}, y = {Y[2 * h], Y[2 * h + 1]}, z = {Z[2 * h], Z[2 * h + 1]};
+                    const v2f_t lhs = d * x;
+                    const v2f_t rhs = __builtin_elementwise_fma(nQ21, y, __builtin_elementwise_fma(z, K21, P21));
+                    if (!(lhs[0] < rhs[0])) pm1 |= 1u << (4 * j + 2 * h);
+                    if (!(lhs[1] < rhs[1])) pm1 |= 1u << (4 * j + 2 * h + 1);
+                }
+            }
+            if (!live1) pm1 = 0;
+            if (rel < rel0 || rel + 32 > rel1) {
+#pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    const int i = rel + (g & 3) + 8 * (g >> 2) + 4 * half;
+                    if (i < rel0 || i >= rel1) pm1 &= ~(1u << g);
+                }
+            }
+            const int n1 = __popc(pm1);
+            if (__ballot(n1 > 0)) {
+                const int myq1 = live1 ? qi_s[col + 32] : 0;
+                const uint32_t myob1 = live1 ? ob_s[col + 32] : 0;
+                uint4 *dst1 = a.surv + static_cast<int64_t>(myq1) * a.cap;
+                const int on1 = __shfl_xor(n1, 32, kWave);
+                uint32_t base = 0;
+                if (half == 0 && n1 + on1 > 0)
+                    base = __hip_atomic_fetch_add(a.surv_cnt + myq1, static_cast<uint32_t>(n1 + on1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                base = __shfl(base, col, kWave);
+                if (half) base += on1;
+                for (uint32_t pm = pm1; pm; pm &= pm - 1, base++) {
+                    const int g = __ffs(pm) - 1;
+                    const uint32_t r = static_cast<uint32_t>(rel + (g & 3) + 8 * (g >> 2) + 4 * half);
+                    if (base < a.cap) dst1[base] = make_uint4(myob1 + r, static_cast<uint32_t>(rb0) + r, 0xff800000u, 0x7f800000u);  // [-inf, +inf]
                 }
             }
         }

@@ -1038,7 +1038,13 @@ def test_ivf_home_list_pass(eng, oracle, metric, dim, tune):
         tune.unset("HOME_STRAYS")
         tune.set("STREAM_HOME", "0")
         check(300, 10, 12, "home off")
+        tune.set("STREAM_WIDE2", "1")      # the bounds pass with two 32-query column blocks per group (production: the largest batches)
+        check(300, 10, 12, "home off, two column blocks")
         tune.set("STREAM_HOME", "1")
+        check(300, 10, 12, "two column blocks")
+        check(300, 100, 50, "two column blocks")
+        check(170, 10, 1, "two column blocks")
+        tune.unset("STREAM_WIDE2")
         tune.set("STREAM_CAP", "300")      # some lists overflow (and home rows that do not fit send a query through the fallback)
         check(300, 10, 12, "mixed fallback", expect_few=False)
         tune.set("STREAM_HEAVY_MEAN", "0")
