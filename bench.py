@@ -625,7 +625,7 @@ def ivf_roofline(engine, dev, args, traffic):
            "frac_like_for_like_note": "the kernel that does the REFERENCE's work per candidate (f32 list scan, one GEMV per (query, "
                                       "list) pair, bounds pass off: roofline.f32_scan) as traffic / time / 8 TB/s -- frac itself "
                                       "is the int8 bounds kernel's, which decides ~97 % of the candidates without their f32 row",
-           "kernel": "stream_bounds_kernel<3, true, false> (v_mfma_i32_32x32x32_i8; 1.6 queries per probed list at this batch: the "
+           "kernel": "stream_bounds_kernel<3, true, false, 1> (v_mfma_i32_32x32x32_i8; 1.6 queries per probed list at this batch: the "
                      "lane = row epilogue)",
            "workload": "hnsw.ivf-flat %d x 768, nlist=1024 nprobe=32, batch of 32 queries per launch: bounds of every candidate "
                        "from the int8 list rows against the query's running threshold, %.0f survivors per query appended "
@@ -748,7 +748,7 @@ def ivf_dataset(dev, n, nlist, nq_all):
     return x, Qa
 
 
-PMC_SCAN_KERNEL = "stream_bounds_kernel<3, true, false>"    # the bounds kernel for dim 768 (batch 32: the lane = row epilogue)
+PMC_SCAN_KERNEL = "stream_bounds_kernel<3, true, false"    # the bounds kernel for dim 768 (batch 32: the lane = row epilogue)
 PMC_F32_KERNEL = "scan_kernel<3, 8, false, 0>"       # ROLE_LIST_SCAN instantiation: the f32 scan (bounds pass off)
 # every kernel of one batch-32 search through the survivor stream (roofline.search)
 PMC_SEARCH_KERNELS = ("ivf_route_kernel", "ivf_route_dist_kernel", "ivf_route_tail_kernel", "ivf_worklist_kernel",
