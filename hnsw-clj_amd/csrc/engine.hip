@@ -498,8 +498,11 @@ __device__ __forceinline__ const uint64_t *select_small_wg(const float *in, int6
 // The tail of the routing of query qi, run by one whole workgroup once all of the query's centroid distances are in
 // a.dense: pick the nprobe nearest, write the probe table, file the pairs by list, seed the threshold.  COH: the
 // distances were written by other workgroups of THIS launch (agent-scope loads), not by an earlier one.
+template <int NCH>
+__device__ __forceinline__ void route_encode(const RouteArgs &a, int qi, const float4 (&q)[NCH], int lane);
+
 template <int NCH, int RB, bool L2, bool COH>
-__device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsigned char *smem) {
+__device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsigned char *smem, bool encode_here = false) {
     __shared__ int64_t tail_qcnt;
     __shared__ uint32_t tail_cover;
     constexpr int kHead = 16;
@@ -525,6 +528,9 @@ __device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsign
     if (a.nprobe <= kWave) keys = select_small_wg<COH>(a.dense + static_cast<int64_t>(qi) * a.nlist, a.nlist, a.nprobe, smem);
     else select_topk_wg<COH>(s, qi, kNWave, smem, &keys);
     HG_IVF_STAMP(a.dbg, 18, qi == 0 && threadIdx.x == 0);  // nprobe nearest centroids selected
+    // (the tail launch: the query's int8 codes by an otherwise idle wave WHILE wave 0 writes the probe table -- ahead of the
+    // selection the encoding wave kept the other three waiting at the selection's barrier)
+    if (encode_here && a.qcodes && a.tau && wave == kNWave - 1) route_encode<NCH>(a, qi, q, lane);
     if (wave == 0) {
         // the query's probe table: offsets of the probed lists in its candidate stream (probe_pairs_kernel, one wave)
         uint32_t carry = 0, gcarry = 0;
@@ -875,12 +881,12 @@ __global__ __launch_bounds__(kWG) void ivf_route_tail_kernel(RouteArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int qi = blockIdx.x;
-    if (a.qcodes && wave == kNWave - 1) {
+    if (a.qcodes && !a.tau && wave == kNWave - 1) {  // (no threshold wanted: the tail does not load the query itself)
         float4 q[NCH];
         load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
         route_encode<NCH>(a, qi, q, lane);
     }
-    route_tail_wg<NCH, RB, L2, false>(a, qi, smem);
+    route_tail_wg<NCH, RB, L2, false>(a, qi, smem, true);
 }
 
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
