@@ -1741,7 +1741,7 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf *bufs[] = {&idx->s_q,   &idx->s_partial, &idx->s_ord,   &idx->s_dist, &idx->s_pairs, &idx->s_ids,
-                      &idx->s_outd, &idx->s_probes,  &idx->s_stats, &idx->s_misc, &idx->s_misc2, &idx->s_vis, &idx->s_qp, &idx->s_qn, &idx->s_tile, &idx->s_grp, &idx->s_done, &idx->s_pf, &idx->s_bk, &idx->s_heavy, &idx->s_home, &idx->s_dh};
+                      &idx->s_outd, &idx->s_probes,  &idx->s_stats, &idx->s_misc, &idx->s_misc2, &idx->s_vis, &idx->s_qp, &idx->s_qn, &idx->s_tile, &idx->s_grp, &idx->s_done, &idx->s_pf, &idx->s_solo, &idx->s_bk, &idx->s_heavy, &idx->s_home, &idx->s_dh};
     for (DevBuf *b : bufs) b->release();
     for (int s = 0; s < PROF_N; s++)
         for (auto &pr : idx->prof_ev[s]) {

@@ -185,7 +185,7 @@ struct hnswgpu_index {
     std::vector<int32_t> h_listids;
 
     // scratch (grown on demand, reused across calls; calls are serialised by `mu`)
-    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2, s_vis, s_qp, s_qn, s_tile, s_grp, s_done, s_pf, s_bk, s_heavy, s_home, s_dh;
+    hg::DevBuf s_q, s_partial, s_ord, s_dist, s_pairs, s_ids, s_outd, s_probes, s_stats, s_misc, s_misc2, s_vis, s_qp, s_qn, s_tile, s_grp, s_done, s_pf, s_solo, s_bk, s_heavy, s_home, s_dh;
     // s_bk: the per-list pair counters of the IVF survivor stream -- zero between searches (the work-list kernel clears
     // them behind its last read); bk_dirty = a search was enqueued past the point that fills them but not past the
     // work-list kernel (an error in between): the next search clears them itself
@@ -240,6 +240,9 @@ bool attr_needed(bool (&done)[64]);
         }                                                                 \
     } while (0)
 
+// small HNSW launches, one query over several CUs (solo.hip)
+bool solo_enabled(int ef);
+int launch_hnsw_solo(hnswgpu_index *idx, HnswArgs a, hipStream_t st);
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);
 int ensure_qrows(hnswgpu_index *idx, hipStream_t st);
 // int8 codes + per-row bound terms of `n` rows into freshly allocated *crows / *cmeta (the caller owns them)

@@ -76,6 +76,10 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
         nw = 4;
         grid = std::min(a.nq, 256);
     }
+    if (pf && solo_enabled(a.ef)) {
+        a.nwords = static_cast<int32_t>((a.n + 31) / 32);
+        return launch_hnsw_solo(idx, a, st);  // one query over several CUs (solo_kernels.hpp)
+    }
     if (pf) {
         // one mailbox per query; four regions in rotation, so that launches in flight (two Slots) never share one
         nw = 4;

@@ -1175,6 +1175,13 @@ struct HnswArgs {
     int32_t pf_groups;
     int32_t pf_hints;  // unexpanded entries looked at per expansion (the best pf_hints of the list)
     uint32_t pf_seq;
+    // solo mode (solo_kernels.hpp: one query over several CUs): the node-keyed tables of what the helpers publish --
+    // solo_rec[query][slot of a node][neighbour slot] = (tag << 32) | distance bits, solo_claim[query][slot] = tag of the node
+    // whose evaluation somebody has asked for, tag = (launch number, node); 2^solo_log2s slots per query
+    unsigned long long *solo_rec;
+    uint32_t *solo_claim;
+    int32_t solo_log2s;
+    int32_t solo_chase;  // the helpers append the neighbours they find closer than the owner's window themselves
     // Host-polled completion (small synchronous calls whose queries and results live in mapped pinned host memory):
     // every workgroup counts itself in done_cnt when it has no work left; the last one copies *again_cnt to
     // host_again, resets the counter and stores flag_val to host_flag -- the host thread spins on that word.

@@ -16,7 +16,12 @@ os.environ.setdefault("HNSWGPU_PREFILTER", "2")
 # list on a handle with int8 rows, 12 without: the parity tests' small indexes sit on both sides of 12, so the test
 # processes pin it there (every regime then runs at test size); test_ivf_production_boundary covers the default.
 os.environ.setdefault("HNSWGPU_TILE_PAIRS", "12")
-# (both are among the six names the library reads from the environment, once, when it is loaded; every other switch a
+# Small HNSW launches spread one query over several CUs (solo_kernels.hpp) from ef 200 by default; the parity tests search
+# with every ef, mostly small ones, so the test processes take that path at EVERY ef (hnsw-clj_amd/_native.py applies
+# HNSWGPU_TUNE through hnswgpu_set_tuning when the library is loaded); test_helpers_evaluate_small_launches also runs the
+# round-2 helper kernel (SOLO = 0) and the default rule.
+os.environ.setdefault("HNSWGPU_TUNE", "SOLO=2")
+# (the first two are among the six names the library reads from the environment, once, when it is loaded; every other switch a
 # test flips goes through hnswgpu_set_tuning: the `tune` fixture below)
 
 

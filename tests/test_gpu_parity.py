@@ -619,14 +619,19 @@ def test_ivf_build_golden(eng, oracle, name):
         assert all(i in members for i in ids.ravel() if i >= 0)
 
 
+@pytest.mark.parametrize("solo", [2, 0, 1])
 @pytest.mark.parametrize("metric,dim,M", [("cosine", 136, 16), ("l2", 72, 16), ("dot", 300, 32)])
-def test_helpers_evaluate_small_launches(eng, oracle, metric, dim, M):
+def test_helpers_evaluate_small_launches(eng, oracle, tune, metric, dim, M, solo):
     """Launches of a handful of queries: helper workgroups on idle CUs evaluate the neighbours of the candidates the
-    traversal will expand next and publish the distances (kernels.hpp: pf_res); the traversal gathers only what has not
-    arrived.  Timing decides WHICH distances arrive, never what they are: ids, distance bits and both counters equal the
-    oracle's for 1 / 3 / 20 / 64 queries, several times over, and the device counters show that published distances
-    were used (the int8 test is switched off here, so every neighbour not gathered locally was published)."""
+    traversal will expand next and publish the distances; the traversal gathers only what has not arrived.  solo = 2: one
+    query over several CUs at every ef (solo_kernels.hpp: an owner workgroup keeps the reference's order -- its sequencer
+    wave holds the list as main list + admission buffer --, its fetcher waves copy published distances into an LDS cache,
+    the helpers evaluate and chase); 0: the round-2 helper kernel (kernels.hpp: pf_res); 1: the default rule (from ef 200).
+    Timing decides WHICH distances arrive, never what they are: ids, distance bits and both counters equal the oracle's for
+    1 / 3 / 20 / 64 queries, several times over, and the device counters show that published distances were used (the int8
+    test is switched off here, so every neighbour not gathered locally was published)."""
     O = oracle
+    tune.set("SOLO", solo)
     code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
     base = _data(O, 20000, dim, "clustered", seed=51)
     base[9000:9100] = base[17]                                  # ties among the candidates
@@ -634,19 +639,20 @@ def test_helpers_evaluate_small_launches(eng, oracle, metric, dim, M):
     with eng.Index(base, metric) as idx:
         idx.hnsw_build(M, 80, 42)                               # M = 32: 64 neighbour slots, 16 per helper
         g = idx.get_graph()
-        oi, od, ost, _ = O.hnsw_search(base, g, Q, 10, ef=96, metric=code, mode=O.MODE_DEV)
         idx.set_rejection_test(0)
         idx.set_profiling(True)
         used = 0
-        for rep in range(3):
-            for lo, hi in [(0, 1), (1, 4), (4, 24), (0, 64), (63, 64)]:
-                idx.rejection_stats(reset=True)
-                ids, d, st = idx.hnsw_search(Q[lo:hi], 10, 96, want_stats=True)
-                gathered, neighbours = idx.rejection_stats(reset=True)
-                assert_exact(ids, d, oi[lo:hi], od[lo:hi], "helpers rep %d queries %d..%d" % (rep, lo, hi))
-                np.testing.assert_array_equal(st, ost[lo:hi])
-                assert neighbours == int(ost[lo:hi, 0].sum()) and gathered <= neighbours
-                used += neighbours - gathered
+        for ef in (96, 640):                                    # (640: the headline's operating point -- a long list, many merges)
+            oi, od, ost, _ = O.hnsw_search(base, g, Q, 10, ef=ef, metric=code, mode=O.MODE_DEV)
+            for rep in range(3 if ef == 96 else 1):
+                for lo, hi in [(0, 1), (1, 4), (4, 24), (0, 64), (63, 64)]:
+                    idx.rejection_stats(reset=True)
+                    ids, d, st = idx.hnsw_search(Q[lo:hi], 10, ef, want_stats=True)
+                    gathered, neighbours = idx.rejection_stats(reset=True)
+                    assert_exact(ids, d, oi[lo:hi], od[lo:hi], "helpers ef %d rep %d queries %d..%d" % (ef, rep, lo, hi))
+                    np.testing.assert_array_equal(st, ost[lo:hi])
+                    assert neighbours == int(ost[lo:hi, 0].sum()) and gathered <= neighbours
+                    used += neighbours - gathered
         idx.set_profiling(False)
         assert used > 0, "no published distance was ever used"
 
