@@ -11,10 +11,11 @@ static int solo_groups() {
     return v < 0 ? 0 : (v > 31 ? 31 : static_cast<int>(v));
 }
 
-// HNSWGPU_TUNE_SOLO: 1 (default) = launches whose list is long enough for the split to pay (ef >= kSoloMinEf: a search of ~120
-// expansions is a descent whose every step waits for the step before it, and the round-2 helpers serve it as well), 2 = every
-// small launch, 0 = never
-constexpr int kSoloMinEf = 200;
+// HNSWGPU_TUNE_SOLO: 1 (default) = launches whose list is long enough for the split to pay (ef >= kSoloMinEf: a search of a few
+// dozen expansions is a descent whose every step waits for the step before it, and the round-2 helpers serve it as well --
+// 31k x 768 clustered, one query, round-2 helpers / this kernel: ef 50 249 / 255 us, ef 100 378 / 350, ef 200 612 / 524, ef 640
+// 1,900 / 1,210), 2 = every small launch, 0 = never
+constexpr int kSoloMinEf = 96;
 bool solo_enabled(int ef) {
     const int64_t m = tune(HNSWGPU_TUNE_SOLO, 1);
     return solo_groups() > 0 && (m >= 2 || (m == 1 && ef >= kSoloMinEf));
@@ -24,7 +25,9 @@ int launch_hnsw_solo(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     const int nch = idx->nch;
     a.qrows = nullptr;  // the owner's own int8 pass stays off: for a handful of queries it costs what it saves
     a.pf_groups = std::max(1, std::min(solo_groups(), idx->cus / std::max(a.nq, 1) - 1));
-    a.pf_hints = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(32, tune(HNSWGPU_TUNE_PF_HINTS, 16))));
+    // the window the fetchers keep evaluated ahead of the sequencer: 8 entries for short searches (ef 100: 350 us against 382
+    // with 16), 16 from ef 256 (ef 640: 1.21 ms against 1.25 with 8, 1.28 with 32)
+    a.pf_hints = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(32, tune(HNSWGPU_TUNE_PF_HINTS, a.ef < 256 ? 8 : 16))));
     a.solo_chase = tune(HNSWGPU_TUNE_SOLO_CHASE, 1) != 0 ? 1 : 0;
     const int grid = 8 * ((a.nq + 7) / 8) * (1 + a.pf_groups);
     // slots per query of the node-keyed tables: one per row while that stays small (no collisions), else ~32 per list

@@ -143,7 +143,7 @@ __device__ __forceinline__ void solo_helper(const HnswArgs &a, uint32_t *mail, i
                         // launch's number alone, be it this node's or one that shares the slot: two such nodes would otherwise
                         // take the slot from each other, and append each other, for ever)
                         if (want) want = (atomicMax(claim + solo_slot(static_cast<uint32_t>(myid), a.solo_log2s, a.n), mytag) >> 18) != (mytag >> 18);
-                        const uint64_t pm = __ballot(want);
+                        const uint64_t pm = __builtin_amdgcn_ballot_w64(want);
                         n_chase += __popcll(pm);
                         if (pm) {
                             const int leader = __ffsll(static_cast<unsigned long long>(pm)) - 1;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void solo_fetcher(const HnswArgs &a, const SoloLds &L
                     en.y = static_cast<uint32_t>(ev >> 32);
                 }
                 const bool un = !(en.y & kExpanded);
-                const uint64_t um = __ballot(un);
+                const uint64_t um = __builtin_amdgcn_ballot_w64(un);
                 const int pos = cm + __popcll(um & ((1ull << lane) - 1ull));
                 if (un && pos < 64) win[pos] = (static_cast<unsigned long long>(en.y) << 32) | en.x;
                 cm += __popcll(um);
@@ -284,7 +284,7 @@ __device__ __forceinline__ void solo_fetcher(const HnswArgs &a, const SoloLds &L
                 en.y = static_cast<uint32_t>(ev >> 32);
             }
             const bool un = !(en.y & kExpanded);
-            const uint64_t um = __ballot(un);
+            const uint64_t um = __builtin_amdgcn_ballot_w64(un);
             const int pos = __popcll(um & ((1ull << lane) - 1ull));
             if (un) win[pos] = (static_cast<unsigned long long>(en.y) << 32) | en.x;
             cb = __popcll(um);
@@ -335,20 +335,20 @@ __device__ __forceinline__ void solo_fetcher(const HnswArgs &a, const SoloLds &L
         const bool mine = lane < wcnt && w.y < static_cast<uint32_t>(a.n) && solo_half(w.y) == static_cast<uint32_t>(f);
         bool seen = false, isnew = false;
         uint64_t unc = 0;
-        for (uint64_t mm = __ballot(mine); mm; mm &= mm - 1) {
+        for (uint64_t mm = __builtin_amdgcn_ballot_w64(mine); mm; mm &= mm - 1) {
             const int j = __ffsll(static_cast<unsigned long long>(mm)) - 1;
             const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.y), j));
-            const uint64_t hit = __ballot(mgr && s_node == c);
+            const uint64_t hit = __builtin_amdgcn_ballot_w64(mgr && s_node == c);
             if (hit) seen = seen || (lane == __ffsll(static_cast<unsigned long long>(hit)) - 1);
             else unc |= 1ull << j;
         }
         for (uint64_t mm = unc; mm; mm &= mm - 1) {
             const int j = __ffsll(static_cast<unsigned long long>(mm)) - 1;
             const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.y), j));
-            uint64_t fm = __ballot(mgr && s_node == kSoloFree);
+            uint64_t fm = __builtin_amdgcn_ballot_w64(mgr && s_node == kSoloFree);
             bool steal = false;
             if (!fm) {  // no free slot: take one whose node has left the window (the sequencer re-checks the node after its reads)
-                fm = __ballot(mgr && !seen && !isnew);
+                fm = __builtin_amdgcn_ballot_w64(mgr && !seen && !isnew);
                 steal = true;
             }
             if (!fm) break;
@@ -373,7 +373,7 @@ __device__ __forceinline__ void solo_fetcher(const HnswArgs &a, const SoloLds &L
                 const uint32_t mytag = solo_tag(a.pf_seq, s_node);
                 push = atomicMax(claim + solo_slot(s_node, a.solo_log2s, a.n), mytag) != mytag;  // (the owner asks once per slot it fills)
             }
-            const uint64_t pm = __ballot(push);
+            const uint64_t pm = __builtin_amdgcn_ballot_w64(push);
             if (pm) {
                 const int leader = __ffsll(static_cast<unsigned long long>(pm)) - 1;
                 unsigned long long base = 0;
@@ -390,7 +390,7 @@ __device__ __forceinline__ void solo_fetcher(const HnswArgs &a, const SoloLds &L
         }
         // ---- poll the incomplete slots, four at a time: lane j = neighbour slot j of the node
         const bool pend = mgr && s_node < kSoloBusy && (s_valid & degmask) != degmask;
-        for (uint64_t pm = __ballot(pend); pm;) {
+        for (uint64_t pm = __builtin_amdgcn_ballot_w64(pend); pm;) {
             int Lq[4];
             uint32_t cq[4], stq[4];
             unsigned long long wq[4];
@@ -421,7 +421,7 @@ __device__ __forceinline__ void solo_fetcher(const HnswArgs &a, const SoloLds &L
                 const bool ok = lane < deg && static_cast<uint32_t>(wq[u] >> 32) == solo_tag(a.pf_seq, cq[u]);
                 const bool pad = lane < deg && (idq[u] < 0 || idq[u] >= a.n);
                 if (ok) c_d[sl * kMaxDeg + lane] = __uint_as_float(static_cast<uint32_t>(wq[u]));
-                const uint64_t vm = __ballot(ok || pad);
+                const uint64_t vm = __builtin_amdgcn_ballot_w64(ok || pad);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the data before the words that announce it
                 if (lane == Lq[u]) {
                     if (vm & ~s_valid) busy = true;
@@ -434,7 +434,7 @@ __device__ __forceinline__ void solo_fetcher(const HnswArgs &a, const SoloLds &L
                 }
             }
         }
-        if (!__ballot(busy)) __builtin_amdgcn_s_sleep(4);
+        if (!__builtin_amdgcn_ballot_w64(busy)) __builtin_amdgcn_s_sleep(4);
     }
     if (cnt_push && lane == 0) {
         atomicAdd(cnt_push, n_push);
@@ -466,7 +466,7 @@ __device__ __forceinline__ void solo_gather(const HnswArgs &a, const float4 (&q)
         int myj = -1;
 #pragma unroll
         for (int b = 0; b < RB; b++) {
-            const uint64_t hit = __ballot(isset && rank == t0 + b);
+            const uint64_t hit = __builtin_amdgcn_ballot_w64(isset && rank == t0 + b);
             const int jb = hit ? __ffsll(static_cast<unsigned long long>(hit)) - 1 : -1;
             myj = lane == b ? jb : myj;
         }
@@ -580,6 +580,7 @@ __global__ __launch_bounds__(kWG) void hnsw_solo_kernel(HnswArgs a) {
                 int tbase = 0;
                 float worst = 0.0f;         // of `nearest`, while it holds ef entries
                 bool dirty = false;         // the buffer differs from its mirror
+                bool dirty_sc = false;      // ... only its entry count does
                 auto load_front = [&](int from) {
                     fbase = from;
                     const int i = fbase + lane;
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(kWG) void hnsw_solo_kernel(HnswArgs a) {
                     if (i < lm) e = curA[i];
                     fd = __uint_as_float(e.x);
                     fi = e.y;
-                    fun = __ballot(i < lm && !(e.y & kExpanded));
+                    fun = __builtin_amdgcn_ballot_w64(i < lm && !(e.y & kExpanded));
                 };
                 auto load_tail = [&]() {
                     tbase = pm > kWave ? pm - kWave : 0;
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(kWG) void hnsw_solo_kernel(HnswArgs a) {
                         const bool more = phys > kWave || total > a.cap;
                         phys = phys > kWave ? kWave : phys;
                         const bool tie = lane < phys && curA[ef_l + (lane < phys ? lane : 0)].x == wbits;
-                        const uint64_t nt = ~__ballot(tie);
+                        const uint64_t nt = ~__builtin_amdgcn_ballot_w64(tie);
                         const int run = nt ? __ffsll(static_cast<unsigned long long>(nt)) - 1 : kWave;
                         if (run == phys && more && lane == 0) sc[6] = 1;  // ties may have been cut off: the query is repeated
                         lm = ef_l + run;
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(kWG) void hnsw_solo_kernel(HnswArgs a) {
                     if (level == 0) {
                         h_l0++;
                         const uint32_t cn = lane < kSoloSlots ? vnode[lane] : kSoloFree;
-                        const uint64_t hm = __ballot(cn == node);
+                        const uint64_t hm = __builtin_amdgcn_ballot_w64(cn == node);
                         if (hm) {
                             const int sl = __ffsll(static_cast<unsigned long long>(hm)) - 1;
                             // (in this order, volatile: the valid mask before the data it announces, the node again after
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(kWG) void hnsw_solo_kernel(HnswArgs a) {
                         if (level == 0) {
                             const bool ok = lane < deg && static_cast<uint32_t>(pubw >> 32) == solo_tag(a.pf_seq, node);
                             if (ok) dist = __uint_as_float(static_cast<uint32_t>(pubw));
-                            valid = __ballot(ok);
+                            valid = __builtin_amdgcn_ballot_w64(ok);
                         }
                     }
                     SOLO_STAMP(1);
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(kWG) void hnsw_solo_kernel(HnswArgs a) {
                         const uint32_t old = atomicOr(&bits[nb_id >> 5], bit);
                         fresh = !(old & bit);
                     }
-                    const uint64_t fm = __ballot(fresh);
+                    const uint64_t fm = __builtin_amdgcn_ballot_w64(fresh);
                     n_hop++;
                     if (fm == 0) continue;
                     n_eval += __popcll(fm);
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(kWG) void hnsw_solo_kernel(HnswArgs a) {
                             pubw = coherent_load(rec + static_cast<int64_t>(solo_slot(node, a.solo_log2s, a.n)) * a.M0 + lane);
                         const bool ok = ((need >> lane) & 1ull) && static_cast<uint32_t>(pubw >> 32) == solo_tag(a.pf_seq, node);
                         if (ok) dist = __uint_as_float(static_cast<uint32_t>(pubw));
-                        need &= ~__ballot(ok);
+                        need &= ~__builtin_amdgcn_ballot_w64(ok);
                         if (need == 0) h_poll++;
                     }
                     SOLO_STAMP(3);
@@ -794,14 +795,9 @@ __global__ __launch_bounds__(kWG) void hnsw_solo_kernel(HnswArgs a) {
                         // more than one trip: the assistant wave takes every second one (hand-over through LDS: ids and mask
                         // before the request word, its distances before the answer word)
                         uint64_t mine_m = need, theirs = 0;
-#ifndef HG_SOLO_NO_ASSIST
-                        if (nneed > RB)
-#else
-                        if (false)
-#endif
-                        {
+                        if (nneed > RB) {
                             const int rank = __popcll(need & ((1ull << lane) - 1ull));
-                            mine_m = __ballot(((need >> lane) & 1ull) && ((rank / RB) & 1) == 0);
+                            mine_m = __builtin_amdgcn_ballot_w64(((need >> lane) & 1ull) && ((rank / RB) & 1) == 0);
                             theirs = need & ~mine_m;
                             ldsv(Ls.g_ids)[lane] = nb_id;
                             g_seq++;
@@ -821,7 +817,7 @@ __global__ __launch_bounds__(kWG) void hnsw_solo_kernel(HnswArgs a) {
                     // ---- admission (:195-204), the reference's own loop: the fresh neighbours in adjacency order, each
                     //      against the worst of `nearest` as the ones before it have left it
                     const bool isfull = pm + pb >= ef_l;
-                    const uint64_t smask = __ballot(fresh && (!isfull || dist < worst));  // (the worst only shrinks)
+                    const uint64_t smask = __builtin_amdgcn_ballot_w64(fresh && (!isfull || dist < worst));  // (the worst only shrinks)
 #ifdef HG_SOLO_STAMPS
                     if (level == 0 && smask) {
                         dg[isfull ? 0 : 1]++;
@@ -830,27 +826,107 @@ __global__ __launch_bounds__(kWG) void hnsw_solo_kernel(HnswArgs a) {
 #endif
                     // (63 admissions at most between two merges: the buffer has 64 lanes, and the tail window of 64 main entries
                     // covers every eviction)
-#ifndef HG_SOLO_NO_HOIST
+                    SOLO_STAMP(5);
                     if (smask && nb + __popcll(smask) > kWave - 1) {
                         compact();
                         top_worst();
                     }
-#endif
+                    SOLO_STAMP(6);
+                    if (smask & (smask - 1)) {
+                        // ---- two or more survivors: all of them at once.  One pass in adjacency order decides every admission
+                        //      exactly as the sequential loop would -- a survivor is admitted iff fewer than ef of {`nearest` as the
+                        //      expansion found it, the survivors before it} are <= it (the entries those have pushed out of
+                        //      `nearest` meanwhile were larger than it anyway) -- and collects the merge counts; the admitted ones
+                        //      then enter the buffer together (a scatter through its LDS mirror), and what they push out of `nearest`
+                        //      (:203-204) is the nev largest of its two tails, found by all lanes at once (a merge-path split).
+                        int before = 0, arank = 0, cball = 0, shb = 0;
+                        uint64_t am = 0;
+                        const bool tvalid = tbase + lane < pm;
 #pragma unroll 1
-                    for (uint64_t mm = smask; mm; mm &= mm - 1) {
+                        for (uint64_t mm = smask; mm; mm &= mm - 1) {
+                            const int sv = __ffsll(static_cast<unsigned long long>(mm)) - 1;
+                            const float ds = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dist), sv));
+                            const int cb = __popcll(__builtin_amdgcn_ballot_w64(lane < pb && bd <= ds));
+                            const int cw = __popcll(__builtin_amdgcn_ballot_w64(tvalid && td <= ds));
+                            const int bs = __builtin_amdgcn_readlane(before, sv);
+                            // (smaller than every main entry the tail window shows, and the window does not start at 0: at most
+                            // ef - 64 main + buffer entries are <= it, and fewer than 64 survivors precede it)
+                            const int tm = (cw == 0 && tbase > 0) ? 0 : tbase + cw;
+                            const bool adm = tm + cb + bs < ef_l;
+                            before += (lane > sv && ds <= dist) ? 1 : 0;
+                            if (adm) {
+                                am |= 1ull << sv;
+                                shb += (ds < bd) ? 1 : 0;
+                                arank += (ds < dist || (ds == dist && sv < lane)) ? 1 : 0;
+                                cball = lane == sv ? cb : cball;
+                            }
+                        }
+                        const int nadm = __popcll(am);
+                        if (nadm) {
+                            const bool isadm = (am >> lane) & 1ull;
+                            if (lane < nb) {
+                                bm[lane + shb].x = __float_as_uint(bd);
+                                bm[lane + shb].y = bi;
+                            }
+                            if (isadm) {
+                                bm[cball + arank].x = __float_as_uint(dist);
+                                bm[cball + arank].y = static_cast<uint32_t>(nb_id);
+                            }
+                            nb += nadm;
+                            {
+                                const uint32_t ex = bm[lane].x, ey = bm[lane].y;
+                                bd = lane < nb ? __uint_as_float(ex) : __uint_as_float(0x7f800000u);
+                                bi = lane < nb ? ey : kExpanded;
+                            }
+                            bun = __builtin_amdgcn_ballot_w64(lane < nb && !(bi & kExpanded));
+                            const int pbn = pb + nadm;
+                            const int nev = pm + pbn > ef_l ? pm + pbn - ef_l : 0;
+                            if (nev) {
+                                // lane e: e entries leave the main list's tail, nev - e the buffer's.  Right iff what stays is
+                                // before what leaves: main entries are the older ones (a tie: the buffer entry leaves)
+                                const int e = lane, eb = nev - lane;
+                                const bool feas = e <= nev && e <= pm && eb <= pbn;
+                                const int i_mk = pm - e - 1, i_me = pm - e, i_bk = pbn - eb - 1, i_be = pbn - eb;
+                                const float m_keep = __uint_as_float(curA[i_mk > 0 ? i_mk : 0].x);
+                                const float m_ev = __uint_as_float(curA[(feas && e > 0) ? i_me : 0].x);
+                                const float b_keep = __uint_as_float(bm[(feas && i_bk > 0) ? i_bk : 0].x);
+                                const float b_ev = __uint_as_float(bm[(feas && eb > 0) ? i_be : 0].x);
+                                const bool ca = i_mk < 0 || eb == 0 || m_keep <= b_ev;
+                                const bool cb2 = i_bk < 0 || e == 0 || b_keep < m_ev;
+                                const uint64_t okm = __builtin_amdgcn_ballot_w64(feas && ca && cb2);
+                                int em = okm ? __ffsll(static_cast<unsigned long long>(okm)) - 1 : -1;
+                                if (em < 0) {  // (cannot happen for comparable distances; NaNs: one at a time, the sequential rule)
+                                    em = 0;
+                                    int pmm = pm, pbb = pbn;
+                                    for (int t = 0; t < nev; t++) {
+                                        const uint32_t wmb = pmm > 0 ? curA[pmm - 1].x : 0u;
+                                        const uint32_t wbb = pbb > 0 ? bm[pbb - 1].x : 0u;
+                                        if (pmm > 0 && (pbb == 0 || fkey(wmb) > fkey(wbb))) {
+                                            pmm--;
+                                            em++;
+                                        } else {
+                                            pbb--;
+                                        }
+                                    }
+                                }
+                                pm -= em;
+                                pb = pbn - (nev - em);
+                            } else {
+                                pb = pbn;
+                            }
+                            top_worst();
+                            dirty_sc = true;  // (the mirror IS the buffer now)
+                        }
+                    }
+#pragma unroll 1
+                    for (uint64_t mm = (smask & (smask - 1)) == 0 ? smask : 0; mm; mm &= mm - 1) {  // ONE survivor: straight into its place
                         const int j = __ffsll(static_cast<unsigned long long>(mm)) - 1;
                         const uint32_t djb = static_cast<uint32_t>(__builtin_amdgcn_readlane(__float_as_int(dist), j));
                         const uint32_t idj = static_cast<uint32_t>(__builtin_amdgcn_readlane(nb_id, j));
                         if (pm + pb >= ef_l && fkey(djb) >= worst_k) continue;  // (:195-198, a strict <)
-#ifdef HG_SOLO_NO_HOIST
-                        if (nb >= kWave - 1) {
-                            compact();
-                            top_worst();
-                        }
-#endif
                         // behind the buffer entries <= it (ties: admission order; lanes >= nb hold +inf)
                         const float dj = __uint_as_float(djb);
-                        const int r0 = __popcll(__ballot(bd <= dj));
+                        const int r0 = __popcll(__builtin_amdgcn_ballot_w64(bd <= dj));
                         const int r = r0 < nb ? r0 : nb;  // (an infinite distance: behind everything)
                         const float sd = __uint_as_float(wave_shr1(__float_as_uint(bd)));
                         const uint32_t si = wave_shr1(bi);
@@ -874,17 +950,19 @@ __global__ __launch_bounds__(kWG) void hnsw_solo_kernel(HnswArgs a) {
                         top_worst();
                         dirty = true;
                     }
-                    if (dirty) {  // the fetchers see the buffer through its mirror
-                        bm[lane].x = __float_as_uint(bd);
-                        bm[lane].y = bi;
-                        if (lane == 0) {
-                            sc[3] = nb;
-                            sc[1] = lm;
-                            sc[0] = fun ? fbase + __ffsll(static_cast<unsigned long long>(fun)) - 1 : fbase + kWave;
+                    SOLO_STAMP(7);
+                    if (dirty) Ls.bmir[lane] = make_uint2(__float_as_uint(bd), bi);  // the fetchers see the buffer through its mirror
+                    if (dirty || dirty_sc) {
+                        if (lane == 0) {  // (plain stores: hints, and the LDS takes a wave's stores in order)
+                            Ls.sc[3] = nb;
+                            Ls.sc[1] = lm;
+                            Ls.sc[0] = fun ? fbase + __ffsll(static_cast<unsigned long long>(fun)) - 1 : fbase + kWave;
                         }
+                        asm volatile("" ::: "memory");
                         dirty = false;
+                        dirty_sc = false;
                     }
-                    SOLO_STAMP(5);
+                    SOLO_STAMP(8);
                 }
                 compact();
                 if (lane == 0) {

@@ -328,7 +328,7 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_IVF_HALF 2 /* 0 = no half-precision copy of the IVF list rows (+50 % of the base).  env HNSWGPU_IVF_HALF */
 #define HNSWGPU_TUNE_IVF_CALIBRATE 3 /* 0 = mode-1 handles skip the first-search measurement of what the int8 bounds separate.  env HNSWGPU_IVF_CALIBRATE */
 #define HNSWGPU_TUNE_BUILD_THREADS 4 /* host threads of the HNSW linker (0 = min(16, cores)); the graph does not depend on it.  env HNSWGPU_BUILD_THREADS */
-#define HNSWGPU_TUNE_PREFETCH 5 /* helper workgroups per query of small HNSW launches (0 = none, default 4).  env HNSWGPU_PREFETCH */
+#define HNSWGPU_TUNE_PREFETCH 5 /* helper workgroups per query of small HNSW launches (0 = none; default 8 for launches that spread a query over several CUs, 4 for the round-2 helpers).  env HNSWGPU_PREFETCH */
 #define HNSWGPU_TUNE_SEED_BOUNDS 6 /* 0 = every k-means++ round a full f32 pass (A/B) */
 #define HNSWGPU_TUNE_TILE_WGS 7 /* target workgroup count of the tile scan's work list */
 #define HNSWGPU_TUNE_TILE_PERSIST 8 /* tiles per work item of the persistent tile scan (0 = one workgroup per item) */
@@ -362,7 +362,7 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_SELECT_W 36 /* waves per query of select_topk_kernel (0 = auto) */
 #define HNSWGPU_TUNE_HNSW_NW 37 /* waves per query of the traversal kernel: 1 / 2 / 4 (0 = by batch size) */
 #define HNSWGPU_TUNE_VIS_GLOBAL 38 /* 1 = the traversal's visited set in HBM stamps whatever the index size (tests) */
-#define HNSWGPU_TUNE_PF_HINTS 39 /* unexpanded list entries the traversal posts to its helpers per expansion (default 4) */
+#define HNSWGPU_TUNE_PF_HINTS 39 /* unexpanded list entries kept evaluated ahead of the traversal by its helpers (solo launches: the fetchers' window, default 8 below ef 256 and 16 from there; round-2 helpers: entries posted per expansion, default 4) */
 #define HNSWGPU_TUNE_PF_EVAL 40 /* 0 = the helpers only warm the L2 (A/B) */
 #define HNSWGPU_TUNE_ZEROCOPY 41 /* 0 = small synchronous HNSW calls stage through copies instead of mapped pinned memory (A/B) */
 #define HNSWGPU_TUNE_BUILD_TIMING 42 /* 1 = hnswgpu_hnsw_build prints where its time went to stderr */
@@ -373,7 +373,7 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_HOME_STRAYS 47 /* home-list batches: a query the bounds pass appended no more than this many candidates to skips the per-survivor half-precision pass (the finish kernel fetches their f32 rows; default 32) */
 #define HNSWGPU_TUNE_ROUTE_MFMA 48 /* centroid distances of IVF batches on the f32 matrix cores in the GEMV order (the same bits): -1 from 256 queries (cosine / dot, rows of 256 / 512 / 768 elements), 0 never, 1 whenever possible, > 1 that many slices of the table per group of 16 queries */
 #define HNSWGPU_TUNE_STREAM_WIDE2 49 /* bounds pass of the largest batches with two 32-query column blocks per group (a staged list row meets 64 queries, four-wave workgroups): -1 from 256 (query, list) pairs per list, 0 never, 1 whenever the wide deferring epilogue runs */
-#define HNSWGPU_TUNE_SOLO 50 /* small HNSW launches, one query over several CUs (an owner workgroup keeps the reference's order, helper workgroups evaluate and chase ahead of it): 1 = from ef 200 (default), 2 = always, 0 = never (the round-2 helpers) */
+#define HNSWGPU_TUNE_SOLO 50 /* small HNSW launches, one query over several CUs (an owner workgroup keeps the reference's order, helper workgroups evaluate and chase ahead of it): 1 = from ef 96 (default), 2 = always, 0 = never (the round-2 helpers) */
 #define HNSWGPU_TUNE_SOLO_CHASE 51 /* 0 = the helpers only evaluate what the owner asks for (A/B) */
 #define HNSWGPU_TUNE_SOLO_SLOTS 52 /* log2 of the slots per query of the helpers' node-keyed tables (0 = auto) */
 #define HNSWGPU_TUNE_COUNT 53

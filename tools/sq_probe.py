@@ -67,8 +67,8 @@ for ef in efs:
                      b[37] / max(b[36], 1), b[38] / b[32], b[39]), flush=True)
             print("   ring entries evaluated %.2f per expansion, of them appended by helpers (chase) %.2f" % (b[59] / b[32], b[60] / b[32]))
             if b[40:50].sum() > 0:   # -DHG_SOLO_STAMPS (tools/build_solo_stamps.sh): shader cycles of the sequencer per expansion
-                names = ["select", "cache / adjacency", "visited filter", "one more look", "own gather", "admission", "-",
-                         "-", "-", "short-cut tails"]
+                names = ["select", "cache / adjacency", "visited filter", "one more look", "own gather", "survivor test", "buffer merge",
+                         "admission", "mirror", "short-cut tails"]
                 print("   sequencer cycles per level-0 expansion: " + ", ".join(
                     "%s %.0f" % (names[i], b[40 + i] / b[32]) for i in range(10) if names[i] != "-") + "; total %.0f" % (b[40:50].sum() / b[32]))
                 d = b[50:58].astype(float)
