@@ -524,7 +524,7 @@ def ivf_roofline(engine, dev, args, traffic):
     roofline.achieved / frac are TRAFFIC / kernel time against the 8 TB/s HBM spec -- a fraction of the roofline, never
     above 1; without a PMC pass (N > 1, --no-pmc) they fall back to the unique bytes, a lower bound of the traffic."""
     n, nlist, nprobe = args.ivf_n, 1024, 32
-    x, Qa = ivf_dataset(dev, n, nlist, 4096)
+    x, Qa = ivf_dataset(dev, n, nlist, 16384)
     base_h = None if args.no_cpu else x.cpu().numpy()   # for the oracle beside every timed batch size (ivf_parity_check)
     idx = engine.Index(x, "cosine", dev.index)
     del x
@@ -535,7 +535,7 @@ def ivf_roofline(engine, dev, args, traffic):
     cent_h, off, lids_h = idx.get_ivf()
     lens = np.diff(off)
     out = {}
-    for nq in (1, 32, 256, 1024, 2048, 4096, "4096_nohome", "32_f32", "4096_f32"):
+    for nq in (1, 32, 256, 1024, 2048, 4096, 8192, 16384, "4096_nohome", "32_f32", "4096_f32"):
         f32_only = isinstance(nq, str) and nq.endswith("_f32")   # the same batch with the int8 / half-precision rows switched off
         no_home = isinstance(nq, str) and nq.endswith("_nohome")  # ... with the home-list pass of large batches switched off (A/B, same box)
         key, nq = nq, int(nq.split("_")[0]) if isinstance(nq, str) else nq
@@ -655,6 +655,8 @@ def ivf_roofline(engine, dev, args, traffic):
            "batch_1024": out[1024],
            "batch_2048": out[2048],
            "batch_4096": out[4096],
+           "batch_8192": out[8192],      # (from 256 (query, list) pairs per list the bounds pass takes TWO 32-query column blocks
+           "batch_16384": out[16384],    #  per staged row: stream_bounds_kernel<3, false, true, 2>; each leg with its own parity_checked)
            "batch_4096_home_list_pass_off": out["4096_nohome"],
            "stream_note": "batches of 1.5 M candidates and more (48 queries here) pass the int8 survivors (survivors_per_query of batch_32: ~3 % of the "
                           "candidates) through half-precision list rows before any f32 row is fetched: survivors_per_query "
@@ -742,8 +744,12 @@ def ivf_dataset(dev, n, nlist, nq_all):
     x = centers[which] + 0.3 * torch.randn(n, DIM, generator=g, device=dev)
     x /= x.norm(dim=1, keepdim=True)
     g.manual_seed(43)
-    qw = torch.randint(0, nlist, (nq_all,), generator=g, device=dev)
-    Qa = centers[qw] + 0.3 * torch.randn(nq_all, DIM, generator=g, device=dev)
+    blocks = []                       # (in blocks of 4096: the first 4096 queries are the same draws whatever nq_all is)
+    for b0 in range(0, nq_all, 4096):
+        m = min(4096, nq_all - b0)
+        qw = torch.randint(0, nlist, (m,), generator=g, device=dev)
+        blocks.append(centers[qw] + 0.3 * torch.randn(m, DIM, generator=g, device=dev))
+    Qa = torch.cat(blocks) if len(blocks) > 1 else blocks[0]
     Qa /= Qa.norm(dim=1, keepdim=True)
     return x, Qa
 

@@ -87,6 +87,8 @@ _SIGS = {
     "hnswgpu_ivf_home_bounds": ["p", "p", "i32", "i64", "i64", "p", "p"],
     "hnswgpu_set_rejection_test": ["p", "i32"],
     "hnswgpu_get_rejection_stats": ["p", "p", "p", "i32"],
+    "hnswgpu_launch_count": ["i32", "p"],
+    "hnswgpu_hnsw_rejection_state": ["p", "p", "p", "p"],
     "hnswgpu_set_tuning": ["i32", "i64"],
     "hnswgpu_get_tuning": ["i32", "p", "p"],
     "hnswgpu_group_create": ["p", "i32", "i32", "i32", "p"],
@@ -98,7 +100,7 @@ _SIGS = {
     "hnswgpu_group_hnsw_search": ["p", "p", "i32", "i32", "i32", "p", "p"],
 }
 # keys of hnswgpu_set_tuning (include/hnswgpu.h: HNSWGPU_TUNE_*), in the header's order
-TUNE_KEYS = ['TILE_PAIRS', 'PREFILTER', 'IVF_HALF', 'IVF_CALIBRATE', 'BUILD_THREADS', 'PREFETCH', 'SEED_BOUNDS', 'TILE_WGS', 'TILE_PERSIST', 'STREAM_BUCKET', 'STREAM_WGS', 'FINISH_ORDER', 'STREAM_CAP', 'STREAM_MID', 'STREAM_NARROW', 'FINISH_ADAPT', 'FINISH_BISECT', 'FINISH_SLICES', 'FINISH_SPAN', 'STREAM_HEAVY', 'STREAM_HEAVY_MEAN', 'STREAM_HEAVY_MIN', 'MID_SLICES', 'MID_COMPACT', 'IVF_CODES', 'SCAN_ORDER', 'IVF_FUSED', 'IVF_GROUP', 'STREAM_ROUTE', 'STREAM_GROUP', 'ROUTE_GROUP', 'MID_WIDE', 'MERGE_W', 'SCAN_BLOCKS', 'ROUTE_WGS', 'TILE', 'SELECT_W', 'HNSW_NW', 'VIS_GLOBAL', 'PF_HINTS', 'PF_EVAL', 'ZEROCOPY', 'BUILD_TIMING', 'BUILD_BATCH', 'STREAM_HOME', 'HOME_CHUNK', 'HOME_DEPTH', 'HOME_STRAYS', 'ROUTE_MFMA', 'STREAM_WIDE2', 'SOLO', 'SOLO_CHASE', 'SOLO_SLOTS']
+TUNE_KEYS = ['TILE_PAIRS', 'PREFILTER', 'IVF_HALF', 'IVF_CALIBRATE', 'BUILD_THREADS', 'PREFETCH', 'SEED_BOUNDS', 'TILE_WGS', 'TILE_PERSIST', 'STREAM_BUCKET', 'STREAM_WGS', 'FINISH_ORDER', 'STREAM_CAP', 'STREAM_MID', 'STREAM_NARROW', 'FINISH_ADAPT', 'FINISH_BISECT', 'FINISH_SLICES', 'FINISH_SPAN', 'STREAM_HEAVY', 'STREAM_HEAVY_MEAN', 'STREAM_HEAVY_MIN', 'MID_SLICES', 'MID_COMPACT', 'IVF_CODES', 'SCAN_ORDER', 'IVF_FUSED', 'IVF_GROUP', 'STREAM_ROUTE', 'STREAM_GROUP', 'ROUTE_GROUP', 'MID_WIDE', 'MERGE_W', 'SCAN_BLOCKS', 'ROUTE_WGS', 'TILE', 'SELECT_W', 'HNSW_NW', 'VIS_GLOBAL', 'PF_HINTS', 'PF_EVAL', 'ZEROCOPY', 'BUILD_TIMING', 'BUILD_BATCH', 'STREAM_HOME', 'HOME_CHUNK', 'HOME_DEPTH', 'HOME_STRAYS', 'ROUTE_MFMA', 'STREAM_WIDE2', 'SOLO', 'SOLO_CHASE', 'SOLO_SLOTS', 'HNSW_CALIBRATE', 'HNSW_CALIBRATE_PCT']
 TUNE_DEFAULT = -(1 << 63)
 
 
@@ -106,6 +108,16 @@ def set_tuning(name, value=None):
     """hnswgpu_set_tuning by name (lower or upper case); value None restores the default.  Process-wide."""
     key = TUNE_KEYS.index(name.upper())
     check(lib().hnswgpu_set_tuning(key, TUNE_DEFAULT if value is None else int(value)))
+
+
+LAUNCH_COUNTERS = ["bounds_two_column_blocks", "hnsw_solo", "hnsw_helpers", "hnsw_rejection", "hnsw_plain"]
+
+
+def debug_counter(name):
+    """hnswgpu_launch_count by name: launches that took the named kernel variant since the library was loaded."""
+    v = C.c_int64(0)
+    check(lib().hnswgpu_launch_count(LAUNCH_COUNTERS.index(name), C.byref(v)))
+    return v.value
 
 
 def get_tuning(name):

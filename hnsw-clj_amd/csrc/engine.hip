@@ -197,6 +197,7 @@ int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narr
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "bounds pass grid too large");
     const bool two = qblocks == 2 && !narrow && a.defer;  // two 32-query column blocks per group (the work list was built for them)
     HG_REQUIRE(qblocks == 1 || two, HNSWGPU_EINVAL, "bounds pass: two column blocks need the wide deferring epilogue");
+    if (two) count_launch(HNSWGPU_COUNT_BOUNDS_TWO_BLOCKS);
     const size_t lds = stream_lds_bytes(nch, narrow, two ? 2 : 1, two ? 4 : kTileWaves);
 #define CALLV(N, NARROW, DEFER, QB)                                                                                    \
     do {                                                                                                               \
@@ -1299,6 +1300,7 @@ bool tile_path_ok(const hnswgpu_index *idx) {
 int tile_mode() { return static_cast<int>(tune(HNSWGPU_TUNE_TILE, -1)); }
 
 std::atomic<int64_t> g_tune[HNSWGPU_TUNE_COUNT];
+std::atomic<int64_t> g_launch_count[HNSWGPU_COUNT_N];
 // The six environment variables include/hnswgpu.h documents, read once when the library is loaded.
 static const struct TuneInit {
     TuneInit() {
@@ -1749,6 +1751,9 @@ int hnswgpu_destroy(hnswgpu_index *idx) {
             (void)hipEventDestroy(pr.second);
         }
     if (idx->ev_last) (void)hipEventDestroy(idx->ev_last);
+    if (idx->ev_hnsw_cal) (void)hipEventDestroy(idx->ev_hnsw_cal);
+    if (idx->d_hnsw_cal) (void)hipFree(idx->d_hnsw_cal);
+    if (idx->hnsw_cal_host) (void)hipHostFree(idx->hnsw_cal_host);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     if (idx->h_pin) (void)hipHostFree(idx->h_pin);
     for (auto &sl : idx->slots) {
@@ -2221,9 +2226,11 @@ int hnswgpu_ivf_half_bounds(hnswgpu_index *idx, const float *q, const int32_t *l
 int hnswgpu_ivf_home_bounds(hnswgpu_index *idx, const float *Q, int32_t nq, int64_t row_begin, int64_t row_end, float *out_lb,
                             float *out_ub) {
     HG_REQUIRE(idx && Q && out_lb && out_ub && nq >= 1, HNSWGPU_EINVAL, "null argument");
-    HG_REQUIRE(row_begin >= 0 && row_begin < row_end && row_end <= idx->n && row_end - row_begin < (1 << 24), HNSWGPU_EINVAL, "row range");
     std::lock_guard<std::mutex> lk(idx->mu);
+    // (under the lock: hnswgpu_hnsw_add grows idx->n)
+    HG_REQUIRE(row_begin >= 0 && row_begin < row_end && row_end <= idx->n && row_end - row_begin < (1 << 24), HNSWGPU_EINVAL, "row range");
     HG_HIP(hipSetDevice(idx->device));
+    try {  // (the work lists and the staging below are host vectors: no exception crosses the C boundary)
     HG_REQUIRE(idx->d_lhalf, HNSWGPU_EINVAL, "this handle has no half-precision list rows (no lists, no int8 rows, or HNSWGPU_IVF_HALF=0)");
     HG_REQUIRE(idx->ld % 128 == 0, HNSWGPU_EINVAL, "the home-list pass serves rows of whole 128-element steps");
     hipStream_t st = idx->stream;
@@ -2281,6 +2288,10 @@ int hnswgpu_ivf_home_bounds(hnswgpu_index *idx, const float *Q, int32_t nq, int6
             out_ub[i * len + r] = host[i * hstride + r].y;
         }
     return 0;
+    } catch (const std::bad_alloc &) {
+        set_error("host allocation failed in hnswgpu_ivf_home_bounds");
+        return HNSWGPU_ENOMEM;
+    }
 }
 
 int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode) {
@@ -2289,7 +2300,10 @@ int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode) {
     std::lock_guard<std::mutex> lk(idx->mu);
     HG_HIP(hipSetDevice(idx->device));
     idx->rejection_mode = mode;
-    idx->ivf_calibrated = idx->ivf_stream_off = false;  // (mode 1 measures again at the next IVF search)
+    // (mode 1 measures again at the next IVF search -- but not a SHARD of a larger index: its verdict is the whole index's
+    // (hnswgpu_ivf_set_stream_state); measuring alone it could take another kernel path than its siblings, and the sharded
+    // answer would no longer be the unsharded one bit for bit)
+    if (idx->d_glistoff == nullptr) idx->ivf_calibrated = idx->ivf_stream_off = false;
     if (mode != 0 && (idx->has_graph || idx->nlist > 0)) {  // int8 rows now for what exists, else with the graph / lists
         hipStream_t st = idx->stream;
         HG_TRY(begin_call(idx, st));
@@ -2299,6 +2313,21 @@ int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode) {
         HG_TRY(end_call(idx, st));
         HG_HIP(hipStreamSynchronize(st));
     }
+    return 0;
+}
+
+int hnswgpu_hnsw_rejection_state(hnswgpu_index *idx, int32_t *state, int32_t *off, double *frac) {
+    HG_REQUIRE(idx, HNSWGPU_EINVAL, "idx is null");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (state) *state = idx->hnsw_cal_state;
+    if (off) *off = idx->hnsw_rej_off ? 1 : 0;
+    if (frac) *frac = idx->hnsw_cal_frac;
+    return 0;
+}
+
+int hnswgpu_launch_count(int32_t which, int64_t *out) {
+    HG_REQUIRE(which >= 0 && which < HNSWGPU_COUNT_N && out, HNSWGPU_EINVAL, "no such launch counter: %d", which);
+    *out = hg::g_launch_count[which].load(std::memory_order_relaxed);
     return 0;
 }
 

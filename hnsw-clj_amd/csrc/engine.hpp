@@ -22,6 +22,8 @@
 namespace hg {
 
 void set_error(const char *fmt, ...);
+extern std::atomic<int64_t> g_launch_count[HNSWGPU_COUNT_N];  // hnswgpu_launch_count
+inline void count_launch(int which) { g_launch_count[which].fetch_add(1, std::memory_order_relaxed); }
 
 #define HG_HIP(expr)                                                                             \
     do {                                                                                         \
@@ -97,6 +99,15 @@ struct hnswgpu_index {
     float4 *d_lhmeta = nullptr;
     unsigned long long *d_rej_stats = nullptr;  // [2], counted by the traversal while profiling is on
     int rejection_mode = 1;  // 0 = off, 1 = batches that fill the chip (launch_hnsw_idx), 2 = every launch
+    // HNSW, mode 1: the first large launch on a graph counts what the int8 test decides (f32 rows fetched / neighbours
+    // evaluated, launch_hnsw_idx); where it rejects too little to pay for its own bytes -- rows whose neighbours all lie
+    // within the bounds' width of the list's worst -- the later large launches evaluate every neighbour in f32.  0 = not
+    // measured, 1 = measured (the counters are on their way to hnsw_cal_host), 2 = decided; reset with the graph.
+    int hnsw_cal_state = 0;
+    bool hnsw_rej_off = false;
+    double hnsw_cal_frac = 0.0;  // f32 rows / neighbours of the measured launch
+    unsigned long long *d_hnsw_cal = nullptr, *hnsw_cal_host = nullptr;  // [2] device counters, pinned host copy
+    hipEvent_t ev_hnsw_cal = nullptr;
     // IVF, mode 1: the first search measures what the int8 bounds separate on THIS data (ivf_calibrate) and switches the
     // survivor stream off for the handle when they leave more than a quarter of the candidates
     bool ivf_calibrated = false, ivf_calibrating = false, ivf_stream_off = false;

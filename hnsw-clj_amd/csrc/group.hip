@@ -186,8 +186,12 @@ int hnswgpu_group_set_ivf(hnswgpu_group *g, const float *base, int64_t n, const 
     for (int64_t i = 0; i < n; i++) HG_REQUIRE(list_ids[i] >= 0 && list_ids[i] < n, HNSWGPU_EINVAL, "list_ids[%lld] out of range", (long long)i);
     std::lock_guard<std::mutex> lk(g->mu);
     const int nd = static_cast<int>(g->devices.size());
-    try {
+    // (whatever fails in there: the group is left EMPTY, not with fresh members beside the old n / nlist / kind)
+    auto deal = [&]() -> int {
         group_clear_members(g);
+        g->n = 0;
+        g->nlist = 0;
+        g->kind = 0;
         std::vector<int64_t> glen(nlist);
         for (int l = 0; l < nlist; l++) glen[l] = list_off[l + 1] - list_off[l];
         std::vector<int32_t> order(nlist), owner(nlist);
@@ -231,10 +235,18 @@ int hnswgpu_group_set_ivf(hnswgpu_group *g, const float *base, int64_t n, const 
             off_any |= off;
         }
         for (int r = 0; r < nd; r++) HG_TRY(hnswgpu_ivf_set_stream_state(g->m[r].idx, off_any));
+        return 0;
+    };
+    int rc;
+    try {
+        rc = deal();
     } catch (const std::bad_alloc &) {
-        group_clear_members(g);
         set_error("host allocation failed while dealing the lists");
-        return HNSWGPU_ENOMEM;
+        rc = HNSWGPU_ENOMEM;
+    }
+    if (rc != 0) {
+        group_clear_members(g);
+        return rc;
     }
     g->n = n;
     g->nlist = nlist;
@@ -251,13 +263,23 @@ int hnswgpu_group_hnsw_build(hnswgpu_group *g, const float *base, int64_t n, int
     std::lock_guard<std::mutex> lk(g->mu);
     const int nd = static_cast<int>(g->devices.size());
     group_clear_members(g);
-    for (int r = 0; r < nd; r++) {
-        auto &mm = g->m[r];
-        const int64_t r0 = n * r / nd, r1 = n * (r + 1) / nd;
-        HG_TRY(hnswgpu_create(base + static_cast<size_t>(r0) * g->dim, r1 - r0, g->dim, g->metric, g->devices[r], &mm.idx));
-        if (r1 > r0) HG_TRY(hnswgpu_hnsw_build(mm.idx, M, ef_construction, seed + r));
-        mm.n = r1 - r0;
-        mm.row0 = r0;
+    g->n = 0;
+    g->nlist = 0;
+    g->kind = 0;
+    auto build = [&]() -> int {
+        for (int r = 0; r < nd; r++) {
+            auto &mm = g->m[r];
+            const int64_t r0 = n * r / nd, r1 = n * (r + 1) / nd;
+            HG_TRY(hnswgpu_create(base + static_cast<size_t>(r0) * g->dim, r1 - r0, g->dim, g->metric, g->devices[r], &mm.idx));
+            if (r1 > r0) HG_TRY(hnswgpu_hnsw_build(mm.idx, M, ef_construction, seed + r));
+            mm.n = r1 - r0;
+            mm.row0 = r0;
+        }
+        return 0;
+    };
+    if (const int rc = build(); rc != 0) {
+        group_clear_members(g);  // (a failed build leaves the group empty)
+        return rc;
     }
     g->n = n;
     g->kind = 2;

@@ -55,6 +55,22 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     // 31k x 768, ef 100, ms per launch without / with: 256 queries 0.537 / 0.571, 512: 0.607 / 0.590, 768: 0.817 /
     // 0.611, 1024: 1.05 / 0.74, 10000: 9.9 / 4.4 (tools/hnsw_batch_sweep.py) -- on from two queries per CU.
     if (!(idx->rejection_mode == 2 || (idx->rejection_mode == 1 && a.nq >= 2 * idx->cus && idx->dim >= 128))) a.qrows = nullptr;
+    // Mode 1 also MEASURES (once per graph, on its first large launch): the int8 stage pays while it keeps enough f32 rows
+    // from being fetched -- 31k x 768 clustered, ef 640: half of them; 1.25M x 1536 clustered, ef 256: a tenth, and the
+    // launch then requests 1.15x the bytes of the plain traversal (profiles/r04_config5_hnsw_shard.txt).  Results never
+    // depend on it.  Nothing here blocks: the counters travel to pinned host memory behind an event a later launch looks at.
+    bool calibrate = false;
+    if (a.qrows && idx->rejection_mode == 1 && !a.q_rows && !a.q_index && tune(HNSWGPU_TUNE_HNSW_CALIBRATE, 1) != 0) {
+        if (idx->hnsw_cal_state == 1 && idx->ev_hnsw_cal && hipEventQuery(idx->ev_hnsw_cal) == hipSuccess) {
+            const double f32_rows = static_cast<double>(idx->hnsw_cal_host[0]), nb = static_cast<double>(idx->hnsw_cal_host[1]);
+            idx->hnsw_cal_frac = nb > 0 ? f32_rows / nb : 0.0;
+            const double keep = static_cast<double>(tune(HNSWGPU_TUNE_HNSW_CALIBRATE_PCT, 65)) / 100.0;
+            idx->hnsw_rej_off = nb > 0 && idx->hnsw_cal_frac > keep;  // the test leaves more than that of the rows to fetch
+            idx->hnsw_cal_state = 2;
+        }
+        if (idx->hnsw_cal_state == 2 && idx->hnsw_rej_off) a.qrows = nullptr;
+        calibrate = idx->hnsw_cal_state == 0 && !a.rej_stats;
+    }
     const bool vg = force_vg() || a.n > kLdsVisitedMaxRows;
     const bool pf = pf_groups() > 0 && !vg && !a.q_rows && !a.q_index && a.nq <= kPfMaxQueries && hnsw_nw() == 0 &&
                     a.n < (1LL << 31) && a.M0 <= kMaxDeg;
@@ -141,6 +157,17 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
         a.gen_base = idx->vis_gen;
         idx->vis_gen += static_cast<uint32_t>(gens);
     }
+    if (calibrate && a.qrows) {
+        if (!idx->d_hnsw_cal) {
+            HG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_hnsw_cal), 2 * sizeof(unsigned long long)));
+            HG_HIP(hipHostMalloc(reinterpret_cast<void **>(&idx->hnsw_cal_host), 2 * sizeof(unsigned long long), hipHostMallocDefault));
+            HG_HIP(hipEventCreateWithFlags(&idx->ev_hnsw_cal, hipEventDisableTiming));
+        }
+        HG_HIP(hipMemsetAsync(idx->d_hnsw_cal, 0, 2 * sizeof(unsigned long long), st));
+        a.rej_stats = idx->d_hnsw_cal;
+    } else {
+        calibrate = false;
+    }
     size_t lds = hnsw_lds_bytes(a.cap, a.nwords, nw);
     HG_REQUIRE(lds <= kMaxLds, HNSWGPU_ELIMIT,
                "HNSW search state (%zu B: ef=%d, n=%lld) exceeds the 160 KiB LDS of a CU", lds, a.ef, (long long)a.n);
@@ -203,11 +230,20 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
 #undef CALL_NW
 #undef CALL_K
     HG_HIP(hipGetLastError());
+    count_launch(pf ? HNSWGPU_COUNT_HNSW_HELPERS : (a.qrows ? HNSWGPU_COUNT_HNSW_REJECTION : HNSWGPU_COUNT_HNSW_PLAIN));
+    if (calibrate) {
+        HG_HIP(hipMemcpyAsync(idx->hnsw_cal_host, idx->d_hnsw_cal, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HG_HIP(hipEventRecord(idx->ev_hnsw_cal, st));
+        idx->hnsw_cal_state = 1;
+    }
     return 0;
 }
 
 static void free_graph(hnswgpu_index *idx) {
     idx->graph_gen++;  // searches in flight on a slot stream compare it before their repeat pass
+    idx->build_flags = 0;  // (an installed graph has none: engine.hpp; hnswgpu_hnsw_build_ex sets them once its graph stands)
+    idx->hnsw_cal_state = 0;  // the next graph is measured afresh
+    idx->hnsw_rej_off = false;
     void *ptrs[] = {idx->d_levels, idx->d_l0, idx->d_upadj, idx->d_upoff};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1531,9 +1567,10 @@ int hnswgpu_hnsw_build_ex(hnswgpu_index *idx, int32_t M, int32_t ef_construction
     HG_HIP(hipMemsetAsync(idx->d_upadj, 0xff, sizeof(int32_t) * std::max<int64_t>(blocks, 1) * M, st));
     g.entry = 0;  // first element becomes the entry point (:229-231)
     g.top = g.levels[0];
-    idx->build_flags = flags;
     HG_TRY(insert_batches(idx, g, 1, ef_construction, st, flags));
-    return publish_graph(idx, g, st);
+    HG_TRY(publish_graph(idx, g, st));
+    idx->build_flags = flags;  // (only a graph that stands carries its builder: hnswgpu_hnsw_add inserts the same way)
+    return 0;
 }
 
 // insert-single on a LIVE index (ultra_fast.clj:216-275, reached by add-vector! src/hnsw/api.clj:30-33 and add!

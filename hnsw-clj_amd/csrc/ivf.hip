@@ -769,7 +769,23 @@ static int ivf_tile_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32
 }
 
 // scratch of the survivor stream, carved out of s_qn: [QueryScal x nq | tau x nq | survivor count x nq]
+// The tuning values ONE search decides its passes by, read once (ivf_search_enqueue): the table is process-wide and another
+// thread may change it between the routing and the scan of the same search -- with the home-list decision flipping in between
+// the routing would seed no threshold for a scan that expects one (every query through the overflow fallback).
+struct StreamTune {
+    int64_t stream_mid, finish_order, stream_home, mid_slices, mid_compact, home_strays;
+    void read() {
+        stream_mid = tune(HNSWGPU_TUNE_STREAM_MID, -1);
+        finish_order = tune(HNSWGPU_TUNE_FINISH_ORDER, 512);  // 0 = never (A/B)
+        stream_home = tune(HNSWGPU_TUNE_STREAM_HOME, -1);
+        mid_slices = tune(HNSWGPU_TUNE_MID_SLICES, 0);
+        mid_compact = tune(HNSWGPU_TUNE_MID_COMPACT, 1);
+        home_strays = tune(HNSWGPU_TUNE_HOME_STRAYS, 32);
+    }
+};
+
 struct StreamScratch {
+    StreamTune tn;
     uint32_t *qcodes;
     QueryScal *qscal;
     uint32_t *tau, *surv_cnt;
@@ -819,14 +835,14 @@ static int stream_scratch(hnswgpu_index *idx, int32_t nq, StreamScratch &s) {
 // are a few per cent of the candidates: from ~1.5 M candidates per batch (48 queries x 32 lists x 977 rows; 5 queries at 10 M
 // rows) the pass saves more than its launch costs -- measured at 1M x 768: batch 32 0.183 ms without vs 0.195 with, 64:
 // 0.250 vs 0.243, 128: 0.298 vs 0.277.  HNSWGPU_TUNE_STREAM_MID=<queries> overrides (tests: 1 = always; 0 = never).
-static bool ivf_mid_mode(const hnswgpu_index *idx, int32_t nq, int32_t nprobe) {
-    const int64_t mid_env = tune(HNSWGPU_TUNE_STREAM_MID, -1);
+static bool ivf_mid_mode(const hnswgpu_index *idx, int32_t nq, int32_t nprobe, const StreamTune &tn) {
+    const int64_t mid_env = tn.stream_mid;
     const int64_t cand = static_cast<int64_t>(nq) * nprobe * ivf_mean_len(idx);
     return idx->d_lhalf != nullptr && !idx->ivf_calibrating && (mid_env >= 0 ? (mid_env > 0 && nq >= mid_env) : cand >= 1500000);
 }
 // are the queries of a batch served in the order of their nearest list (grouped bounds pass, large batches)?
-static bool ivf_ordered_mode(const hnswgpu_index *idx, int32_t nq, bool grouped) {
-    const int64_t order_min = tune(HNSWGPU_TUNE_FINISH_ORDER, 512);  // 0 = never (A/B)
+static bool ivf_ordered_mode(const hnswgpu_index *idx, int32_t nq, bool grouped, const StreamTune &tn) {
+    const int64_t order_min = tn.finish_order;
     return grouped && order_min > 0 && nq >= order_min && idx->nlist <= kOrderMaxLists;
 }
 // The home-list pass (stream_kernels.hpp, step 1a): batches in which the lists are home to about a query each or more --
@@ -835,11 +851,11 @@ static bool ivf_ordered_mode(const hnswgpu_index *idx, int32_t nq, bool grouped)
 // 128-element steps; from 512 queries and half a query per list (measured on the bench index, on / off: batch
 // 128 0.265 / 0.266 ms, 256 0.321 / 0.318, 512 0.383 / 0.399, 1024 0.480 / 0.558); HNSWGPU_TUNE_STREAM_HOME: -1 this rule, 0
 // never, 1 whenever the queries are ordered.  Decided BEFORE the routing (whose tail then skips the threshold seed) and again by the scan: one rule.
-static bool ivf_home_mode(const hnswgpu_index *idx, int32_t nq, int32_t nprobe, bool grouped) {
-    const int64_t home_env = tune(HNSWGPU_TUNE_STREAM_HOME, -1);
+static bool ivf_home_mode(const hnswgpu_index *idx, int32_t nq, int32_t nprobe, bool grouped, const StreamTune &tn) {
+    const int64_t home_env = tn.stream_home;
     const int64_t hstride = (idx->max_list_len + 15) / 16 * 16;
-    return ivf_mid_mode(idx, nq, nprobe) && ivf_ordered_mode(idx, nq, grouped) && idx->ld % 128 == 0 &&
-           home_env != 0 && tune(HNSWGPU_TUNE_MID_SLICES, 0) <= 1 && tune(HNSWGPU_TUNE_MID_COMPACT, 1) != 0 &&
+    return ivf_mid_mode(idx, nq, nprobe, tn) && ivf_ordered_mode(idx, nq, grouped, tn) && idx->ld % 128 == 0 &&
+           home_env != 0 && tn.mid_slices <= 1 && tn.mid_compact != 0 &&
            (home_env > 0 || (nq >= 512 && 2LL * nq >= idx->nlist)) && static_cast<int64_t>(nq) * hstride * 8 <= (2LL << 30) &&
            (static_cast<int64_t>(nq) / home_group(idx->nch) + std::min<int64_t>(nq, idx->nlist)) * ((idx->max_list_len + 4095) / 4096) < (1LL << 30);
 }
@@ -866,12 +882,13 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows, tpc = cr / kTileRows;
     b.chunk_rows = static_cast<int32_t>(cr);
     b.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
-    const bool mid = ivf_mid_mode(idx, nq, nprobe);
-    const int64_t order_min = tune(HNSWGPU_TUNE_FINISH_ORDER, 512);  // 0 = never (A/B)
-    const bool ordered = d_probes != nullptr && ivf_ordered_mode(idx, nq, grouped);
+    const StreamTune &tn = sc.tn;  // (one reading of the tuning table per search: the routing decided by the same values)
+    const bool mid = ivf_mid_mode(idx, nq, nprobe, tn);
+    const int64_t order_min = tn.finish_order;
+    const bool ordered = d_probes != nullptr && ivf_ordered_mode(idx, nq, grouped, tn);
     const int64_t hstride = (idx->max_list_len + 15) / 16 * 16;
     const int home_gq = home_group(idx->nch);
-    bool home = d_probes != nullptr && ivf_home_mode(idx, nq, nprobe, grouped);  // (the routing took the same decision)
+    bool home = d_probes != nullptr && ivf_home_mode(idx, nq, nprobe, grouped, tn);  // (the routing took the same decision)
     int64_t home_chunk = 256, home_bound = 0;
     if (const int64_t hc = tune(HNSWGPU_TUNE_HOME_CHUNK, 0); hc >= 64) home_chunk = hc / 64 * 64;
     if (home) {
@@ -1070,7 +1087,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         ha.list = idx->s_heavy.as<int32_t>() + 4;
         if (home) {  // ... and the queries the bounds pass appended more than a few candidates to
             ha.first = home_first;
-            ha.few = static_cast<uint32_t>(std::max<int64_t>(0, tune(HNSWGPU_TUNE_HOME_STRAYS, 32)));
+            ha.few = static_cast<uint32_t>(std::max<int64_t>(0, tn.home_strays));
             ha.todo_cnt = idx->s_heavy.as<uint32_t>() + 1;
             ha.todo = ha.list + nq;
         }
@@ -1097,13 +1114,13 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         ma.cap = cap;
         ma.nq = nq;
         ma.slices = qorder ? 1 : static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(16, 4096 / nq)));
-        if (const int64_t sl = tune(HNSWGPU_TUNE_MID_SLICES, 0)) ma.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(sl, 64)));  // tuning
+        if (const int64_t sl = tn.mid_slices) ma.slices = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(sl, 64)));  // tuning
         ma.qorder = ma.slices == 1 ? qorder : nullptr;
         // one workgroup per query sees the whole list: it also applies the threshold of the upper bounds and compacts the
         // list (up to 4096 entries: 16 KB of LDS -- more would cost the kernel its occupancy; a longer list is left to the finish kernel's own pass)
         ma.tau = b.tau;
         ma.k = k;
-        ma.compact = ma.slices == 1 && tune(HNSWGPU_TUNE_MID_COMPACT, 1) ? static_cast<int32_t>(std::min<int64_t>(cap, 4096)) : 0;
+        ma.compact = ma.slices == 1 && tn.mid_compact ? static_cast<int32_t>(std::min<int64_t>(cap, 4096)) : 0;
         ma.half = idx->d_lhalf;
         ma.hmeta = idx->d_lhmeta;
         ma.ld = idx->ld;
@@ -1123,7 +1140,7 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
             ma.todo = f.heavy_list + nq;
             ma.todo_slices = 8;
         }
-        ma.first_few = static_cast<int32_t>(tune(HNSWGPU_TUNE_HOME_STRAYS, 32));
+        ma.first_few = static_cast<int32_t>(tn.home_strays);
         HG_TRY(launch_mid(ma, idx->nch, st));
     }
     return launch_finish(f, idx->nch, st);
@@ -1292,6 +1309,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     // still use both for padded queries and norms, and must not move s_qn afterwards)
     StreamScratch sc;
     memset(&sc, 0, sizeof(sc));
+    sc.tn.read();
     const int stream_route_max = static_cast<int>(tune(HNSWGPU_TUNE_STREAM_ROUTE, 12));  // largest batch routed by the one-launch routing kernel
     const int stream_group_min = static_cast<int>(tune(HNSWGPU_TUNE_STREAM_GROUP, 5));    // queries from which the bounds pass groups the pairs by list
     if (use_code) {
@@ -1300,7 +1318,7 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     }
     bool codes_done = false;
     // the home-list pass of large batches (ivf_home_mode): the routing's tail leaves the thresholds to it
-    const bool home_mode = use_code && sc.bk_cnt != nullptr && probes_buf != nullptr && ivf_home_mode(idx, nq, nprobe, true);
+    const bool home_mode = use_code && sc.bk_cnt != nullptr && probes_buf != nullptr && ivf_home_mode(idx, nq, nprobe, true, sc.tn);
     // queries from which a GEMV-order batch routes through the group kernel
     // (Euclidean 1M x 768: 512 queries 0.85 vs 0.87 ms (GEMV vs group), 1024: 1.50 vs 1.43, 4096: 5.08 vs 4.70)
     const int route_group_min = static_cast<int>(tune(HNSWGPU_TUNE_ROUTE_GROUP, 1024));

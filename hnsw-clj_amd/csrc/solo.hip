@@ -104,6 +104,7 @@ int launch_hnsw_solo(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
 #undef CALL_SL
 #undef CALL_S
     HG_HIP(hipGetLastError());
+    count_launch(HNSWGPU_COUNT_HNSW_SOLO);
     return 0;
 }
 

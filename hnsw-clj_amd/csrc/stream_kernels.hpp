@@ -413,7 +413,9 @@ __global__ __launch_bounds__(QB == 1 ? kTileThreads : 256) void stream_bounds_ke
         bool home = false;
         if (a.home_pairs && qi >= 0) {
             const Pair hp = a.home_pairs[static_cast<int64_t>(qi) * a.home_nprobe];
-            home = hp.row_begin == rb0 && hp.row_end > hp.row_begin;
+            // (the query's FIRST pair, told by its place in the candidate stream, not by its list: hnswgpu_ivf_search_lists may name
+            // a list twice, and only the first pair's rows came through the home-list pass)
+            home = hp.row_begin == rb0 && hp.row_end > hp.row_begin && ob == hp.ord_base;
         }
         const uint64_t hb = __ballot(home);
         if (tid == 0) {
@@ -778,7 +780,7 @@ struct HomeArgs {
     const int32_t *nitems;
     const int32_t *qorder;   // the queries in the order of their nearest list
     const uint2 *half;       // [rows][ld / 4] four halves each (row-major)
-    const float4 *hmeta;     // (scale, E, 0, 1 / |v|)
+    const float4 *hmeta;     // (scale, E, |v as stored|^2, 1 / |v|): the squared norm feeds the Euclidean home-list bounds
     int64_t ld;              // elements per row, a multiple of 128
     const float *Q;
     int64_t qld;
@@ -1458,7 +1460,7 @@ struct MidArgs {
     int32_t compact;           // entries the k-th smallest upper bound does not exclude (dynamic LDS: 4 B x compact entries)
     const int32_t *qorder;     // optional (slices == 1): the queries in the order of their nearest list (as the finish kernel)
     const uint2 *half;         // [rows][ld / 4] four halves each
-    const float4 *hmeta;       // (scale, E, 0, 1 / |v|)
+    const float4 *hmeta;       // (scale, E, |v as stored|^2, 1 / |v|)
     int64_t ld;
     const float *Q;
     int64_t qld;

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native
-from ._native import COSINE, DOT, L2, check, get_tuning, lib, set_tuning  # noqa: F401
+from ._native import COSINE, DOT, L2, check, debug_counter, get_tuning, lib, set_tuning  # noqa: F401
 
 METRICS = {"cosine": COSINE, "l2": L2, "euclidean": L2, "dot": DOT, COSINE: COSINE, L2: L2, DOT: DOT}
 PROF_IVF_SCAN, PROF_HNSW, PROF_ASSIGN = 0, 1, 2
@@ -130,6 +130,12 @@ class Index:
     def set_rejection_test(self, mode):
         """0 = off, 1 = large batches (default), 2 = every launch: int8 rejection test of the HNSW traversal."""
         check(lib().hnswgpu_set_rejection_test(self._h, int(mode)))
+
+    def hnsw_rejection_state(self):
+        """hnswgpu_hnsw_rejection_state: (state, off, frac) -- what rejection mode 1 has measured on this graph."""
+        st, off, fr = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+        check(lib().hnswgpu_hnsw_rejection_state(self._h, C.byref(st), C.byref(off), C.byref(fr)))
+        return st.value, bool(off.value), fr.value
 
     def rejection_stats(self, reset=True):
         """(f32 rows fetched, neighbours evaluated) by the HNSW traversals since the last reset, while profiling was on."""

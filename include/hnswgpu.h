@@ -270,6 +270,15 @@ int hnswgpu_load(const char *path, int32_t device, hnswgpu_index **out);
  * launch stream.  which: 0 = IVF list scan, 1 = HNSW traversal, 2 = k-means assignment scan.
  * Returns the accumulated kernel ms and launch count since the last reset (forces a stream sync). */
 int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
+/* Process-wide counters of the kernel variants launches have taken since the library was loaded -- so that a test (or a
+ * benchmark line) can say WHICH path produced the results it checked, not only that the rule would have chosen it. */
+#define HNSWGPU_COUNT_BOUNDS_TWO_BLOCKS 0 /* IVF bounds pass with two 32-query column blocks per staged row (stream_bounds_kernel<.., QB = 2>) */
+#define HNSWGPU_COUNT_HNSW_SOLO 1         /* small HNSW launches that spread a query over several CUs (solo_kernels.hpp) */
+#define HNSWGPU_COUNT_HNSW_HELPERS 2      /* small HNSW launches of the round-2 helper kernel */
+#define HNSWGPU_COUNT_HNSW_REJECTION 3    /* HNSW traversal launches with the int8 rejection test on */
+#define HNSWGPU_COUNT_HNSW_PLAIN 4        /* ... and with every neighbour evaluated in f32 */
+#define HNSWGPU_COUNT_N 8
+int hnswgpu_launch_count(int32_t which, int64_t *out);
 /* The HNSW traversal decides most neighbours (those that cannot enter a full result list, ultra_fast.clj:195-198) from
  * an int8 copy of the rows: a lower bound of the distance that is already >= the list's worst needs no f32 row
  * (hnsw-clj_amd/csrc/kernels.hpp: quantize_rows_kernel; results and counters are unchanged by construction).  This
@@ -311,6 +320,12 @@ int hnswgpu_set_rejection_test(hnswgpu_index *idx, int32_t mode);
 /* While profiling is on the traversal counts the neighbours it evaluated and the f32 rows it had to fetch for them
  * (everything with the test off): the bytes a search really moved = neighbours * (int8 row + 16 B) + f32_rows * 4 * dim. */
 int hnswgpu_get_rejection_stats(hnswgpu_index *idx, int64_t *f32_rows, int64_t *neighbours, int32_t reset);
+/* Mode 1 measures what the traversal's int8 test decides on THIS graph (its first large launch counts f32 rows fetched /
+ * neighbours evaluated; nothing blocks: a later launch reads the counters) and evaluates every neighbour in f32 from then
+ * on where the test left more than 65 % of the rows to fetch (HNSWGPU_TUNE_HNSW_CALIBRATE_PCT) -- on such rows the int8 stage
+ * costs bytes instead of saving them.  state: 0 = not measured yet, 1 = measured, not yet read, 2 = decided; off: the
+ * verdict; frac: f32 rows / neighbours of the measured launch.  Results never depend on it. */
+int hnswgpu_hnsw_rejection_state(hnswgpu_index *idx, int32_t *state, int32_t *off, double *frac);
 int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int64_t *launches, int32_t reset);
 
 /* ---- tuning and test switches --------------------------------------------------------------------------------------
@@ -376,7 +391,9 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_SOLO 50 /* small HNSW launches, one query over several CUs (an owner workgroup keeps the reference's order, helper workgroups evaluate and chase ahead of it): 1 = from ef 96 (default), 2 = always, 0 = never (the round-2 helpers) */
 #define HNSWGPU_TUNE_SOLO_CHASE 51 /* 0 = the helpers only evaluate what the owner asks for (A/B) */
 #define HNSWGPU_TUNE_SOLO_SLOTS 52 /* log2 of the slots per query of the helpers' node-keyed tables (0 = auto) */
-#define HNSWGPU_TUNE_COUNT 53
+#define HNSWGPU_TUNE_HNSW_CALIBRATE 53 /* 0 = rejection mode 1 never measures what the traversal's int8 test decides (it then stays on for every large launch) */
+#define HNSWGPU_TUNE_HNSW_CALIBRATE_PCT 54 /* the int8 test of the traversal is switched off for a graph when it leaves more than this many percent of the neighbours' f32 rows to fetch (default 65) */
+#define HNSWGPU_TUNE_COUNT 55
 int hnswgpu_set_tuning(int32_t key, int64_t value);
 int hnswgpu_get_tuning(int32_t key, int64_t *value, int32_t *is_set);
 

@@ -36,7 +36,8 @@ def _check_topk(ids, d, n, k):
 @pytest.fixture(scope="module")
 def shard3(eng):
     """One GPU's share of configs[3]: 1.25M x 768 clustered-normalised rows (1024 true centres), nlist 1024 built on the
-    device (k-means++ seed 42, 10 Lloyd passes), 4096 held-out queries of the same mixture.  Shared by the tests below."""
+    device (k-means++ seed 42, 10 Lloyd passes), 16,384 held-out queries of the same mixture (in blocks of 4096 draws: the
+    first 4096 are the ones rounds 1-4 used).  Shared by the tests below."""
     import torch
 
     dev = torch.device("cuda", 0)
@@ -47,7 +48,8 @@ def shard3(eng):
     x = cen[torch.randint(0, nlist, (n,), generator=g, device=dev)] + 0.3 * torch.randn(n, 768, generator=g, device=dev)
     x /= x.norm(dim=1, keepdim=True)
     g.manual_seed(43)
-    Q = cen[torch.randint(0, nlist, (4096,), generator=g, device=dev)] + 0.3 * torch.randn(4096, 768, generator=g, device=dev)
+    Q = torch.cat([cen[torch.randint(0, nlist, (4096,), generator=g, device=dev)] + 0.3 * torch.randn(4096, 768, generator=g, device=dev)
+                   for _ in range(4)])
     Q = (Q / Q.norm(dim=1, keepdim=True)).contiguous()
     base = x.cpu().numpy()
     qh = Q.cpu().numpy()
@@ -106,11 +108,13 @@ def test_config3_ivf_per_gpu_shard(eng, oracle, shard3):
     assert_topk_parity(res[1024][0][:16], res[1024][1][:16], fi, fd, "config3 vs f64 oracle")
 
 
-@pytest.mark.parametrize("nq", [256, 1024, 4096])
+@pytest.mark.parametrize("nq", [256, 1024, 4096, 8192, 16384])
 def test_config3_ivf_production_path_against_oracle(eng, oracle, shard3, nq, tune):
     """The path a DEFAULT handle takes (what bench.py times and `profiles/` report): no pinned boundary, rejection mode 1
     with its first-search calibration -- int8 bounds on the matrix cores -> half-precision pass -> f32 finish, cosine --
-    at 1.25M x 768 / nlist 1024 / nprobe 32 / k 10 and batches of 256 / 1024 / 4096 (ivf_flat.clj:217-294).  A 64-query
+    at 1.25M x 768 / nlist 1024 / nprobe 32 / k 10 and batches of 256 / 1024 / 4096 / 8192 / 16384 (ivf_flat.clj:217-294; from
+    256 (query, list) pairs per list -- 8192 queries here -- the bounds pass meets a staged list row with TWO 32-query column
+    blocks, stream_bounds_kernel<.., QB = 2>: the library's launch counter says that it ran).  A 64-query
     subsample spread over the batch is compared with the oracle: ids and distance bits against its device (GEMV) order,
     ids and distances within 1e-4 against its f64 reference order; the counters say that the stream and the
     half-precision pass really ran (a handle whose calibration had switched the stream off would take the f32 scans)."""
@@ -127,9 +131,11 @@ def test_config3_ivf_production_path_against_oracle(eng, oracle, shard3, nq, tun
         idx.ivf_search_dev(Qb, k, nprobe)     # (calibration + scratch growth happen here)
         idx.set_profiling(True)
         idx.rejection_stats(reset=True)
+        wide0 = eng.debug_counter("bounds_two_column_blocks")
         i1, d1 = idx.ivf_search_dev(Qb, k, nprobe)
         torch.cuda.synchronize()
         f32_rows, cand = idx.rejection_stats(reset=True)
+        assert (eng.debug_counter("bounds_two_column_blocks") > wide0) == (nq * nprobe >= 256 * s["nlist"]), "bounds pass: column blocks"
         idx.set_profiling(False)
         i2, d2 = idx.ivf_search_dev(Qb, k, nprobe)
         torch.cuda.synchronize()
@@ -151,6 +157,45 @@ def test_config3_ivf_production_path_against_oracle(eng, oracle, shard3, nq, tun
     finally:
         idx.set_profiling(False)
         idx.set_rejection_test(2)             # the suite's mode for the tests that share this index
+
+
+@pytest.mark.parametrize("nq", [1024, 4096])
+def test_config3_ivf_euclidean_large_batches_against_oracle(eng, oracle, shard3, nq, tune):
+    """The Euclidean metric at configs[3]'s per-GPU size through the path a DEFAULT handle takes (int8 bounds on the matrix
+    cores, the home-list pass through `|q - v'|^2 = |q|^2 - 2 q.v' + |v'|^2`, the per-survivor half-precision pass, f32
+    finish; euclidean-distance-ultra, ultra_fast.clj:43-51, inside ivf_flat.clj:217-294): batches of 1024 and 4096 on the
+    same 1.25M x 768 rows, own k-means lists, a 64-query subsample against the oracle -- ids and distance bits in its device
+    (GEMV) order, ids and distances within 1e-4 against its f64 order.  (test_ivf_stream_equals_the_f32_scan_at_scale
+    compares the stream with the engine's own f32 scan; this puts the oracle beside the published large-batch numbers.)"""
+    import torch
+
+    O = oracle
+    s = shard3
+    base, Q, qh, n = s["base"], s["Q"], s["qh"], s["n"]
+    nprobe, k, nlist = 32, 10, 1024
+    tune.unset("TILE_PAIRS")
+    with eng.Index(torch.from_numpy(base).to(Q.device), "l2") as idx:
+        idx.set_rejection_test(1)             # the default mode: calibrates at the first IVF search
+        idx.ivf_build(nlist, 4, 42)
+        cent, off, lids = idx.get_ivf()
+        Qb = Q[:nq].contiguous()
+        idx.ivf_search_dev(Qb, k, nprobe)     # (calibration + scratch growth happen here)
+        idx.set_profiling(True)
+        idx.rejection_stats(reset=True)
+        i1, d1 = idx.ivf_search_dev(Qb, k, nprobe)
+        torch.cuda.synchronize()
+        f32_rows, cand = idx.rejection_stats(reset=True)
+        idx.set_profiling(False)
+        ids, d = i1.cpu().numpy(), d1.cpu().numpy()
+        _check_topk(ids, d, n, k)
+        assert cand >= nq * nprobe * 600, (f32_rows, cand)
+        assert f32_rows < 0.005 * cand, "f32 rows per query %.1f of %.1f candidates: the half-precision pass did not run" % (
+            f32_rows / nq, cand / nq)
+        sub = np.unique(np.linspace(0, nq - 1, 64).astype(np.int64))
+        oi, od, _ = O.ivf_search(base, cent, off, lids, qh[sub], k, nprobe, metric=O.L2, mode=O.MODE_DEV)
+        assert_exact(ids[sub], d[sub], oi, od, "config3 Euclidean production path, batch %d, vs oracle (GEMV order)" % nq)
+        fi, fd, _ = O.ivf_search(base, cent, off, lids, qh[sub[:16]], k, nprobe, metric=O.L2)   # f64 reference order
+        assert_topk_parity(ids[sub[:16]], d[sub[:16]], fi, fd, "config3 Euclidean production path, batch %d, vs f64 oracle" % nq)
 
 
 def test_config4_hnsw_per_gpu_shard(eng, oracle):
