@@ -254,6 +254,8 @@ bool attr_needed(bool (&done)[64]);
 // small HNSW launches, one query over several CUs (solo.hip)
 bool solo_enabled(int ef);
 int launch_hnsw_solo(hnswgpu_index *idx, HnswArgs a, hipStream_t st);
+// large HNSW launches, one wave per query on a main list + admission buffer (wave.hip)
+int launch_hnsw_wave(hnswgpu_index *idx, const HnswArgs &a, int grid, size_t lds, bool vg, hipStream_t st);
 int launch_norms(int nch, const float *rows, int64_t ld, int64_t n, float *out, hipStream_t st);
 int ensure_qrows(hnswgpu_index *idx, hipStream_t st);
 // int8 codes + per-row bound terms of `n` rows into freshly allocated *crows / *cmeta (the caller owns them)

@@ -26,6 +26,11 @@ static size_t hnsw_lds_bytes(int cap, int nwords, int nw) {
 
 constexpr size_t kMaxLds = 160 * 1024;
 
+static size_t wave_lds_bytes(int cap, int nwords) {
+    // wave_kernels.hpp: hnsw_wave_kernel's layout -- the main list, the buffer's image, the expansion's candidates, the visited set
+    return sizeof(uint2) * cap + sizeof(uint2) * kWave + 2 * sizeof(int32_t) * kMaxDeg + sizeof(uint32_t) * nwords + 16;
+}
+
 // tuning override (HNSWGPU_TUNE_HNSW_NW = 1 | 2 | 4); 0 = choose by batch size
 static int hnsw_nw() {
     const int64_t v = tune(HNSWGPU_TUNE_HNSW_NW, 0);
@@ -85,7 +90,14 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     // CU cannot hide the hop's dependent round trips, so the queries that fit get more waves each (the int8 and f32 steps
     // of a hop then run side by side).  31k x 768 clustered, 10,000 queries, QPS with 1 / 2 / 4 waves: ef 400 729k / 784k /
     // 513k, ef 800 250k / 343k / 258k, ef 1600 60k / 89k / 116k, ef 3200 10.8k / 17.7k / 25.6k (tools/large_ef_nw.py).
-    if (hnsw_nw() == 0)
+    // Launches that fill the chip with one wave per query take the kernel whose list is a main list + a register-resident
+    // admission buffer (wave_kernels.hpp) while enough of its queries fit a CU (8 bytes of LDS per list slot): no positional
+    // merge per expansion, the next candidate out of register windows.  HNSWGPU_TUNE_HNSW_WAVE = 0: never (A/B).
+    const size_t wlds = wave_lds_bytes(a.cap, vg ? 0 : a.nwords);
+    const int64_t wave_mode = tune(HNSWGPU_TUNE_HNSW_WAVE, 1);  // 2 = every launch it can serve (tests)
+    const bool use_wave = wave_mode != 0 && !pf && !a.q_rows && !a.q_index && hnsw_nw() == 0 && wlds <= kMaxLds && a.M0 <= kMaxDeg &&
+                          (wave_mode >= 2 || (nw == 1 && kMaxLds / wlds >= 13));
+    if (hnsw_nw() == 0 && !use_wave)
         while (nw < 4 && static_cast<int64_t>(kMaxLds / hnsw_lds_bytes(a.cap, vg ? 0 : a.nwords, nw)) * nw < 13) nw *= 2;
     int grid = a.nq;
     if (a.q_index) {  // repeat pass: few (usually no) work items, one large-list workgroup per CU at most
@@ -168,9 +180,20 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     } else {
         calibrate = false;
     }
-    size_t lds = hnsw_lds_bytes(a.cap, a.nwords, nw);
+    size_t lds = use_wave ? wave_lds_bytes(a.cap, a.nwords) : hnsw_lds_bytes(a.cap, a.nwords, nw);
     HG_REQUIRE(lds <= kMaxLds, HNSWGPU_ELIMIT,
                "HNSW search state (%zu B: ef=%d, n=%lld) exceeds the 160 KiB LDS of a CU", lds, a.ef, (long long)a.n);
+    if (use_wave) {
+        HG_TRY(launch_hnsw_wave(idx, a, grid, lds, vg, st));
+        count_launch(a.qrows ? HNSWGPU_COUNT_HNSW_REJECTION : HNSWGPU_COUNT_HNSW_PLAIN);
+        count_launch(HNSWGPU_COUNT_HNSW_WAVE);
+        if (calibrate) {
+            HG_HIP(hipMemcpyAsync(idx->hnsw_cal_host, idx->d_hnsw_cal, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HG_HIP(hipEventRecord(idx->ev_hnsw_cal, st));
+            idx->hnsw_cal_state = 1;
+        }
+        return 0;
+    }
     bool l2 = a.metric == METRIC_L2;
 #define CALL_K(N, R, L, W, V)                                                                                \
     do {                                                                                                     \

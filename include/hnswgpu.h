@@ -277,6 +277,7 @@ int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
 #define HNSWGPU_COUNT_HNSW_HELPERS 2      /* small HNSW launches of the round-2 helper kernel */
 #define HNSWGPU_COUNT_HNSW_REJECTION 3    /* HNSW traversal launches with the int8 rejection test on */
 #define HNSWGPU_COUNT_HNSW_PLAIN 4        /* ... and with every neighbour evaluated in f32 */
+#define HNSWGPU_COUNT_HNSW_WAVE 5         /* large HNSW launches on the one-wave-per-query kernel with the admission buffer (wave_kernels.hpp) */
 #define HNSWGPU_COUNT_N 8
 int hnswgpu_launch_count(int32_t which, int64_t *out);
 /* The HNSW traversal decides most neighbours (those that cannot enter a full result list, ultra_fast.clj:195-198) from
@@ -393,7 +394,8 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_SOLO_SLOTS 52 /* log2 of the slots per query of the helpers' node-keyed tables (0 = auto) */
 #define HNSWGPU_TUNE_HNSW_CALIBRATE 53 /* 0 = rejection mode 1 never measures what the traversal's int8 test decides (it then stays on for every large launch) */
 #define HNSWGPU_TUNE_HNSW_CALIBRATE_PCT 54 /* the int8 test of the traversal is switched off for a graph when it leaves more than this many percent of the neighbours' f32 rows to fetch (default 65) */
-#define HNSWGPU_TUNE_COUNT 55
+#define HNSWGPU_TUNE_HNSW_WAVE 55 /* large HNSW launches on the one-wave-per-query kernel with the admission buffer: 1 = launches that fill the chip with one wave per query while 13 such queries fit a CU (default), 0 = never (A/B), 2 = every launch it can serve (tests) */
+#define HNSWGPU_TUNE_COUNT 56
 int hnswgpu_set_tuning(int32_t key, int64_t value);
 int hnswgpu_get_tuning(int32_t key, int64_t *value, int32_t *is_set);
 

@@ -657,6 +657,39 @@ def test_helpers_evaluate_small_launches(eng, oracle, tune, metric, dim, M, solo
         assert used > 0, "no published distance was ever used"
 
 
+@pytest.mark.parametrize("vis_global", [0, 1])
+@pytest.mark.parametrize("metric,dim,M", [("cosine", 136, 16), ("l2", 72, 16), ("dot", 300, 32), ("cosine", 768, 8)])
+def test_wave_kernel_against_oracle(eng, oracle, tune, metric, dim, M, vis_global):
+    """Large launches run one wave per query on a main list + a register-resident admission buffer (wave_kernels.hpp: the
+    list of solo_kernels.hpp's sequencer) instead of the single-workgroup kernel's positional merge; search-layer-ultra,
+    ultra_fast.clj:151-212.  Forced here for batches of 130 and 600 queries (HNSW_WAVE = 2; by default launches that fill the
+    chip take it: test_timed_launch_configurations_against_oracle, test_full_size_31k_properties), with the int8 rejection
+    test on and off, the visited set in LDS and in HBM stamps, duplicated rows (hundreds of exact ties at the list's worst:
+    ghosts, and lists that overflow into the repeat pass), ef from 1 to 900: ids, distance bits and both counters equal the
+    oracle's, and the launch counter says the kernel ran."""
+    O = oracle
+    code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
+    base = _data(O, 12000, dim, "clustered", seed=61)
+    base[7000:7300] = base[23]                                  # 300 copies of one row
+    base[100:140] = base[5]
+    Q = np.concatenate([_data(O, 598, dim, "clustered", seed=62), base[23:24], base[5:6]]).astype(np.float32)
+    tune.set("HNSW_WAVE", 2)
+    tune.set("VIS_GLOBAL", vis_global)
+    with eng.Index(base, metric) as idx:
+        idx.hnsw_build(M, 80, 42)
+        g = idx.get_graph()
+        for ef, k in ((1, 1), (10, 10), (96, 10), (333, 100), (900, 10)):
+            oi, od, ost, _ = O.hnsw_search(base, g, Q, k, ef=ef, metric=code, mode=O.MODE_DEV)
+            for mode in (2, 0):
+                idx.set_rejection_test(mode)
+                for nq in (130, 600):
+                    n0 = eng.debug_counter("hnsw_wave")
+                    ids, d, st = idx.hnsw_search(Q[-nq:], k, ef, want_stats=True)
+                    assert eng.debug_counter("hnsw_wave") > n0, "the wave kernel did not run"
+                    assert_exact(ids, d, oi[-nq:], od[-nq:], "wave kernel %s ef %d mode %d nq %d" % (metric, ef, mode, nq))
+                    np.testing.assert_array_equal(st, ost[-nq:])
+
+
 @pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
 def test_rejection_test_modes_agree(eng, oracle, metric):
     """hnswgpu_set_rejection_test: off, large batches only, every launch -- ids, distance bits and the evals / hops

@@ -7,4 +7,4 @@ make -C hnsw-clj_amd/csrc -j6 > /dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -DHG_SOLO_STAMPS \
   -c hnsw-clj_amd/csrc/solo.hip -o build_dbg/solo_stamps.o
 cd hnsw-clj_amd/csrc
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build_dbg/libhnswgpu_solostamps.so engine.o ivf.o hnsw.o persist.o group.o ../../build_dbg/solo_stamps.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build_dbg/libhnswgpu_solostamps.so engine.o ivf.o hnsw.o wave.o persist.o group.o ../../build_dbg/solo_stamps.o

@@ -16,13 +16,13 @@ from hnsw_clj_amd import _native, engine
 
 efs = [int(x) for x in sys.argv[1:]] or [100, 640]
 dist = os.environ.get("SQ_DIST", "clustered")
-cache = "/tmp/sq_%s.npz" % dist
+cache = "/tmp/sq_%s_%s.npz" % (dist, os.environ.get("SQ_QUERIES", "256"))
 if os.path.exists(cache):
     z = np.load(cache)
     base, queries = z["base"], z["q"]
 else:
     base = bench.make_31k(dist, 42, 31173)
-    queries = bench.make_31k(dist, 43, 256)
+    queries = bench.make_31k(dist, 43, int(os.environ.get("SQ_QUERIES", "256")))
     np.savez(cache, base=base, q=queries)
 dev = torch.device("cuda", 0)
 idx = engine.Index(base, "cosine", 0)
@@ -76,7 +76,7 @@ for ef in efs:
                       "survivors; merges of the buffer into the list: %.2f per query" % (100 * d[0] / b[32], d[2] / max(d[0], 1),
                       100 * d[1] / b[32], d[3] / max(d[1], 1), b[58] / 110.0 / nq))
             buf[32:61] = 0
-        if stamps and nq == 1:
+        if stamps and (nq == 1 or os.environ.get("SQ_STAMPS_ANY")):
             names = ["level set-up", "select+adjacency+visited", "rejection test (int8 rows)", "f32 row gather+distances",
                      "merge 1 (rank)", "merge 2 (admit)", "merge 3 (scatter)", "epilogue"]
             slots = [0, 1, 8, 2, 3, 4, 5, 6]
