@@ -90,13 +90,16 @@ int launch_hnsw_idx(hnswgpu_index *idx, HnswArgs a, hipStream_t st) {
     // CU cannot hide the hop's dependent round trips, so the queries that fit get more waves each (the int8 and f32 steps
     // of a hop then run side by side).  31k x 768 clustered, 10,000 queries, QPS with 1 / 2 / 4 waves: ef 400 729k / 784k /
     // 513k, ef 800 250k / 343k / 258k, ef 1600 60k / 89k / 116k, ef 3200 10.8k / 17.7k / 25.6k (tools/large_ef_nw.py).
-    // Launches that fill the chip with one wave per query take the kernel whose list is a main list + a register-resident
-    // admission buffer (wave_kernels.hpp) while enough of its queries fit a CU (8 bytes of LDS per list slot): no positional
-    // merge per expansion, the next candidate out of register windows.  HNSWGPU_TUNE_HNSW_WAVE = 0: never (A/B).
+    // Launches that fill the chip with one wave per query, and every launch with a long list, take the kernel whose list is a
+    // main list + a register-resident admission buffer (wave_kernels.hpp: no positional merge per expansion, the next
+    // candidate out of register windows; 8 bytes of LDS per list slot).  31k x 768 clustered, QPS single-workgroup kernel /
+    // this one (tools/wave_sweep.py): 10,000 queries ef 50 4.55M / 4.80M, ef 640 516k / 778k, ef 1600 151k / 263k, ef 3200 51k /
+    // 91k; 2,048 queries ef 640 467k / 554k; 256 queries ef 50 459k / 418k (four waves per query are the better shape for a
+    // short list on a chip that is not full), ef 640 82k / 92k, ef 3200 13.9k / 22.7k.  HNSWGPU_TUNE_HNSW_WAVE = 0: never (A/B).
     const size_t wlds = wave_lds_bytes(a.cap, vg ? 0 : a.nwords);
     const int64_t wave_mode = tune(HNSWGPU_TUNE_HNSW_WAVE, 1);  // 2 = every launch it can serve (tests)
-    const bool use_wave = wave_mode != 0 && !pf && !a.q_rows && !a.q_index && hnsw_nw() == 0 && wlds <= kMaxLds && a.M0 <= kMaxDeg &&
-                          (wave_mode >= 2 || (nw == 1 && kMaxLds / wlds >= 13));
+    const bool use_wave = wave_mode != 0 && !pf && !a.q_index && hnsw_nw() == 0 && wlds <= kMaxLds && a.M0 <= kMaxDeg &&
+                          (wave_mode >= 2 || nw == 1 || a.ef >= 640);
     if (hnsw_nw() == 0 && !use_wave)
         while (nw < 4 && static_cast<int64_t>(kMaxLds / hnsw_lds_bytes(a.cap, vg ? 0 : a.nwords, nw)) * nw < 13) nw *= 2;
     int grid = a.nq;

@@ -285,7 +285,8 @@ struct WaveList {
 };
 
 // One wave per query (workgroups of one wave; persistent: workgroup b serves queries b, b + gridDim.x, ...).  VG = visited set in
-// HBM stamps.  Not for build launches or the repeat pass (hnsw_search_kernel keeps those).
+// HBM stamps.  Build launches too (q_rows: the query is a base row, the best entry of every upper level <= the node's level is
+// emitted for the linker, all ef candidates of layer 0 are the result); the repeat pass stays with hnsw_search_kernel.
 template <int NCH, int RB, bool L2, bool VG>
 __global__ __launch_bounds__(kWave) void hnsw_wave_kernel(HnswArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -300,11 +301,13 @@ __global__ __launch_bounds__(kWave) void hnsw_wave_kernel(HnswArgs a) {
     const int nvec = static_cast<int>(a.ld / 4);
     uint32_t gen = a.gen_base;
     for (int qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
+        const float *qptr = a.q_rows ? a.rows + static_cast<int64_t>(a.q_rows[qi]) * a.ld : a.Q + static_cast<int64_t>(qi) * a.qld;
         float4 q[NCH];
-        load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+        load_query<NCH>(q, qptr, a.dim, lane);
         const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
         QueryCode<NCH> qc;  // the query's side of the rejection test
         if (a.qrows != nullptr) encode_query<NCH>(q, qc);
+        const int qlevel = a.q_levels ? a.q_levels[qi] : -1;
         int64_t n_eval = 0, n_hop = 0, n_exact = 0;
         int len = 0;
         bool over = false;
@@ -317,7 +320,8 @@ __global__ __launch_bounds__(kWave) void hnsw_wave_kernel(HnswArgs a) {
             len = 1;
             n_eval = 1;
         }
-        for (int level = a.max_level; level >= 0; level--) {
+        const int top_l = (a.ref_start && qlevel >= 0 && qlevel < a.max_level) ? qlevel : a.max_level;
+        for (int level = top_l; level >= 0; level--) {
             const int ef_l = level > 0 ? 1 : a.ef;
             // fresh visited set per layer (:156); entries carried from the level above are marked
             if (VG) {
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(kWave) void hnsw_wave_kernel(HnswArgs a) {
             if (len > ef_l) len = ef_l;
             // the reference re-evaluates its entry points at every layer (:162-167); the values are reused here, but counted so
             // that `evals` is the reference's number of distance calls
-            if (level != a.max_level) n_eval += len;
+            if (level != top_l) n_eval += len;
             for (int i = lane; i < len; i += kWave) {
                 uint2 e = curA[i];
                 e.y &= ~kExpanded;
@@ -435,6 +439,10 @@ __global__ __launch_bounds__(kWave) void hnsw_wave_kernel(HnswArgs a) {
             }
             len = L.end_level();
             over = over || L.overflow;
+            if (a.q_rows && level > 0 && level <= qlevel && lane == 0) {  // build: the nearest node of this layer, for the linker
+                a.up_out_ids[static_cast<int64_t>(qi) * a.up_stride + (level - 1)] = len > 0 ? static_cast<int32_t>(curA[0].y & ~kExpanded) : -1;
+                a.up_out_dist[static_cast<int64_t>(qi) * a.up_stride + (level - 1)] = len > 0 ? __uint_as_float(curA[0].x) : 0.0f;
+            }
         }
         // ---- results: ascending, take k (:362-370; the distances are reused, not recomputed)
         const int real = len < a.ef ? len : a.ef;

@@ -394,7 +394,7 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_SOLO_SLOTS 52 /* log2 of the slots per query of the helpers' node-keyed tables (0 = auto) */
 #define HNSWGPU_TUNE_HNSW_CALIBRATE 53 /* 0 = rejection mode 1 never measures what the traversal's int8 test decides (it then stays on for every large launch) */
 #define HNSWGPU_TUNE_HNSW_CALIBRATE_PCT 54 /* the int8 test of the traversal is switched off for a graph when it leaves more than this many percent of the neighbours' f32 rows to fetch (default 65) */
-#define HNSWGPU_TUNE_HNSW_WAVE 55 /* large HNSW launches on the one-wave-per-query kernel with the admission buffer: 1 = launches that fill the chip with one wave per query while 13 such queries fit a CU (default), 0 = never (A/B), 2 = every launch it can serve (tests) */
+#define HNSWGPU_TUNE_HNSW_WAVE 55 /* large HNSW launches on the one-wave-per-query kernel with the admission buffer: 1 = launches that fill the chip with one wave per query, and every launch from ef 640 (default), 0 = never (A/B), 2 = every launch it can serve (tests) */
 #define HNSWGPU_TUNE_COUNT 56
 int hnswgpu_set_tuning(int32_t key, int64_t value);
 int hnswgpu_get_tuning(int32_t key, int64_t *value, int32_t *is_set);
