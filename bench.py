@@ -336,6 +336,8 @@ def main():
                                         "p95": round(lat_h[int(len(lat_h) * 0.95)], 4),
                                         "path": "hnswgpu_hnsw_search, host buffers in and out (the reference's search-knn seam): "
                                                 "query and results in mapped pinned memory, one launch, host-polled completion"},
+            "launch_paths": {k: engine.debug_counter(k) for k in ("hnsw_wave", "hnsw_solo", "hnsw_helpers", "hnsw_rejection", "hnsw_plain")},
+            "hnsw_rejection_state": dict(zip(("state", "int8_test_off", "f32_rows_per_neighbour"), idx.hnsw_rejection_state())),
             "single_query_latency_dev_ms": {"p50": round(lat[len(lat) // 2], 4), "min": round(lat[0], 4),
                                             "p95": round(lat[int(len(lat) * 0.95)], 4),
                                             "path": "hnswgpu_hnsw_search_dev on torch's stream + torch.cuda.synchronize()"},
@@ -352,7 +354,10 @@ def main():
                                           "re-reads",
                           "raw_fetch_size_bytes": (traffic or {}).get("hnsw", None) and traffic["hnsw"]["raw_fetch_size_bytes"],
                           "peak_range": list(IC_GATHER_GBS), "frac_of_hbm_spec": round(hnsw_gbs / HBM_PEAK_GBS, 4),
-                          "kernel": "hnsw_search_kernel", "avg_launch_ms": round(hnsw_avg_ms, 4),
+                          "kernel": "hnsw_wave_kernel (one wave per query: main list in LDS + register-resident admission buffer, "
+                                    "wave_kernels.hpp) -- %d of the launches of this process; hnsw_search_kernel serves the repeat "
+                                    "pass and small launches" % engine.debug_counter("hnsw_wave"),
+                          "avg_launch_ms": round(hnsw_avg_ms, 4),
                           "algorithmic_bytes_per_query": int(hnsw_bytes_q),
                           "algorithmic_GBs": round(hnsw_algo_gbs, 1),
                           "requested_bytes_per_query": int(moved_q),
@@ -484,6 +489,16 @@ def by_distribution(engine, dev, args, want_cpu):
                 out[name].update(cpu_point(idx, base, qh, first[0]))
             o = out[name]
             o["better_at_0.98"] = "exact scan" if (not o["reached_0.98"] or o["exact_knn_qps"] > o["qps"]) else "hnsw"
+            # The rule a caller can apply WITHOUT timing both (hnsw-clj_amd/ultra_fast.py: search_batch(route=True), hnsw.gpu/
+            # search-knn-routed): the traversal evaluates E(ef) rows per query at random, the exact scan streams all n once per
+            # batch through the matrix cores -- take the scan when E(ef) >= n / 3.  routed_qps = what that rule delivers here.
+            st = torch.zeros((min(nq, 256), 2), dtype=torch.int64, device=dev)
+            idx.hnsw_search_dev(Q[:min(nq, 256)], K, first[0], stats=st)
+            torch.cuda.synchronize()
+            evals = float(st[:, 0].double().mean())
+            o["evals_per_query"] = round(evals, 1)
+            o["routed_to"] = "exact scan" if (evals >= N31K / 3.0 or not o["reached_0.98"]) else "hnsw"
+            o["routed_qps"] = o["exact_knn_qps"] if o["routed_to"] == "exact scan" else o["qps"]
         log("by_distribution %s: %s (%.1fs)" % (name, out[name], time.time() - t0))
     out["note"] = ("i.i.d. gaussian / uniform 768-d have no neighbourhood structure: recall 0.98 needs ef in the thousands, where "
                    "the traversal evaluates most of the base per query -- on those sets the GPU's exact scan (recall 1.0) is the "
@@ -832,7 +847,7 @@ def pmc_traffic(args):
                 for row in csv.DictReader(open(f)):
                     if row["Counter_Name"] != ctr:
                         continue
-                    if "hg::hnsw_search_kernel<" in row["Kernel_Name"]:      # (dispatch id, bytes): the timed launches are the last
+                    if "hg::hnsw_search_kernel<" in row["Kernel_Name"] or "hg::hnsw_wave_kernel<" in row["Kernel_Name"]:  # (dispatch id, bytes): the timed launches are the last
                         vals_h.append((int(row.get("Dispatch_Id", len(vals_h))), float(row["Counter_Value"]) * 1024.0))
                     if PMC_SCAN_KERNEL in row["Kernel_Name"]:
                         vals.append(float(row["Counter_Value"]))

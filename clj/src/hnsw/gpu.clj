@@ -138,6 +138,32 @@
   [idx ^doubles query-vec k]
   (first (search-batch idx [query-vec] k)))
 
+(defn search-batch-routed
+  "search-batch with the crossover the device offers and the reference has no word for: the traversal evaluates E(ef) rows per
+   query, gathered at random; the exact scan (hnswgpu_exact_knn: every row once per batch through the matrix cores) answers at
+   recall 1.0 -- the cheaper way to at least the same recall once E(ef) >= n / 3 (31k x 768: 1.5M QPS exact against 0.78M through
+   the graph at ef 640, 90k at ef 3200).  E(ef) comes from the traversal's own counters (the `stats` argument of
+   hnswgpu_hnsw_search: evals, expansions per query) on up to 32 of the queries.  The neighbours of a routed batch are the
+   exact ones: at least as good as the graph's, not necessarily the same (hnsw-clj_amd/ultra_fast.py: search_batch route=True)."
+  [idx queries k & {:keys [ef] :or {ef 0}}]
+  (with-open [arena (Arena/ofConfined)]
+    (let [pilot (vec (take 32 queries))
+          np (count pilot)
+          q (floats-of arena pilot (:dim idx))
+          ids (.allocate arena (* 4 np k) 4)
+          ds (.allocate arena (* 4 np k) 4)
+          st (.allocate arena (* 16 np) 8)]
+      (check (.invokeWithArguments ^MethodHandle @h-search [(:handle idx) q (int np) (int k) (int ef) ids ds st]))
+      (let [evals (/ (reduce + (map #(.getAtIndex st ValueLayout/JAVA_LONG (* 2 (long %))) (range np))) (double np))]
+        (if (>= evals (/ (count (:ids idx)) 3.0))
+          (let [nq (count queries)
+                qa (floats-of arena (vec queries) (:dim idx))
+                ia (.allocate arena (* 4 nq k) 4)
+                da (.allocate arena (* 4 nq k) 4)]
+            (check (.invokeWithArguments ^MethodHandle @h-exact [(:handle idx) qa (int nq) (int k) ia da]))
+            (mapv #(results idx ia da % k) (range nq)))
+          (search-batch idx queries k :ef ef))))))
+
 (defn build-ivf-index
   "hnsw.ann.partition.ivf-flat/build-index (src/hnsw/ann/partition/ivf_flat.clj:137-211,300-303)."
   [data & {:keys [num-partitions max-iterations metric] :or {num-partitions 24 max-iterations 10 metric :cosine}}]

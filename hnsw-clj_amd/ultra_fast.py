@@ -102,14 +102,33 @@ def search_knn(graph, query_vec, k, ef=None):
     return _format(graph, ids[0], d[0])
 
 
-def search_batch(graph, queries, k, ef=None):
-    """All queries in ONE launch: the seam of BatchSearchIndex/search-batch* (api/protocol.clj:58-67)."""
+def routed_to_exact_scan(graph, queries, k, ef=None):
+    """The crossover rule of ``search_batch(route=True)``: the traversal evaluates E(ef) rows per query, gathered at random;
+    the exact scan (hnswgpu_exact_knn: every row once per batch, through the matrix cores) answers at recall 1.0 -- it is the
+    cheaper way to at least the same recall once E(ef) >= n / 3 (31k x 768 on one MI355X: 1.5M QPS exact against 0.78M
+    through the graph at ef 640, 90k at ef 3200; bench.py: by_distribution.*.routed_qps).  E(ef) is measured once per
+    (graph, k, ef) on up to 32 of the queries."""
+    key = (int(k), int(ef or 0))
+    cache = graph.__dict__.setdefault("_route", {})
+    if key not in cache:
+        _, _, st = graph.index.hnsw_search(np.asarray(queries, np.float32)[:32], int(k), ef or 0, want_stats=True)
+        cache[key] = float(st[:, 0].mean()) >= graph.index.n / 3.0
+    return cache[key]
+
+
+def search_batch(graph, queries, k, ef=None, route=False):
+    """All queries in ONE launch: the seam of BatchSearchIndex/search-batch* (api/protocol.clj:58-67).  ``route=True`` (not
+    in the reference) answers by the exact scan where that is cheaper than the traversal at this ef (routed_to_exact_scan):
+    the neighbours are then the exact ones -- at least as good as the graph's, not necessarily the same."""
     queries = np.asarray(queries, np.float32)
     if len(queries) == 0:
         return []
     if graph.index.n == 0:
         return [[] for _ in queries]
-    ids, d = graph.index.hnsw_search(queries, int(k), ef or 0)
+    if route and routed_to_exact_scan(graph, queries, k, ef):
+        ids, d = graph.index.exact_knn(queries, int(k))
+    else:
+        ids, d = graph.index.hnsw_search(queries, int(k), ef or 0)
     return [_format(graph, ids[i], d[i]) for i in range(len(queries))]
 
 

@@ -2267,6 +2267,12 @@ def test_reference_api_mirror(eng, oracle):
     assert len(calls) == 20 and threaded == [ultra_fast.search_knn(index, v, 10, ef=64) for v in vecs[:20]]
     bm = parallel_search.benchmark_parallel_search(index, list(vecs[:30]), 5, my_search, 4)
     assert bm["completed"] == 30 and bm["threads"] == 4 and bm["qps"] > 0
+    # route=True (not in the reference): the exact scan answers where the traversal would evaluate a third of the base and more
+    assert ultra_fast.search_batch(index, vecs[:8], 5, ef=10, route=True) == ultra_fast.search_batch(index, vecs[:8], 5, ef=10)
+    assert not ultra_fast.routed_to_exact_scan(index, vecs[:8], 5, ef=10) and ultra_fast.routed_to_exact_scan(index, vecs[:8], 5, ef=100)
+    ex_ids, _ = index.index.exact_knn(vecs[:8], 5)                   # (ef 100 on 100 rows evaluates every row)
+    assert [[r["id"] for r in row] for row in ultra_fast.search_batch(index, vecs[:8], 5, ef=100, route=True)] == \
+        [["vec_%d" % i for i in row] for row in ex_ids]
     gp = protocol.GpuHnswIndex(index)
     assert gp.search_batch_star(vecs[:3], 4)[2] == ultra_fast.search_knn(index, vecs[2], 4)
     assert protocol.default_batch_search(gp, vecs[:3], 4, None) == gp.search_batch_star(vecs[:3], 4)   # protocol.clj:92-95
