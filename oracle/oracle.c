@@ -1122,6 +1122,286 @@ static int srt_cmp(const void *x, const void *y) {
     return (a->ord > b->ord) - (a->ord < b->ord); /* stable */
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* 4b. graph/insert LITERALLY (src/hnsw/graph.clj:239-295) -- a CPU-only study, not a parity mode. */
+/*                                                                                              */
+/* What orc_hnsw_build_ex does NOT reproduce of hnsw.graph/insert: the walk starts at layer           */
+/* min(level, entry-level) with the entry point itself (no descent from the top, :275-278), searches with ef-construction   */
+/* on every layer it visits, then for EVERY layer 0..level runs a second search-layer with num-closest M over the layer-0    */
+/* result as entry points -- which returns all of them and what the expansion admits (:280-282: `nearest` starts with every  */
+/* entry point and is only pruned one entry per admission) -- links the new node to EVERY returned node (its own list stays  */
+/* unpruned until a later insert prunes it as somebody's neighbour), also on layers above those nodes' own level, and         */
+/* prunes only the neighbours (:283-287).  Adjacency sets are unbounded here, so the graph cannot live in the engine's        */
+/* fixed rows; this section builds it on the heap and searches it with graph.clj:115-161,297-320 (ef a parameter), to put     */
+/* its recall / ef curve beside the bounded variant's.  Set iteration order (Clojure hash sets: unspecified) = insertion       */
+/* order here; (apply min-key / max-key ...) ties = the first.                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t *a;
+    int32_t n, cap;
+} lset_t; /* a set of node ids in insertion order */
+typedef struct {
+    int64_t n;
+    int maxlev;        /* levels 0..maxlev-1 have storage */
+    lset_t *adj;       /* [n][maxlev] */
+    int32_t *levels;
+    int32_t entry;
+} lit_t;
+static inline lset_t *lit_set(lit_t *g, int32_t node, int level) { return &g->adj[(int64_t)node * g->maxlev + level]; }
+static inline int vis_test_set(visited_t *v, int32_t p) { /* 1 if p was visited already */
+    if (v->bits[p >> 6] & (1ULL << (p & 63))) return 1;
+    v->bits[p >> 6] |= 1ULL << (p & 63);
+    v->touched[v->nt++] = p;
+    return 0;
+}
+static inline void vis_clear(visited_t *v) {
+    for (int i = 0; i < v->nt; i++) v->bits[v->touched[i] >> 6] = 0;
+    v->nt = 0;
+}
+static int lset_has(const lset_t *s, int32_t x) {
+    for (int i = 0; i < s->n; i++)
+        if (s->a[i] == x) return 1;
+    return 0;
+}
+static void lset_add(lset_t *s, int32_t x) {
+    if (lset_has(s, x)) return;
+    if (s->n == s->cap) {
+        s->cap = s->cap ? 2 * s->cap : 8;
+        s->a = (int32_t *)realloc(s->a, sizeof(int32_t) * (size_t)s->cap);
+    }
+    s->a[s->n++] = x;
+}
+static void lset_del(lset_t *s, int32_t x) {
+    for (int i = 0; i < s->n; i++)
+        if (s->a[i] == x) {
+            for (int t = i; t + 1 < s->n; t++) s->a[t] = s->a[t + 1];
+            s->n--;
+            return;
+        }
+}
+/* search-layer, graph.clj:115-161: returns (keys @nearest) in out[] (unordered), their distances in out_d[] */
+static int lit_search_layer(lit_t *g, const dist_ctx *c, const int32_t *eps, int neps, int num_closest, int level, visited_t *vis,
+                            heap_t *cand, heap_t *near, int32_t *out, double *out_d, int64_t *n_eval) {
+    cand->n = 0;
+    near->n = 0;
+    vis->nt = 0;
+    int64_t seq = 0;
+    for (int i = 0; i < neps; i++) { /* :127-132: every entry point into both maps, whatever num-closest is */
+        if (vis_test_set(vis, eps[i])) continue;
+        cand_t e = {ctx_dist(c, eps[i]), seq++, eps[i]};
+        (*n_eval)++;
+        heap_push(cand, e);
+        heap_push(near, e);
+    }
+    while (cand->n > 0) { /* :135 */
+        cand_t cur = heap_pop(cand);
+        if (!(near->n < num_closest || cur.d <= near->a[0].d)) continue; /* :141-144 (the loop drains) */
+        const lset_t *nb = lit_set(g, cur.id, level);
+        for (int j = 0; j < nb->n; j++) {
+            const int32_t x = nb->a[j];
+            if (vis_test_set(vis, x)) continue; /* :147-148 */
+            const double d = ctx_dist(c, x);
+            (*n_eval)++;
+            if (near->n < num_closest || d < near->a[0].d) { /* :151-154 */
+                cand_t e = {d, seq++, x};
+                heap_push(cand, e);
+                heap_push(near, e);
+                if (near->n > num_closest) (void)heap_pop(near); /* :157-159: ONE entry leaves per admission */
+            }
+        }
+    }
+    const int cnt = near->n;
+    for (int i = 0; i < cnt; i++) {
+        out[i] = near->a[i].id;
+        if (out_d) out_d[i] = near->a[i].d;
+    }
+    vis_clear(vis);
+    return cnt;
+}
+
+typedef struct {
+    lit_t g;
+    dist_ctx c;
+    float *norms;
+    int M, efc;
+} lit_index;
+
+void *orc_lit_build(const float *base, int64_t n, int dim, int metric, int mode, int M, int efc, int64_t seed, int64_t *counters) {
+    lit_index *L = (lit_index *)calloc(1, sizeof(lit_index));
+    L->M = M;
+    L->efc = efc;
+    L->g.n = n;
+    L->g.levels = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    jrandom rng;
+    jr_init(&rng, seed);
+    const double ml = 1.0 / log(2.0);
+    int top = 0;
+    for (int64_t i = 0; i < n; i++) { /* assign-level, graph.clj:93-98 */
+        const double u = jr_next_double(&rng);
+        int lv = (int)(ml * (-log(u)));
+        if (u == 0.0 || lv > 30) lv = 30;
+        L->g.levels[i] = lv;
+        if (lv > top) top = lv;
+    }
+    L->g.maxlev = top + 1;
+    L->g.adj = (lset_t *)calloc((size_t)n * (size_t)L->g.maxlev + 1, sizeof(lset_t));
+    L->g.entry = -1;
+    L->c.metric = metric;
+    L->c.mode = mode;
+    L->c.dim = dim;
+    L->c.base = base;
+    L->c.norms = NULL;
+    if (mode != ORC_MODE_F64 && metric == ORC_COSINE) {
+        L->norms = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+        orc_norms(base, n, dim, mode, L->norms);
+        L->c.norms = L->norms;
+    }
+    visited_t vis;
+    vis.bits = (uint64_t *)calloc((size_t)(n + 63) / 64 + 1, sizeof(uint64_t));
+    vis.touched = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    heap_t cand, near;
+    heap_init(&cand, 1024, 0);
+    heap_init(&near, 1024, 1);
+    int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 8));
+    int32_t *lnk = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 8));
+    int prcap = 4096;
+    prune_t *pr = (prune_t *)malloc(sizeof(prune_t) * (size_t)prcap);
+    prune_t *disc = (prune_t *)malloc(sizeof(prune_t) * (size_t)prcap);
+    int32_t *sel = (int32_t *)malloc(sizeof(int32_t) * (size_t)prcap);
+    int64_t ev = 0, hev = 0, nprune = 0, maxdeg = 0;
+    for (int64_t id = 0; id < n; id++) {
+        const int level = L->g.levels[id];
+        if (L->g.entry < 0) { /* :251-255 */
+            L->g.entry = (int32_t)id;
+            continue;
+        }
+        dist_ctx c = L->c;
+        ctx_set_query(&c, base + id * (int64_t)dim);
+        const int entry_level = L->g.levels[L->g.entry];
+        int ncur = 1;
+        cur[0] = L->g.entry;
+        const int start = level < entry_level ? level : entry_level;
+        for (int lc = start; lc >= 0; lc--) /* :275-278: (if (> lc level) 1 ef-construction) is always ef-construction here */
+            ncur = lit_search_layer(&L->g, &c, cur, ncur, efc, lc, &vis, &cand, &near, cur, NULL, &ev);
+        for (int lc = 0; lc <= level; lc++) { /* :280-287 */
+            const int nl = lit_search_layer(&L->g, &c, cur, ncur, M, lc, &vis, &cand, &near, lnk, NULL, &ev);
+            const int maxm = lc == 0 ? 2 * M : M; /* prune-connections, :208-232 (max-M = M as default-params has it) */
+            for (int t = 0; t < nl; t++) {
+                const int32_t nb = lnk[t];
+                if (nb == (int32_t)id) continue;
+                lset_add(lit_set(&L->g, (int32_t)id, lc), nb); /* connect-nodes :201-206 */
+                lset_add(lit_set(&L->g, nb, lc), (int32_t)id);
+                lset_t *s = lit_set(&L->g, nb, lc);
+                if (s->n > maxdeg) maxdeg = s->n;
+                if (s->n <= maxm) continue;
+                if (s->n + 4 > prcap) {
+                    prcap = 2 * s->n + 8;
+                    pr = (prune_t *)realloc(pr, sizeof(prune_t) * (size_t)prcap);
+                    disc = (prune_t *)realloc(disc, sizeof(prune_t) * (size_t)prcap);
+                    sel = (int32_t *)realloc(sel, sizeof(int32_t) * (size_t)prcap);
+                }
+                const int cnt = s->n;
+                for (int j = 0; j < cnt; j++) {
+                    pr[j].id = s->a[j];
+                    pr[j].d = pair_dist(&L->c, nb, s->a[j]);
+                    pr[j].ord = j;
+                    ev++;
+                }
+                const int keep = select_heuristic(&L->c, pr, cnt, maxm, 0, sel, NULL, disc, &hev);
+                nprune++;
+                for (int j = 0; j < cnt; j++) { /* the dropped edges leave BOTH sets (:226-231) */
+                    const int32_t x = pr[j].id;
+                    int kept = 0;
+                    for (int r = 0; r < keep && !kept; r++) kept = sel[r] == x;
+                    if (!kept) {
+                        lset_del(lit_set(&L->g, nb, lc), x);
+                        lset_del(lit_set(&L->g, x, lc), nb);
+                    }
+                }
+            }
+        }
+        if (level > entry_level) L->g.entry = (int32_t)id; /* :290-292 */
+    }
+    if (counters) {
+        counters[0] = ev;
+        counters[1] = hev;
+        counters[2] = nprune;
+        counters[3] = maxdeg;
+        int64_t edges = 0, over = 0;
+        for (int64_t i = 0; i < n; i++) {
+            edges += lit_set(&L->g, (int32_t)i, 0)->n;
+            if (lit_set(&L->g, (int32_t)i, 0)->n > 2 * M) over++;
+        }
+        counters[4] = edges;
+        counters[5] = over; /* nodes whose own layer-0 list was never pruned */
+    }
+    free(vis.bits);
+    free(vis.touched);
+    free(cand.a);
+    free(near.a);
+    free(cur);
+    free(lnk);
+    free(pr);
+    free(disc);
+    free(sel);
+    return L;
+}
+
+/* search-knn, graph.clj:297-320, with ef as a parameter (the reference fixes it at (max k 50)); one query */
+static int lit_search_knn(lit_index *L, const float *q, int k, int ef, visited_t *vis, heap_t *cand, heap_t *near, int32_t *cur,
+                          double *curd, int32_t *out_ids, double *out_d, int64_t *n_eval) {
+    dist_ctx c = L->c;
+    ctx_set_query(&c, q);
+    int ncur = 1;
+    cur[0] = L->g.entry;
+    for (int level = L->g.levels[L->g.entry]; level >= 0; level--)
+        ncur = lit_search_layer(&L->g, &c, cur, ncur, level > 0 ? 1 : ef, level, vis, cand, near, cur, curd, n_eval);
+    srt_t *tmp = (srt_t *)malloc(sizeof(srt_t) * (size_t)(ncur + 1));
+    for (int i = 0; i < ncur; i++) {
+        tmp[i].d = curd[i];
+        tmp[i].id = cur[i];
+        tmp[i].ord = i;
+    }
+    qsort(tmp, (size_t)ncur, sizeof(srt_t), srt_cmp);
+    const int m = ncur < k ? ncur : k;
+    for (int i = 0; i < k; i++) {
+        out_ids[i] = i < m ? tmp[i].id : -1;
+        out_d[i] = i < m ? tmp[i].d : INFINITY;
+    }
+    free(tmp);
+    return m;
+}
+void orc_lit_search(void *handle, const float *Q, int nq, int k, int ef, int32_t *out_ids, double *out_d, int64_t *evals) {
+    lit_index *L = (lit_index *)handle;
+    const int64_t n = L->g.n;
+    visited_t vis;
+    vis.bits = (uint64_t *)calloc((size_t)(n + 63) / 64 + 1, sizeof(uint64_t));
+    vis.touched = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    heap_t cand, near;
+    heap_init(&cand, 1024, 0);
+    heap_init(&near, 1024, 1);
+    int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 8));
+    double *curd = (double *)malloc(sizeof(double) * (size_t)(n + 8));
+    int64_t ev = 0;
+    for (int i = 0; i < nq; i++)
+        lit_search_knn(L, Q + (int64_t)i * L->c.dim, k, ef, &vis, &cand, &near, cur, curd, out_ids + (int64_t)i * k, out_d + (int64_t)i * k, &ev);
+    if (evals) *evals = ev;
+    free(vis.bits);
+    free(vis.touched);
+    free(cand.a);
+    free(near.a);
+    free(cur);
+    free(curd);
+}
+void orc_lit_free(void *handle) {
+    lit_index *L = (lit_index *)handle;
+    for (int64_t i = 0; i < L->g.n * L->g.maxlev; i++) free(L->g.adj[i].a);
+    free(L->g.adj);
+    free(L->g.levels);
+    free(L->norms);
+    free(L);
+}
+
 typedef struct {
     dist_ctx c;
     int64_t n;

@@ -290,6 +290,41 @@ def hnsw_search(base, graph, Q, k, ef=None, metric=COSINE, mode=MODE_F64, nthrea
 
 
 # ---- ground truth ------------------------------------------------------------------------------
+class LiteralGraph:
+    """src/hnsw/graph.clj:239-295 `insert` restated LITERALLY (unbounded neighbour sets: the new node is linked to every node
+    its second search returns and pruned only when a later insert prunes it as somebody's neighbour; ef-construction on
+    every layer; the walk starts at min(level, entry-level)) with graph.clj:115-161,297-320 as its search -- a CPU-only study
+    of its recall / ef curve beside the bounded variant the engine builds (oracle.c section 4b)."""
+
+    def __init__(self, base, metric=COSINE, M=16, ef_construction=200, seed=42, mode=MODE_FAST):
+        self.base = _f32(base)
+        n, dim = self.base.shape
+        cnt = np.zeros(8, np.int64)
+        L = lib()
+        L.orc_lit_build.restype = C.c_void_p
+        L.orc_lit_build.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]
+        L.orc_lit_search.restype = None
+        L.orc_lit_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_lit_free.restype = None
+        L.orc_lit_free.argtypes = [C.c_void_p]
+        self._h = C.c_void_p(L.orc_lit_build(_p(self.base), n, dim, int(metric), int(mode), M, ef_construction, int(seed), _p(cnt)))
+        self.counters = dict(zip(("search_evals", "selection_evals", "prunes", "max_degree_seen", "layer0_edges", "layer0_lists_never_pruned"),
+                                 cnt[:6].tolist()))
+
+    def search(self, Q, k, ef):
+        Q = _f32(Q)
+        ids = np.empty((len(Q), k), np.int32)
+        d = np.empty((len(Q), k), np.float64)
+        ev = C.c_int64(0)
+        lib().orc_lit_search(self._h, _p(Q), len(Q), k, ef, _p(ids), _p(d), C.byref(ev))
+        return ids, d, ev.value / max(len(Q), 1)
+
+    def close(self):
+        if self._h:
+            lib().orc_lit_free(self._h)
+            self._h = None
+
+
 def exact_knn(base, Q, k, metric=COSINE, mode=MODE_F64, nthreads=1):
     """src/hnsw/bench.clj:72-84 compute-exact-knn over the full base."""
     base, Q = _f32(base), _f32(Q)
