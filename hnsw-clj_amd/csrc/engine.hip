@@ -417,11 +417,11 @@ int scan_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_quer
 
 // zero-initialised per-query counters of the fused tails (each tail resets its own counter: zero between calls)
 int ensure_counters(hnswgpu_index *idx, size_t n, hipStream_t st) {
-    const size_t bytes = sizeof(uint32_t) * 2 * n;  // [n] scan tails | [n] route tails
+    const size_t bytes = sizeof(uint32_t) * (2 * n + 2);  // [n] scan tails | [n] route tails | 2 words of the folded work list
     if (bytes <= idx->s_done.cap) return 0;
     HG_TRY(idx->s_done.ensure(bytes));
     HG_HIP(hipMemsetAsync(idx->s_done.p, 0, idx->s_done.cap, st));
-    idx->s_done_n = idx->s_done.cap / (sizeof(uint32_t) * 2);
+    idx->s_done_n = (idx->s_done.cap - 2 * sizeof(uint32_t)) / (sizeof(uint32_t) * 2);
     return 0;
 }
 
@@ -482,6 +482,8 @@ struct RouteArgs {
     uint2 *bk_mem;           // [nlist][bk_cap] (query, offset of the list in the query's candidate stream)
     int32_t bk_cap;
     int32_t home;            // the home-list pass follows: no seed for a query whose nearest list holds k rows (its threshold comes from there)
+    int32_t wl_on;           // kWorklistParts extra workgroups of the tail's launch build the bounds pass's work list (worklist_part_wg)
+    WorklistArgs wl;
     unsigned long long *dbg;  // -DHG_IVF_STAMPS diagnostic builds only
 };
 
@@ -589,6 +591,8 @@ __device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsign
             if (a.surv_cnt) a.surv_cnt[qi] = any_over ? 0x80000000u : 0u;
         }
         wait_stores_acked();  // the probe table may be read back by the other waves below
+        // (this query's pairs are filed: the work list's workgroups count the queries in)
+        if (a.wl_on && lane == 0) (void)__hip_atomic_fetch_add(a.wl.filed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         HG_IVF_STAMP(a.dbg, 19, qi == 0 && threadIdx.x == 0);  // probe table written, pairs filed
     }
     if (!a.tau) return;
@@ -629,6 +633,10 @@ __global__ __launch_bounds__(kWG) void ivf_route_kernel(RouteArgs a) {
     const int wave = threadIdx.x >> 6;
     const int qi = blockIdx.x / a.blocks_per_query, bx = blockIdx.x % a.blocks_per_query;
     HG_IVF_STAMP(a.dbg, 16, blockIdx.x == 0 && threadIdx.x == 0);  // first workgroup of the routing kernel starts
+    if (qi >= a.nq) {  // the extra workgroups behind the queries' own: the bounds pass's work list
+        if (a.wl_on) worklist_part_wg(a.wl, static_cast<int>(blockIdx.x) - a.nq * a.blocks_per_query);
+        return;
+    }
     const int64_t r0 = static_cast<int64_t>(bx) * a.rows_per_block;
     const int64_t r1 = r0 + a.rows_per_block < a.nlist ? r0 + a.rows_per_block : a.nlist;
     if (r0 < r1) {
@@ -882,6 +890,10 @@ __global__ __launch_bounds__(kWG) void ivf_route_tail_kernel(RouteArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int qi = blockIdx.x;
+    if (qi >= a.nq) {  // the extra workgroups behind the queries' own: the bounds pass's work list
+        if (a.wl_on) worklist_part_wg(a.wl, qi - a.nq);
+        return;
+    }
     if (a.qcodes && !a.tau && wave == kNWave - 1) {  // (no threshold wanted: the tail does not load the query itself)
         float4 q[NCH];
         load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
@@ -905,6 +917,10 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
         a.bk_mem = rs->bk_mem;
         a.bk_cap = rs->bk_cap;
         a.home = rs->home;
+        if (rs->wl && rs->bk_cnt) {
+            a.wl = *rs->wl;
+            a.wl_on = 1;
+        }
     }
     a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions
     a.rows = idx->d_lrows;
@@ -931,6 +947,8 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
     HG_TRY(ensure_counters(idx, nq, st));
     a.dense = idx->s_tile.as<float>();
     a.done = idx->s_done.as<uint32_t>() + idx->s_done_n;
+    a.wl.filed = idx->s_done.as<uint32_t>() + 2 * idx->s_done_n;  // two words behind the per-query counters
+    const unsigned extra = a.wl_on ? kWorklistParts : 0;         // workgroups behind the queries' own
     a.listoff = idx->d_listoff;
     a.glistoff = idx->d_glistoff ? idx->d_glistoff : idx->d_listoff;
     a.pairs = pairs;
@@ -970,7 +988,7 @@ do {                                                                            
             }
 #undef CALLM
             HG_HIP(hipGetLastError());
-#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_tail_kernel<N, R, L>), dim3(static_cast<unsigned>(nq)), dim3(kWG), lds, st, a)
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_tail_kernel<N, R, L>), dim3(static_cast<unsigned>(nq) + extra), dim3(kWG), lds, st, a)
             HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
             HG_HIP(hipGetLastError());
@@ -990,14 +1008,14 @@ do {                                                                            
         HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
         HG_HIP(hipGetLastError());
-#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_tail_kernel<N, R, L>), dim3(static_cast<unsigned>(nq)), dim3(kWG), lds, st, a)
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_tail_kernel<N, R, L>), dim3(static_cast<unsigned>(nq) + extra), dim3(kWG), lds, st, a)
         HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
         HG_HIP(hipGetLastError());
         return 0;
     }
     const int64_t blocks = static_cast<int64_t>(nq) * a.blocks_per_query;
-#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks)), dim3(kWG), lds, st, a)
+#define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_kernel<N, R, L>), dim3(static_cast<unsigned>(blocks) + extra), dim3(kWG), lds, st, a)
     HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
     HG_HIP(hipGetLastError());

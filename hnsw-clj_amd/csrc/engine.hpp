@@ -288,6 +288,7 @@ struct RouteStream {
     uint2 *bk_mem;
     int32_t bk_cap;
     int32_t home;  // the home-list pass follows (stream_kernels.hpp, step 1a): a query whose nearest list holds k rows gets its threshold there
+    const struct WorklistArgs *wl;  // optional: the bounds pass's work list by extra workgroups of the tail's launch (filed: set by the launch)
 };
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
                      int32_t *qcnt, hipStream_t st, const RouteStream *rs = nullptr, bool two_launches = false);

@@ -793,6 +793,7 @@ struct StreamScratch {
     uint32_t *bk_cnt;
     uint2 *bk_mem;
     int32_t bk_cap;
+    bool wl_folded;  // the routing tail's launch has built the bounds pass's work list (worklist_part_wg)
 };
 
 // Buckets for the pairs of a batch: room for the whole batch under every list (a list may be probed by every query) as
@@ -860,6 +861,40 @@ static bool ivf_home_mode(const hnswgpu_index *idx, int32_t nq, int32_t nprobe, 
            (static_cast<int64_t>(nq) / home_group(idx->nch) + std::min<int64_t>(nq, idx->nlist)) * ((idx->max_list_len + 4095) / 4096) < (1LL << 30);
 }
 
+// The bounds pass's cut of the lists into work items -- by the routing (which builds the work list of a small batch inside
+// its tail's launch) and by the scan: one rule.
+struct WorkPlan {
+    int64_t chunk_rows;  // rows per work item: whole tiles; enough working workgroups to fill the chip a few times over
+    int32_t nchunks;
+    bool narrow;         // which epilogue: few queries per probed list -> lane = row
+    int qblocks;         // 32-query column blocks per group
+    int64_t wbound;      // grouped: items <= sum over lists of ceil(members / 32) * chunks <= (npairs / 32 + nlist) * nchunks
+};
+static WorkPlan stream_work_plan(const hnswgpu_index *idx, int32_t nq, int32_t nprobe, bool grouped, const StreamTune &tn) {
+    WorkPlan p;
+    const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
+    const int64_t mean = ivf_mean_len(idx);
+    const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows, max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows;
+    const int64_t tgt = tune(HNSWGPU_TUNE_STREAM_WGS, 2048);
+    const int64_t units = grouped ? std::min<int64_t>(npairs, idx->nlist) : npairs;  // lists (or pairs) that have work
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + units - 1) / std::max<int64_t>(units, 1)));
+    const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows, tpc = cr / kTileRows;
+    p.chunk_rows = cr;
+    p.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
+    const bool mid = ivf_mid_mode(idx, nq, nprobe, tn);
+    // The largest batches (a list probed by 256 queries and more on average, entries appended without bounds): two 32-query
+    // column blocks per group -- every staged row operand meets 64 queries, the lists leave L2 half as often
+    const int64_t wide2 = tune(HNSWGPU_TUNE_STREAM_WIDE2, -1);  // -1 that rule, 0 never, 1 whenever the epilogue allows
+    const int64_t narrow_env = tune(HNSWGPU_TUNE_STREAM_NARROW, -1);  // A/B: 0 / 1 force
+    p.narrow = narrow_env >= 0 ? narrow_env != 0 : npairs < 6LL * idx->nlist;
+    p.qblocks = grouped && mid && !p.narrow && idx->nch <= 4 /* (64 queries' codes: two workgroups per CU still fit) */ &&
+                        wide2 != 0 && (wide2 > 0 || npairs >= 256LL * idx->nlist)
+                    ? 2
+                    : 1;
+    p.wbound = (npairs / kTileQ + idx->nlist) * p.nchunks;
+    return p;
+}
+
 // The list scan as a survivor stream (stream_kernels.hpp): int8 bounds with a running threshold -> compact survivor
 // lists -> f32 distances (GEMV order), top-k, ids and distances written by the finish kernel.  The query codes, tau = none
 // and empty survivor lists are set up by the routing step.
@@ -872,17 +907,12 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     int64_t blocks;
     const int32_t *qorder = nullptr;  // large batches: the queries in the order of their nearest list (below)
     const int64_t stride = (static_cast<int64_t>(nprobe) * idx->max_list_len + 3) / 4 * 4;
-    // rows per workgroup: whole tiles; enough working workgroups to fill the chip a few times over
-    const int64_t mean = ivf_mean_len(idx);
-    const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows, max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows;
-    const int64_t tgt = tune(HNSWGPU_TUNE_STREAM_WGS, 2048);
     const bool grouped = sc.bk_cnt != nullptr;
-    const int64_t units = grouped ? std::min<int64_t>(npairs, idx->nlist) : npairs;  // lists (or pairs) that have work
-    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + units - 1) / std::max<int64_t>(units, 1)));
-    const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows, tpc = cr / kTileRows;
-    b.chunk_rows = static_cast<int32_t>(cr);
-    b.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
     const StreamTune &tn = sc.tn;  // (one reading of the tuning table per search: the routing decided by the same values)
+    const WorkPlan plan = stream_work_plan(idx, nq, nprobe, grouped, tn);
+    const int64_t cr = plan.chunk_rows;
+    b.chunk_rows = static_cast<int32_t>(cr);
+    b.nchunks = plan.nchunks;
     const bool mid = ivf_mid_mode(idx, nq, nprobe, tn);
     const int64_t order_min = tn.finish_order;
     const bool ordered = d_probes != nullptr && ivf_ordered_mode(idx, nq, grouped, tn);
@@ -907,18 +937,10 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         home_nit = reinterpret_cast<int32_t *>(home_desc + home_bound);
         home_first = reinterpret_cast<uint32_t *>(home_nit + 16);
     }
-    // The largest batches (a list probed by 256 queries and more on average, entries appended without bounds): two 32-query
-    // column blocks per group -- every staged row operand meets 64 queries, the lists leave L2 half as often
-    const int64_t wide2 = tune(HNSWGPU_TUNE_STREAM_WIDE2, -1);  // -1 that rule, 0 never, 1 whenever the epilogue allows
-    const int64_t narrow_env = tune(HNSWGPU_TUNE_STREAM_NARROW, -1);  // A/B: 0 / 1 force
-    const bool narrow = narrow_env >= 0 ? narrow_env != 0 : npairs < 6LL * idx->nlist;
-    const int qblocks = grouped && mid && !narrow && idx->nch <= 4 /* (64 queries' codes: two workgroups per CU still fit) */ &&
-                                wide2 != 0 && (wide2 > 0 || npairs >= 256LL * idx->nlist)
-                            ? 2
-                            : 1;
+    const bool narrow = plan.narrow;
+    const int qblocks = plan.qblocks;
     if (grouped) {
-        // the work list: items <= sum over lists of ceil(members / 32) * chunks <= (npairs / 32 + nlist) * nchunks
-        const int64_t wbound = (npairs / kTileQ + idx->nlist) * b.nchunks;
+        const int64_t wbound = plan.wbound;
         HG_REQUIRE(wbound < 2147483647LL, HNSWGPU_ELIMIT, "bounds pass work list too large");
         HG_TRY(idx->s_misc2.ensure(sizeof(WorkDesc) * static_cast<size_t>(wbound) + 64));
         WorkDesc *desc = idx->s_misc2.as<WorkDesc>();
@@ -936,10 +958,12 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
             }
             qorder = idx->s_stats.as<int32_t>();
         }
-        hipLaunchKernelGGL(ivf_worklist_kernel, dim3(qorder ? 2 : 1), dim3(1024), olds, st, sc.bk_cnt, sc.bk_cap, idx->nlist,
-                           idx->d_listoff, cr, b.nchunks, desc, nit, d_probes, nq, idx->s_stats.as<int32_t>(), nprobe,
-                           home_desc, home_nit, home_gq, static_cast<int>(home_chunk), kTileQ * qblocks);
-        HG_HIP(hipGetLastError());
+        if (!sc.wl_folded) {  // (a small batch's list was built inside the routing tail's launch: worklist_part_wg)
+            hipLaunchKernelGGL(ivf_worklist_kernel, dim3(qorder ? 2 : 1), dim3(1024), olds, st, sc.bk_cnt, sc.bk_cap, idx->nlist,
+                               idx->d_listoff, cr, b.nchunks, desc, nit, d_probes, nq, idx->s_stats.as<int32_t>(), nprobe,
+                               home_desc, home_nit, home_gq, static_cast<int>(home_chunk), kTileQ * qblocks);
+            HG_HIP(hipGetLastError());
+        }
         idx->bk_dirty = false;  // (the kernel leaves the counters zero)
         b.wi_desc = desc;
         b.nitems = nit;
@@ -1072,7 +1096,11 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     const int64_t mid_slices = !mid ? 0 : (qorder ? 1 : std::max<int64_t>(1, std::min<int64_t>(16, 4096 / nq)));
     const bool heavy = tune(HNSWGPU_TUNE_STREAM_HEAVY, 1) != 0 && ((mid && mid_slices < 8) || f.slices < 8);
     constexpr int kHeavySlices = 64;
-    const size_t keys = static_cast<size_t>(nq) * (heavy ? std::max(f.slices, kHeavySlices) : f.slices) * (k <= kWave ? 1 : kNWave) * k;
+    // keys per query handed to its last workgroup: the slices' lists -- or, for a short survivor list spread over many
+    // workgroups (small batches), a key per survivor (FinishArgs::direct; measured at batch 32: see DESIGN)
+    f.direct = f.slices >= 16 && !heavy && k <= kWave ? static_cast<int32_t>(std::max<int64_t>(0, std::min<int64_t>(1024, tune(HNSWGPU_TUNE_FINISH_DIRECT, 1024)))) : 0;
+    f.pstride = std::max<int64_t>(static_cast<int64_t>(heavy ? std::max(f.slices, kHeavySlices) : f.slices) * (k <= kWave ? 1 : kNWave) * k, f.direct);
+    const size_t keys = static_cast<size_t>(nq) * f.pstride;
     HG_TRY(idx->s_partial.ensure(sizeof(uint64_t) * keys));
     if (heavy) {
         HG_TRY(idx->s_heavy.ensure(sizeof(int32_t) * (2 * static_cast<size_t>(nq) + 4)));
@@ -1319,6 +1347,29 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     bool codes_done = false;
     // the home-list pass of large batches (ivf_home_mode): the routing's tail leaves the thresholds to it
     const bool home_mode = use_code && sc.bk_cnt != nullptr && probes_buf != nullptr && ivf_home_mode(idx, nq, nprobe, true, sc.tn);
+    // small grouped batches: the bounds pass's work list by extra workgroups of the routing tail's launch (larger ones order
+    // their queries in a second workgroup of ivf_worklist_kernel: they keep that launch)
+    WorklistArgs wl;
+    memset(&wl, 0, sizeof(wl));
+    const bool fold_wl = use_code && sc.bk_cnt != nullptr && !d_given_probes && !ivf_ordered_mode(idx, nq, true, sc.tn) &&
+                         tune(HNSWGPU_TUNE_WORKLIST_FOLD, 1) != 0 && static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20);
+    if (fold_wl) {
+        const WorkPlan plan = stream_work_plan(idx, nq, nprobe, true, sc.tn);
+        HG_REQUIRE(plan.wbound < 2147483647LL, HNSWGPU_ELIMIT, "bounds pass work list too large");
+        HG_TRY(idx->s_misc2.ensure(sizeof(WorkDesc) * static_cast<size_t>(plan.wbound) + 64));
+        HG_TRY(ensure_counters(idx, nq, st));
+        wl.bk_cnt = sc.bk_cnt;
+        wl.bk_cap = sc.bk_cap;
+        wl.nlist = idx->nlist;
+        wl.list_off = idx->d_listoff;
+        wl.chunk_rows = plan.chunk_rows;
+        wl.max_chunks = plan.nchunks;
+        wl.tq = kTileQ * plan.qblocks;
+        wl.desc = idx->s_misc2.as<WorkDesc>();
+        wl.nitems = reinterpret_cast<int32_t *>(wl.desc + plan.wbound);
+        wl.surv_cnt = sc.surv_cnt;
+        wl.nq = nq;
+    }
     // queries from which a GEMV-order batch routes through the group kernel
     // (Euclidean 1M x 768: 512 queries 0.85 vs 0.87 ms (GEMV vs group), 1024: 1.50 vs 1.43, 4096: 5.08 vs 4.70)
     const int route_group_min = static_cast<int>(tune(HNSWGPU_TUNE_ROUTE_GROUP, 1024));
@@ -1341,16 +1392,18 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
     if (!use_tile && (fused_mode || (use_code && nq <= stream_route_max)) && static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20)) {
         // small batches: distances to the centroids, the choice of the nprobe nearest and the probe table in ONE launch
         // (for the survivor stream also the query codes, tau = none and the empty survivor lists)
-        RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap, home_mode ? 1 : 0};
+        RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap, home_mode ? 1 : 0, fold_wl ? &wl : nullptr};
         HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, use_code ? &rs : nullptr));
         codes_done = use_code;
+        sc.wl_folded = use_code && fold_wl;
     } else if (use_code && static_cast<int64_t>(nq) * idx->nlist <= (64LL << 20)) {
         // survivor stream, larger batches: the centroid distances by a pass that serves a group of queries per fetch of a
         // centroid row (the GEMV order, same bits), then ONE launch for everything else of the routing -- select, probe
         // table, pairs filed by list, query codes, first thresholds
-        RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap, home_mode ? 1 : 0};
+        RouteStream rs = {sc.qcodes, sc.qscal, sc.tau, sc.surv_cnt, k, sc.bk_cnt, sc.bk_mem, sc.bk_cap, home_mode ? 1 : 0, fold_wl ? &wl : nullptr};
         HG_TRY(launch_ivf_route(idx, d_Q, nq, nprobe, idx->s_pairs.as<Pair>(), probes_buf, qcnt_buf, st, &rs, true));
         codes_done = true;
+        sc.wl_folded = fold_wl;
     } else {
     if (use_tile)  // every query against the centroid table on the tile kernel as well
         HG_TRY(tile_topk_all(idx, idx->s_qp.as<float>(), idx->s_qn.as<float>(), nq, idx->d_cent, idx->d_cnorms, idx->nlist,

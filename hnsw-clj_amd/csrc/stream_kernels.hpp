@@ -222,6 +222,131 @@ struct WorkDesc {
     int32_t list, mem0, cnt, pad;
 };
 
+// The work list of a small batch built INSIDE the routing tail's launch (ivf_worklist_kernel is a launch of its own between the
+// tail and the bounds pass: ~6 us of a 160-us batch-32 search for ~2 us of work).  The tail launch carries kWorklistParts extra
+// workgroups behind the queries' own; they wait until every query has filed its pairs (RouteArgs: the `filed` counter, bumped
+// by a query's workgroup between its probe table and its threshold seed -- the seed's ~5 us of f32 rows run beside this), scan
+// the per-list counts and fill every kWorklistParts-th item each.  Workgroups are dispatched in index order and the queries'
+// workgroups wait for nobody, so the wait ends; should it not within two seconds (it cannot, short of a fault), the list is left
+// empty and every query marked for the finish kernel's fallback, the plain f32 scan.  The item order is ivf_worklist_kernel's.
+constexpr int kWorklistParts = 4;
+struct WorklistArgs {
+    uint32_t *bk_cnt;        // [nlist] members filed per list; zero again when the last part is through
+    int32_t bk_cap, nlist;
+    const int64_t *list_off;
+    int64_t chunk_rows;
+    int32_t max_chunks, tq;  // tq: members per group
+    WorkDesc *desc;
+    int32_t *nitems;
+    uint32_t *filed;         // [2]: queries that have filed their pairs | parts that are through (both zero between searches)
+    uint32_t *surv_cnt;      // [nq] (the fallback mark)
+    int32_t nq;
+};
+
+__device__ __forceinline__ void worklist_part_wg(const WorklistArgs &a, int part) {
+    __shared__ int32_t wl_off[1025];   // exclusive item offsets of this pass's lists
+    __shared__ int32_t wl_cnt[1024];   // members per list (capped)
+    __shared__ int32_t wl_part[kNWave];
+    __shared__ int32_t wl_ok;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    if (tid == 0) {
+        const unsigned long long t0 = wall_clock64();
+        int ok = 1;
+        while (coherent_load(a.filed) < static_cast<uint32_t>(a.nq)) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 200000000ull) {  // 2 s at 100 MHz
+                ok = 0;
+                break;
+            }
+        }
+        wl_ok = ok;
+    }
+    __syncthreads();
+    const bool ok = wl_ok != 0;
+    int carry = 0;
+    for (int l0 = 0; ok && l0 < a.nlist; l0 += 1024) {
+        // four consecutive lists per thread: counts -> items, scanned within the thread, the wave, the workgroup
+        int nw[4], run = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int l = l0 + 4 * tid + j;
+            int c = 0, nch = 0;
+            if (l < a.nlist) {
+                const uint32_t filed = coherent_load(a.bk_cnt + l);
+                c = filed < static_cast<uint32_t>(a.bk_cap) ? static_cast<int>(filed) : a.bk_cap;
+                const int64_t rows = a.list_off[l + 1] - a.list_off[l];
+                nch = (c > 0 && rows > 0) ? static_cast<int>(tile_nchunks(rows, a.chunk_rows, a.max_chunks)) : 0;
+            }
+            wl_cnt[4 * tid + j] = c;
+            nw[j] = ((c + a.tq - 1) / a.tq) * nch;
+            run += nw[j];
+        }
+        int incl = run;
+        for (int o = 1; o < kWave; o <<= 1) {
+            const int v = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += v;
+        }
+        if (lane == kWave - 1) wl_part[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += wl_part[w];
+        int at = before + incl - run;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            wl_off[4 * tid + j] = at;
+            at += nw[j];
+        }
+        if (tid == kWG - 1) wl_off[1024] = at;
+        __syncthreads();
+        const int total = wl_off[1024];
+        for (int w = part * kWG + tid; w < total; w += kWorklistParts * kWG) {
+            int lo = 0, hi = 1023;  // the last list of this pass whose offset <= w
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (wl_off[mid] <= w) lo = mid;
+                else hi = mid - 1;
+            }
+            const int ll = l0 + lo, k = w - wl_off[lo];
+            const int cc = wl_cnt[lo];
+            const int ngl = (cc + a.tq - 1) / a.tq;
+            const int ch = k / ngl, g = k - ch * ngl;  // chunk-major
+            const int64_t rb0 = a.list_off[ll], rws = a.list_off[ll + 1] - rb0;
+            const int64_t tiles = (rws + kTileRows - 1) / kTileRows;
+            const int64_t nchl = tile_nchunks(rws, a.chunk_rows, a.max_chunks);
+            const int64_t per = (tiles + nchl - 1) / nchl * kTileRows;
+            const int64_t a0 = ch * per, a1 = a0 + per < rws ? a0 + per : rws;
+            WorkDesc d;
+            d.rb0 = rb0;
+            d.r0_off = static_cast<int32_t>(a0);
+            d.r1_off = static_cast<int32_t>(a1 > a0 ? a1 : a0);
+            d.list = ll;
+            d.mem0 = g * a.tq;
+            d.cnt = cc - g * a.tq < a.tq ? cc - g * a.tq : a.tq;
+            d.pad = 0;
+            a.desc[carry + w] = d;
+        }
+        carry += total;
+        __syncthreads();  // (wl_off / wl_cnt are rewritten by the next pass)
+    }
+    if (part == 0 && tid == 0) *a.nitems = ok ? carry : 0;
+    if (!ok && part == 0)
+        for (int q = tid; q < a.nq; q += kWG) a.surv_cnt[q] = 0x80000000u;
+    // the last part through leaves the counters zero for the next search (every part has read them by then)
+    __shared__ int32_t wl_last;
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(a.filed + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wl_last = prev == static_cast<uint32_t>(kWorklistParts) - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!wl_last) return;
+    for (int l = tid; l < a.nlist; l += kWG) coherent_store(a.bk_cnt + l, 0u);
+    if (tid == 0) {
+        coherent_store(a.filed, 0u);
+        coherent_store(a.filed + 1, 0u);
+    }
+}
+
 struct StreamArgs {
     // grouped mode: the (query, list) pairs were filed under their list by the routing step (bk_mem); one workgroup per
     // (list, group of <= 32 members, chunk of the list's rows)
@@ -1126,7 +1251,10 @@ struct FinishArgs {
     const float *Q;
     int64_t qld;
     int32_t dim, metric;
-    uint64_t *partial;     // [nq][slices][k] (k <= 64) or [nq][slices][4][k]
+    uint64_t *partial;     // [nq][pstride]: [slices][k] (k <= 64) or [slices][4][k] per query -- or the keys of a short list, see direct
+    int64_t pstride;       // keys per query in there
+    int32_t direct;        // survivor lists of up to `direct` entries (<= 1024; 0: never) skip the per-wave and per-workgroup
+                           // lists: a key per survivor, written where it was evaluated; the query's last workgroup picks the k smallest
     uint32_t *done;        // [nq], zero between calls
     const int32_t *listids;
     int32_t *out_ids;      // [nq][k]
@@ -1176,6 +1304,11 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, i
     uint64_t *mylist = lists + wave * a.k;
     int cnt = 0;
     uint64_t thr = ~0ull, mine = ~0ull;
+    // A short list spread over many workgroups (a handful of queries: dozens of slices, a step or two per wave): every key
+    // straight to partial[qi][i].  The per-wave lists took one insertion per key (~0.15 us each, serial), wave 0 then
+    // inserted the other three waves' keys (3 us), and the merge read slices x k keys -- no fewer than the list itself.
+    const bool direct = a.direct > 0 && !over && regk && slices > 1 && a.k >= a.bisect_min && nsv <= static_cast<uint32_t>(a.direct);
+    uint64_t *dkeys = a.partial + static_cast<int64_t>(qi) * a.pstride;
     // ---- before any f32 row is fetched: the survivors' UPPER bounds give a threshold of their own.  k candidates whose
     // upper bounds are <= T are k candidates at most T away, so D_k <= T; T = the k-th smallest of the 256 threads'
     // minima over a strided share of the list each (the k smallest upper bounds sit in k different shares but for the odd
@@ -1230,6 +1363,7 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, i
         const bool s = in && !(l > tau);  // NaN (no bound) survives
         uint64_t m = __ballot(s);
         if (!m) {
+            if (direct && in) coherent_store(dkeys + i, static_cast<uint64_t>(~0ull));
             const float tg = tau_decode(tnext);
             tau = tg < tau ? tg : tau;
             continue;
@@ -1274,6 +1408,10 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, i
         }
         // the step's keys into this wave's top-k, one at a time (the insertion code exists once, not once per row in flight)
         const uint64_t key = s ? make_key(dmine, o) : ~0ull;
+        if (direct) {
+            if (in) coherent_store(dkeys + i, key);
+            continue;
+        }
         uint64_t mask = __ballot(key < thr);
         while (mask) {
             const int bl = __ffsll(static_cast<unsigned long long>(mask)) - 1;
@@ -1313,7 +1451,9 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, i
         }
     }
     // ---- this workgroup's partial list (k <= 64: its four lists merged into one first)
-    if (regk) {
+    if (direct) {
+        // (nothing to hand over but the keys already written)
+    } else if (regk) {
         if (wave != 0 && lane < a.k) lists[wave * a.k + lane] = mine;
         __syncthreads();
         if (wave == 0) {
@@ -1325,12 +1465,12 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, i
                     thr = wave_kth_reg(mine, a.k);
                 }
             if (slices > 1) {
-                uint64_t *dstp = a.partial + (static_cast<int64_t>(qi) * slices + sl) * a.k;
+                uint64_t *dstp = dkeys + static_cast<int64_t>(sl) * a.k;
                 if (lane < a.k) coherent_store(dstp + lane, mine);
             }
         }
     } else {
-        uint64_t *dstp = a.partial + ((static_cast<int64_t>(qi) * slices + sl) * kNWave + wave) * a.k;
+        uint64_t *dstp = dkeys + (static_cast<int64_t>(sl) * kNWave + wave) * a.k;
         for (int i = lane; i < a.k; i += kWave) coherent_store(dstp + i, i < cnt ? mylist[i] : static_cast<uint64_t>(~0ull));
     }
     // ---- tail: the last workgroup of query qi merges the partial lists, maps the winners to row ids
@@ -1348,7 +1488,7 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, i
         if (!tail_last) return;
     }
     HG_IVF_STAMP(a.dbg, 26, qi == 0 && threadIdx.x == 0);  // the last workgroup of query 0 begins the merge
-    const int64_t nkeys = static_cast<int64_t>(slices) * (regk ? 1 : kNWave) * a.k;
+    const int64_t nkeys = direct ? static_cast<int64_t>(nsv) : static_cast<int64_t>(slices) * (regk ? 1 : kNWave) * a.k;
     uint32_t *ord_s = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (kNWave + 1) * a.k);  // [k]
     float *dist_s = reinterpret_cast<float *>(ord_s + a.k);                                         // [k]
     // (the probe table of the query -- where each probed list starts in the candidate stream and in the list rows -- is
@@ -1373,7 +1513,7 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, i
             dist_s[lane] = mine != ~0ull ? key_dist(mine) : __uint_as_float(0x7f800000u);
         }
     } else if (regk && a.k >= a.bisect_min) {  // the k smallest of the partial lists by bisection (topk_small_wg), not by insertion
-        const uint64_t *part = a.partial + static_cast<int64_t>(qi) * nkeys;
+        const uint64_t *part = dkeys;
         uint64_t *scr = reinterpret_cast<uint64_t *>(pgo_s + npe);  // [kNWave][k]
         const uint64_t *fin = topk_small_wg(nkeys, a.k, lists, lists + kNWave * a.k, scr, [&](int64_t i) { return coherent_load(part + i); });
         if (wave != 0) return;
@@ -1384,13 +1524,13 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, i
         }
     } else {
         MergeArgs mg;
-        mg.partial = a.partial;
+        mg.partial = dkeys;  // (this query's keys: "query 0" of the merge)
         mg.keys_per_query = nkeys;
         mg.nq = 0;
         mg.k = a.k;
         mg.out_ord = nullptr;
         mg.out_dist = nullptr;
-        merge_topk_wg<true>(mg, qi, kNWave, smem, ord_s, dist_s);  // waves 1..3 return from it after its barrier
+        merge_topk_wg<true>(mg, 0, kNWave, smem, ord_s, dist_s);  // waves 1..3 return from it after its barrier
     }
     if (wave != 0) return;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

@@ -2268,8 +2268,14 @@ def test_reference_api_mirror(eng, oracle):
     bm = parallel_search.benchmark_parallel_search(index, list(vecs[:30]), 5, my_search, 4)
     assert bm["completed"] == 30 and bm["threads"] == 4 and bm["qps"] > 0
     # route=True (not in the reference): the exact scan answers where the traversal would evaluate a third of the base and more
-    assert ultra_fast.search_batch(index, vecs[:8], 5, ef=10, route=True) == ultra_fast.search_batch(index, vecs[:8], 5, ef=10)
-    assert not ultra_fast.routed_to_exact_scan(index, vecs[:8], 5, ef=10) and ultra_fast.routed_to_exact_scan(index, vecs[:8], 5, ef=100)
+    # (on 100 rows even ef 10 evaluates more than a third of them -- 32 neighbours per expansion: the rule's "traversal" side
+    # is checked on 3,000 rows, where ef 10 stays far below 1,000 evaluations and ef 1,500 cannot)
+    big_v = datagen.generate_dataset(3000, 64)
+    big = ultra_fast.build_index(datagen.indexed(big_v), show_progress=False)
+    assert not ultra_fast.routed_to_exact_scan(big, big_v[:8], 5, ef=10) and ultra_fast.routed_to_exact_scan(big, big_v[:8], 5, ef=1500)
+    assert ultra_fast.search_batch(big, big_v[:8], 5, ef=10, route=True) == ultra_fast.search_batch(big, big_v[:8], 5, ef=10)
+    big.close()
+    assert ultra_fast.routed_to_exact_scan(index, vecs[:8], 5, ef=100)
     ex_ids, _ = index.index.exact_knn(vecs[:8], 5)                   # (ef 100 on 100 rows evaluates every row)
     assert [[r["id"] for r in row] for row in ultra_fast.search_batch(index, vecs[:8], 5, ef=100, route=True)] == \
         [["vec_%d" % i for i in row] for row in ex_ids]
