@@ -652,7 +652,7 @@ def ivf_roofline(engine, dev, args, traffic):
                          "pair (SURVEY 8d).  The search reads each probed list once per batch in int8 and f32 rows only for "
                          "the candidates whose lower bound does not exclude them from the k nearest, so algorithmic_GBs is "
                          "a throughput figure far above any memory rate -- frac is the kernel's own traffic over its time",
-           "search": {"what": "ONE batch-32 search end to end (routing distances, routing tail, work list, bounds pass, finish): "
+           "search": {"what": "ONE batch-32 search end to end (routing distances, routing tail with the work list built in the same launch, bounds pass, finish): "
                               "all the bytes its launches moved / its wall time",
                       "wall_ms": r["search_wall_ms"], "traffic": tr_s, "bytes_needed": int(need_search),
                       "achieved": round(ach_s, 1), "unit": "GB/s", "frac": round(ach_s / HBM_PEAK_GBS, 4),

@@ -478,6 +478,8 @@ struct RouteArgs {
     int32_t seed_rows;       // ... of its first max(k, seed_rows) rows (stream_seed_rows)
     const float *rows;       // list rows (f32) + norms
     const float *row_norms;
+    const uint2 *half;       // optional: their half-precision copy + meta words -- the threshold seed reads those (seed_tau_wg)
+    const float4 *hmeta;
     uint32_t *bk_cnt;        // [nlist] members filed per list (zeroed before the launch), or null
     uint2 *bk_mem;           // [nlist][bk_cap] (query, offset of the list in the query's candidate stream)
     int32_t bk_cap;
@@ -606,12 +608,12 @@ __device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsign
         if (threadIdx.x == 0) a.tau[qi] = 0xffffffffu;
         return;
     }
-    const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+    const float qn = (a.metric == METRIC_COS || (a.half && a.metric == METRIC_DOT)) ? query_norm<NCH>(q) : 0.0f;
     // the head's table entries are in LDS (no dependent global reads) when they cover the rows the seed looks at
     const bool head_ok = a.nprobe <= kHead || tail_cover >= static_cast<uint32_t>(kSeedMax);
     const Pair *pp = head_ok ? head_s : a.pairs + static_cast<int64_t>(qi) * a.nprobe;
     seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, pp, head_ok ? (a.nprobe < kHead ? a.nprobe : kHead) : a.nprobe, tail_qcnt, a.k,
-                             a.rows, a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi, a.seed_rows);
+                             a.rows, a.row_norms, a.ld, reinterpret_cast<float *>(smem), a.tau + qi, a.seed_rows, a.half, a.hmeta);
     HG_IVF_STAMP(a.dbg, 20, qi == 0 && threadIdx.x == 0);  // threshold seeded
 }
 
@@ -925,6 +927,10 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
     a.dbg = g_tile_dbg_buf;  // null outside diagnostic sessions
     a.rows = idx->d_lrows;
     a.row_norms = idx->d_lnorms;
+    if (idx->d_lhalf && tune(HNSWGPU_TUNE_SEED_HALF, 1) != 0) {
+        a.half = idx->d_lhalf;
+        a.hmeta = idx->d_lhmeta;
+    }
     a.cent = idx->d_cent;
     a.cnorms = idx->d_cnorms;
     a.ld = idx->ld;

@@ -875,7 +875,9 @@ static WorkPlan stream_work_plan(const hnswgpu_index *idx, int32_t nq, int32_t n
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
     const int64_t mean = ivf_mean_len(idx);
     const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows, max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows;
-    const int64_t tgt = tune(HNSWGPU_TUNE_STREAM_WGS, 2048);
+    // (grouped small batches -- a query or two per probed list -- in finer items: batch 32 on the bench index, target 1024 /
+    // 2048 / 4096 / 8192: 145.3 / 144.7 / 142.3 / 142.5 us per search)
+    const int64_t tgt = tune(HNSWGPU_TUNE_STREAM_WGS, grouped && npairs < 6LL * idx->nlist ? 4096 : 2048);
     const int64_t units = grouped ? std::min<int64_t>(npairs, idx->nlist) : npairs;  // lists (or pairs) that have work
     const int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + units - 1) / std::max<int64_t>(units, 1)));
     const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows, tpc = cr / kTileRows;
@@ -1445,6 +1447,10 @@ static int ivf_search_enqueue(hnswgpu_index *idx, const float *d_Q, int32_t nq, 
             pa.rows = idx->d_lrows;
             pa.row_norms = idx->d_lnorms;
             pa.ld = idx->ld;
+            if (idx->d_lhalf && tune(HNSWGPU_TUNE_SEED_HALF, 1) != 0) {
+                pa.half = idx->d_lhalf;
+                pa.hmeta = idx->d_lhmeta;
+            }
             pa.qcodes = sc.qcodes;
             pa.qscal = sc.qscal;
             pa.tau = sc.tau;

@@ -390,16 +390,192 @@ __device__ __forceinline__ void wave_topk_sorted(const uint64_t (&key)[S], uint6
     __builtin_amdgcn_wave_barrier();
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave: four row_shr DPP steps inside the rows of 16, then row_bcast:15 / :31 carry
+// the row totals on (the GFX9 controls gfx950 still has) -- six VALU adds, no LDS-crossbar trip.
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// The k <= 64 smallest of up to 1024 keys (four per thread of a 256-thread workgroup, all-ones = none, distinct), ascending
+// into fin[0, k) (all-ones padded) -- by HISTOGRAMS of the distance words instead of a bisection of the key space: a pass
+// bins every key of the current range into 256 bins (one LDS atomic each), one wave scans the counts and names the bin
+// that holds the k-th smallest, and the next pass looks at that bin alone (8 more bits of the distance word) while it
+// still holds more than a few dozen keys; then the keys below the boundary bin and the keys in it are compacted and placed
+// by rank.  A pass is ~100 instructions per wave where a bisection step is ~20 and a bisection needs ~20 steps on each of two
+// levels (one wave executes ~100 dependent instructions per microsecond: picking 32 of 1024 centroid distances took 7 us, the
+// finish kernel's merge another 7).  Returns false -- nothing written -- when the boundary bin cannot be thinned below the
+// candidate buffer (hundreds of equal distances): the caller then bisects as before.  All 256 threads call it.
+// minimum / maximum over the 64 lanes (the same six DPP steps, identity for the lanes a step does not reach), wave-uniform
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    auto step = [](uint32_t x, uint32_t o) { return o < x ? o : x; };
+    const int id = -1;
+    v = step(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(id, static_cast<int>(v), 0x111, 0xF, 0xF, false)));
+    v = step(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(id, static_cast<int>(v), 0x112, 0xF, 0xF, false)));
+    v = step(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(id, static_cast<int>(v), 0x114, 0xF, 0xF, false)));
+    v = step(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(id, static_cast<int>(v), 0x118, 0xF, 0xF, false)));
+    v = step(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(id, static_cast<int>(v), 0x142, 0xA, 0xF, false)));
+    v = step(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(id, static_cast<int>(v), 0x143, 0xC, 0xF, false)));
+    return __builtin_amdgcn_readlane(v, kWave - 1);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+
+constexpr int kHistCand = 256;
+struct alignas(16) TopkHistLds {
+    uint32_t hist[256];
+    uint64_t cand[kHistCand];
+    uint32_t wmin[kNWave], wmax[kNWave], wcnt[kNWave];
+    uint32_t bin, below, inbin, ncand;
+};
+__device__ __forceinline__ bool topk_hist_wg(const uint64_t (&key)[4], int k, uint64_t *fin, TopkHistLds &L) {
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    uint32_t hw[4];
+    bool valid[4];
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    int nv = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        hw[s] = static_cast<uint32_t>(key[s] >> 32);
+        valid[s] = key[s] != ~0ull;
+        mn = valid[s] && hw[s] < mn ? hw[s] : mn;
+        mx = valid[s] && hw[s] > mx ? hw[s] : mx;
+        nv += __popcll(__ballot(valid[s]));
+    }
+    // the range of the valid distance words and their number, over the workgroup
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    L.hist[tid] = 0;
+    if (lane == 0) {
+        L.wmin[wave] = mn;
+        L.wmax[wave] = mx;
+        L.wcnt[wave] = static_cast<uint32_t>(nv);
+    }
+    if (tid < k) fin[tid] = ~0ull;
+    if (tid == 0) L.ncand = 0;
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < kNWave; w++) {
+        mn = L.wmin[w] < mn ? L.wmin[w] : mn;
+        mx = L.wmax[w] > mx ? L.wmax[w] : mx;
+        total += L.wcnt[w];
+    }
+    if (total == 0) return true;  // (fin is all-ones)
+    uint32_t K = static_cast<uint32_t>(k) < total ? static_cast<uint32_t>(k) : total;  // the K-th smallest valid key is the last one selected
+    uint32_t base = mn;
+    int sh = 32 - __builtin_clz((mx - mn) | 1u) - 8;  // (mx - mn) >> sh < 256
+    sh = sh < 0 ? 0 : sh;
+    bool in_range[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) in_range[s] = valid[s];
+    for (;;) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            if (in_range[s]) atomicAdd(&L.hist[(hw[s] - base) >> sh], 1u);
+        __syncthreads();
+        if (wave == 0) {
+            const uint4 h = *reinterpret_cast<const uint4 *>(L.hist + 4 * lane);
+            *reinterpret_cast<uint4 *>(L.hist + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);  // (for the next pass)
+            const int mine = static_cast<int>(h.x + h.y + h.z + h.w);
+            const int incl = wave_scan_incl(mine);
+            const uint64_t reach = __ballot(incl >= static_cast<int>(K));  // (the last lane's total is the range's population >= K)
+            const int Ln = __ffsll(static_cast<unsigned long long>(reach)) - 1;
+            if (lane == Ln) {
+                uint32_t c = static_cast<uint32_t>(incl - mine);  // keys in the bins of the lanes before
+                uint32_t b = 4 * lane, inb = h.x;
+                if (c + h.x < K) {
+                    c += h.x;
+                    b++;
+                    inb = h.y;
+                    if (c + h.y < K) {
+                        c += h.y;
+                        b++;
+                        inb = h.z;
+                        if (c + h.z < K) {
+                            c += h.z;
+                            b++;
+                            inb = h.w;
+                        }
+                    }
+                }
+                L.bin = b;
+                L.below = c;
+                L.inbin = inb;
+            }
+        }
+        __syncthreads();
+        const uint32_t b = L.bin, below = L.below, inbin = L.inbin;
+        // the next range: the boundary bin alone
+#pragma unroll
+        for (int s = 0; s < 4; s++) in_range[s] = in_range[s] && ((hw[s] - base) >> sh) == b;
+        base += b << sh;
+        K -= below;
+        if (inbin <= 32u || sh == 0) break;
+        sh = sh > 8 ? sh - 8 : 0;  // (L.bin / below / inbin are rewritten behind the next pass's first barrier: every thread has read them)
+    }
+    // selected: every valid key below the boundary bin (there are k_sel - K of them) and the keys in it (>= K, the K smallest count)
+    int c = 0;
+    uint64_t m[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const bool sel = valid[s] && (hw[s] < base || in_range[s]);
+        m[s] = __ballot(sel);
+        c += __popcll(m[s]);
+    }
+    uint32_t at = 0;
+    if (lane == 0 && c > 0) at = atomicAdd(&L.ncand, static_cast<uint32_t>(c));
+    at = __builtin_amdgcn_readfirstlane(at);
+    const uint64_t below_me = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        if ((m[s] >> lane) & 1ull) {
+            const uint32_t i = at + static_cast<uint32_t>(__popcll(m[s] & below_me));
+            if (i < static_cast<uint32_t>(kHistCand)) L.cand[i] = key[s];
+        }
+        at += static_cast<uint32_t>(__popcll(m[s]));
+    }
+    __syncthreads();
+    const int nc = static_cast<int>(L.ncand);
+    if (nc > kHistCand) return false;  // (uniform: the bisection path re-reads the keys)
+    if (tid < nc) {
+        const uint64_t v = L.cand[tid];
+        int rank = 0, j = 0;
+        for (; j + 4 <= nc; j += 4) {  // uniform addresses: LDS broadcasts, two keys per read
+            const uint64_t o0 = L.cand[j], o1 = L.cand[j + 1], o2 = L.cand[j + 2], o3 = L.cand[j + 3];
+            rank += (o0 < v ? 1 : 0) + (o1 < v ? 1 : 0) + (o2 < v ? 1 : 0) + (o3 < v ? 1 : 0);
+        }
+        for (; j < nc; j++) rank += L.cand[j] < v ? 1 : 0;
+        if (rank < k) fin[rank] = v;
+    }
+    __syncthreads();
+    return true;
+}
+
 // The k <= 64 smallest of n keys (key_of(i), i < n; distinct; all-ones = none), ascending, by the four waves of a
 // workgroup: each wave picks the k smallest of its interleaved quarter (chunks of 4 x 256 keys, the best so far carried
 // along), then all four merge their lists by rank.  Returns fin (k keys, all-ones padded) to wave 0, null to the others
 // (behind the last barrier: they touch none of the buffers again).  lists: [kNWave][k], fin: [k], scratch: [kNWave][k] of LDS.
 template <class KeyOf>
 __device__ __forceinline__ const uint64_t *topk_small_wg(int64_t n, int k, uint64_t *lists, uint64_t *fin, uint64_t *scratch,
-                                                         KeyOf key_of) {
+                                                         KeyOf key_of, bool hist = true /* (false: tools/micro/topk_select.hip times the bisection) */) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     constexpr int S = 4;
+    if (hist && n <= S * kWG) {  // one chunk: by histograms (topk_hist_wg); a boundary of hundreds of equal distances falls through
+        __shared__ TopkHistLds hist_lds;
+        uint64_t key[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const int64_t i = s * kWG + wave * kWave + lane;
+            key[s] = i < n ? key_of(i) : ~0ull;
+        }
+        if (topk_hist_wg(key, k, fin, hist_lds)) return wave == 0 ? fin : nullptr;
+    }
     uint64_t *myscr = scratch + wave * k;
     uint64_t *mylist = lists + wave * k;
     uint64_t carry = ~0ull;

@@ -100,10 +100,20 @@ __host__ inline int stream_seed_rows(int nq, int64_t n, int nlist) {
     return static_cast<int>(rows < 16 ? 16 : (rows > kSeedMax ? kSeedMax : rows));
 }
 
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void half_bounds(int metric, float sum, float qn, float4 mt, float &lb, float &ub);
+
+// With the half-precision copy of the list rows (`half` / `hmeta`, stream step 1b's operands) the head is read from THERE
+// and the threshold is the k-th smallest UPPER bound (half_bounds: k candidates are at most that far, as the half-precision
+// passes of larger batches argue): half the bytes.  One workgroup reads at what one CU's path to memory carries -- ~21 GB/s
+// (profiles/r02_one_cu_gather_microbench.txt) -- so 64 f32 rows (192 KB) were 9.7 us of a batch-32 search's 18-us routing
+// tail and 32 rows 5.1 us of a single query's; the bounds are ~1e-4 above the distances, far inside what separates the k-th
+// of 64 sampled rows from the k-th of the list.  qn: |q| (cosine and dot), unused for L2.
 template <int NCH, int RB, bool L2>
 __device__ __forceinline__ void seed_tau_wg(const float4 (&q)[NCH], float qn, int metric, const Pair *pp, int nprobe,
                                             int64_t qcnt, int k, const float *rows, const float *row_norms, int64_t ld,
-                                            float *dist_s /* [kSeedMax] LDS */, uint32_t *tau_out, int sample = 64) {
+                                            float *dist_s /* [kSeedMax] LDS */, uint32_t *tau_out, int sample = 64,
+                                            const uint2 *half = nullptr, const float4 *hmeta = nullptr) {
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     int m = k > sample ? k : sample;  // (large batches sample fewer rows: thousands of queries x 64 rows is the index again)
     m = (m + 31) & ~31;
@@ -114,7 +124,76 @@ __device__ __forceinline__ void seed_tau_wg(const float4 (&q)[NCH], float qn, in
         return;
     }
     const int nvec = static_cast<int>(ld / 4);
-    for (int j0 = wave * RB; j0 < m; j0 += kNWave * RB) {
+    // half rows: twice the f32 path's rows in flight per wave (64 rows: ONE round trip of the workgroup), the meta words
+    // fetched behind the rows (their scale is needed only once the rows are in)
+    constexpr int HB = RB == 8 ? 16 : RB;
+    for (int j0 = wave * HB; half && j0 < m; j0 += kNWave * HB) {
+        int64_t myrow = 0;
+        const bool mine = lane < HB && j0 + lane < m;
+        if (mine) {
+            const uint32_t o = static_cast<uint32_t>(j0 + lane);
+            int lo = 0, hi = nprobe - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pp[mid].ord_base <= o) lo = mid;
+                else hi = mid - 1;
+            }
+            myrow = pp[lo].row_begin + (o - pp[lo].ord_base);
+        }
+        const int rlo = static_cast<int>(myrow), rhi = static_cast<int>(myrow >> 32);
+        uint2 w[HB][NCH];
+#pragma unroll
+        for (int b = 0; b < HB; b++) {
+            const int64_t row = (static_cast<int64_t>(__builtin_amdgcn_readlane(rhi, b)) << 32) |
+                                static_cast<uint32_t>(__builtin_amdgcn_readlane(rlo, b));
+            const uint2 *rp = half + row * nvec;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) w[b][c] = j0 + b < m && c * kWave + lane < nvec ? rp[c * kWave + lane] : make_uint2(0u, 0u);
+        }
+        float4 mt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (mine) mt = hmeta[myrow];
+        float accs[HB];
+#pragma unroll
+        for (int b = 0; b < HB; b++) {  // (ivf_mid_kernel's arithmetic)
+            const float sc = L2 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mt.x), b)) : 0.0f;
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const h4_t h = __builtin_bit_cast(h4_t, w[b][c]);
+                const float hv[4] = {static_cast<float>(h[0]), static_cast<float>(h[1]), static_cast<float>(h[2]), static_cast<float>(h[3])};
+                const float qv[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (L2) {
+                        const float d = qv[j] - hv[j] * sc;
+                        acc = __builtin_fmaf(d, d, acc);
+                    } else {
+                        acc = __builtin_fmaf(qv[j], hv[j], acc);
+                    }
+                }
+            }
+            accs[b] = acc;
+        }
+        float tot;  // lane b < HB: row b's sum, beside its meta word
+        if constexpr (HB == 16) {
+            float lo8[8], hi8[8];
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                lo8[b] = accs[b];
+                hi8[b] = accs[8 + b];
+            }
+            const float t0 = wave_sum8(lo8, lane), t1 = wave_sum8(hi8, lane);  // every lane l: the total of row (l & 7) of its eight
+            tot = lane < 8 ? t0 : t1;
+        } else {
+            tot = rows_sum_to_lane<RB>(accs, lane);
+        }
+        if (mine) {
+            float lb, ub;
+            half_bounds(metric, tot, qn, mt, lb, ub);
+            dist_s[j0 + lane] = ub == ub ? ub : __builtin_inff();
+        }
+    }
+    for (int j0 = wave * RB; !half && j0 < m; j0 += kNWave * RB) {
         // lane b < RB resolves candidate j0 + b of the stream to its list row (as ivf_finish_kernel does)
         int64_t myrow = 0;
         float myrn = 0.0f;
@@ -183,6 +262,8 @@ struct PrepArgs {
     const float *rows;
     const float *row_norms;
     int64_t ld;
+    const uint2 *half;    // optional: the half-precision copy of the list rows and its meta words (the seed reads those)
+    const float4 *hmeta;
     uint32_t *qcodes;
     QueryScal *qscal;
     uint32_t *tau;
@@ -195,7 +276,7 @@ __global__ __launch_bounds__(kWG) void ivf_query_prep_kernel(PrepArgs a) {
     const int qi = blockIdx.x;
     float4 q[NCH];
     load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
-    const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+    const float qn = (a.metric == METRIC_COS || (a.half && a.metric == METRIC_DOT)) ? query_norm<NCH>(q) : 0.0f;
     if (wave == kNWave - 1) {
         QueryCode<NCH> qc;
         encode_query<NCH>(q, qc);
@@ -211,7 +292,7 @@ __global__ __launch_bounds__(kWG) void ivf_query_prep_kernel(PrepArgs a) {
         }
     }
     seed_tau_wg<NCH, RB, L2>(q, qn, a.metric, a.pairs + static_cast<int64_t>(qi) * a.nprobe, a.nprobe, a.qcnt[qi], a.k, a.rows,
-                             a.row_norms, a.ld, dist_s, a.tau + qi, a.seed_rows);
+                             a.row_norms, a.ld, dist_s, a.tau + qi, a.seed_rows, a.half, a.hmeta);
 }
 
 // One work item of the grouped bounds pass: rows [rb0 + r0_off, rb0 + r1_off) of inverted list `list` (which starts at row

@@ -397,7 +397,8 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_HNSW_WAVE 55 /* large HNSW launches on the one-wave-per-query kernel with the admission buffer: 1 = launches that fill the chip with one wave per query, and every launch from ef 640 (default), 0 = never (A/B), 2 = every launch it can serve (tests) */
 #define HNSWGPU_TUNE_FINISH_DIRECT 56 /* small IVF batches (16 and more finish workgroups per query): survivor lists of up to this many entries hand a key per survivor straight to the query's last workgroup instead of per-wave / per-workgroup top-k lists (default 1024 = the most; 0 = never: A/B) */
 #define HNSWGPU_TUNE_WORKLIST_FOLD 57 /* 0 = the bounds pass's work list of a small IVF batch stays a launch of its own instead of extra workgroups of the routing tail's launch (A/B) */
-#define HNSWGPU_TUNE_COUNT 58
+#define HNSWGPU_TUNE_SEED_HALF 58 /* 0 = a query's first threshold from f32 rows of its nearest list even where the half-precision copy exists (A/B; default 1: the k-th smallest upper bound of the sampled rows' half-precision copies, half the bytes) */
+#define HNSWGPU_TUNE_COUNT 59
 int hnswgpu_set_tuning(int32_t key, int64_t value);
 int hnswgpu_get_tuning(int32_t key, int64_t *value, int32_t *is_set);
 
