@@ -40,6 +40,7 @@ __global__ __launch_bounds__(kWG) void heuristic_select_kernel(HeurArgs a) {
     __shared__ int32_t res[kMaxDeg];
     __shared__ uint8_t state[kSelMaxCand];
     __shared__ int32_t sflag[2];
+    __shared__ int32_t sflag2[3];
     const int t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int64_t o0 = a.off[t];
@@ -84,9 +85,99 @@ __global__ __launch_bounds__(kWG) void heuristic_select_kernel(HeurArgs a) {
         if (my_pos[u] >= 0) cid[my_pos[u]] = my_id[u];
     __syncthreads();
     int nres = 0;
-    if (tid == 0) sflag[1] = 0;
+    if (tid == 0) {
+        sflag[1] = 0;
+        sflag2[0] = sflag2[1] = sflag2[2] = 0;
+    }
     for (int i = tid; i < C; i += kWG) state[i] = 0;
     __syncthreads();
+    // The rows already taken stay IN REGISTERS: wave w keeps taken rows [KR w, KR w + KR) from the moment each of them was the
+    // candidate (its row is in every wave's registers then), so a candidate costs ONE row fetch -- the next candidate's, issued
+    // while this one is decided -- and one barrier.  (Fetching the taken rows again for every candidate was up to 528 rows of a
+    // 33-candidate task and ~1,600 of a new node's 200: the 1.25M x 1536 build moved ~20 TB that way.)  Same pairs, same
+    // arithmetic, same order of decisions.  Tasks that want more links than 4 x KR, and rows beyond 6 KB, reload as before.
+    constexpr int KR = 8;
+    constexpr bool kKeep = NCH <= 6;
+    if (kKeep && m <= kNWave * KR) {
+        float4 r[KR][NCH];
+#pragma unroll
+        for (int t = 0; t < KR; t++)
+#pragma unroll
+            for (int c = 0; c < NCH; c++) r[t][c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float myrn = 0.0f;  // lane t < KR: the norm of this wave's taken row t
+        // (rows of up to 4 KB: the next candidate's row is fetched into registers while this one is decided; longer rows would
+        // push the kernel past 256 registers -- one workgroup per CU -- so they are fetched when needed, out of the L2 the touches
+        // below have filled, and the second workgroup on the CU covers the wait)
+        constexpr bool kAhead = NCH <= 4;
+        float4 q[NCH], qx[kAhead ? NCH : 1];
+        float qn = 0.0f, qnx = 0.0f;
+        if (kAhead && C > 0) {
+            load_row<NCH>(q, a.rows + static_cast<int64_t>(cid[0]) * a.ld, nvec, lane, true);
+            qn = a.metric == METRIC_COS ? a.row_norms[cid[0]] : 0.0f;
+        }
+        // (further ahead the rows are only TOUCHED -- wave w one dword per 128-byte line of candidate i + 2 + w's row, a register
+        // each -- so that the fetch one candidate ahead finds them in the L2: the rows of a task are scattered over the base, and
+        // at a workgroup or two per CU a fetch from memory is longer than a decision takes)
+        uint32_t sink = 0, touched = 0;
+        auto touch = [&](int i) -> uint32_t {
+            const int32_t c = cid[i < C ? i : C - 1];
+            const int line = lane < (nvec + 7) / 8 ? lane : 0;
+            return reinterpret_cast<const uint32_t *>(a.rows + static_cast<int64_t>(c) * a.ld)[32 * line];
+        };
+        if (wave + 1 < C) touched = touch(1 + wave);
+        for (int i = 0; i < C && nres < m; i++) {
+            const float dc = cd[i];
+            if constexpr (kAhead) {
+                const bool more = i + 1 < C;
+                const int32_t cx = cid[more ? i + 1 : i];
+                load_row<NCH>(qx, a.rows + static_cast<int64_t>(cx) * a.ld, nvec, lane, more);
+                qnx = (more && a.metric == METRIC_COS) ? a.row_norms[cx] : 0.0f;
+            } else {
+                load_row<NCH>(q, a.rows + static_cast<int64_t>(cid[i]) * a.ld, nvec, lane, true);
+                qn = a.metric == METRIC_COS ? a.row_norms[cid[i]] : 0.0f;
+            }
+            sink ^= touched;  // (last iteration's: long since in)
+            touched = (wave == (i & 3) && i + 5 < C) ? touch(i + 5) : 0u;
+            bool closer = false;
+            if (nres > 0) {
+                const int have = nres - wave * KR;  // this wave's taken rows (<= 0: none yet)
+                bool mine = false;
+                if (have > 0) {
+                    float sv[KR];
+#pragma unroll
+                    for (int t = 0; t < KR; t++) sv[t] = lane_partial<NCH, L2>(q, r[t]);
+                    const float sm = rows_sum_to_lane<KR>(sv, lane);
+                    if (lane < KR && lane < have) mine = finish_dist(a.metric, sm, qn, myrn) < dc;
+                }
+                // (three flags in turn: the one cleared here was last read before the PREVIOUS barrier and is written behind this one)
+                if (__ballot(mine) && lane == 0) atomicOr(&sflag2[i % 3], 1);
+                if (tid == 0) sflag2[(i + 1) % 3] = 0;
+                __syncthreads();
+                closer = sflag2[i % 3] != 0;
+            }
+            if (tid == 0) state[i] = closer ? 2 : 1;  // 1 = taken, 2 = discarded (read by thread 0 alone, below)
+            if (!closer) {
+                if (wave == nres / KR) {  // (uniform per wave)
+                    const int slot = nres % KR;
+#pragma unroll
+                    for (int t = 0; t < KR; t++)
+                        if (t == slot) {
+#pragma unroll
+                            for (int c = 0; c < NCH; c++) r[t][c] = q[c];
+                        }
+                    if (lane == slot) myrn = qn;
+                }
+                nres++;
+            }
+            if constexpr (kAhead) {
+#pragma unroll
+                for (int c = 0; c < NCH; c++) q[c] = qx[c];
+                qn = qnx;
+            }
+        }
+        if ((sink ^ touched) == 0x9e3779b9u && a.ntasks < 0) a.out_cnt[t] = -1;  // (never: keeps the touches alive)
+        __syncthreads();
+    } else {
     for (int i = 0; i < C && nres < m; i++) {
         const int32_t c = cid[i];
         const float dc = cd[i];
@@ -125,26 +216,28 @@ __global__ __launch_bounds__(kWG) void heuristic_select_kernel(HeurArgs a) {
         if (!closer) nres++;
         __syncthreads();
     }
-    // output: the taken ones in selection order; then, with extend, the discarded ones in their order (:191-195)
-    if (tid == 0) {
+    }
+    // output: the taken ones in selection order; then, with extend, the discarded ones in their order (:191-195) -- wave 0,
+    // 64 candidates per step (one thread walking the list was ~10 us of a 200-candidate task)
+    if (wave == 0) {
         int n = 0;
         int32_t *oi = a.out_id + static_cast<int64_t>(t) * a.out_stride;
         float *od = a.out_d + static_cast<int64_t>(t) * a.out_stride;
-        for (int i = 0; i < C && n < m; i++)
-            if (state[i] == 1) {
-                oi[n] = cid[i];
-                od[n] = cd[i];
-                n++;
-            }
-        if (a.extend)
-            for (int i = 0; i < C && n < m; i++)
-                if (state[i] == 2) {
-                    oi[n] = cid[i];
-                    od[n] = cd[i];
-                    n++;
+        for (int pass = 1; pass <= (a.extend ? 2 : 1); pass++)
+            for (int base = 0; base < C && n < m; base += kWave) {
+                const int i = base + lane;
+                const bool is = i < C && state[i] == pass;
+                const uint64_t mk = __ballot(is);
+                const int pos = n + __popcll(mk & ((1ull << lane) - 1ull));
+                if (is && pos < m) {
+                    oi[pos] = cid[i];
+                    od[pos] = cd[i];
                 }
-        a.out_cnt[t] = n;
-        for (int j = n; j < a.out_stride; j++) {
+                n += __popcll(mk);
+            }
+        n = n < m ? n : m;
+        if (lane == 0) a.out_cnt[t] = n;
+        for (int j = n + lane; j < a.out_stride; j += kWave) {
             oi[j] = -1;
             od[j] = 0.0f;
         }

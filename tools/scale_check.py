@@ -14,6 +14,8 @@ import torch
 import bench
 from hnsw_clj_amd import engine
 
+for kv in filter(None, os.environ.get("TUNE", "").split(",")):     # tuning-table overrides, e.g. TUNE=BUILD_TIMING=1
+    engine.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(1)
@@ -79,6 +81,20 @@ if sys.argv[1] == "hnsw":
               "requested = %.0f GB/s (%.2f of 8 TB/s); the reference algorithm's bytes: %.2f GB"
               % (ef, rec, len(Q), dt * 1e3, len(Q) / dt, ev, hp, f32_rows / len(Q), gb, gb / dt,
                  gb / dt / 8000, alg), flush=True)
+    print("  the traversal's int8 test on this graph (rejection mode 1, measured on the first large launch): state %d, "
+          "switched off: %s, f32 rows per neighbour with it on: %.3f" % idx.hnsw_rejection_state(), flush=True)
+    # the same launches with the test forced on (mode 2) -- what the per-graph measurement saves or costs
+    idx.set_rejection_test(2)
+    for ef in (256,):
+        for _ in range(2):
+            idx.hnsw_search_dev(Q, 10, ef)
+        torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(3):
+            idx.hnsw_search_dev(Q, 10, ef)
+        torch.cuda.synchronize()
+        dt = (time.time() - t) / 3
+        print("  ef %3d with the int8 test forced on (mode 2): %.2f ms = %.0f QPS" % (ef, dt * 1e3, len(Q) / dt), flush=True)
 else:
     n, dim, nlist = 10_000_000, 768, 1024
     cen = torch.randn(nlist, dim, generator=g, device=dev)
