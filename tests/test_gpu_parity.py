@@ -1477,6 +1477,46 @@ def test_ivf_routing_and_merge_break_ties_by_position(eng, oracle, metric, tune)
                 assert_exact(ids, d, oi, od, "ties %s mid=%s nq=%d nprobe=%d k=%d" % (metric, mid, nq, nprobe, k))
 
 
+@pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
+def test_ivf_small_batch_schedules_of_round_5(eng, oracle, metric, tune):
+    """Round 5's schedules of small batches, each on and off, against the oracle: the k smallest of <= 1024 keys by LDS
+    histograms (kernels.hpp: topk_hist_wg -- 700 centroids of which 300 are IDENTICAL put hundreds of equal distances across
+    the nprobe-th place: the candidate buffer overflows and the call bisects; groups of eight identical ones put a handful
+    there), the bounds pass's work list inside the routing tail's launch (worklist_part_wg: 700 lists are not a multiple of
+    the four lists a thread scans; batches of 6 = the one-launch routing, 14 and 40 = the tail launch), a key per survivor to
+    the finish kernel's last workgroup (400 identical rows: more than 256 equal keys), the first threshold from half rows."""
+    O = oracle
+    code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
+    rs = np.random.RandomState(11)
+    dim, nlist, n = 136, 700, 9100
+    uniq = rs.randn(nlist, dim).astype(np.float32)
+    cen = uniq.copy()
+    cen[100:400] = uniq[100]                                     # 300 identical centroids
+    cen[400:560] = np.repeat(uniq[400:420], 8, axis=0)           # groups of eight identical ones
+    base = (cen[rs.randint(0, nlist, n)] + 0.05 * rs.randn(n, dim)).astype(np.float32)
+    base[1000:1400] = base[7]                                    # 400 identical rows
+    lids = rs.permutation(n).astype(np.int32)
+    off = (np.arange(nlist + 1, dtype=np.int64) * 13)
+    Q = np.concatenate([base[7:8], cen[100:101], cen[400:401],
+                        (cen[rs.randint(0, nlist, 37)] + 0.05 * rs.randn(37, dim))]).astype(np.float32)
+    with eng.Index(base, metric) as idx:
+        idx.set_rejection_test(2)
+        idx.set_ivf(cen, off, lids)
+        tune.set("IVF_CODES", "1")
+        want = {}
+        for nq, nprobe, k in [(1, 7, 10), (6, 64, 10), (14, 7, 64), (40, 33, 10), (40, 64, 64)]:
+            want[(nq, nprobe, k)] = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=code, mode=O.MODE_DEV)
+        for fold, direct, half in [(1, 1024, 1), (0, 1024, 1), (1, 0, 1), (1, 1024, 0), (0, 0, 0), (1, 300, 1)]:
+            tune.set("WORKLIST_FOLD", fold)
+            tune.set("FINISH_DIRECT", direct)
+            tune.set("SEED_HALF", half)
+            for (nq, nprobe, k), (oi, od, op) in want.items():
+                ids, d, probes = idx.ivf_search(Q[:nq], k, nprobe, want_probes=True)
+                what = "%s fold=%d direct=%d half=%d nq=%d nprobe=%d k=%d" % (metric, fold, direct, half, nq, nprobe, k)
+                np.testing.assert_array_equal(probes, op, err_msg=what)
+                assert_exact(ids, d, oi, od, what)
+
+
 @pytest.mark.parametrize("kind", ["gaussian", "clustered"])
 def test_ivf_calibration_keeps_the_stream_for_data_it_helps(eng, oracle, kind):
     """Mode 1 (the default outside this suite) measures once per set of lists what the int8 bounds separate on the
