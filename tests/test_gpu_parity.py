@@ -729,6 +729,49 @@ def test_rejection_test_modes_agree(eng, oracle, metric):
         np.testing.assert_array_equal(res[2][2][sub], ost)
 
 
+@pytest.mark.parametrize("kind", ["gaussian", "clustered"])
+def test_traversal_int8_test_is_calibrated_per_graph(eng, oracle, kind):
+    """Rejection mode 1 measures on a graph's first large launch what the traversal's int8 test decides there
+    (hnswgpu_hnsw_rejection_state: state 0 -> 1 -> 2) and switches it off for that graph when it leaves more than 65 % of the
+    neighbours' f32 rows to fetch; afterwards a launch fetches what a launch without the test fetches (off) or fewer rows (on).  Ids,
+    distance bits and counters never depend on the verdict: equal to mode 0's and to the oracle's on a subsample."""
+    O = oracle
+    if kind == "gaussian":
+        base = _data(O, 9000, 256, "gaussian", seed=71)       # i.i.d.: every neighbour lies within the bounds' width of the worst
+        Q = _data(O, 1300, 256, "gaussian", seed=72)
+    else:
+        base = _data(O, 9000, 256, "clustered", seed=71)
+        Q = _data(O, 1300, 256, "clustered", seed=72)
+    with eng.Index(base, "cosine") as idx:
+        idx.hnsw_build(12, 60, 42)
+        idx.set_rejection_test(0)
+        idx.set_profiling(True)
+        idx.rejection_stats(reset=True)
+        want = idx.hnsw_search(Q, 10, 48, want_stats=True)
+        rows_untested, _ = idx.rejection_stats(reset=True)     # f32 rows a launch fetches without the test
+        idx.set_profiling(False)
+        idx.set_rejection_test(1)                              # (mode 0 launches measure nothing: the graph is still unmeasured)
+        assert idx.hnsw_rejection_state()[0] == 0
+        got = [idx.hnsw_search(Q, 10, 48, want_stats=True) for _ in range(3)]
+        state, off, frac = idx.hnsw_rejection_state()
+        assert state == 2 and 0.0 < frac <= 1.0 and off == (frac > 0.65), (state, off, frac)
+        idx.set_profiling(True)
+        idx.rejection_stats(reset=True)
+        got.append(idx.hnsw_search(Q, 10, 48, want_stats=True))
+        f32_rows, neighbours = idx.rejection_stats(reset=True)
+        idx.set_profiling(False)
+        assert neighbours == int(want[2][:, 0].sum())
+        assert (f32_rows == rows_untested) if off else (f32_rows < rows_untested), (off, f32_rows, rows_untested, neighbours)
+        for g in got:
+            np.testing.assert_array_equal(g[0], want[0])
+            np.testing.assert_array_equal(g[1].view(np.uint32), want[1].view(np.uint32))
+            np.testing.assert_array_equal(g[2], want[2])
+        gr = idx.get_graph()
+        oi, od, ost, _ = O.hnsw_search(base, gr, Q[:32], 10, ef=48, metric=O.COSINE, mode=O.MODE_DEV)
+        assert_exact(want[0][:32], want[1][:32], oi, od, "calibrated traversal vs oracle, %s" % kind)
+        np.testing.assert_array_equal(want[2][:32], ost)
+
+
 def test_ivf_euclidean_large_batch_all_gemv_order(eng, oracle):
     """A Euclidean batch of more than 1024 queries: routing through the register-row group kernel, bounds on the matrix
     cores (dozens of queries per probed list), refine in the GEMV order -- every stage keeps the one arithmetic the
