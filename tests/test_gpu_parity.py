@@ -1560,6 +1560,45 @@ def test_ivf_small_batch_schedules_of_round_5(eng, oracle, metric, tune):
                 assert_exact(ids, d, oi, od, what)
 
 
+def test_ivf_randomised_small_batches(eng, oracle, tune):
+    """Random IVF configurations in the regime round 5 rescheduled -- 1 to 60 queries through the survivor stream: list counts
+    around and beyond the 1024 keys the histogram selection takes in one chunk, nprobe / k from 1 to 64, three metrics, rows with
+    duplicates, lists of very different lengths (empty ones included) -- against the oracle's GEMV order, probes included.
+    HNSWGPU_SOAK=<n>: n more seeds."""
+    O = oracle
+    tune.set("IVF_CODES", "1")
+    for seed in [77] + [7700 + i for i in range(int(os.environ.get("HNSWGPU_SOAK", "0")))]:
+        rs = np.random.RandomState(seed)
+        for case in range(14):
+            dim = int(rs.choice([130, 256, 768]))
+            nlist = int(rs.choice([37, 300, 700, 1023, 1024, 1500]))
+            n = int(rs.choice([3000, 8000]))
+            metric = int(rs.choice([O.COSINE, O.L2, O.DOT]))
+            cen = _data(O, nlist, dim, "gaussian", seed=seed + case)
+            if rs.rand() < 0.5:
+                cen[nlist // 3:nlist // 3 + min(nlist // 4, 280)] = cen[0]   # many identical centroids: equal routing distances
+            w = rs.rand(nlist) ** 3                                          # a few long lists, many short or empty ones
+            assign = rs.choice(nlist, n, p=w / w.sum())
+            base = (cen[assign] + 0.1 * rs.randn(n, dim)).astype(np.float32)
+            if rs.rand() < 0.5:
+                base[rs.randint(0, n, n // 8)] = base[5]                     # hundreds of identical rows
+            off, lids = O.lists_from_assign(assign, nlist)
+            nq = int(rs.choice([1, 3, 6, 13, 32, 60]))
+            nprobe = int(rs.choice([1, 8, 32, 64]))
+            k = int(rs.choice([1, 10, 40]))
+            if metric != O.L2 and nq * min(nprobe, nlist) > 12 * nlist:      # (beyond it cosine / dot take the k-ordered tile scan)
+                nq = max(1, 12 * nlist // min(nprobe, nlist))
+            Q = np.vstack([base[5:6], (cen[rs.randint(0, nlist, nq)] + 0.1 * rs.randn(nq, dim))]).astype(np.float32)[:nq]
+            tag = "seed %d case %d dim=%d nlist=%d n=%d metric=%d nq=%d nprobe=%d k=%d" % (seed, case, dim, nlist, n, metric, nq, nprobe, k)
+            with eng.Index(base, metric) as idx:
+                idx.set_rejection_test(2)
+                idx.set_ivf(cen, off, lids)
+                ids, d, pr = idx.ivf_search(Q, k, nprobe, want_probes=True)
+                oi, od, opr = O.ivf_search(base, cen, off, lids, Q, k, nprobe, metric=metric, mode=O.MODE_DEV)
+                np.testing.assert_array_equal(pr[:, :min(nprobe, nlist)], opr, err_msg=tag)
+                assert_exact(ids, d, oi, od, tag)
+
+
 @pytest.mark.parametrize("kind", ["gaussian", "clustered"])
 def test_ivf_calibration_keeps_the_stream_for_data_it_helps(eng, oracle, kind):
     """Mode 1 (the default outside this suite) measures once per set of lists what the int8 bounds separate on the
