@@ -195,10 +195,12 @@ int launch_mid(const MidArgs &a0, int nch, hipStream_t st) {
 int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narrow, hipStream_t st, int qblocks) {
     if (blocks <= 0) return 0;
     HG_REQUIRE(blocks < 2147483647LL, HNSWGPU_ELIMIT, "bounds pass grid too large");
-    const bool two = qblocks == 2 && !narrow && a.defer;  // two 32-query column blocks per group (the work list was built for them)
-    HG_REQUIRE(qblocks == 1 || two, HNSWGPU_EINVAL, "bounds pass: two column blocks need the wide deferring epilogue");
-    if (two) count_launch(HNSWGPU_COUNT_BOUNDS_TWO_BLOCKS);
-    const size_t lds = stream_lds_bytes(nch, narrow, two ? 2 : 1, two ? 4 : kTileWaves);
+    const bool wide = (qblocks == 2 || qblocks == 4) && !narrow && a.defer;  // several 32-query column blocks per group (the work list was built for them)
+    HG_REQUIRE(qblocks == 1 || wide, HNSWGPU_EINVAL, "bounds pass: several column blocks need the wide deferring epilogue");
+    const bool two = wide && qblocks == 2, four = wide && qblocks == 4;
+    if (wide) count_launch(HNSWGPU_COUNT_BOUNDS_TWO_BLOCKS);
+    const size_t lds = stream_lds_bytes(nch, narrow, qblocks, stream_waves(qblocks));
+    HG_REQUIRE(lds <= 160 * 1024, HNSWGPU_ELIMIT, "bounds pass: the group's codes do not fit the LDS");
 #define CALLV(N, NARROW, DEFER, QB)                                                                                    \
     do {                                                                                                               \
         static bool attr_done[64] = {};                                                                                \
@@ -206,11 +208,12 @@ int launch_stream_bounds(const StreamArgs &a, int64_t blocks, int nch, bool narr
             HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_bounds_kernel<N, NARROW, DEFER, QB>),    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
         hipLaunchKernelGGL((stream_bounds_kernel<N, NARROW, DEFER, QB>), dim3(static_cast<unsigned>(blocks)),          \
-                           dim3(QB == 1 ? kTileThreads : 256), lds, st, a);                                            \
+                           dim3(stream_waves(QB) * kWave), lds, st, a);                                                \
     } while (0)
 #define CALL(N, R, L)                         \
     do {                                      \
         if (narrow) CALLV(N, true, false, 1); \
+        else if (four) CALLV(N, false, true, 4); \
         else if (two) CALLV(N, false, true, 2); \
         else if (a.defer) CALLV(N, false, true, 1); \
         else CALLV(N, false, false, 1);       \

@@ -873,26 +873,38 @@ struct WorkPlan {
 static WorkPlan stream_work_plan(const hnswgpu_index *idx, int32_t nq, int32_t nprobe, bool grouped, const StreamTune &tn) {
     WorkPlan p;
     const int64_t npairs = static_cast<int64_t>(nq) * nprobe;
-    const int64_t mean = ivf_mean_len(idx);
-    const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows, max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows;
-    // (grouped small batches -- a query or two per probed list -- in finer items: batch 32 on the bench index, target 1024 /
-    // 2048 / 4096 / 8192: 145.3 / 144.7 / 142.3 / 142.5 us per search)
-    const int64_t tgt = tune(HNSWGPU_TUNE_STREAM_WGS, grouped && npairs < 6LL * idx->nlist ? 4096 : 2048);
-    const int64_t units = grouped ? std::min<int64_t>(npairs, idx->nlist) : npairs;  // lists (or pairs) that have work
-    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + units - 1) / std::max<int64_t>(units, 1)));
-    const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows, tpc = cr / kTileRows;
-    p.chunk_rows = cr;
-    p.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
     const bool mid = ivf_mid_mode(idx, nq, nprobe, tn);
     // The largest batches (a list probed by 256 queries and more on average, entries appended without bounds): two 32-query
     // column blocks per group -- every staged row operand meets 64 queries, the lists leave L2 half as often
     const int64_t wide2 = tune(HNSWGPU_TUNE_STREAM_WIDE2, -1);  // -1 that rule, 0 never, 1 whenever the epilogue allows
     const int64_t narrow_env = tune(HNSWGPU_TUNE_STREAM_NARROW, -1);  // A/B: 0 / 1 force
     p.narrow = narrow_env >= 0 ? narrow_env != 0 : npairs < 6LL * idx->nlist;
-    p.qblocks = grouped && mid && !p.narrow && idx->nch <= 4 /* (64 queries' codes: two workgroups per CU still fit) */ &&
-                        wide2 != 0 && (wide2 > 0 || npairs >= 256LL * idx->nlist)
-                    ? 2
-                    : 1;
+    // (round 5 built FOUR blocks as well -- the list's rows out of the L2 once per 128 members -- and measured them slower at every
+    // batch size, 4096: 0.324 vs 0.281 ms, 16384: 0.862 vs 0.800 (two) / 0.864 (one): it is not the re-streamed rows that bound the
+    // pass at these sizes but a matrix instruction's 1 KB query operand out of LDS -- four SIMDs at one instruction per 32 cycles
+    // ARE the LDS's 128 bytes per cycle.  1 forces two blocks, 4 four, wherever the wide deferring epilogue runs.)
+    p.qblocks = 1;
+    if (grouped && mid && !p.narrow && idx->nch <= 4 /* (128 queries' codes of 1024 bytes: 128 KB of LDS) */ && wide2 != 0) {
+        if (wide2 == 4) p.qblocks = 4;
+        else if (wide2 > 0 || npairs >= 256LL * idx->nlist) p.qblocks = 2;
+    }
+    // (Also built in round 5 and removed again: the members' codes in REGISTERS -- a 32-member column block per wave, four or
+    // eight waves walking the same rows, no LDS operand at all -- on the hope that the CU's L1 would serve the second to eighth
+    // reader of a row operand: it does not (batch 4096: 0.386 vs 0.241 ms, 16384: 1.02 vs 0.67).)
+    const int64_t mean = ivf_mean_len(idx);
+    const int64_t mean_tiles = (mean + kTileRows - 1) / kTileRows, max_tiles = (idx->max_list_len + kTileRows - 1) / kTileRows;
+    // (grouped small batches -- a query or two per probed list -- in finer items: batch 32 on the bench index, target 1024 /
+    // 2048 / 4096 / 8192: 145.3 / 144.7 / 142.3 / 142.5 us per search)
+    const int64_t tgt = tune(HNSWGPU_TUNE_STREAM_WGS, grouped && npairs < 6LL * idx->nlist ? 4096 : 2048);
+    // units of work the target is spread over: the lists (or pairs) that have work -- times the GROUPS a list's members form (round
+    // 5: a list probed by 128 queries is four items per chunk already; cut into two chunks as well, every item staged its 24 KB of
+    // query codes for two row blocks per wave -- whole lists: batch 4096 0.389 -> 0.313 ms, 16384 0.819 -> 0.655 in the diagnostic build)
+    int64_t units = grouped ? std::min<int64_t>(npairs, idx->nlist) : npairs;
+    if (grouped) units *= std::max<int64_t>(1, npairs / (std::max<int64_t>(units, 1) * kTileQ * p.qblocks));
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(mean_tiles, (tgt + units - 1) / std::max<int64_t>(units, 1)));
+    const int64_t cr = ((mean_tiles + want - 1) / want) * kTileRows, tpc = cr / kTileRows;
+    p.chunk_rows = cr;
+    p.nchunks = static_cast<int32_t>(std::max<int64_t>(1, (max_tiles + tpc / 2) / tpc));
     p.wbound = (npairs / kTileQ + idx->nlist) * p.nchunks;
     return p;
 }

@@ -523,14 +523,24 @@ __device__ __forceinline__ bool stream_reject(int dot, float4 r, float4 qt) {
 // kernel is bound by the L2s, not by HBM.  Two accumulators are ~150 registers: four-wave workgroups, three per CU (eight-wave
 // ones fit once: 358 us against 283 at batch 4096).  At batch 2048 / 4096 it is no faster than one block (194 vs 189, 280 vs 284
 // us: what the L2s are spared the lower occupancy takes back), so only batches with 256 and more pairs per list take it.
+// QB column blocks of 32 queries per group (1, 2 or 4): every staged row operand meets 32 QB queries -- one matrix instruction per
+// block on the same A registers, an accumulator each -- so a list whose members fill several blocks leaves the L2 once per QB
+// blocks instead of once per block (batch 4096 on the bench index: 128 members per list, four passes of 0.77 GB out of the L2s
+// were 287 us against 144 at batch 1024, where there is one).  Two blocks: four waves; four blocks: eight waves (their codes are
+// 96 KB of LDS at 768 dimensions: one workgroup per CU, and eight waves keep 64 KB of row operands in flight).
+__host__ __device__ constexpr int stream_waves(int qb) { return qb == 1 ? kTileWaves : (qb == 2 ? 4 : 8); }
 template <int NCH, bool NARROW, bool DEFER, int QB = 1>
-__global__ __launch_bounds__(QB == 1 ? kTileThreads : 256) void stream_bounds_kernel(StreamArgs a) {
-    static_assert(QB == 1 || (QB == 2 && !NARROW && DEFER), "two column blocks: the wide deferring epilogue only");
+__global__ __launch_bounds__(stream_waves(QB) * kWave) void stream_bounds_kernel(StreamArgs a) {
+    static_assert(QB == 1 || ((QB == 2 || QB == 4) && !NARROW && DEFER), "several column blocks: the wide deferring epilogue only");
     constexpr int S = NCH * 8;  // steps of 32 bytes
-    constexpr int PF = 8;       // operand loads in flight per wave
+    // operand loads in flight per wave.  (Round 5, tools/bounds_pmc.sh at batch 16384: the waves wait on memory 61 % of the time
+    // -- SQ_WAIT_ANY / SQ_WAVE_CYCLES --, the matrix cores are 25 % busy, LDS waits 2 %; twelve loads in flight instead of eight
+    // made the two-column-block kernel SLOWER, 0.80 vs 0.64 ms: it is the L2s' delivery rate, ~9 TB/s, not the waves' latency.)
+    constexpr int PF = 8;
     constexpr int TQ = kTileQ * QB;                     // queries per group
-    constexpr int NWV = QB == 1 ? kTileWaves : 4;       // waves per workgroup
+    constexpr int NWV = stream_waves(QB);               // waves per workgroup
     constexpr int NTHR = NWV * kWave;
+    static_assert(TQ <= NTHR, "a thread per member sets the group up");
     extern __shared__ __align__(16) unsigned char smem[];
     v4i_t *qb_s = reinterpret_cast<v4i_t *>(smem);                               // [QB][S][2][32]
     QueryScal *qs_s = reinterpret_cast<QueryScal *>(qb_s + S * 64 * QB);         // [TQ]
@@ -623,10 +633,10 @@ __global__ __launch_bounds__(QB == 1 ? kTileThreads : 256) void stream_bounds_ke
             // a list twice, and only the first pair's rows came through the home-list pass)
             home = hp.row_begin == rb0 && hp.row_end > hp.row_begin && ob == hp.ord_base;
         }
-        const uint64_t hb = __ballot(home);
-        if (tid == 0) {
-            home_mask_s[0] = static_cast<uint32_t>(hb);
-            if (QB > 1) home_mask_s[1] = static_cast<uint32_t>(hb >> 32);
+        const uint64_t hb = __ballot(home);  // (a wave of this branch = 64 members = two column blocks)
+        if (lane == 0) {
+            home_mask_s[2 * wave] = static_cast<uint32_t>(hb);
+            if (2 * wave + 1 < QB) home_mask_s[2 * wave + 1] = static_cast<uint32_t>(hb >> 32);
         }
     }
     __syncthreads();
@@ -654,7 +664,10 @@ __global__ __launch_bounds__(QB == 1 ? kTileThreads : 256) void stream_bounds_ke
     const int myq = live ? qi_s[col] : 0;
     const uint32_t myob = live ? ob_s[col] : 0;
     uint4 *dst = a.surv + static_cast<int64_t>(myq) * a.cap;
-    const bool live1 = QB > 1 && col + 32 < cnt && !((home_mask_s[QB - 1] >> col) & 1u);  // (second column block: queries 32 .. 63)
+    uint32_t livex = 0;  // bit x - 1: this lane's column of column block x (queries 32 x .. 32 x + 31) is a member and not at home here
+#pragma unroll
+    for (int x = 1; x < QB; x++)
+        if (col + 32 * x < cnt && !((home_mask_s[x] >> col) & 1u)) livex |= 1u << (x - 1);
     const v4i_t *ap = tile + (b * S) * 64 + lane;  // this wave's current block
     const v4i_t *qb_mine = qb_s + half * 32 + col;   // B operand of step s: qb_mine[s * 64]
     for (; b < b1; b += NWV, ap += static_cast<int64_t>(NWV) * S * 64) {
@@ -667,7 +680,9 @@ __global__ __launch_bounds__(QB == 1 ? kTileThreads : 256) void stream_bounds_ke
             terms_w[64 + lane] = mcur.z;
         }
         v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        v16i_t acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (QB == 2: the second column block)
+        v16i_t accx[QB > 1 ? QB - 1 : 1];  // (the further column blocks)
+#pragma unroll
+        for (int x = 0; x < (QB > 1 ? QB - 1 : 1); x++) accx[x] = acc;
         {
             const v4i_t *p = ap;
             const v4i_t *qp = qb_mine;
@@ -678,7 +693,8 @@ __global__ __launch_bounds__(QB == 1 ? kTileThreads : 256) void stream_bounds_ke
                     const v4i_t cur = av[u];
                     av[u] = p[(PF + u) * 64];
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur, qp[u * 64], acc, 0, 0, 0);
-                    if (QB > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur, qp[u * 64 + S * 64], acc1, 0, 0, 0);
+#pragma unroll
+                    for (int x = 1; x < QB; x++) accx[x - 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur, qp[u * 64 + x * S * 64], accx[x - 1], 0, 0, 0);
                 }
                 p += PF * 64;
                 qp += PF * 64;
@@ -686,7 +702,8 @@ __global__ __launch_bounds__(QB == 1 ? kTileThreads : 256) void stream_bounds_ke
 #pragma unroll
             for (int u = 0; u < PF; u++) {
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[u], qp[u * 64], acc, 0, 0, 0);
-                if (QB > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[u], qp[u * 64 + S * 64], acc1, 0, 0, 0);
+#pragma unroll
+                for (int x = 1; x < QB; x++) accx[x - 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[u], qp[u * 64 + x * S * 64], accx[x - 1], 0, 0, 0);
             }
         }
         metar = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -813,8 +830,11 @@ __global__ __launch_bounds__(QB == 1 ? kTileThreads : 256) void stream_bounds_ke
                 }
             }
         }
-        if (QB > 1) {  // ---- the second column block of the group: the same test on its accumulator, entries without bounds
-            const float4 myqt1 = qt_s[col + 32];  // (from LDS per block: held in registers they cost the kernel a workgroup per CU)
+#pragma unroll
+        for (int x = 1; x < QB; x++) {  // ---- the further column blocks of the group: the same test on their accumulators, entries without bounds
+            const v16i_t &acc1 = accx[x - 1];
+            const bool live1 = (livex >> (x - 1)) & 1u;
+            const float4 myqt1 = qt_s[col + 32 * x];  // (from LDS per block: held in registers they cost the kernel a workgroup per CU)
             const v2f_t P21 = {myqt1.x, myqt1.x}, nQ21 = {-myqt1.y, -myqt1.y}, K21 = {myqt1.z, myqt1.z};
             uint32_t pm1 = 0;
 #pragma unroll
@@ -842,8 +862,8 @@ __global__ __launch_bounds__(QB == 1 ? kTileThreads : 256) void stream_bounds_ke
             }
             const int n1 = __popc(pm1);
             if (__ballot(n1 > 0)) {
-                const int myq1 = live1 ? qi_s[col + 32] : 0;
-                const uint32_t myob1 = live1 ? ob_s[col + 32] : 0;
+                const int myq1 = live1 ? qi_s[col + 32 * x] : 0;
+                const uint32_t myob1 = live1 ? ob_s[col + 32 * x] : 0;
                 uint4 *dst1 = a.surv + static_cast<int64_t>(myq1) * a.cap;
                 const int on1 = __shfl_xor(n1, 32, kWave);
                 uint32_t base = 0;

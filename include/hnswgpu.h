@@ -388,7 +388,7 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_HOME_DEPTH 46 /* operand loads in flight per wave of the home-list pass: 4 / 8 / 12 / 16 / 24, the largest that divides the 32-element steps of a row and does not exceed this (default 12) */
 #define HNSWGPU_TUNE_HOME_STRAYS 47 /* home-list batches: a query the bounds pass appended no more than this many candidates to skips the per-survivor half-precision pass (the finish kernel fetches their f32 rows; default 32) */
 #define HNSWGPU_TUNE_ROUTE_MFMA 48 /* centroid distances of IVF batches on the f32 matrix cores in the GEMV order (the same bits): -1 from 256 queries (cosine / dot, rows of 256 / 512 / 768 elements), 0 never, 1 whenever possible, > 1 that many slices of the table per group of 16 queries */
-#define HNSWGPU_TUNE_STREAM_WIDE2 49 /* bounds pass of the largest batches with two 32-query column blocks per group (a staged list row meets 64 queries, four-wave workgroups): -1 from 256 (query, list) pairs per list, 0 never, 1 whenever the wide deferring epilogue runs */
+#define HNSWGPU_TUNE_STREAM_WIDE2 49 /* bounds pass of large batches with several 32-query column blocks per group (a staged list row meets 64 / 128 queries): -1 = two blocks from 256 (query, list) pairs per list, 0 never, 1 = two blocks and 4 = four blocks (measured slower: A/B, tests) whenever the wide deferring epilogue runs */
 #define HNSWGPU_TUNE_SOLO 50 /* small HNSW launches, one query over several CUs (an owner workgroup keeps the reference's order, helper workgroups evaluate and chase ahead of it): 1 = from ef 96 (default), 2 = always, 0 = never (the round-2 helpers) */
 #define HNSWGPU_TUNE_SOLO_CHASE 51 /* 0 = the helpers only evaluate what the owner asks for (A/B) */
 #define HNSWGPU_TUNE_SOLO_SLOTS 52 /* log2 of the slots per query of the helpers' node-keyed tables (0 = auto) */

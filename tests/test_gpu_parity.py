@@ -1126,6 +1126,15 @@ def test_ivf_home_list_pass(eng, oracle, metric, dim, tune):
         check(300, 10, 12, "two column blocks")
         check(300, 100, 50, "two column blocks")
         check(170, 10, 1, "two column blocks")
+        tune.set("STREAM_WIDE2", "4")      # ... with four (production from 96 pairs per list): groups of up to 128 members
+        wide0 = eng.debug_counter("bounds_two_column_blocks")
+        check(300, 10, 12, "four column blocks")
+        assert (eng.debug_counter("bounds_two_column_blocks") > wide0) == (dim <= 1024)   # (rows of up to 1024 bytes of codes)
+        check(300, 100, 50, "four column blocks")
+        check(170, 10, 1, "four column blocks")
+        tune.set("STREAM_HOME", "0")
+        check(300, 10, 12, "home off, four column blocks")
+        tune.set("STREAM_HOME", "1")
         tune.unset("STREAM_WIDE2")
         tune.set("STREAM_CAP", "300")      # some lists overflow (and home rows that do not fit send a query through the fallback)
         check(300, 10, 12, "mixed fallback", expect_few=False)

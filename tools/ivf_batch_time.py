@@ -17,6 +17,11 @@ metric = os.environ.get("METRIC", "cosine")   # METRIC=l2: no tile path, every b
 idx = engine.Index(x, metric, 0)
 del x
 idx.ivf_build(1024, 10, 42)
+if os.environ.get("ABLATE"):          # -DHG_DIAG builds only (tools/build_stamps.sh): the bounds pass with parts cut out, results WRONG
+    import ctypes as C
+    from hnsw_clj_amd import _native
+    _native.lib().hnswgpu_debug_set_ablation(C.c_int32(0), C.c_int32(int(os.environ["ABLATE"])))
+    print("ablation of the bounds pass: %s (1 no epilogue, 8 the test without appends, 4 no slot counter)" % os.environ["ABLATE"], flush=True)
 import numpy as np
 _, _off, _ = idx.get_ivf()
 _lens = np.diff(_off)
