@@ -20,6 +20,7 @@ struct HeurArgs {
     const int32_t *m;         // [ntasks] links wanted (2M at layer 0, M above), or null: m_all
     int32_t m_all;
     int32_t extend;           // extend-candidates? (graph.clj:191-195)
+    int32_t keep_rows;        // the taken rows stay in registers (round 5; 0 = every candidate fetches them again: A/B)
     int32_t out_stride;       // >= max m
     int32_t *out_id;          // [ntasks][out_stride] in selection order, -1 padded
     float *out_d;             // [ntasks][out_stride]
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(kWG) void heuristic_select_kernel(HeurArgs a) {
     // arithmetic, same order of decisions.  Tasks that want more links than 4 x KR, and rows beyond 6 KB, reload as before.
     constexpr int KR = 8;
     constexpr bool kKeep = NCH <= 6;
-    if (kKeep && m <= kNWave * KR) {
+    if (kKeep && a.keep_rows && m <= kNWave * KR) {
         float4 r[KR][NCH];
 #pragma unroll
         for (int t = 0; t < KR; t++)

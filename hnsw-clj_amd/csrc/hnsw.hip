@@ -1016,6 +1016,7 @@ static int launch_heur(hnswgpu_index *idx, HeurArgs a, hipStream_t st) {
     a.ld = idx->ld;
     a.dim = idx->dim;
     a.metric = idx->metric;
+    a.keep_rows = tune(HNSWGPU_TUNE_BUILD_KEEP_ROWS, 1) != 0 ? 1 : 0;
     const bool l2 = idx->metric == METRIC_L2;
 #define CALL(N, R, L) hipLaunchKernelGGL((heuristic_select_kernel<N, R, L>), dim3(a.ntasks), dim3(kWG), 0, st, a)
     HG_DISPATCH(idx->nch, l2, CALL);

@@ -26,6 +26,14 @@ for i in range(0, n, 250_000):
     x[i:i + m] = y / y.norm(dim=1, keepdim=True)
 idx = engine.Index(x, "cosine", 0)
 torch.cuda.synchronize()
-t = time.time()
-idx.hnsw_build(16, 200, 42, **bench.BUILDERS[builder])
-print("HNSW build %d x %d (%s builder): %.2f s" % (n, dim, builder, time.time() - t), flush=True)
+graphs = []
+for keep in [int(v) for v in os.environ.get("KEEP", "1").split(",")]:   # KEEP=0,1,0,1: the selection kernel's two forms on one box
+    engine.set_tuning("BUILD_KEEP_ROWS", keep)
+    t = time.time()
+    idx.hnsw_build(16, 200, 42, **bench.BUILDERS[builder])
+    print("HNSW build %d x %d (%s builder, taken rows in registers: %d): %.2f s" % (n, dim, builder, keep, time.time() - t), flush=True)
+    g = idx.get_graph()
+    graphs.append(g.l0_adj.copy() if hasattr(g, "l0_adj") else None)
+if len(graphs) > 1 and graphs[0] is not None:
+    import numpy as np
+    print("layer-0 adjacency equal across the builds: %s" % all(np.array_equal(graphs[0], h) for h in graphs[1:]), flush=True)
