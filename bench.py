@@ -598,6 +598,15 @@ def ivf_roofline(engine, dev, args, traffic):
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - t1) * 1e6)
     lat = sorted(lat[10:])
+    # ... and through the reference's seam: host buffers in and out (hnswgpu_ivf_search: query and results in mapped pinned
+    # memory, the caller spins on a flag the last launch sets)
+    qh1 = Qa[:64].cpu().numpy()
+    lat_host = []
+    for i in range(60):
+        t1 = time.perf_counter()
+        idx.ivf_search(qh1[i:i + 1], K, nprobe)
+        lat_host.append((time.perf_counter() - t1) * 1e6)
+    lat_host = sorted(lat_host[10:])
     # recall of the IVF configuration against exact kNN (GPU brute force)
     ti, _ = idx.exact_knn_dev(Qa[:256].contiguous(), K)
     ii, _ = idx.ivf_search_dev(Qa[:256].contiguous(), K, nprobe)
@@ -687,6 +696,9 @@ def ivf_roofline(engine, dev, args, traffic):
                        "frac": round(o["unique_rows"] * code_row / 1e9 / (o["avg_scan_ms"] * 1e-3) / HBM_PEAK_GBS, 4),
                        "end_to_end_us": {"p50": round(lat[len(lat) // 2], 1), "min": round(lat[0], 1),
                                          "p95": round(lat[int(len(lat) * 0.95)], 1)},
+                       "host_entry_us": {"p50": round(lat_host[len(lat_host) // 2], 1), "min": round(lat_host[0], 1),
+                                         "p95": round(lat_host[int(len(lat_host) * 0.95)], 1),
+                                         "path": "hnswgpu_ivf_search, host buffers in and out (search-knn's seam)"},
                        "end_to_end_frac_of_reference_bytes": round(o["algorithmic_GB"] * 1e9 / (lat[len(lat) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                        "note": "one query, 32 lists: the bounds pass reads them once in int8 (achieved / frac: those bytes over "
                                "the bounds kernel's time); end to end = routing, bounds, finish in one call + sync, priced at "

@@ -1786,7 +1786,73 @@ int hnswgpu_ivf_search_lists(hnswgpu_index *idx, const float *Q, int32_t nq, int
 }
 
 // One launch for a set of queued synchronous IVF requests with the same (k, nprobe); see combine_search.
+// The flag a synchronous caller spins on: behind the search's last launch on the same stream, whose results are in the mapped
+// block by then.
+__global__ void slot_signal_kernel(uint32_t *flag, uint32_t val) {
+    __threadfence_system();
+    __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Small synchronous batches (the reference's search-knn seam: one query per call): queries and results in a block of mapped
+// pinned host memory -- the routing kernel reads the queries there, the finish kernel writes ids and distances there --, a
+// one-thread launch behind them sets a flag the caller spins on.  No upload, no downloads, no hipStreamSynchronize (what the
+// hnsw path has done since round 2: hnsw_search_batch_slot): one query, host buffers in and out, 72 -> ~50 us per call.
+constexpr int32_t kIvfZcMaxQueries = 16;
+static int ivf_search_batch_slot(hnswgpu_index *idx, const std::vector<hnswgpu_index::SearchReq *> &batch, int32_t total) {
+    const int32_t k = batch[0]->k;
+    const size_t cnt = static_cast<size_t>(total) * k;
+    const size_t qb = sizeof(float) * static_cast<size_t>(total) * idx->dim, ib = sizeof(int32_t) * cnt, db = sizeof(float) * cnt;
+    const size_t o_q = 64, o_i = (o_q + qb + 63) & ~size_t(63), o_d = o_i + ((ib + 63) & ~size_t(63)), bytes = o_d + db;
+    hnswgpu_index::Slot *slot = nullptr;
+    std::unique_lock<std::mutex> sl;
+    for (auto &s : idx->slots) {
+        sl = std::unique_lock<std::mutex>(s.mu, std::try_to_lock);
+        if (sl.owns_lock()) {
+            slot = &s;
+            break;
+        }
+    }
+    if (!slot) {
+        slot = &idx->slots[0];
+        sl = std::unique_lock<std::mutex>(slot->mu);
+    }
+    HG_HIP(hipSetDevice(idx->device));
+    HG_TRY(slot_prepare(*slot, bytes));
+    char *hp = static_cast<char *>(slot->h), *dp = static_cast<char *>(slot->d);
+    float *hq = reinterpret_cast<float *>(hp + o_q);
+    size_t o = 0;
+    for (auto *r : batch) {
+        memcpy(hq + o, r->Q, sizeof(float) * static_cast<size_t>(r->nq) * idx->dim);
+        o += static_cast<size_t>(r->nq) * idx->dim;
+    }
+    const uint32_t flag_val = ++slot->seq;
+    volatile uint32_t *h_flag = reinterpret_cast<volatile uint32_t *>(hp);
+    {
+        std::lock_guard<std::mutex> lk(idx->mu);  // the index state is read (and the launches enqueued) under its lock
+        HG_REQUIRE(idx->nlist > 0, HNSWGPU_ESTATE, "index has no IVF lists (call hnswgpu_ivf_build / hnswgpu_set_ivf)");
+        const int32_t np = std::min(batch[0]->ef, idx->nlist);
+        HG_TRY(begin_call(idx, slot->st));
+        HG_TRY(ivf_search_enqueue(idx, reinterpret_cast<const float *>(dp + o_q), total, k, np, reinterpret_cast<int32_t *>(dp + o_i),
+                                  reinterpret_cast<float *>(dp + o_d), nullptr, slot->st));
+        hipLaunchKernelGGL(slot_signal_kernel, dim3(1), dim3(1), 0, slot->st, reinterpret_cast<uint32_t *>(dp), flag_val);
+        HG_HIP(hipGetLastError());
+        HG_TRY(end_call(idx, slot->st));
+    }
+    HG_TRY(slot_wait(*slot, h_flag, flag_val));
+    const int32_t *hi = reinterpret_cast<const int32_t *>(hp + o_i);
+    const float *hd = reinterpret_cast<const float *>(hp + o_d);
+    int64_t q0 = 0;
+    for (auto *r : batch) {
+        const size_t c = static_cast<size_t>(r->nq) * k;
+        memcpy(r->out_ids, hi + q0 * k, sizeof(int32_t) * c);
+        memcpy(r->out_dist, hd + q0 * k, sizeof(float) * c);
+        q0 += r->nq;
+    }
+    return 0;
+}
+
 static int ivf_search_batch(hnswgpu_index *idx, const std::vector<hnswgpu_index::SearchReq *> &batch, int32_t total) {
+    if (tune(HNSWGPU_TUNE_ZEROCOPY, 1) != 0 && total <= kIvfZcMaxQueries) return ivf_search_batch_slot(idx, batch, total);
     const int32_t k = batch[0]->k;
     const int64_t cnt = static_cast<int64_t>(total) * k;
     std::lock_guard<std::mutex> lk(idx->mu);
