@@ -420,11 +420,11 @@ int scan_topk(hnswgpu_index *idx, ScanArgs a, int32_t nq, int32_t pairs_per_quer
 
 // zero-initialised per-query counters of the fused tails (each tail resets its own counter: zero between calls)
 int ensure_counters(hnswgpu_index *idx, size_t n, hipStream_t st) {
-    const size_t bytes = sizeof(uint32_t) * (2 * n + 2);  // [n] scan tails | [n] route tails | 2 words of the folded work list
+    const size_t bytes = sizeof(uint32_t) * (2 * n + 4);  // [n] scan tails | [n] route tails | 2 words of the folded work list | the queries finished (flagged calls)
     if (bytes <= idx->s_done.cap) return 0;
     HG_TRY(idx->s_done.ensure(bytes));
     HG_HIP(hipMemsetAsync(idx->s_done.p, 0, idx->s_done.cap, st));
-    idx->s_done_n = (idx->s_done.cap - 2 * sizeof(uint32_t)) / (sizeof(uint32_t) * 2);
+    idx->s_done_n = (idx->s_done.cap - 4 * sizeof(uint32_t)) / (sizeof(uint32_t) * 2);
     return 0;
 }
 

@@ -158,6 +158,11 @@ struct hnswgpu_index {
         uint32_t seq = 0;              // value the flag takes when the current launch has finished
     };
     Slot slots[2];
+    // a small synchronous IVF call in flight (ivf.hip: ivf_search_batch_slot): the flag word its last kernel sets, taken by the
+    // finish kernel's launch when the search goes through it (zc_taken), by a one-thread launch behind the search otherwise
+    uint32_t *zc_flag = nullptr;
+    uint32_t zc_val = 0;
+    bool zc_taken = false;
     void *h_pin = nullptr;    // pinned host staging of a large combined batch (queries in, results out)
     size_t h_pin_cap = 0;
     // cross-stream ordering of the shared scratch buffers: the last call's completion event

@@ -1149,6 +1149,12 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
     f.out_dist = d_out_dist;
     f.out_gord = d_out_gord;
     f.stats = (idx->prof || idx->ivf_calibrating) ? idx->d_rej_stats : nullptr;
+    if (idx->zc_flag && !heavy && !idx->ivf_calibrating) {  // a flagged synchronous call: the last query's workgroup tells the caller
+        f.host_flag = idx->zc_flag;
+        f.flag_val = idx->zc_val;
+        f.done_q = idx->s_done.as<uint32_t>() + 2 * idx->s_done_n + 2;
+        idx->zc_taken = true;
+    }
     f.qorder = f.slices == 1 ? qorder : nullptr;
     f.main_blocks = static_cast<int32_t>(f.qorder ? (static_cast<int64_t>(nq) + 7) / 8 * 8 : static_cast<int64_t>(nq) * f.slices);
     if (mid) {
@@ -1832,10 +1838,17 @@ static int ivf_search_batch_slot(hnswgpu_index *idx, const std::vector<hnswgpu_i
         HG_REQUIRE(idx->nlist > 0, HNSWGPU_ESTATE, "index has no IVF lists (call hnswgpu_ivf_build / hnswgpu_set_ivf)");
         const int32_t np = std::min(batch[0]->ef, idx->nlist);
         HG_TRY(begin_call(idx, slot->st));
-        HG_TRY(ivf_search_enqueue(idx, reinterpret_cast<const float *>(dp + o_q), total, k, np, reinterpret_cast<int32_t *>(dp + o_i),
-                                  reinterpret_cast<float *>(dp + o_d), nullptr, slot->st));
-        hipLaunchKernelGGL(slot_signal_kernel, dim3(1), dim3(1), 0, slot->st, reinterpret_cast<uint32_t *>(dp), flag_val);
-        HG_HIP(hipGetLastError());
+        idx->zc_flag = reinterpret_cast<uint32_t *>(dp);
+        idx->zc_val = flag_val;
+        idx->zc_taken = false;
+        const int rc = ivf_search_enqueue(idx, reinterpret_cast<const float *>(dp + o_q), total, k, np, reinterpret_cast<int32_t *>(dp + o_i),
+                                          reinterpret_cast<float *>(dp + o_d), nullptr, slot->st);
+        idx->zc_flag = nullptr;
+        if (rc) return rc;
+        if (!idx->zc_taken) {  // (a path without the finish kernel: the flag by a launch of its own behind it)
+            hipLaunchKernelGGL(slot_signal_kernel, dim3(1), dim3(1), 0, slot->st, reinterpret_cast<uint32_t *>(dp), flag_val);
+            HG_HIP(hipGetLastError());
+        }
         HG_TRY(end_call(idx, slot->st));
     }
     HG_TRY(slot_wait(*slot, h_flag, flag_val));

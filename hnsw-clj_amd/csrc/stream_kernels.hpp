@@ -1368,6 +1368,9 @@ struct FinishArgs {
     int32_t heavy_slices, main_blocks;
     int32_t adapt;         // spread a short survivor list over all the waves of the query's workgroups (see span)
     int32_t prepass;       // the upper bounds are worth a look first (ivf_mid_kernel has tightened them)
+    uint32_t *host_flag;   // optional (small synchronous calls, results in mapped host memory): the workgroup that writes the LAST
+    uint32_t *done_q;      // query's results (counted in done_q, zero between calls) sets *host_flag = flag_val for the spinning caller
+    uint32_t flag_val;
     unsigned long long *dbg;  // -DHG_IVF_STAMPS diagnostic builds only
 };
 
@@ -1655,6 +1658,17 @@ __device__ __forceinline__ void finish_wg(const FinishArgs &a, int qi, int sl, i
         if (a.out_gord) a.out_gord[static_cast<int64_t>(qi) * a.k + i] = go;
     }
     HG_IVF_STAMP(a.dbg, 27, qi == 0 && lane == 0);  // results written
+    if (a.host_flag) {
+        wait_stores_acked();  // this query's results are out
+        if (lane == 0) {
+            const uint32_t prev = __hip_atomic_fetch_add(a.done_q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == static_cast<uint32_t>(a.nq) - 1) {
+                __hip_atomic_store(a.done_q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                __hip_atomic_store(a.host_flag, a.flag_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 template <int NCH, int RB, bool L2>
