@@ -100,7 +100,7 @@ _SIGS = {
     "hnswgpu_group_hnsw_search": ["p", "p", "i32", "i32", "i32", "p", "p"],
 }
 # keys of hnswgpu_set_tuning (include/hnswgpu.h: HNSWGPU_TUNE_*), in the header's order
-TUNE_KEYS = ['TILE_PAIRS', 'PREFILTER', 'IVF_HALF', 'IVF_CALIBRATE', 'BUILD_THREADS', 'PREFETCH', 'SEED_BOUNDS', 'TILE_WGS', 'TILE_PERSIST', 'STREAM_BUCKET', 'STREAM_WGS', 'FINISH_ORDER', 'STREAM_CAP', 'STREAM_MID', 'STREAM_NARROW', 'FINISH_ADAPT', 'FINISH_BISECT', 'FINISH_SLICES', 'FINISH_SPAN', 'STREAM_HEAVY', 'STREAM_HEAVY_MEAN', 'STREAM_HEAVY_MIN', 'MID_SLICES', 'MID_COMPACT', 'IVF_CODES', 'SCAN_ORDER', 'IVF_FUSED', 'IVF_GROUP', 'STREAM_ROUTE', 'STREAM_GROUP', 'ROUTE_GROUP', 'MID_WIDE', 'MERGE_W', 'SCAN_BLOCKS', 'ROUTE_WGS', 'TILE', 'SELECT_W', 'HNSW_NW', 'VIS_GLOBAL', 'PF_HINTS', 'PF_EVAL', 'ZEROCOPY', 'BUILD_TIMING', 'BUILD_BATCH', 'STREAM_HOME', 'HOME_CHUNK', 'HOME_DEPTH', 'HOME_STRAYS', 'ROUTE_MFMA', 'STREAM_WIDE2', 'SOLO', 'SOLO_CHASE', 'SOLO_SLOTS', 'HNSW_CALIBRATE', 'HNSW_CALIBRATE_PCT', 'HNSW_WAVE', 'FINISH_DIRECT', 'WORKLIST_FOLD', 'SEED_HALF', 'BUILD_KEEP_ROWS']
+TUNE_KEYS = ['TILE_PAIRS', 'PREFILTER', 'IVF_HALF', 'IVF_CALIBRATE', 'BUILD_THREADS', 'PREFETCH', 'SEED_BOUNDS', 'TILE_WGS', 'TILE_PERSIST', 'STREAM_BUCKET', 'STREAM_WGS', 'FINISH_ORDER', 'STREAM_CAP', 'STREAM_MID', 'STREAM_NARROW', 'FINISH_ADAPT', 'FINISH_BISECT', 'FINISH_SLICES', 'FINISH_SPAN', 'STREAM_HEAVY', 'STREAM_HEAVY_MEAN', 'STREAM_HEAVY_MIN', 'MID_SLICES', 'MID_COMPACT', 'IVF_CODES', 'SCAN_ORDER', 'IVF_FUSED', 'IVF_GROUP', 'STREAM_ROUTE', 'STREAM_GROUP', 'ROUTE_GROUP', 'MID_WIDE', 'MERGE_W', 'SCAN_BLOCKS', 'ROUTE_WGS', 'TILE', 'SELECT_W', 'HNSW_NW', 'VIS_GLOBAL', 'PF_HINTS', 'PF_EVAL', 'ZEROCOPY', 'BUILD_TIMING', 'BUILD_BATCH', 'STREAM_HOME', 'HOME_CHUNK', 'HOME_DEPTH', 'HOME_STRAYS', 'ROUTE_MFMA', 'STREAM_WIDE2', 'SOLO', 'SOLO_CHASE', 'SOLO_SLOTS', 'HNSW_CALIBRATE', 'HNSW_CALIBRATE_PCT', 'HNSW_WAVE', 'FINISH_DIRECT', 'WORKLIST_FOLD', 'SEED_HALF', 'BUILD_KEEP_ROWS', 'QUERY_WAVES']
 TUNE_DEFAULT = -(1 << 63)
 
 

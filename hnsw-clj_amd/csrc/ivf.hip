@@ -1053,7 +1053,12 @@ static int ivf_stream_scan(hnswgpu_index *idx, const float *d_Q, int32_t nq, int
         hs.surv_cnt = b.surv_cnt;
         hs.first = home_first;
         hs.tau = b.tau;
-        hipLaunchKernelGGL(ivf_home_select_kernel, dim3(nq), dim3(kWG), 0, st, hs);
+        // (large batches: a wave per query, four queries per workgroup -- the per-query chain four times as often per CU)
+        const int64_t pqw = tune(HNSWGPU_TUNE_QUERY_WAVES, -1);  // -1 from 2048 queries, 0 never, 1 wherever a wave can serve a query
+        if (k <= kWave && pqw != 0 && (pqw > 0 || nq >= 2048))
+            hipLaunchKernelGGL(ivf_home_select_wave_kernel, dim3((nq + kNWave - 1) / kNWave), dim3(kWG), 0, st, hs);
+        else
+            hipLaunchKernelGGL(ivf_home_select_kernel, dim3(nq), dim3(kWG), 0, st, hs);
         HG_HIP(hipGetLastError());
     }
     hipEvent_t e0;

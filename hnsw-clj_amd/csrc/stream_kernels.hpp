@@ -1271,6 +1271,79 @@ static __global__ __launch_bounds__(kWG) void ivf_home_select_kernel(HomeSelectA
     }
 }
 
+// The same with ONE WAVE per query, four queries per workgroup (round 5, batches from 2048 queries, k <= 64).  A workgroup per
+// query is a chain of dependent round trips -- counter, table entry, the list's bounds, rank, stores: ~16 us whatever the
+// batch -- of which a CU holds eight: batch 16384 took 8 rounds = 133 us.  A wave per query is the same chain four times as
+// often per CU; nothing in it needs more than 64 lanes (16 bounds per lane at 977 rows, the k-th smallest of the 64 lane
+// minima by v_readlane ranks, a DPP prefix sum for the places), and there is no barrier left.
+constexpr int kHomeKeepW = 16;
+static __global__ __launch_bounds__(kWG) void ivf_home_select_wave_kernel(HomeSelectArgs a) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int qi = static_cast<int>(blockIdx.x) * kNWave + wave;
+    if (qi >= a.nq) return;
+    const uint32_t nsv0 = a.surv_cnt[qi];
+    const Pair hp = a.pairs[static_cast<int64_t>(qi) * a.nprobe];
+    if (lane == 0) a.first[qi] = 0u;
+    if (nsv0 > a.cap) return;  // (a bucket overflowed in the routing: the finish kernel walks the candidate stream)
+    const int hlen = static_cast<int>(hp.row_end - hp.row_begin);
+    if (hlen <= 0) return;
+    const float2 *hd = a.dh + static_cast<int64_t>(qi) * a.hstride;
+    const float inf = __builtin_inff();
+    float2 b[kHomeKeepW];
+#pragma unroll
+    for (int j = 0; j < kHomeKeepW; j++) {
+        const int r = lane + j * kWave;
+        b[j] = r < hlen ? hd[r] : make_float2(inf, inf);
+    }
+    float ub_min = inf;
+#pragma unroll
+    for (int j = 0; j < kHomeKeepW; j++) ub_min = b[j].y < ub_min ? b[j].y : ub_min;  // (NaN: no upper bound, not counted)
+    for (int r = lane + kHomeKeepW * kWave; r < hlen; r += kWave) {
+        const float u = hd[r].y;
+        ub_min = u < ub_min ? u : ub_min;
+    }
+    // the k-th smallest of the 64 lanes' minima: k candidates are at most that far (ranks are a permutation of 0..63)
+    const uint32_t v = tau_encode(ub_min);
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < kWave; j++) {
+        const uint32_t o = __builtin_amdgcn_readlane(v, j);
+        rank += (o < v || (o == v && j < lane)) ? 1 : 0;
+    }
+    const uint32_t kth = __builtin_amdgcn_readlane(v, __ffsll(static_cast<unsigned long long>(__ballot(rank == a.k - 1))) - 1);
+    const float T = tau_decode(kth);
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kHomeKeepW; j++) cnt += (lane + j * kWave < hlen && !(b[j].x > T)) ? 1 : 0;  // NaN (no bound) stays
+    for (int r = lane + kHomeKeepW * kWave; r < hlen; r += kWave) cnt += !(hd[r].x > T) ? 1 : 0;
+    const int incl = wave_scan_incl(cnt);
+    const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(incl, kWave - 1));
+    uint32_t at = static_cast<uint32_t>(incl - cnt);
+    uint4 *sv = a.surv + static_cast<int64_t>(qi) * a.cap;
+    const uint32_t hob = hp.ord_base, hrb = static_cast<uint32_t>(hp.row_begin);
+#pragma unroll
+    for (int j = 0; j < kHomeKeepW; j++) {
+        const int r = lane + j * kWave;
+        if (r < hlen && !(b[j].x > T)) {
+            if (at < a.cap) sv[at] = make_uint4(hob + static_cast<uint32_t>(r), hrb + static_cast<uint32_t>(r), __float_as_uint(b[j].x), __float_as_uint(b[j].y));
+            at++;
+        }
+    }
+    for (int r = lane + kHomeKeepW * kWave; r < hlen; r += kWave) {
+        const float2 e = hd[r];
+        if (!(e.x > T)) {
+            if (at < a.cap) sv[at] = make_uint4(hob + static_cast<uint32_t>(r), hrb + static_cast<uint32_t>(r), __float_as_uint(e.x), __float_as_uint(e.y));
+            at++;
+        }
+    }
+    if (lane == 0) {
+        const bool fits = total <= a.cap;
+        a.surv_cnt[qi] = fits ? total : static_cast<uint32_t>(a.cap) + 1u;  // (more than fit: the walk of the candidate stream)
+        a.first[qi] = fits ? total : 0u;
+        if (T < inf) (void)__hip_atomic_fetch_min(a.tau + qi, tau_encode(T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Step 2: survivors -> f32 distances -> the k nearest -> results.
 // ------------------------------------------------------------------------------------------------

@@ -399,7 +399,8 @@ int hnswgpu_get_profile(hnswgpu_index *idx, int32_t which, double *total_ms, int
 #define HNSWGPU_TUNE_WORKLIST_FOLD 57 /* 0 = the bounds pass's work list of a small IVF batch stays a launch of its own instead of extra workgroups of the routing tail's launch (A/B) */
 #define HNSWGPU_TUNE_SEED_HALF 58 /* 0 = a query's first threshold from f32 rows of its nearest list even where the half-precision copy exists (A/B; default 1: the k-th smallest upper bound of the sampled rows' half-precision copies, half the bytes) */
 #define HNSWGPU_TUNE_BUILD_KEEP_ROWS 59 /* 0 = the builder's heuristic selection fetches the already selected rows again for every candidate instead of keeping them in registers (A/B; the graph does not depend on it) */
-#define HNSWGPU_TUNE_COUNT 60
+#define HNSWGPU_TUNE_QUERY_WAVES 60 /* the per-query kernels of large IVF batches (home-list selection) with one WAVE per query, four queries per workgroup, instead of a workgroup per query: -1 from 2048 queries, 0 never, 1 wherever a wave can serve a query (k <= 64) */
+#define HNSWGPU_TUNE_COUNT 61
 int hnswgpu_set_tuning(int32_t key, int64_t value);
 int hnswgpu_get_tuning(int32_t key, int64_t *value, int32_t *is_set);
 

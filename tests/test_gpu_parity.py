@@ -1136,6 +1136,14 @@ def test_ivf_home_list_pass(eng, oracle, metric, dim, tune):
         check(300, 10, 12, "home off, four column blocks")
         tune.set("STREAM_HOME", "1")
         tune.unset("STREAM_WIDE2")
+        tune.set("QUERY_WAVES", "1")       # the per-query kernels with a wave per query (production from 2048 queries)
+        check(300, 10, 12, "a wave per query")
+        check(41, 64, 12, "a wave per query")
+        check(300, 100, 50, "a wave per query (k beyond a wave: the workgroup kernels)")
+        check(3, 1, 12, "a wave per query")
+        tune.set("QUERY_WAVES", "0")
+        check(300, 10, 12, "a workgroup per query")
+        tune.unset("QUERY_WAVES")
         tune.set("STREAM_CAP", "300")      # some lists overflow (and home rows that do not fit send a query through the fallback)
         check(300, 10, 12, "mixed fallback", expect_few=False)
         tune.set("STREAM_HEAVY_MEAN", "0")
