@@ -110,7 +110,7 @@ def set_tuning(name, value=None):
     check(lib().hnswgpu_set_tuning(key, TUNE_DEFAULT if value is None else int(value)))
 
 
-LAUNCH_COUNTERS = ["bounds_two_column_blocks", "hnsw_solo", "hnsw_helpers", "hnsw_rejection", "hnsw_plain", "hnsw_wave"]
+LAUNCH_COUNTERS = ["bounds_two_column_blocks", "hnsw_solo", "hnsw_helpers", "hnsw_rejection", "hnsw_plain", "hnsw_wave", "route_tail_waves"]
 
 
 def debug_counter(name):

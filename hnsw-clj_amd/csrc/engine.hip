@@ -487,6 +487,7 @@ struct RouteArgs {
     uint2 *bk_mem;           // [nlist][bk_cap] (query, offset of the list in the query's candidate stream)
     int32_t bk_cap;
     int32_t home;            // the home-list pass follows: no seed for a query whose nearest list holds k rows (its threshold comes from there)
+    int32_t defer_file;      // the pairs are filed under their lists by ivf_bucket_fill_kernel behind the tail (large batches), not here
     int32_t wl_on;           // kWorklistParts extra workgroups of the tail's launch build the bounds pass's work list (worklist_part_wg)
     WorklistArgs wl;
     unsigned long long *dbg;  // -DHG_IVF_STAMPS diagnostic builds only
@@ -503,6 +504,71 @@ __device__ __forceinline__ const uint64_t *select_small_wg(const float *in, int6
     });
 }
 
+// The probe table of query qi from its nprobe nearest lists (keys: (distance, list), ascending, in LDS): offsets of the probed
+// lists in the query's candidate stream, the pairs filed under their lists, the empty survivor list.  One wave.
+constexpr int kRouteHead = 16;
+__device__ __forceinline__ void route_probe_table(const RouteArgs &a, int qi, const uint64_t *keys, int lane, Pair *head_s,
+                                                  uint32_t *tail_cover, int64_t *tail_qcnt) {
+    // the query's probe table: offsets of the probed lists in its candidate stream (probe_pairs_kernel, one wave)
+    uint32_t carry = 0, gcarry = 0;
+    bool over = false;
+    for (int p0 = 0; p0 < a.nprobe; p0 += kWave) {
+        const int p = p0 + lane;
+        uint32_t l = 0xffffffffu;
+        if (p < a.nprobe) {
+            const uint64_t key = keys[p];
+            if (key != ~0ull) l = static_cast<uint32_t>(key);
+        }
+        Pair pr;
+        pr.q = qi;
+        pr.pad = 0;
+        pr.row_begin = pr.row_end = 0;
+        uint32_t glen = 0;
+        if (l != 0xffffffffu) {
+            pr.row_begin = a.listoff[l];
+            pr.row_end = a.listoff[l + 1];
+            glen = static_cast<uint32_t>(a.glistoff[l + 1] - a.glistoff[l]);
+        }
+        const uint32_t len = static_cast<uint32_t>(pr.row_end - pr.row_begin);
+        uint32_t incl = len, gincl = glen;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, kWave), go = __shfl_up(gincl, off, kWave);
+            if (lane >= off) {
+                incl += o;
+                gincl += go;
+            }
+        }
+        pr.ord_base = carry + incl - len;
+        pr.gord_base = gcarry + gincl - glen;
+        if (p < a.nprobe) {
+            a.pairs[static_cast<int64_t>(qi) * a.nprobe + p] = pr;
+            if (a.probes) a.probes[static_cast<int64_t>(qi) * a.nprobe + p] = l == 0xffffffffu ? -1 : static_cast<int32_t>(l);
+            if (head_s && p < kRouteHead) head_s[p] = pr;
+            if (tail_cover && (p == kRouteHead - 1 || (p < kRouteHead && p == a.nprobe - 1))) *tail_cover = carry + incl;  // candidates the head covers
+            if (a.bk_cnt && len > 0 && !a.defer_file) {  // file the pair under its list: the bounds pass serves a list's members together
+                const uint32_t slot = __hip_atomic_fetch_add(a.bk_cnt + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < static_cast<uint32_t>(a.bk_cap))
+                    a.bk_mem[static_cast<int64_t>(l) * a.bk_cap + slot] = make_uint2(static_cast<uint32_t>(qi), pr.ord_base);
+                else
+                    over = true;
+            }
+        }
+        carry += __shfl(incl, kWave - 1, kWave);
+        gcarry += __shfl(gincl, kWave - 1, kWave);
+    }
+    if (a.qcnt && lane == 0) a.qcnt[qi] = static_cast<int32_t>(carry);
+    const bool any_over = __ballot(over) != 0;
+    if (lane == 0) {
+        if (tail_qcnt) *tail_qcnt = carry;
+        // an empty survivor list -- or, when a bucket was full, the mark that sends the query through the finish
+        // kernel's fallback (the plain f32 scan of all its candidates)
+        if (a.surv_cnt) a.surv_cnt[qi] = any_over ? 0x80000000u : 0u;
+    }
+    wait_stores_acked();  // the probe table may be read back by the other waves below
+    // (this query's pairs are filed: the work list's workgroups count the queries in)
+    if (a.wl_on && lane == 0) (void)__hip_atomic_fetch_add(a.wl.filed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The tail of the routing of query qi, run by one whole workgroup once all of the query's centroid distances are in
 // a.dense: pick the nprobe nearest, write the probe table, file the pairs by list, seed the threshold.  COH: the
 // distances were written by other workgroups of THIS launch (agent-scope loads), not by an earlier one.
@@ -513,7 +579,7 @@ template <int NCH, int RB, bool L2, bool COH>
 __device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsigned char *smem, bool encode_here = false) {
     __shared__ int64_t tail_qcnt;
     __shared__ uint32_t tail_cover;
-    constexpr int kHead = 16;
+    constexpr int kHead = kRouteHead;
     __shared__ Pair head_s[kHead];  // the first probes' table entries, for the threshold seed below
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -540,64 +606,7 @@ __device__ __forceinline__ void route_tail_wg(const RouteArgs &a, int qi, unsign
     // selection the encoding wave kept the other three waiting at the selection's barrier)
     if (encode_here && a.qcodes && a.tau && wave == kNWave - 1) route_encode<NCH>(a, qi, q, lane);
     if (wave == 0) {
-        // the query's probe table: offsets of the probed lists in its candidate stream (probe_pairs_kernel, one wave)
-        uint32_t carry = 0, gcarry = 0;
-        bool over = false;
-        for (int p0 = 0; p0 < a.nprobe; p0 += kWave) {
-            const int p = p0 + lane;
-            uint32_t l = 0xffffffffu;
-            if (p < a.nprobe) {
-                const uint64_t key = keys[p];
-                if (key != ~0ull) l = static_cast<uint32_t>(key);
-            }
-            Pair pr;
-            pr.q = qi;
-            pr.pad = 0;
-            pr.row_begin = pr.row_end = 0;
-            uint32_t glen = 0;
-            if (l != 0xffffffffu) {
-                pr.row_begin = a.listoff[l];
-                pr.row_end = a.listoff[l + 1];
-                glen = static_cast<uint32_t>(a.glistoff[l + 1] - a.glistoff[l]);
-            }
-            const uint32_t len = static_cast<uint32_t>(pr.row_end - pr.row_begin);
-            uint32_t incl = len, gincl = glen;
-            for (int off = 1; off < kWave; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off, kWave), go = __shfl_up(gincl, off, kWave);
-                if (lane >= off) {
-                    incl += o;
-                    gincl += go;
-                }
-            }
-            pr.ord_base = carry + incl - len;
-            pr.gord_base = gcarry + gincl - glen;
-            if (p < a.nprobe) {
-                a.pairs[static_cast<int64_t>(qi) * a.nprobe + p] = pr;
-                if (a.probes) a.probes[static_cast<int64_t>(qi) * a.nprobe + p] = l == 0xffffffffu ? -1 : static_cast<int32_t>(l);
-                if (p < kHead) head_s[p] = pr;
-                if (p == kHead - 1 || (p < kHead && p == a.nprobe - 1)) tail_cover = carry + incl;  // candidates the head covers
-                if (a.bk_cnt && len > 0) {  // file the pair under its list: the bounds pass serves a list's members together
-                    const uint32_t slot = __hip_atomic_fetch_add(a.bk_cnt + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (slot < static_cast<uint32_t>(a.bk_cap))
-                        a.bk_mem[static_cast<int64_t>(l) * a.bk_cap + slot] = make_uint2(static_cast<uint32_t>(qi), pr.ord_base);
-                    else
-                        over = true;
-                }
-            }
-            carry += __shfl(incl, kWave - 1, kWave);
-            gcarry += __shfl(gincl, kWave - 1, kWave);
-        }
-        if (a.qcnt && lane == 0) a.qcnt[qi] = static_cast<int32_t>(carry);
-        const bool any_over = __ballot(over) != 0;
-        if (lane == 0) {
-            tail_qcnt = carry;
-            // an empty survivor list -- or, when a bucket was full, the mark that sends the query through the finish
-            // kernel's fallback (the plain f32 scan of all its candidates)
-            if (a.surv_cnt) a.surv_cnt[qi] = any_over ? 0x80000000u : 0u;
-        }
-        wait_stores_acked();  // the probe table may be read back by the other waves below
-        // (this query's pairs are filed: the work list's workgroups count the queries in)
-        if (a.wl_on && lane == 0) (void)__hip_atomic_fetch_add(a.wl.filed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        route_probe_table(a, qi, keys, lane, head_s, &tail_cover, &tail_qcnt);
         HG_IVF_STAMP(a.dbg, 19, qi == 0 && threadIdx.x == 0);  // probe table written, pairs filed
     }
     if (!a.tau) return;
@@ -907,6 +916,197 @@ __global__ __launch_bounds__(kWG) void ivf_route_tail_kernel(RouteArgs a) {
     route_tail_wg<NCH, RB, L2, false>(a, qi, smem, true);
 }
 
+template <int NCH>
+__global__ void ivf_route_tail_wave_kernel(RouteArgs a);
+static int launch_route_tail_wave(const RouteArgs &a, int nch, hipStream_t st);
+
+// The (query, list) pairs of a LARGE batch filed under their lists (round 5).  The tail's own way is one agent-scope atomicAdd
+// per pair on its list's counter: at batch 16384 that is 524k atomics on 1024 addresses, 512 in a row per address -- the tail
+// kernel took 160 - 177 us of which ~25 are its work.  Here a workgroup takes ~8192 consecutive pairs, ranks them per list in
+// an LDS histogram (LDS atomics), reserves each list's run with ONE global atomicAdd per (workgroup, list) -- 64 per address
+// instead of 512 -- and scatters the members.  The members of a list end up in another order than the tail would have filed
+// them in (results do not depend on it: survivors carry order keys); a full bucket marks its query for the finish kernel's
+// fallback as before.
+struct BucketArgs {
+    const int32_t *probes;  // [npairs] list of pair i = query i / nprobe, probe i % nprobe (-1: none)
+    const Pair *pairs;      // [npairs]
+    const int64_t *listoff;
+    int32_t npairs, nprobe, nlist, per_wg;
+    uint32_t *bk_cnt;
+    uint2 *bk_mem;
+    int32_t bk_cap;
+    uint32_t *surv_cnt;
+};
+constexpr int kBucketPairs = 8;  // pairs per thread
+__global__ __launch_bounds__(1024) void ivf_bucket_fill_kernel(BucketArgs a) {
+    extern __shared__ uint32_t bhist[];  // [nlist]: pairs of this workgroup per list, then the base of their run in the bucket
+    const int tid = threadIdx.x;
+    const int p0 = static_cast<int>(blockIdx.x) * a.per_wg, p1 = p0 + a.per_wg < a.npairs ? p0 + a.per_wg : a.npairs;
+    for (int l = tid; l < a.nlist; l += 1024) bhist[l] = 0u;
+    __syncthreads();
+    int32_t myl[kBucketPairs];
+    uint32_t myrank[kBucketPairs];
+#pragma unroll
+    for (int u = 0; u < kBucketPairs; u++) {
+        const int i = p0 + u * 1024 + tid;
+        myl[u] = -1;
+        myrank[u] = 0;
+        if (i < p1) {
+            const int32_t l = a.probes[i];
+            if (l >= 0 && a.listoff[l + 1] > a.listoff[l]) {
+                myl[u] = l;
+                myrank[u] = atomicAdd(&bhist[l], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int l = tid; l < a.nlist; l += 1024) {
+        const uint32_t c = bhist[l];
+        bhist[l] = c ? __hip_atomic_fetch_add(a.bk_cnt + l, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kBucketPairs; u++) {
+        if (myl[u] < 0) continue;
+        const int i = p0 + u * 1024 + tid;
+        const uint32_t slot = bhist[myl[u]] + myrank[u];
+        const int q = i / a.nprobe;
+        if (slot < static_cast<uint32_t>(a.bk_cap))
+            a.bk_mem[static_cast<int64_t>(myl[u]) * a.bk_cap + slot] = make_uint2(static_cast<uint32_t>(q), a.pairs[i].ord_base);
+        else
+            a.surv_cnt[q] = 0x80000000u;  // (the bucket is full: the query takes the finish kernel's plain f32 scan)
+    }
+}
+
+// The same tail with ONE WAVE per query, four queries per workgroup (round 5: large home-list batches -- a query's threshold comes
+// from the home-list pass --, nprobe and k <= 64).  A workgroup per query is a chain of ~15 us of which a CU holds eight:
+// 16384 queries took 170 us.  A wave takes 16 distances per lane and chunk, picks the nprobe nearest by the bisection of the key
+// space started from its lane minima (wave_topk_sorted), writes the probe table, files the pairs, encodes the query.
+template <int NCH>
+__global__ __launch_bounds__(kWG) void ivf_route_tail_wave_kernel(RouteArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];  // [kNWave][2][nprobe] keys: a wave's list and its scratch
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int qi = static_cast<int>(blockIdx.x) * kNWave + wave;
+    if (qi >= a.nq) return;
+    uint64_t *mylist = reinterpret_cast<uint64_t *>(smem) + static_cast<size_t>(wave) * 2 * a.nprobe, *myscr = mylist + a.nprobe;
+    float4 q[NCH];
+    load_query<NCH>(q, a.Q + static_cast<int64_t>(qi) * a.qld, a.dim, lane);
+    constexpr int S = 16;
+    const float *in = a.dense + static_cast<int64_t>(qi) * a.nlist;
+    uint64_t carry = ~0ull;
+    for (int base = 0; base < a.nlist; base += S * kWave) {
+        uint64_t key[S];
+#pragma unroll
+        for (int s2 = 0; s2 < S; s2++) {
+            const int i = base + s2 * kWave + lane;
+            key[s2] = i < a.nlist ? make_key(in[i], static_cast<uint32_t>(i)) : ~0ull;
+        }
+        wave_topk_sorted<S>(key, carry, a.nprobe, myscr, mylist, lane);
+        carry = lane < a.nprobe ? mylist[lane] : ~0ull;
+    }
+    route_probe_table(a, qi, mylist, lane, nullptr, nullptr, nullptr);
+    if (a.qcodes) route_encode<NCH>(a, qi, q, lane);
+    if (!a.tau) return;
+    // the threshold comes from the home-list pass -- unless the nearest list is shorter than k (rare: a seed by this wave alone,
+    // from the first <= 64 rows of the candidate stream in f32: any k exact distances bound the k-th)
+    const uint64_t k0 = mylist[0];
+    int64_t len0 = 0;
+    if (k0 != ~0ull) {
+        const uint32_t l0 = static_cast<uint32_t>(k0);
+        len0 = a.listoff[l0 + 1] - a.listoff[l0];
+    }
+    if (len0 >= a.k) {
+        if (lane == 0) a.tau[qi] = 0xffffffffu;
+        return;
+    }
+    const Pair *pp = a.pairs + static_cast<int64_t>(qi) * a.nprobe;  // (this wave's own stores, acknowledged in route_probe_table)
+    const Pair last = pp[a.nprobe - 1];
+    const int64_t qcnt = static_cast<int64_t>(last.ord_base) + (last.row_end - last.row_begin);
+    const int m = static_cast<int>(qcnt < kWave ? qcnt : kWave);
+    if (m < a.k) {  // fewer candidates than k: nothing can be excluded
+        if (lane == 0) a.tau[qi] = 0xffffffffu;
+        return;
+    }
+    int64_t myrow = 0;
+    float myrn = 0.0f;
+    if (lane < m) {
+        int lo = 0, hi = a.nprobe - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pp[mid].ord_base <= static_cast<uint32_t>(lane)) lo = mid;
+            else hi = mid - 1;
+        }
+        myrow = pp[lo].row_begin + (static_cast<uint32_t>(lane) - pp[lo].ord_base);
+        myrn = a.metric == METRIC_COS ? a.row_norms[myrow] : 0.0f;
+    }
+    const float qn = a.metric == METRIC_COS ? query_norm<NCH>(q) : 0.0f;
+    const int nvec = static_cast<int>(a.ld / 4);
+    float mine = __builtin_inff();
+    for (int j = 0; j < m; j++) {  // (one row per trip: a few dozen rows of the rare query that needs them)
+        const int64_t row = (static_cast<int64_t>(__builtin_amdgcn_readlane(static_cast<int>(myrow >> 32), j)) << 32) |
+                            static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myrow), j));
+        float4 r[NCH];
+        load_row<NCH>(r, a.rows + row * a.ld, nvec, lane, true);
+        const float sum = a.metric == METRIC_L2 ? wave_sum(lane_partial<NCH, true>(q, r)) : wave_sum(lane_partial<NCH, false>(q, r));
+        const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrn), j));
+        const float d = finish_dist(a.metric, sum, qn, rn);
+        if (lane == j) mine = d == d ? d : __builtin_inff();
+    }
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < kWave; j++) {
+        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), j));
+        rank += (o < mine || (o == mine && j < lane)) ? 1 : 0;
+    }
+    const uint64_t sel = __ballot(rank == a.k - 1);
+    const float kth = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), __ffsll(static_cast<unsigned long long>(sel)) - 1));
+    if (lane == 0) a.tau[qi] = kth < __builtin_inff() ? tau_encode(kth) : 0xffffffffu;
+}
+
+static int launch_bucket_fill(const RouteArgs &r, hipStream_t st) {
+    BucketArgs b;
+    memset(&b, 0, sizeof(b));
+    b.probes = r.probes;
+    b.pairs = r.pairs;
+    b.listoff = r.listoff;
+    const int64_t npairs = static_cast<int64_t>(r.nq) * r.nprobe;
+    HG_REQUIRE(npairs < 2147483647LL && r.probes && r.surv_cnt, HNSWGPU_EINVAL, "bucket fill: too many pairs, or no probe table");
+    b.npairs = static_cast<int32_t>(npairs);
+    b.nprobe = r.nprobe;
+    b.nlist = r.nlist;
+    b.per_wg = kBucketPairs * 1024;
+    b.bk_cnt = r.bk_cnt;
+    b.bk_mem = r.bk_mem;
+    b.bk_cap = r.bk_cap;
+    b.surv_cnt = r.surv_cnt;
+    const unsigned blocks = static_cast<unsigned>((npairs + b.per_wg - 1) / b.per_wg);
+    const size_t lds = sizeof(uint32_t) * static_cast<size_t>(r.nlist);
+    HG_REQUIRE(lds <= 48 * 1024, HNSWGPU_ELIMIT, "bucket fill: too many lists for its LDS histogram");
+    hipLaunchKernelGGL(ivf_bucket_fill_kernel, dim3(blocks), dim3(1024), lds, st, b);
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_route_tail_wave(const RouteArgs &a, int nch, hipStream_t st) {
+    count_launch(HNSWGPU_COUNT_ROUTE_TAIL_WAVES);
+    const size_t lds = sizeof(uint64_t) * kNWave * 2 * static_cast<size_t>(a.nprobe);
+    const unsigned blocks = static_cast<unsigned>((a.nq + kNWave - 1) / kNWave);
+    switch (nch) {
+#define CALLW(N) case N: hipLaunchKernelGGL((ivf_route_tail_wave_kernel<N>), dim3(blocks), dim3(kWG), lds, st, a); break
+        CALLW(1);
+        CALLW(2);
+        CALLW(3);
+        CALLW(4);
+        CALLW(6);
+        CALLW(8);
+        CALLW(12);
+#undef CALLW
+        default: set_error("unsupported row length"); return HNSWGPU_ELIMIT;
+    }
+    HG_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t nprobe, Pair *pairs, int32_t *probes,
                      int32_t *qcnt, hipStream_t st, const RouteStream *rs, bool two_launches) {
     RouteArgs a;
@@ -966,6 +1166,10 @@ int launch_ivf_route(hnswgpu_index *idx, const float *d_Q, int32_t nq, int32_t n
     const size_t lds = std::max<size_t>(sizeof(uint64_t) * ((nprobe <= kWave ? 2 * kNWave : kNWave) + 1) * nprobe, sizeof(float) * kSeedMax);
     HG_REQUIRE(lds <= 48 * 1024, HNSWGPU_ELIMIT, "nprobe too large for the fused routing kernel");
     const bool l2 = a.metric == METRIC_L2;
+    // the tail with a wave per query: large home-list batches (a query whose nearest list is shorter than k seeds its threshold itself)
+    const int64_t pqw = tune(HNSWGPU_TUNE_QUERY_WAVES, -1);
+    const bool wave_tail = two_launches && rs && rs->home && !a.wl_on && a.bk_cnt && a.tau && a.probes && a.surv_cnt && nprobe <= kWave &&
+                           rs->k <= kWave && idx->nlist <= 12 * 1024 && pqw != 0 && (pqw > 0 || nq >= 2048);
     if (two_launches) {
         // larger batches: the distances by workgroups that share their centroid rows among a group of queries, then the tail
         // as a launch of its own (plain loads: the distances come from an earlier launch)
@@ -997,6 +1201,12 @@ do {                                                                            
             }
 #undef CALLM
             HG_HIP(hipGetLastError());
+            if (wave_tail) {
+                a.defer_file = 1;
+                HG_TRY(launch_route_tail_wave(a, idx->nch, st));
+                HG_TRY(launch_bucket_fill(a, st));
+                return 0;
+            }
 #define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_tail_kernel<N, R, L>), dim3(static_cast<unsigned>(nq) + extra), dim3(kWG), lds, st, a)
             HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
@@ -1017,6 +1227,12 @@ do {                                                                            
         HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL
         HG_HIP(hipGetLastError());
+        if (wave_tail) {
+            a.defer_file = 1;
+            HG_TRY(launch_route_tail_wave(a, idx->nch, st));
+            HG_TRY(launch_bucket_fill(a, st));
+            return 0;
+        }
 #define CALL(N, R, L) hipLaunchKernelGGL((ivf_route_tail_kernel<N, R, L>), dim3(static_cast<unsigned>(nq) + extra), dim3(kWG), lds, st, a)
         HG_DISPATCH(idx->nch, l2, CALL);
 #undef CALL

@@ -185,6 +185,7 @@ struct hnswgpu_index {
     // IVF-FLAT (device: centroids + rows re-ordered so every list is contiguous)
     int nlist = 0;
     int64_t max_list_len = 0;
+    int64_t min_list_len = 0;  // (of this handle's lists; a shard: of the lists it holds -- the wave-per-query routing tail needs k rows in every list)
     float *d_cent = nullptr, *d_cnorms = nullptr, *d_lrows = nullptr, *d_lnorms = nullptr;
     int64_t *d_listoff = nullptr;
     int32_t *d_listids = nullptr;

@@ -481,7 +481,11 @@ static int install_lists(hnswgpu_index *idx, int32_t nlist, const int64_t *off, 
     idx->h_listoff.assign(off, off + nlist + 1);
     idx->h_listids.assign(ids, ids + n);
     idx->max_list_len = 0;
-    for (int l = 0; l < nlist; l++) idx->max_list_len = std::max(idx->max_list_len, off[l + 1] - off[l]);
+    idx->min_list_len = nlist > 0 ? off[1] - off[0] : 0;
+    for (int l = 0; l < nlist; l++) {
+        idx->max_list_len = std::max(idx->max_list_len, off[l + 1] - off[l]);
+        idx->min_list_len = std::min(idx->min_list_len, off[l + 1] - off[l]);
+    }
     idx->nlist = nlist;
     HG_TRY(ensure_list_codes(idx, st));
     HG_TRY(ensure_list_half(idx, st));

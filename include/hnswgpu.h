@@ -278,6 +278,7 @@ int hnswgpu_set_profiling(hnswgpu_index *idx, int32_t on);
 #define HNSWGPU_COUNT_HNSW_REJECTION 3    /* HNSW traversal launches with the int8 rejection test on */
 #define HNSWGPU_COUNT_HNSW_PLAIN 4        /* ... and with every neighbour evaluated in f32 */
 #define HNSWGPU_COUNT_HNSW_WAVE 5         /* large HNSW launches on the one-wave-per-query kernel with the admission buffer (wave_kernels.hpp) */
+#define HNSWGPU_COUNT_ROUTE_TAIL_WAVES 6   /* IVF routing tails launched with one wave per query (ivf_route_tail_wave_kernel) */
 #define HNSWGPU_COUNT_N 8
 int hnswgpu_launch_count(int32_t which, int64_t *out);
 /* The HNSW traversal decides most neighbours (those that cannot enter a full result list, ultra_fast.clj:195-198) from

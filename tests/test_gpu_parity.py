@@ -1137,7 +1137,9 @@ def test_ivf_home_list_pass(eng, oracle, metric, dim, tune):
         tune.set("STREAM_HOME", "1")
         tune.unset("STREAM_WIDE2")
         tune.set("QUERY_WAVES", "1")       # the per-query kernels with a wave per query (production from 2048 queries)
+        tw0 = eng.debug_counter("route_tail_waves")
         check(300, 10, 12, "a wave per query")
+        assert eng.debug_counter("route_tail_waves") > tw0
         check(41, 64, 12, "a wave per query")
         check(300, 100, 50, "a wave per query (k beyond a wave: the workgroup kernels)")
         check(3, 1, 12, "a wave per query")
@@ -1575,6 +1577,39 @@ def test_ivf_small_batch_schedules_of_round_5(eng, oracle, metric, tune):
                 what = "%s fold=%d direct=%d half=%d nq=%d nprobe=%d k=%d" % (metric, fold, direct, half, nq, nprobe, k)
                 np.testing.assert_array_equal(probes, op, err_msg=what)
                 assert_exact(ids, d, oi, od, what)
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2", "dot"])
+def test_ivf_wave_per_query_kernels_with_short_home_lists(eng, oracle, metric, tune):
+    """The wave-per-query routing tail and home-list selection of large batches (forced here): queries whose NEAREST list
+    holds fewer rows than k get their first threshold from the wave itself (the home-list pass has nothing to give them),
+    next to queries with ordinary home lists and to empty lists -- probes, ids and distance bits against the oracle."""
+    O = oracle
+    code = {"cosine": O.COSINE, "l2": O.L2, "dot": O.DOT}[metric]
+    rs = np.random.RandomState(3)
+    dim, nlist, n = 256, 48, 6000
+    cen = rs.randn(nlist, dim).astype(np.float32)
+    sizes = np.array([3] * 6 + [0] * 2 + [1] * 2 + [0] * (nlist - 10))
+    rest = n - sizes.sum()
+    sizes[10:] = rest // (nlist - 10)
+    sizes[-1] += n - sizes.sum()
+    assign = np.repeat(np.arange(nlist), sizes)
+    base = (cen[assign] + 0.1 * rs.randn(n, dim)).astype(np.float32)
+    off, lids = O.lists_from_assign(assign, nlist)
+    Q = np.concatenate([cen[:10] + 0.01 * rs.randn(10, dim), cen[rs.randint(10, nlist, 90)] + 0.1 * rs.randn(90, dim)]).astype(np.float32)
+    with eng.Index(base, metric) as idx:
+        idx.set_rejection_test(2)
+        idx.set_ivf(cen, off, lids)
+        for key, v in (("TILE_PAIRS", 1 << 40), ("IVF_CODES", 1), ("STREAM_MID", 1), ("FINISH_ORDER", 1), ("STREAM_HOME", 1), ("QUERY_WAVES", 1)):
+            tune.set(key, v)
+        tw0 = eng.debug_counter("route_tail_waves")
+        for nq, k, nprobe in [(100, 10, 6), (100, 2, 12), (37, 64, 20)]:
+            ids, d, pr = idx.ivf_search(Q[:nq], k, nprobe, want_probes=True)
+            oi, od, opr = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=code, mode=O.MODE_DEV)
+            what = "%s nq=%d k=%d nprobe=%d" % (metric, nq, k, nprobe)
+            np.testing.assert_array_equal(pr, opr, err_msg=what)
+            assert_exact(ids, d, oi, od, what)
+        assert eng.debug_counter("route_tail_waves") >= tw0 + 3
 
 
 def test_ivf_randomised_small_batches(eng, oracle, tune):
