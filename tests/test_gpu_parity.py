@@ -1610,6 +1610,12 @@ def test_ivf_wave_per_query_kernels_with_short_home_lists(eng, oracle, metric, t
             np.testing.assert_array_equal(pr, opr, err_msg=what)
             assert_exact(ids, d, oi, od, what)
         assert eng.debug_counter("route_tail_waves") >= tw0 + 3
+        tune.set("STREAM_BUCKET", 3)       # three pairs per list's bucket: most queries overflow one and take the plain f32 scan
+        for nq, k, nprobe in [(100, 10, 6), (37, 5, 20)]:
+            ids, d, pr = idx.ivf_search(Q[:nq], k, nprobe, want_probes=True)
+            oi, od, opr = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=code, mode=O.MODE_DEV)
+            np.testing.assert_array_equal(pr, opr)
+            assert_exact(ids, d, oi, od, "%s tiny buckets nq=%d k=%d nprobe=%d" % (metric, nq, k, nprobe))
 
 
 def test_ivf_randomised_small_batches(eng, oracle, tune):
