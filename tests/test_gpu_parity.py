@@ -1616,6 +1616,24 @@ def test_ivf_wave_per_query_kernels_with_short_home_lists(eng, oracle, metric, t
             oi, od, opr = O.ivf_search(base, cen, off, lids, Q[:nq], k, nprobe, metric=code, mode=O.MODE_DEV)
             np.testing.assert_array_equal(pr, opr)
             assert_exact(ids, d, oi, od, "%s tiny buckets nq=%d k=%d nprobe=%d" % (metric, nq, k, nprobe))
+        tune.unset("STREAM_BUCKET")
+    # 300 lists of which 200 have the SAME centroid: the nprobe-th place of the wave's selection falls inside a tie of hundreds
+    nlist2 = 300
+    cen2 = rs.randn(nlist2, dim).astype(np.float32)
+    cen2[50:250] = cen2[50]
+    assign2 = rs.randint(0, nlist2, n)
+    base2 = (cen2[assign2] + 0.1 * rs.randn(n, dim)).astype(np.float32)
+    off2, lids2 = O.lists_from_assign(assign2, nlist2)
+    Q2 = (cen2[rs.randint(0, nlist2, 64)] + 0.1 * rs.randn(64, dim)).astype(np.float32)
+    Q2[:8] = cen2[50] + 0.01 * rs.randn(8, dim).astype(np.float32)
+    with eng.Index(base2, metric) as idx:
+        idx.set_rejection_test(2)
+        idx.set_ivf(cen2, off2, lids2)
+        for nq, k, nprobe in [(64, 10, 8), (64, 10, 64)]:
+            ids, d, pr = idx.ivf_search(Q2[:nq], k, nprobe, want_probes=True)
+            oi, od, opr = O.ivf_search(base2, cen2, off2, lids2, Q2[:nq], k, nprobe, metric=code, mode=O.MODE_DEV)
+            np.testing.assert_array_equal(pr, opr, err_msg="%s duplicated centroids nprobe=%d" % (metric, nprobe))
+            assert_exact(ids, d, oi, od, "%s duplicated centroids nprobe=%d" % (metric, nprobe))
 
 
 def test_ivf_randomised_small_batches(eng, oracle, tune):
